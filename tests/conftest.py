@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) where no GPU is visible so that a bare `pytest tests/` works here.
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+
+    return get
+
+
+def synth_state(spec, salt):
+    """state dict (plain tensors) for a spec from uncltmo_amd.state_spec, via the hash generator."""
+    from uncltmo_amd import synth
+    from oracle.generator import sincos_relative_pos
+    sd = {}
+    for k, shape, kind in spec:
+        if kind == "buffer":
+            sd[k] = sincos_relative_pos()
+        else:
+            sd[k] = synth.synth_tensor(k, shape, salt)
+    return sd
+
+
+def check_summary(t, g, key, rtol=1e-4, atol=1e-5):
+    """Compare a tensor with a golden summary written by make_golden.summarize()."""
+    assert tuple(t.shape) == tuple(g[key + ".shape"]), (key, t.shape, g[key + ".shape"])
+    f = t.detach().double().reshape(-1).cpu()
+    vals = f[torch.from_numpy(g[key + ".pos"])].numpy()
+    np.testing.assert_allclose(vals, g[key + ".val"], rtol=rtol, atol=atol, err_msg=key)
+    np.testing.assert_allclose(f.abs().sum().item(), g[key + ".abssum"], rtol=rtol, err_msg=key + ".abssum")

@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the UPSTREAM reference, run on CPU in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Needs /root/reference (read-only mount) and the import shims in _ref_shims.py; it cannot run on the GPU
+box and nothing at test time imports it.  Weights and inputs come from uncltmo_amd/synth.py (a
+counter-based hash), so the fixtures only hold *outputs* (full tensors where small, otherwise
+sum / abs-sum / hashed samples).  Fixtures are data; no reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_shims  # noqa: E402
+
+DropPath = _ref_shims.install()
+
+from uncltmo_amd import synth  # noqa: E402
+
+torch.manual_seed(999)
+torch.set_num_threads(8)
+DEV = torch.device("cpu")
+
+
+def summarize(t, key, nsamp=256):
+    """sum, abs-sum and `nsamp` values at hashed flat positions of a tensor."""
+    f = t.detach().double().reshape(-1)
+    pos = np.minimum((synth.hash_uniform("samp:" + key, nsamp).astype(np.float64) * f.numel()).astype(np.int64),
+                     f.numel() - 1)
+    return {key + ".sum": np.float64(f.sum().item()), key + ".abssum": np.float64(f.abs().sum().item()),
+            key + ".pos": pos, key + ".val": t.detach().reshape(-1)[torch.from_numpy(pos)].float().numpy(),
+            key + ".shape": np.array(t.shape, dtype=np.int64)}
+
+
+def build_ref_models(video=False):
+    from utils import model_save_util
+    mk = model_save_util.create_G_net if video else model_save_util.create_G_net2
+    G = mk("unet", DEV, False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, "none", "none", "relu", True, 1,
+           1, 0, "replicate", 2, 0)
+    D = model_save_util.create_D_net(1, 16, DEV, False, "none", True, "simpleD", 3, "none", 3, 0, 0, 0)
+    synth.fill_state_dict(G, "g0")
+    synth.fill_state_dict(D, "d0")
+    return G, D
+
+
+def hook_outputs(G):
+    """Record the output of every stage whose name the oracle also reports."""
+    rec = {}
+    names = {"inc": G.inc, "gcn": G.gcn}
+    for i in range(4):
+        names["down%d" % i] = G.down_path[i]
+        names["up%d" % i] = G.up_path[i]
+    hs = [m.register_forward_hook(lambda mod, inp, out, n=n: rec.__setitem__(n, out)) for n, m in names.items()]
+    return rec, hs
+
+
+def capture_generator(out):
+    G, _ = build_ref_models()
+    # ---- eval forward, N=2
+    G.eval()
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    rec, hs = hook_outputs(G)
+    import models.unet_multi_filters.gcn_lib.torch_edge as te
+    knn = {}
+    orig = te.dense_knn_matrix
+
+    def spy(xx, k=16, relative_pos=None):
+        r = orig(xx, k, relative_pos)
+        knn["idx"] = r[0].clone()
+        return r
+
+    te.dense_knn_matrix = spy
+    with torch.no_grad():
+        y, up = G(x)
+    te.dense_knn_matrix = orig
+    for h in hs:
+        h.remove()
+    out["g_eval.x_out"] = y.numpy()
+    out["g_eval.knn_idx"] = knn["idx"].numpy().astype(np.int64)
+    out.update(summarize(up, "g_eval.up_x"))
+    for n, t in rec.items():
+        out.update(summarize(t, "g_eval." + n))
+    out["relative_pos"] = G.gcn.module[0][0].relative_pos.detach().numpy()
+    # ---- train forward with an injected DropPath keep mask (site-independent: same mask both sites)
+    G.train()
+    DropPath.forced_mask = torch.tensor([1.0, 0.0])
+    with torch.no_grad():
+        y2, up2 = G(x)
+    DropPath.forced_mask = None
+    out.update(summarize(y2, "g_train.x_out", 1024))
+    out.update(summarize(up2, "g_train.up_x"))
+    # ---- shape errors: anything but 256x256 is rejected
+    G.eval()
+    for hw in [(268, 268), (512, 512), (256, 512)]:
+        try:
+            with torch.no_grad():
+                G(torch.zeros(1, 1, *hw))
+            out["g_err.%dx%d" % hw] = np.int64(0)
+        except RuntimeError:
+            out["g_err.%dx%d" % hw] = np.int64(1)
+
+
+def capture_video(out):
+    G, _ = build_ref_models(video=True)
+    G.eval()
+    x = torch.cat([synth.smooth_hdr_frames(1, salt="v%d" % t) for t in range(3)], 0).unsqueeze(0)  # (1,3,1,256,256)
+    with torch.no_grad():
+        y, f = G(x)
+    out["v_eval.feats"] = f.numpy()
+    for t in range(3):
+        out.update(summarize(y[:, t], "v_eval.frame%d" % t, 2048))
+
+
+def capture_discriminator(out):
+    _, D = build_ref_models()
+    D.eval()
+    x = torch.cat([synth.ldr_frames(2, salt="dA"), synth.smooth_hdr_frames(1, salt="dB")], 0)
+    with torch.no_grad():
+        o, f = D(x)
+    out["d.output"] = o.numpy()
+    out["d.fea_final"] = f.numpy()
+    from models import Discriminator
+    P = Discriminator.NLayerDiscriminator(1, ndf=16, n_layers=3, norm_layer="instance_norm", last_activation="none")
+    synth.fill_state_dict(P, "p0")
+    P.eval()
+    with torch.no_grad():
+        po = P(x)
+    out["patchd.output"] = po.numpy()
+
+
+def make_trainer(video):
+    """A trainer instance without its dataset-loading constructor (GanTrainerImg.py:59-137)."""
+    import GanTrainer as GV
+    import GanTrainerImg as GI
+    from models import struct_loss
+    mod = GV if video else GI
+    G, D = build_ref_models(video)
+    tr = mod.GanTrainer.__new__(mod.GanTrainer)
+    tr.netG, tr.netD = G, D
+    tr.optimizerG = torch.optim.Adam(G.parameters(), lr=1e-5, betas=(0.5, 0.999))
+    tr.optimizerD = torch.optim.Adam(D.parameters(), lr=1.5e-5, betas=(0.5, 0.999))
+    tr.pre_train_mode = False
+    tr.final_shape_addition = 0
+    tr.to_crop = 0
+    tr.adv_weight_list = torch.tensor([0.2, 0.2, 0.2])
+    tr.epoch_step1, tr.epoch_step2 = 6, 9
+    tr.train_with_D = 1
+    tr.manual_d_training = 0
+    tr.loss_g_d_factor = 0.1
+    tr.struct_loss_factor = 1.0
+    tr.pyramid_weight_list = torch.tensor([1.0, 1.0, 1.0])
+    tr.struct_loss = struct_loss.StructLoss(window_size=5, pyramid_weight_list=tr.pyramid_weight_list,
+                                            pyramid_pow=False, use_c3=False, struct_method="gamma_ssim",
+                                            crop_input=0, final_shape_addition=0)
+    tr.D_losses, tr.G_loss_d, tr.G_loss_struct = [], [], []
+    tr.errD = tr.errG_d = tr.errG_struct = None
+    mod.printer.print_g_progress = lambda *a, **k: None
+    return tr, mod
+
+
+def step_inputs(video):
+    B, T = 2, 2
+    hdr = torch.stack([torch.cat([synth.smooth_hdr_frames(1, salt="s%d_%d" % (b, t)) for t in range(T)], 0)
+                       for b in range(B)], 0)                      # (B,T,1,256,256)
+    pos = synth.ldr_frames(B * T, salt="spos").reshape(B, T, 1, 256, 256)
+    neg = (synth.ldr_frames(B * T, salt="sneg") ** 2).reshape(B, T, 1, 256, 256)
+    return hdr, hdr.clone(), pos, neg
+
+
+def capture_losses(out):
+    tr, mod = make_trainer(False)
+    a = torch.tensor(synth.hash_uniform("la", 4) * 4 - 2).reshape(4, 1).requires_grad_(True)
+    b = torch.tensor(synth.hash_uniform("lb", 4) * 4 - 2).reshape(4, 1).requires_grad_(True)
+    l = tr.contrastive_D_loss(a, b)
+    l.backward()
+    out["loss.cgan"] = np.float64(l.item())
+    out["loss.cgan.ga"], out["loss.cgan.gb"] = a.grad.numpy(), b.grad.numpy()
+    # nce on D-sized features and on a (small) generator-sized map
+    for tag, shape, (k, c) in [("nce_d", (4, 2, 1, 1), (1, 1e-2)), ("nce_d2", (4, 2, 1, 1), (1e3, 2)),
+                               ("nce_map", (3, 32, 16, 16), (1, 1e-2))]:
+        n = int(np.prod(shape))
+        an = torch.tensor(synth.hash_uniform(tag + "a", n)).reshape(shape).requires_grad_(True)
+        po = torch.tensor(synth.hash_uniform(tag + "p", n)).reshape(shape)
+        ne = torch.tensor(synth.hash_uniform(tag + "n", n)).reshape(shape)
+        l = tr.nce(an, [po], [ne], "InfoNCE", k, c)
+        l.backward()
+        out["loss.%s" % tag] = np.float64(l.item())
+        out["loss.%s.ga" % tag] = an.grad.numpy()
+    # struct loss: per level, pyramid, and d/dfake
+    fake = synth.ldr_frames(2, 64, 64, salt="slf").requires_grad_(True)
+    hdr = synth.smooth_hdr_frames(2, 64, 64, salt="slh")
+    from models import struct_loss
+    win = struct_loss.create_window(5, 1)
+    l1 = struct_loss.struct_loss(fake, hdr, win, 5, 1, torch.nn.MSELoss())
+    out["loss.struct_level"] = np.float64(l1.item())
+    lp = tr.struct_loss(fake, hdr, hdr, tr.pyramid_weight_list)
+    lp.backward()
+    out["loss.struct_pyr"] = np.float64(lp.item())
+    out["loss.struct_pyr.gfake"] = fake.grad.numpy()
+    # bicubic half of a ramp (A=-0.75, align_corners False)
+    ramp = (torch.arange(16.0)[:, None] * 3 + torch.arange(16.0)[None, :] ** 2).reshape(1, 1, 16, 16)
+    out["bicubic_half_ramp"] = torch.nn.functional.interpolate(ramp, scale_factor=0.5, mode="bicubic",
+                                                               align_corners=False).numpy()
+    # TV
+    tv = mod.L_TV() if hasattr(mod, "L_TV") else __import__("GanTrainer").L_TV()
+    f2 = synth.ldr_frames(2, 32, 48, salt="tv").requires_grad_(True)
+    l = tv(f2)
+    l.backward()
+    out["loss.tv"] = np.float64(l.item())
+    out["loss.tv.g"] = f2.grad.numpy()
+    # TMQI naturalness (float64) on 256^2 frames and 128^2 patches
+    from TMQI import TMQI
+    tm = TMQI()
+    fr = torch.cat([synth.smooth_hdr_frames(3, salt="tmq"), synth.ldr_frames(1, salt="tmq2")], 0).numpy()
+    sc = []
+    for i in range(4):
+        sc.append(tm(fr[i, 0], fr[i, 0] * 255)[2])
+        sc.append(tm(fr[i, 0, :128, 128:], fr[i, 0, :128, 128:] * 255)[2])
+    out["tmqi_n"] = np.array(sc, dtype=np.float64)
+    # brightness / contrast L1 and pseudo-label loss with grads
+    fk = synth.smooth_hdr_frames(2, salt="plf").requires_grad_(True)
+    l = tr.pseudo_label_loss(fk, fk.detach())
+    l.backward()
+    out["loss.pseudo"] = np.float64(l.item())
+    out.update(summarize(fk.grad, "loss.pseudo.g", 512))
+    ce = mod.ContrastExtracter()
+    out["gauss_window"] = ce.win.numpy()
+    fk2 = synth.smooth_hdr_frames(2, salt="plf").requires_grad_(True)
+    ld = synth.ldr_frames(2, salt="pll")
+    l = torch.nn.L1Loss()(ce(fk2).mean(dim=[-1, -2]), ce(ld).mean(dim=[-1, -2]))
+    l.backward()
+    out["loss.contrast_l1"] = np.float64(l.item())
+    out.update(summarize(fk2.grad, "loss.contrast_l1.g", 512))
+
+
+def capture_step(out, video, epochs):
+    for ep in epochs:
+        tr, mod = make_trainer(video)
+        tr.netG.train()
+        tr.netD.train()
+        DropPath.forced_mask = None
+        for m in tr.netG.modules():
+            if isinstance(m, DropPath):
+                m.drop_prob = 0.0                       # DropPath off: the third-party RNG is unpinned
+        hdr, gray, pos, neg = step_inputs(video)
+        tag = "%s_step_e%d" % ("vid" if video else "img", ep)
+        tr.train_D(hdr, pos, neg, ep)
+        out[tag + ".errD"] = np.float64(tr.errD.item())
+        out[tag + ".D_after.tail"] = tr.netD.state_dict()["tail.1.weight"].numpy().copy()[:, :64]
+        for k, v in tr.netD.named_parameters():
+            out[tag + ".gradD." + k] = np.float64(v.grad.double().norm().item())
+        try:
+            tr.train_G(hdr, gray, pos, neg, ep)
+        except NameError as e:
+            out[tag + ".nameerror"] = np.int64(1)
+            continue
+        out[tag + ".errG_d"] = np.float64(tr.errG_d.item())
+        out[tag + ".errG_struct"] = np.float64(tr.errG_struct.item())
+        for k, v in tr.netG.named_parameters():
+            if v.grad is not None:
+                out[tag + ".gradG." + k] = np.float64(v.grad.double().norm().item())
+        for k, v in tr.netG.state_dict().items():
+            out[tag + ".G_after." + k] = np.float64(v.double().sum().item())
+        print("captured", tag, out[tag + ".errD"], out[tag + ".errG_d"], out[tag + ".errG_struct"], flush=True)
+
+
+def capture_tiler(out):
+    from utils import model_save_util
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the tiler hard-codes .cuda() (model_save_util.py:414)
+
+    def standin(p, apply_crop=True, diffY=0, diffX=0):
+        yy = torch.arange(256.0).reshape(1, 1, 256, 1) / 255.0
+        xx = torch.arange(256.0).reshape(1, 1, 1, 256) / 255.0
+        return p * (0.5 + xx + 2.0 * yy), None
+
+    for (h, w) in [(272, 272), (400, 528)]:
+        x = synth.hdr_frames(1, h, w, salt="tile%d" % h)
+        r = model_save_util.test_big_size_image2(x, standin, 0, 0, 0)
+        if h == 272:
+            out["tiler.standin.%dx%d" % (h, w)] = r.numpy()
+        else:
+            out.update(summarize(r, "tiler.standin.%dx%d" % (h, w), 16384))
+    G, _ = build_ref_models()
+    G.eval()
+    x = synth.smooth_hdr_frames(1, 272, 272, salt="tileG")
+    out["tiler.realG.272"] = model_save_util.test_big_size_image2(x, G, 0, 0, 0).numpy()
+    # 5-D video tiler with a stand-in
+    def standin5(p, apply_crop=True, diffY=0, diffX=0):
+        yy = torch.arange(256.0).reshape(1, 1, 1, 256, 1) / 255.0
+        xx = torch.arange(256.0).reshape(1, 1, 1, 1, 256) / 255.0
+        return p * (0.5 + xx + 2.0 * yy), None
+    x5 = synth.hdr_frames(2, 300, 272, salt="tile5").reshape(1, 2, 1, 300, 272)
+    out.update(summarize(model_save_util.test_big_size_image(x5, standin5, 0, 0, 0), "tiler.standin5.300x272", 16384))
+    del torch.Tensor.cuda
+
+
+def main():
+    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "tiler"]
+    jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
+            "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
+            "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
+            "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "tiler": lambda o: capture_tiler(o)}
+    for name in which:
+        out = {}
+        jobs[name](out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB", len(out), "entries", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""Pin the CPU oracle against golden vectors captured from the upstream reference (no GPU needed)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_summary, synth_state
+from oracle import discriminator as OD
+from oracle import generator as OG
+from oracle import losses as OL
+from oracle import tiler as OT
+from oracle import tmqi as OTM
+from uncltmo_amd import state_spec, synth
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def sdG():
+    return synth_state(state_spec.generator_spec(), "g0")
+
+
+@pytest.fixture(scope="module")
+def sdD():
+    return synth_state(state_spec.simple_d_spec(), "d0")
+
+
+def test_relative_pos_and_windows(golden):
+    g = golden("generator")
+    np.testing.assert_allclose(OG.sincos_relative_pos().numpy(), g["relative_pos"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(OG.gauss_window().numpy(), golden("losses")["gauss_window"])
+
+
+def test_generator_eval(golden, sdG):
+    g = golden("generator")
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    want = {}
+    with torch.no_grad():
+        y, up = OG.unet_image_forward(sdG, x, want=want)
+    assert rel_l2(y, g["g_eval.x_out"]) < 1e-5
+    np.testing.assert_array_equal(want["knn_idx"].numpy(), g["g_eval.knn_idx"])
+    check_summary(up, g, "g_eval.up_x")
+    for name in ["inc", "down0", "down1", "down2", "down3", "gcn", "up0", "up1", "up2", "up3"]:
+        check_summary(want[name], g, "g_eval." + name)
+
+
+def test_generator_train_mask(golden, sdG):
+    g = golden("generator")
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    keep = torch.tensor([[1.0, 0.0], [1.0, 0.0]])
+    with torch.no_grad():
+        y, up = OG.unet_image_forward(sdG, x, training=True, drop_keep=keep)
+    check_summary(y, g, "g_train.x_out")
+    check_summary(up, g, "g_train.up_x")
+
+
+def test_generator_rejects_other_sizes(golden, sdG):
+    g = golden("generator")
+    for hw in [(268, 268), (512, 512), (256, 512)]:
+        assert g["g_err.%dx%d" % hw] == 1
+        with pytest.raises(ValueError):
+            OG.unet_image_forward(sdG, torch.zeros(1, 1, *hw))
+
+
+def test_video_generator(golden, sdG):
+    g = golden("video")
+    x = torch.cat([synth.smooth_hdr_frames(1, salt="v%d" % t) for t in range(3)], 0).unsqueeze(0)
+    with torch.no_grad():
+        y, f = OG.unet_video_forward(sdG, x)
+    np.testing.assert_allclose(f.numpy(), g["v_eval.feats"], rtol=1e-4, atol=1e-6)
+    for t in range(3):
+        check_summary(y[:, t], g, "v_eval.frame%d" % t)
+
+
+def test_discriminators(golden, sdD):
+    g = golden("disc")
+    x = torch.cat([synth.ldr_frames(2, salt="dA"), synth.smooth_hdr_frames(1, salt="dB")], 0)
+    with torch.no_grad():
+        o, f = OD.simple_d_forward(sdD, x)
+        po = OD.patch_d_forward(synth_state(state_spec.patch_d_spec(), "p0"), x)
+    np.testing.assert_allclose(o.numpy(), g["d.output"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f.numpy(), g["d.fea_final"], rtol=1e-5, atol=1e-7)
+    assert rel_l2(po, g["patchd.output"]) < 1e-5
+
+
+def test_losses(golden):
+    g = golden("losses")
+    a = torch.tensor(synth.hash_uniform("la", 4) * 4 - 2).reshape(4, 1).requires_grad_(True)
+    b = torch.tensor(synth.hash_uniform("lb", 4) * 4 - 2).reshape(4, 1).requires_grad_(True)
+    l = OL.contrastive_d_loss(a, b)
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["loss.cgan"], rtol=1e-6)
+    np.testing.assert_allclose(a.grad.numpy(), g["loss.cgan.ga"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(b.grad.numpy(), g["loss.cgan.gb"], rtol=1e-5, atol=1e-7)
+    for tag, shape, (k, c) in [("nce_d", (4, 2, 1, 1), (1, 1e-2)), ("nce_d2", (4, 2, 1, 1), (1e3, 2)),
+                               ("nce_map", (3, 32, 16, 16), (1, 1e-2))]:
+        n = int(np.prod(shape))
+        an = torch.tensor(synth.hash_uniform(tag + "a", n)).reshape(shape).requires_grad_(True)
+        po = torch.tensor(synth.hash_uniform(tag + "p", n)).reshape(shape)
+        ne = torch.tensor(synth.hash_uniform(tag + "n", n)).reshape(shape)
+        l = OL.nce(an, po, ne, k, c)
+        l.backward()
+        np.testing.assert_allclose(l.item(), g["loss." + tag], rtol=1e-6)
+        np.testing.assert_allclose(an.grad.numpy(), g["loss.%s.ga" % tag], rtol=1e-4, atol=1e-8)
+    fake = synth.ldr_frames(2, 64, 64, salt="slf").requires_grad_(True)
+    hdr = synth.smooth_hdr_frames(2, 64, 64, salt="slh")
+    np.testing.assert_allclose(OL.struct_loss_level(fake, hdr).item(), g["loss.struct_level"], rtol=1e-6)
+    lp = OL.struct_loss_pyramid(fake, hdr, [1.0, 1.0, 1.0])
+    lp.backward()
+    np.testing.assert_allclose(lp.item(), g["loss.struct_pyr"], rtol=1e-6)
+    np.testing.assert_allclose(fake.grad.numpy(), g["loss.struct_pyr.gfake"], rtol=1e-4, atol=1e-7)
+    f2 = synth.ldr_frames(2, 32, 48, salt="tv").requires_grad_(True)
+    l = OL.tv_loss(f2)
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["loss.tv"], rtol=1e-6)
+    np.testing.assert_allclose(f2.grad.numpy(), g["loss.tv.g"], rtol=1e-5, atol=1e-9)
+
+
+def test_tmqi_naturalness(golden):
+    g = golden("losses")
+    fr = torch.cat([synth.smooth_hdr_frames(3, salt="tmq"), synth.ldr_frames(1, salt="tmq2")], 0).numpy()
+    sc = []
+    for i in range(4):
+        sc.append(OTM.naturalness(fr[i, 0] * 255))
+        sc.append(OTM.naturalness(fr[i, 0, :128, 128:] * 255))
+    np.testing.assert_allclose(np.array(sc), g["tmqi_n"], rtol=1e-6, atol=1e-12)
+
+
+def test_pseudo_label_and_contrast(golden):
+    g = golden("losses")
+    fk = synth.smooth_hdr_frames(2, salt="plf").requires_grad_(True)
+    l = OL.pseudo_label_loss(fk)
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["loss.pseudo"], rtol=1e-5)
+    check_summary(fk.grad, g, "loss.pseudo.g", rtol=1e-4, atol=1e-10)
+    fk2 = synth.smooth_hdr_frames(2, salt="plf").requires_grad_(True)
+    _, lc = OL.brightness_contrast_l1(fk2, synth.ldr_frames(2, salt="pll"))
+    lc.backward()
+    np.testing.assert_allclose(lc.item(), g["loss.contrast_l1"], rtol=1e-5)
+    check_summary(fk2.grad, g, "loss.contrast_l1.g", rtol=1e-4, atol=1e-10)
+
+
+def _standin(p, **kw):
+    yy = torch.arange(256.0).reshape(*([1] * (p.dim() - 2)), 256, 1) / 255.0
+    xx = torch.arange(256.0).reshape(*([1] * (p.dim() - 1)), 256) / 255.0
+    return p * (0.5 + xx + 2.0 * yy), None
+
+
+def test_tiler(golden, sdG):
+    g = golden("tiler")
+    x = synth.hdr_frames(1, 272, 272, salt="tile272")
+    np.testing.assert_allclose(OT.tiled_forward(x, _standin).numpy(), g["tiler.standin.272x272"], rtol=1e-6, atol=1e-7)
+    x = synth.hdr_frames(1, 400, 528, salt="tile400")
+    check_summary(OT.tiled_forward(x, _standin), g, "tiler.standin.400x528", rtol=1e-6, atol=1e-7)
+    x5 = synth.hdr_frames(2, 300, 272, salt="tile5").reshape(1, 2, 1, 300, 272)
+    check_summary(OT.tiled_forward(x5, _standin), g, "tiler.standin5.300x272", rtol=1e-6, atol=1e-7)
+    x = synth.smooth_hdr_frames(1, 272, 272, salt="tileG")
+    y = OT.tiled_forward(x, lambda p: OG.unet_image_forward(sdG, p))
+    assert rel_l2(y, g["tiler.realG.272"]) < 1e-5
+    with pytest.raises(ValueError):
+        OT.axis_plan(256)
+    assert OT.tile_count(1024, 1024) == 25 and OT.tile_count(2160, 3840) == 220
