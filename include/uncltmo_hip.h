@@ -1,0 +1,175 @@
+/* uncltmo_hip.h — C ABI of libuncltmo_hip.so, the MI355X (gfx950) kernels behind the UnCLTMO tone-mapping
+ * hot path.
+ *
+ * The reference (cao-cong/UnCLTMO) is pure PyTorch: it has no FFI of its own, every op on the path is a stock
+ * torch.nn / torch.nn.functional call.  Each entry point below therefore cites the reference *call site* it
+ * replaces (file:line in the upstream tree); the Python host in uncltmo_amd/ binds them through ctypes and
+ * mirrors the reference's nn.Module / trainer signatures on top.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless its name ends in _host
+ *  - activations are NHWC ("channel-last"), element type selected by `dtype` (UNCL_F32 / UNCL_BF16);
+ *    accumulation is always fp32; kNN distances, loss reductions and TMQI use fp32 / fp64 as stated
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing, keeps no
+ *    global state; scratch memory is passed in by the caller (`*_workspace_bytes` tells how much)
+ *  - return value: 0 on success, a negative UNCL_ERR_* code otherwise; nothing throws
+ */
+#ifndef UNCLTMO_HIP_H
+#define UNCLTMO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNCL_OK 0
+#define UNCL_ERR_ARG (-1)      /* unsupported shape / dtype / mode */
+#define UNCL_ERR_LAUNCH (-2)   /* hipLaunch reported an error      */
+#define UNCL_ERR_NODEVICE (-3) /* no gfx950 device visible         */
+
+#define UNCL_F32 0
+#define UNCL_BF16 1
+
+#define UNCL_ACT_NONE 0
+#define UNCL_ACT_RELU 1
+#define UNCL_ACT_LRELU 2 /* slope 0.2 */
+#define UNCL_ACT_GELU 3  /* exact erf */
+#define UNCL_ACT_SIGMOID 4
+
+/* input-side fusions of the implicit-GEMM convolution (what the loader synthesises while staging LDS) */
+#define UNCL_SRC_PLAIN 0      /* x = src0                                                                  */
+#define UNCL_SRC_MAXPOOL2 1   /* x = maxpool2x2(src0), floor            (unet_parts.py:212,233)           */
+#define UNCL_SRC_CONCAT_SSR 2 /* x = cat[src0, up(src1), src0^2, sqrt(src0+1e-8)] (unet_parts.py:319-322)
+                                 src1 is replicate-padded to src0's size   (unet_parts.py:292-298)        */
+#define UNCL_SRC_CONCAT2 3    /* x = cat[src0, src1]  ("original_unet" operator, unet_parts.py:311-312)    */
+
+/* what blockIdx.z enumerates besides Cout tiles */
+#define UNCL_Z_NONE 0
+#define UNCL_Z_GROUPS 1   /* grouped 1x1 conv: z = group (gcn_lib/torch_nn.py:58, groups=4)                */
+#define UNCL_Z_UP2X2 2    /* ConvTranspose2d k2 s2 as four 1x1 GEMMs scattering to (2y+dy, 2x+dx)          */
+
+int uncl_version(void);
+int uncl_device_ok(void); /* 1 if device 0 is gfx950, else 0 */
+
+/* ------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (bf16: v_mfma_f32_32x32x16_bf16, f32: v_mfma_f32_32x32x2_f32).
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d (k3 s1) + bias + ReLU in unet_parts.py:19-33,98-112,149-162
+ * (a stride-1 transposed 3x3 is run as a pad-2 convolution over pre-flipped weights), the 1x1 convolutions of
+ * the graph block (Unet_singleFrame.py:25-31, torch_vertex.py:190-199, torch_nn.py:58), the 2x2 stride-2
+ * ConvTranspose2d of `up` (unet_parts.py:269) and `outconv`+sigmoid (unet_parts.py:338-345,
+ * Unet_singleFrame.py:207-209).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct uncl_conv_desc {
+  int dtype;            /* element type of src/out/weights                                   */
+  int ksize;            /* 3 or 1                                                            */
+  int pad;              /* 0 = valid, 2 = "full" (transposed 3x3); 1x1 ignores it            */
+  int src_mode;         /* UNCL_SRC_*                                                        */
+  int N, H, W;          /* logical input extent seen by the conv (after pooling / concat)    */
+  int Cin, Cout;        /* logical channels (per group for UNCL_Z_GROUPS)                    */
+  const void* src0;     /* NHWC                                                              */
+  int src0_H, src0_W, src0_C;
+  const void* src1;     /* second source for the concat modes, else NULL                     */
+  int src1_H, src1_W, src1_C;
+  const void* prev0;    /* video recurrence: channels [0, prev_ch) of src0 are read from this tensor of the
+                           previous frame instead (Unet.py:244,270), NULL if unused             */
+  int prev_ch;
+  const void* weight;   /* packed [z][tap][Cout][Cin] in `dtype` (uncl_pack_conv_weight)     */
+  const float* bias;    /* [Cout_total] fp32 or NULL                                         */
+  int act;              /* UNCL_ACT_* applied to conv+bias                                   */
+  const float* scale_n; /* optional per-sample multiplier (DropPath keep/keep_prob), [N]     */
+  const void* res;      /* optional residual added after act*scale, same layout as out       */
+  int res_batch_stride0;/* 1: residual is broadcast over N (pos_embed)                       */
+  void* out;            /* NHWC, out_H x out_W x out_C                                       */
+  int out_H, out_W, out_C;
+  int z_mode;           /* UNCL_Z_*                                                          */
+  int groups;           /* for UNCL_Z_GROUPS                                                 */
+  /* optional fused trailing 1x1 to one channel + sigmoid (outc): needs Cout == 32             */
+  const float* out1_w;  /* [Cout] fp32 or NULL                                               */
+  const float* out1_b;  /* [1]                                                               */
+  int out1_act;
+  float* out1;          /* [N, Hout, Wout] fp32                                              */
+  int skip_main_store;  /* 1: do not write `out` (inference does not need up_x)              */
+} uncl_conv_desc;
+
+int uncl_conv_igemm(const uncl_conv_desc* d, void* stream);
+
+/* Re-layout one reference-format weight for uncl_conv_igemm.
+ * src: fp32, Conv2d layout (Cout, Cin, k, k) or, if transposed != 0, ConvTranspose2d layout (Cin, Cout, k, k).
+ * dst: [tap][Cout][Cin] in dtype; for a transposed stride-1 3x3 the taps are flipped (tap' = 8 - tap) so that
+ * the kernel runs it as a pad-2 correlation; for the stride-2 2x2 the four taps index (dy, dx) unflipped. */
+int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int Cout, int Cin, int k, int transposed,
+                          int flip, void* stream);
+
+/* First generator layer: Conv2d(1 -> Cout, 3x3, valid) + bias + act, input fp32 (N,H,W), output NHWC.
+ * Replaces inc.conv.conv (unet_parts.py:19,26).  weight: fp32 (Cout,1,3,3). */
+int uncl_conv_in_c1(const float* x, const float* w, const float* b, void* out, int dtype, int N, int H, int W,
+                    int Cout, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Graph block (ViG max-relative conv on the 12x12 bottleneck).
+ * ---------------------------------------------------------------------------------------------------- */
+/* kNN graph: x (N, n, C) NHWC features; L2-normalise over C in fp32, d_ij = |xi|^2 - 2 xi.xj + |xj|^2 +
+ * relative_pos[i][j]; idx = the k smallest d per row, ascending (ties: lower j first).
+ * Replaces DenseDilatedKnnGraph.forward / dense_knn_matrix (torch_edge.py:150-158, :54-86).
+ * workspace: uncl_gcn_knn_workspace_bytes(N, n, C). */
+size_t uncl_gcn_knn_workspace_bytes(int N, int n, int C);
+int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos, int32_t* idx, float* dist_out /*nullable*/,
+                 int N, int n, int C, int k, void* workspace, void* stream);
+/* out (N, n, 2C): out[.., 2c] = x_c, out[.., 2c+1] = max_k (x_c[idx] - x_c).  Replaces MRConv2d.forward
+ * up to its 1x1 conv (torch_vertex.py:22-29). */
+int uncl_gcn_maxrel(const void* x, const int32_t* idx, void* out, int dtype, int N, int n, int C, int k,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Whole-generator forward (image UNet, published topology), one call enqueues every kernel.
+ * Replaces Unet_singleFrame.UNet.forward (Unet_singleFrame.py:177-213).
+ * ---------------------------------------------------------------------------------------------------- */
+#define UNCL_G_NUM_WEIGHTS 26
+typedef struct uncl_gen_weights {
+  int dtype;
+  const float* inc0_w;            /* fp32 (32,1,3,3), consumed directly by uncl_conv_in_c1  */
+  const float* inc0_b;            /* fp32 (32)                                              */
+  const void* w[UNCL_G_NUM_WEIGHTS];     /* packed weights, order = uncl_gen_layer_name(i)  */
+  const float* b[UNCL_G_NUM_WEIGHTS];    /* fp32 biases                                     */
+  const void* pos_embed;          /* (144, 256) NHWC in dtype                               */
+  const float* relative_pos;      /* (144,144) fp32                                         */
+  const float* outc_w;            /* (32) fp32                                              */
+  const float* outc_b;            /* (1) fp32                                               */
+  int act;                        /* UNCL_ACT_RELU or UNCL_ACT_LRELU (generator activation) */
+  int last_act;                   /* UNCL_ACT_SIGMOID / NONE                                */
+} uncl_gen_weights;
+
+typedef struct uncl_gen_run {
+  int N;                      /* number of 256x256 tiles / frames                                          */
+  int chunk;                  /* tiles per pass through the layers (0 = all); sized for the Infinity Cache */
+  int keep_activations;       /* 1: every tile keeps its activations in the workspace (training / video)   */
+  const float* x;             /* fp32 (N,256,256)                                                          */
+  float* out;                 /* fp32 (N,256,256)                                                          */
+  void* up_x;                 /* NHWC (N,256,256,32) in dtype, or NULL (inference never reads it)          */
+  int32_t* knn_idx;           /* optional int32 (N,144,9)                                                  */
+  const float* drop_scale;    /* optional fp32 (2,N): DropPath keep/keep_prob for the two residual sites   */
+  void* workspace;
+  size_t workspace_bytes;
+  const void* prev_workspace; /* video: workspace of the previous frame (same N, keep_activations=1); the
+                                 first C/32 channels entering every down/up stage come from it (Unet.py:244,270) */
+} uncl_gen_run;
+
+const char* uncl_gen_layer_name(int i); /* state_dict prefix of packed weight i, NULL past the end */
+size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep_activations);
+int uncl_gen_forward(const uncl_gen_weights* wts, const uncl_gen_run* run, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Overlap-tile inference (256^2 tiles, stride 192, linear cross-fade).
+ * Replaces test_big_size_image2 / test_big_size_image (utils/model_save_util.py:409-486, :488-565).
+ * ---------------------------------------------------------------------------------------------------- */
+int uncl_tile_count(int H, int W);
+/* frames: fp32 (F,H,W).  tiles: fp32 (F*T, 256, 256), tile t of frame f at index f*T + t (row-major). */
+int uncl_tile_gather(const float* frames, float* tiles, int F, int H, int W, void* stream);
+int uncl_tile_blend(const float* tiles, float* frames, int F, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNCLTMO_HIP_H */

@@ -1,0 +1,44 @@
+"""Thin helpers for the GPU parity tests: drive single kernels through the C ABI (ctypes), exactly as the
+Python host does."""
+import ctypes as C
+
+import torch
+
+from uncltmo_amd import _hip
+
+
+def to_nhwc(t, code):
+    """(N,C,H,W) cpu fp32 -> (N,H,W,C) cuda in the compute dtype."""
+    return t.permute(0, 2, 3, 1).contiguous().to(_hip.torch_dtype(code)).cuda()
+
+
+def from_nhwc(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def pack_weight(w, code, transposed=False, flip=False):
+    """Reference-layout fp32 weight -> packed device tensor."""
+    k = w.shape[2]
+    cout, cin = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    src = w.float().contiguous().cuda()
+    dst = torch.empty(k * k * cout * cin, dtype=_hip.torch_dtype(code), device="cuda")
+    _hip.check(_hip.lib().uncl_pack_conv_weight(src.data_ptr(), dst.data_ptr(), code, cout, cin, k, int(transposed),
+                                                int(flip), _hip.stream_ptr()), "pack")
+    return dst
+
+
+def run_conv(**kw):
+    d = _hip.ConvDesc()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(d, k, v)
+    _hip.check(_hip.lib().uncl_conv_igemm(C.byref(d), _hip.stream_ptr()), "uncl_conv_igemm")
+    torch.cuda.synchronize()
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

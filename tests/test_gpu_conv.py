@@ -1,0 +1,142 @@
+"""GPU parity of the implicit-GEMM convolution kernel (every loader / epilogue mode) against plain torch CPU
+fp32 convolutions of the same op, through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_util import from_nhwc, pack_weight, rel_l2, run_conv, to_nhwc
+from uncltmo_amd import _hip
+
+pytestmark = pytest.mark.gpu
+
+TOL = {_hip.F32: 2e-5, _hip.BF16: 1.5e-2}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def q(t, code):
+    """Round to the compute dtype so that the reference sees the same operands the kernel does."""
+    return t.to(_hip.torch_dtype(code)).float()
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("cin,cout,h,w", [(32, 32, 20, 37), (64, 128, 11, 9), (32, 64, 40, 70), (256, 256, 12, 12)])
+def test_conv3x3_valid(code, cin, cout, h, w):
+    x, wt, b = q(rnd(2, cin, h, w, seed=1), code), q(rnd(cout, cin, 3, 3, seed=2, scale=0.1), code), rnd(cout, seed=3)
+    ref = F.relu(F.conv2d(x, wt, b))
+    out = torch.empty(2, h - 2, w - 2, cout, dtype=_hip.torch_dtype(code), device="cuda")
+    run_conv(dtype=code, ksize=3, pad=0, src_mode=_hip.SRC_PLAIN, N=2, H=h, W=w, Cin=cin, Cout=cout,
+             src0=to_nhwc(x, code), src0_H=h, src0_W=w, src0_C=cin, weight=pack_weight(wt, code), bias=b.cuda(),
+             act=_hip.ACT_RELU, out=out, out_H=h - 2, out_W=w - 2, out_C=cout)
+    assert rel_l2(from_nhwc(out), ref) < TOL[code]
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+def test_conv_transposed3x3_leaky(code):
+    cin, cout, h, w = 64, 32, 13, 33
+    x, wt, b = q(rnd(1, cin, h, w, seed=4), code), q(rnd(cin, cout, 3, 3, seed=5, scale=0.1), code), rnd(cout, seed=6)
+    ref = F.leaky_relu(F.conv_transpose2d(x, wt, b), 0.2)
+    out = torch.empty(1, h + 2, w + 2, cout, dtype=_hip.torch_dtype(code), device="cuda")
+    run_conv(dtype=code, ksize=3, pad=2, src_mode=_hip.SRC_PLAIN, N=1, H=h, W=w, Cin=cin, Cout=cout,
+             src0=to_nhwc(x, code), src0_H=h, src0_W=w, src0_C=cin,
+             weight=pack_weight(wt, code, transposed=True, flip=True), bias=b.cuda(), act=_hip.ACT_LRELU, out=out,
+             out_H=h + 2, out_W=w + 2, out_C=cout)
+    assert rel_l2(from_nhwc(out), ref) < TOL[code]
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+def test_conv_maxpool_loader(code):
+    cin, cout, h, w = 32, 64, 23, 41          # odd sizes: floor pooling drops the last row / column
+    x, wt, b = q(rnd(2, cin, h, w, seed=7), code), q(rnd(cout, cin, 3, 3, seed=8, scale=0.1), code), rnd(cout, seed=9)
+    ref = F.relu(F.conv2d(F.max_pool2d(x, 2), wt, b))
+    hp, wp = h // 2, w // 2
+    out = torch.empty(2, hp - 2, wp - 2, cout, dtype=_hip.torch_dtype(code), device="cuda")
+    run_conv(dtype=code, ksize=3, pad=0, src_mode=_hip.SRC_MAXPOOL2, N=2, H=hp, W=wp, Cin=cin, Cout=cout,
+             src0=to_nhwc(x, code), src0_H=h, src0_W=w, src0_C=cin, weight=pack_weight(wt, code), bias=b.cuda(),
+             act=_hip.ACT_RELU, out=out, out_H=hp - 2, out_W=wp - 2, out_C=cout)
+    assert rel_l2(from_nhwc(out), ref) < TOL[code]
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+def test_conv_concat_ssr_loader_with_replicate_pad(code):
+    c, cout, h, w = 32, 32, 19, 21
+    x2 = q(rnd(1, c, h, w, seed=10).abs(), code)              # skip features are post-ReLU, i.e. >= 0
+    x1 = q(rnd(1, c, h - 1, w - 1, seed=11), code)            # upsampled map is one short (56 vs 57 upstream)
+    wt, b = q(rnd(4 * c, cout, 3, 3, seed=12, scale=0.05), code), rnd(cout, seed=13)
+    x1p = F.pad(x1, (0, 1, 0, 1), mode="replicate")
+    cat = torch.cat([x2, x1p, x2 ** 2, (x2 + 1e-8) ** 0.5], 1)
+    ref = F.relu(F.conv_transpose2d(cat, wt, b))
+    out = torch.empty(1, h + 2, w + 2, cout, dtype=_hip.torch_dtype(code), device="cuda")
+    run_conv(dtype=code, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR, N=1, H=h, W=w, Cin=4 * c, Cout=cout,
+             src0=to_nhwc(x2, code), src0_H=h, src0_W=w, src0_C=c, src1=to_nhwc(x1, code), src1_H=h - 1, src1_W=w - 1,
+             src1_C=c, weight=pack_weight(wt, code, transposed=True, flip=True), bias=b.cuda(), act=_hip.ACT_RELU,
+             out=out, out_H=h + 2, out_W=w + 2, out_C=cout)
+    # the kernel rounds x2^2 and sqrt(x2) to the compute dtype before the MFMA; bf16 gets the looser bound
+    assert rel_l2(from_nhwc(out), ref) < (TOL[code] if code == _hip.F32 else 2e-2)
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+def test_conv1x1_gelu_residual_dropscale(code):
+    n, cin, cout = 3, 256, 256
+    x, wt, b = q(rnd(n, cin, 12, 12, seed=14), code), q(rnd(cout, cin, 1, 1, seed=15, scale=0.1), code), rnd(cout, seed=16)
+    res = q(rnd(n, cout, 12, 12, seed=17), code)
+    sc = torch.tensor([1.0 / 0.95, 0.0, 1.0 / 0.95])
+    ref = F.gelu(F.conv2d(x, wt, b)) * sc.reshape(n, 1, 1, 1) + res
+    out = torch.empty(n, 12, 12, cout, dtype=_hip.torch_dtype(code), device="cuda")
+    run_conv(dtype=code, ksize=1, pad=0, src_mode=_hip.SRC_PLAIN, N=n, H=12, W=12, Cin=cin, Cout=cout,
+             src0=to_nhwc(x, code), src0_H=12, src0_W=12, src0_C=cin, weight=pack_weight(wt, code), bias=b.cuda(),
+             act=_hip.ACT_GELU, scale_n=sc.cuda(), res=to_nhwc(res, code), out=out, out_H=12, out_W=12, out_C=cout)
+    assert rel_l2(from_nhwc(out), ref) < TOL[code]
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+def test_conv1x1_grouped(code):
+    n, cin, cout, g = 2, 512, 512, 4
+    x, wt, b = q(rnd(n, cin, 144, 1, seed=18), code), q(rnd(cout, cin // g, 1, 1, seed=19, scale=0.1), code), rnd(cout, seed=20)
+    ref = F.conv2d(x, wt, b, groups=g)
+    out = torch.empty(n, 144, 1, cout, dtype=_hip.torch_dtype(code), device="cuda")
+    run_conv(dtype=code, ksize=1, pad=0, src_mode=_hip.SRC_PLAIN, N=n, H=144, W=1, Cin=cin // g, Cout=cout // g,
+             src0=to_nhwc(x, code), src0_H=144, src0_W=1, src0_C=cin, weight=pack_weight(wt, code), bias=b.cuda(),
+             act=_hip.ACT_NONE, out=out, out_H=144, out_W=1, out_C=cout, z_mode=_hip.Z_GROUPS, groups=g)
+    assert rel_l2(from_nhwc(out), ref) < TOL[code]
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+def test_conv_transposed2x2_stride2(code):
+    n, c, h, w = 2, 64, 9, 13
+    x, wt, b = q(rnd(n, c, h, w, seed=21), code), q(rnd(c, c, 2, 2, seed=22, scale=0.1), code), rnd(c, seed=23)
+    ref = F.conv_transpose2d(x, wt, b, stride=2)
+    out = torch.empty(n, 2 * h, 2 * w, c, dtype=_hip.torch_dtype(code), device="cuda")
+    run_conv(dtype=code, ksize=1, pad=0, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=c, Cout=c,
+             src0=to_nhwc(x, code), src0_H=h, src0_W=w, src0_C=c, weight=pack_weight(wt, code, transposed=True),
+             bias=b.cuda(), act=_hip.ACT_NONE, out=out, out_H=2 * h, out_W=2 * w, out_C=c, z_mode=_hip.Z_UP2X2)
+    assert rel_l2(from_nhwc(out), ref) < TOL[code]
+
+
+@pytest.mark.parametrize("code", [_hip.F32, _hip.BF16])
+def test_conv_fused_outc_sigmoid_and_broadcast_residual(code):
+    cin, h, w = 32, 14, 40
+    x, wt, b = q(rnd(2, cin, h, w, seed=24), code), q(rnd(cin, 32, 3, 3, seed=25, scale=0.1), code), rnd(32, seed=26)
+    w1, b1 = rnd(1, 32, 1, 1, seed=27), rnd(1, seed=28)
+    up = F.relu(F.conv_transpose2d(x, wt, b))
+    ref1 = torch.sigmoid(F.conv2d(up, w1, b1))
+    out = torch.empty(2, h + 2, w + 2, 32, dtype=_hip.torch_dtype(code), device="cuda")
+    out1 = torch.empty(2, h + 2, w + 2, dtype=torch.float32, device="cuda")
+    run_conv(dtype=code, ksize=3, pad=2, src_mode=_hip.SRC_PLAIN, N=2, H=h, W=w, Cin=cin, Cout=32,
+             src0=to_nhwc(x, code), src0_H=h, src0_W=w, src0_C=cin,
+             weight=pack_weight(wt, code, transposed=True, flip=True), bias=b.cuda(), act=_hip.ACT_RELU, out=out,
+             out_H=h + 2, out_W=w + 2, out_C=32, out1_w=w1.reshape(32).cuda(), out1_b=b1.cuda(),
+             out1_act=_hip.ACT_SIGMOID, out1=out1)
+    assert rel_l2(from_nhwc(out), up) < TOL[code]
+    assert rel_l2(out1.cpu().unsqueeze(1), ref1) < TOL[code]
+
+
+def test_bad_arguments_are_refused():
+    d = _hip.ConvDesc()
+    import ctypes as C
+    assert _hip.lib().uncl_conv_igemm(C.byref(d), None) == -1
+    d.dtype, d.ksize, d.Cin, d.Cout = _hip.BF16, 3, 24, 32     # Cin not a multiple of the 32-channel K-chunk
+    assert _hip.lib().uncl_conv_igemm(C.byref(d), None) == -1

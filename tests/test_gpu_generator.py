@@ -1,0 +1,126 @@
+"""GPU parity of the whole generator forward and of the tiler against the oracle and the reference's goldens."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_summary
+from hip_util import rel_l2
+from oracle import generator as OG
+from oracle import tiler as OT
+from uncltmo_amd import synth, tiler
+from uncltmo_amd.generator import UNet
+
+pytestmark = pytest.mark.gpu
+
+
+def make_g(dtype, chunk=0):
+    g = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+             "replicate", 2, 0, compute_dtype=dtype, chunk=chunk)
+    synth.fill_state_dict(g, "g0")
+    return g.cuda().eval()
+
+
+def cpu_sd(g):
+    return {k: v.detach().cpu() for k, v in g.state_dict().items()}
+
+
+def golden_input():
+    return torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+
+
+def test_generator_fp32_matches_reference_golden(golden):
+    g = golden("generator")
+    net = make_g("fp32")
+    x = golden_input().cuda()
+    with torch.no_grad():
+        y, up = net(x)
+        out2, knn = net.infer(x, want_knn=True)
+    assert y.shape == (2, 1, 256, 256) and up.shape == (2, 32, 256, 256)
+    # tolerance stated by the north star: 1e-4 rel-L2 against the reference's CPU output
+    assert rel_l2(y.cpu(), torch.from_numpy(g["g_eval.x_out"])) < 1e-4
+    assert torch.equal(out2, y)
+    np.testing.assert_array_equal(knn.cpu().numpy().astype(np.int64), g["g_eval.knn_idx"])   # index work: exact
+    check_summary(up.float().cpu(), g, "g_eval.up_x", rtol=2e-3, atol=2e-4)
+
+
+def test_generator_fp32_vs_oracle_other_inputs():
+    net = make_g("fp32", chunk=2)
+    x = torch.cat([synth.smooth_hdr_frames(2, salt="o1"), synth.hdr_frames(1, salt="o2"), torch.zeros(1, 1, 256, 256),
+                   torch.ones(1, 1, 256, 256)], 0)
+    want = {}
+    with torch.no_grad():
+        y, up = net(x.cuda())
+        _, knn = net.infer(x.cuda(), want_knn=True)
+        y_ref, up_ref = OG.unet_image_forward(cpu_sd(net), x, want=want)
+    assert rel_l2(y.cpu(), y_ref) < 1e-4
+    assert rel_l2(up.float().cpu(), up_ref) < 1e-4
+    # constant frames make every node's features position-only; the remaining ties are broken like torch.topk
+    assert (knn.cpu().long() == want["knn_idx"]).float().mean().item() > 0.999
+
+
+def test_generator_bf16_vs_oracle():
+    net = make_g("bf16")
+    x = golden_input()
+    with torch.no_grad():
+        y, up = net(x.cuda())
+        y_ref, up_ref = OG.unet_image_forward(cpu_sd(net), x)
+    # bf16 activations/weights with fp32 accumulation through 27 layers: stated tolerance 3e-2 rel-L2
+    assert rel_l2(y.cpu(), y_ref) < 3e-2
+    assert rel_l2(up.float().cpu(), up_ref) < 5e-2
+
+
+def test_generator_train_mode_with_injected_droppath(golden):
+    g = golden("generator")
+    net = make_g("fp32")
+    net.train()
+    net.forced_drop_keep = [[1.0, 0.0], [1.0, 0.0]]
+    with torch.no_grad():
+        y, up = net(golden_input().cuda())
+    check_summary(y.cpu(), g, "g_train.x_out", rtol=1e-3, atol=1e-5)
+
+
+def test_generator_rejects_other_sizes_and_host_tensors():
+    net = make_g("fp32")
+    for hw in [(268, 268), (512, 512), (256, 512)]:
+        with pytest.raises(ValueError):
+            net(torch.zeros(1, 1, *hw, device="cuda"))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 256, 256))
+
+
+def _standin(p, **kw):
+    yy = torch.arange(256.0, device=p.device).reshape(1, 1, 256, 1) / 255.0
+    xx = torch.arange(256.0, device=p.device).reshape(1, 1, 1, 256) / 255.0
+    return p * (0.5 + xx + 2.0 * yy), None
+
+
+def test_tiler_blend_weights_exact(golden):
+    g = golden("tiler")
+    x = synth.hdr_frames(1, 272, 272, salt="tile272").cuda()
+    y = tiler.test_big_size_image2(x, _standin, 0, 0, 0)
+    np.testing.assert_allclose(y.cpu().numpy(), g["tiler.standin.272x272"], rtol=1e-6, atol=1e-7)
+    x = synth.hdr_frames(1, 400, 528, salt="tile400").cuda()
+    check_summary(tiler.test_big_size_image2(x, _standin, 0, 0, 0).cpu(), g, "tiler.standin.400x528", rtol=1e-6, atol=1e-7)
+    assert tiler.tile_count(1024, 1024) == 25 and tiler.tile_count(2160, 3840) == 220
+    with pytest.raises(ValueError):
+        tiler.tile_count(256, 300)
+
+
+def test_tiler_real_generator(golden):
+    g = golden("tiler")
+    net = make_g("fp32")
+    x = synth.smooth_hdr_frames(1, 272, 272, salt="tileG").cuda()
+    y = tiler.test_big_size_image2(x, net, 0, 0, 0)
+    assert rel_l2(y.cpu(), torch.from_numpy(g["tiler.realG.272"])) < 1e-4
+
+
+def test_tiler_full_size_properties():
+    """1024^2 (25 tiles): with an identity 'model' the cross-fade must reproduce the frame exactly (the blend
+    weights of every pixel sum to one), and tiling must commute with a per-pixel affine map."""
+    x = synth.hdr_frames(2, 1024, 1024, salt="big").cuda()
+    ident = lambda p, **kw: (p, None)
+    y = tiler.test_big_size_image2(x, ident, 0, 0, 0)
+    assert (y - x).abs().max().item() < 2e-6
+    aff = lambda p, **kw: (0.25 * p + 0.5, None)
+    y2 = tiler.test_big_size_image2(x, aff, 0, 0, 0)
+    assert (y2 - (0.25 * x + 0.5)).abs().max().item() < 2e-6

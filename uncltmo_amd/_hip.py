@@ -1,0 +1,129 @@
+"""ctypes binding of libuncltmo_hip.so (the C ABI declared in include/uncltmo_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a kernel is asked to run on a tensor
+that is not on an MI355X, the call raises.  PyTorch is used here only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuncltmo_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+SRC_PLAIN, SRC_MAXPOOL2, SRC_CONCAT_SSR, SRC_CONCAT2 = 0, 1, 2, 3
+Z_NONE, Z_GROUPS, Z_UP2X2 = 0, 1, 2
+G_NUM_WEIGHTS = 26
+
+_ERR = {-1: "UNCL_ERR_ARG (unsupported shape / dtype / mode)", -2: "UNCL_ERR_LAUNCH", -3: "UNCL_ERR_NODEVICE"}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("ksize", C.c_int), ("pad", C.c_int), ("src_mode", C.c_int),
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+        ("src0", C.c_void_p), ("src0_H", C.c_int), ("src0_W", C.c_int), ("src0_C", C.c_int),
+        ("src1", C.c_void_p), ("src1_H", C.c_int), ("src1_W", C.c_int), ("src1_C", C.c_int),
+        ("prev0", C.c_void_p), ("prev_ch", C.c_int),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int),
+        ("scale_n", C.c_void_p), ("res", C.c_void_p), ("res_batch_stride0", C.c_int),
+        ("out", C.c_void_p), ("out_H", C.c_int), ("out_W", C.c_int), ("out_C", C.c_int),
+        ("z_mode", C.c_int), ("groups", C.c_int),
+        ("out1_w", C.c_void_p), ("out1_b", C.c_void_p), ("out1_act", C.c_int), ("out1", C.c_void_p),
+        ("skip_main_store", C.c_int),
+    ]
+
+
+class GenWeights(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("inc0_w", C.c_void_p), ("inc0_b", C.c_void_p),
+        ("w", C.c_void_p * G_NUM_WEIGHTS), ("b", C.c_void_p * G_NUM_WEIGHTS),
+        ("pos_embed", C.c_void_p), ("relative_pos", C.c_void_p), ("outc_w", C.c_void_p), ("outc_b", C.c_void_p),
+        ("act", C.c_int), ("last_act", C.c_int),
+    ]
+
+
+class GenRun(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("chunk", C.c_int), ("keep_activations", C.c_int),
+        ("x", C.c_void_p), ("out", C.c_void_p), ("up_x", C.c_void_p), ("knn_idx", C.c_void_p),
+        ("drop_scale", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("prev_workspace", C.c_void_p),
+    ]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/uncltmo_hip.h declares
+SIGNATURES = {
+    "uncl_version": (C.c_int, []),
+    "uncl_device_ok": (C.c_int, []),
+    "uncl_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "uncl_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]),
+    "uncl_conv_in_c1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p]),
+    "uncl_gcn_knn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "uncl_gcn_knn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_gcn_maxrel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]),
+    "uncl_gen_layer_name": (C.c_char_p, [C.c_int]),
+    "uncl_gen_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "uncl_gen_forward": (C.c_int, [C.POINTER(GenWeights), C.POINTER(GenRun), C.c_void_p]),
+    "uncl_tile_count": (C.c_int, [C.c_int, C.c_int]),
+    "uncl_tile_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uncl_tile_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+
+def lib():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError("libuncltmo_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+                           "g.build()'`; there is no CPU fallback for the hot path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the kernels only take HBM."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("uncltmo_amd kernels need CUDA(HIP) tensors; got a %s tensor. There is no CPU path." % t.device)
+    return t.data_ptr()
+
+
+def dtype_code(dt):
+    if dt in ("bf16", torch.bfloat16):
+        return BF16
+    if dt in ("fp32", "f32", torch.float32):
+        return F32
+    raise ValueError("compute dtype must be 'bf16' or 'fp32', got %r" % (dt,))
+
+
+def torch_dtype(code):
+    return torch.bfloat16 if code == BF16 else torch.float32

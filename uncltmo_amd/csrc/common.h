@@ -1,0 +1,93 @@
+// Shared device/host helpers for the gfx950 kernels of the UnCLTMO hot path.
+// MI355X only: 64-wide wavefronts, MFMA 32x32 tiles, 160 KiB LDS per CU.  No CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uncltmo_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define UNCL_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return UNCL_ERR_LAUNCH;            \
+  } while (0)
+
+// Element traits: a "vec" is always 16 bytes, the unit every loader / LDS access moves.
+template <typename T>
+struct Elem;
+
+template <>
+struct Elem<float> {
+  typedef f32x4 vec;
+  static constexpr int EPV = 4;   // elements per 16-byte vector
+  static constexpr int KC = 16;   // channels per 64-byte K-chunk
+  static __device__ __forceinline__ void unpack(const vec& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
+  }
+  static __device__ __forceinline__ vec pack(const float* f) {
+    vec v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f[i];
+    return v;
+  }
+  static __device__ __forceinline__ vec zero() { return vec{0.f, 0.f, 0.f, 0.f}; }
+};
+
+template <>
+struct Elem<bf16_t> {
+  typedef bf16x8 vec;
+  static constexpr int EPV = 8;
+  static constexpr int KC = 32;
+  static __device__ __forceinline__ void unpack(const vec& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ vec pack(const float* f) {
+    vec v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+    return v;
+  }
+  static __device__ __forceinline__ vec zero() {
+    vec v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
+    return v;
+  }
+};
+
+__device__ __forceinline__ float uncl_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float uncl_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ float uncl_act(float v, int act) {
+  switch (act) {
+    case UNCL_ACT_RELU: return v > 0.f ? v : 0.f;
+    case UNCL_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case UNCL_ACT_GELU: return uncl_gelu(v);
+    case UNCL_ACT_SIGMOID: return uncl_sigmoid(v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

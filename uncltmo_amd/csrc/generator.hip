@@ -1,0 +1,268 @@
+// Whole-generator forward: enqueues every kernel of the published UNet (depth 4, 32 filters, transposed-conv
+// decoder, "square_and_square_root" skip operator, ViG bottleneck) on one stream.
+// Follows Unet_singleFrame.UNet.forward (Unet_singleFrame.py:177-213) / Unet.UNet.forward (Unet.py:213-289).
+//
+// Tiles are processed in chunks sized so that a layer's output is still resident in the 256 MiB Infinity
+// Cache when the next layer reads it; skip tensors and (optionally) all activations stay in the workspace.
+#include "common.h"
+
+namespace {
+
+// spatial size of every stage for a 256x256 input
+constexpr int S_IN = 256;
+constexpr int S_INC0 = 254, S_X0 = 252;   // inc
+constexpr int S_D0A = 124, S_X1 = 122;    // down0 (pool 126)
+constexpr int S_D1A = 59, S_X2 = 57;      // down1 (pool 61)
+constexpr int S_D2A = 26, S_X3 = 24;      // down2 (pool 28)
+constexpr int S_D3A = 10, S_X4 = 12;      // down3 (pool 12): conv -> 10, convT -> 12
+constexpr int NODES = 144;
+
+enum Buf {
+  B_INC0, B_X0, B_D0A, B_X1, B_D1A, B_X2, B_D2A, B_X3, B_D3A, B_X4,
+  B_GFC1, B_GMR, B_GGC, B_GX1, B_FH, B_GOUT,
+  B_U0UP, B_U0A, B_U0, B_U1UP, B_U1A, B_U1, B_U2UP, B_U2A, B_U2, B_U3UP, B_U3A, B_UPX,
+  B_KNN, B_COUNT
+};
+
+struct BufDim { int h, w, c; };
+const BufDim kDims[B_COUNT] = {
+    {254, 254, 32}, {252, 252, 32}, {124, 124, 64}, {122, 122, 64}, {59, 59, 128}, {57, 57, 128},
+    {26, 26, 256},  {24, 24, 256},  {10, 10, 256},  {12, 12, 256},
+    {1, 144, 256},  {1, 144, 512},  {1, 144, 512},  {1, 144, 256},  {1, 144, 256}, {1, 144, 256},
+    {24, 24, 256},  {26, 26, 128},  {28, 28, 128},  {56, 56, 128},  {59, 59, 64},  {61, 61, 64},
+    {122, 122, 64}, {124, 124, 32}, {126, 126, 32}, {252, 252, 32}, {254, 254, 32}, {256, 256, 32},
+    {1, 144, 9}};
+
+struct Layout {
+  size_t off[B_COUNT];
+  size_t per_n[B_COUNT];  // bytes per tile
+  size_t total;
+};
+
+Layout make_layout(int n_alloc, int dtype) {
+  const size_t es = dtype == UNCL_BF16 ? 2 : 4;
+  Layout L;
+  size_t o = 0;
+  for (int b = 0; b < B_COUNT; ++b) {
+    const size_t e = b == B_KNN ? 4 : es;
+    L.per_n[b] = (size_t)kDims[b].h * kDims[b].w * kDims[b].c * e;
+    L.off[b] = o;
+    o += (L.per_n[b] * n_alloc + 255) & ~(size_t)255;
+  }
+  L.total = o;
+  return L;
+}
+
+const char* kNames[] = {
+    "inc.conv.conv1",
+    "down_path.0.mpconv.1.conv", "down_path.0.mpconv.1.conv1",
+    "down_path.1.mpconv.1.conv", "down_path.1.mpconv.1.conv1",
+    "down_path.2.mpconv.1.conv", "down_path.2.mpconv.1.conv1",
+    "down_path.3.mpconv.1.conv", "down_path.3.mpconv.1.conv1",
+    "gcn.module.0.0.fc1.0", "gcn.module.0.0.graph_conv.gconv.nn.0", "gcn.module.0.0.fc2.0",
+    "gcn.module.0.1.fc1.0", "gcn.module.0.1.fc2.0",
+    "up_path.0.up", "up_path.0.conv.conv", "up_path.0.conv.conv1",
+    "up_path.1.up", "up_path.1.conv.conv", "up_path.1.conv.conv1",
+    "up_path.2.up", "up_path.2.conv.conv", "up_path.2.conv.conv1",
+    "up_path.3.up", "up_path.3.conv.conv", "up_path.3.conv.conv1"};
+static_assert(sizeof(kNames) / sizeof(kNames[0]) == UNCL_G_NUM_WEIGHTS, "weight table size");
+
+enum W {
+  W_INC1, W_D0A, W_D0B, W_D1A, W_D1B, W_D2A, W_D2B, W_D3A, W_D3B,
+  W_GFC1, W_GGC, W_GFC2, W_FFC1, W_FFC2,
+  W_U0UP, W_U0A, W_U0B, W_U1UP, W_U1A, W_U1B, W_U2UP, W_U2A, W_U2B, W_U3UP, W_U3A, W_U3B
+};
+
+struct Ctx {
+  const uncl_gen_weights* w;
+  char* ws;          // workspace base for this chunk's activations
+  const char* prev;  // previous frame's workspace base (video) or NULL
+  Layout L;
+  int n;             // tiles in this chunk
+  hipStream_t s;
+  void* ptr(int b) const { return ws + L.off[b]; }
+  const void* pptr(int b) const { return prev ? prev + L.off[b] : nullptr; }
+};
+
+uncl_conv_desc base_desc(const Ctx& c, int wi, int ksize, int pad, int cin, int cout, int act) {
+  uncl_conv_desc d = {};
+  d.dtype = c.w->dtype;
+  d.ksize = ksize;
+  d.pad = pad;
+  d.N = c.n;
+  d.Cin = cin;
+  d.Cout = cout;
+  d.weight = c.w->w[wi];
+  d.bias = c.w->b[wi];
+  d.act = act;
+  return d;
+}
+
+void set_src0(uncl_conv_desc& d, const Ctx& c, int b) {
+  d.src0 = c.ptr(b);
+  d.src0_H = kDims[b].h; d.src0_W = kDims[b].w; d.src0_C = kDims[b].c;
+}
+void set_out(uncl_conv_desc& d, void* p, int b) {
+  d.out = p;
+  d.out_H = kDims[b].h; d.out_W = kDims[b].w; d.out_C = kDims[b].c;
+}
+
+// 3x3 conv (valid or full) reading buffer `in` (optionally through a 2x2 max-pool) into buffer `out`
+int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, bool pool, int prev_ch = 0) {
+  uncl_conv_desc d = base_desc(c, wi, 3, pad, cin, cout, c.w->act);
+  set_src0(d, c, in);
+  d.src_mode = pool ? UNCL_SRC_MAXPOOL2 : UNCL_SRC_PLAIN;
+  d.H = pool ? kDims[in].h / 2 : kDims[in].h;
+  d.W = pool ? kDims[in].w / 2 : kDims[in].w;
+  if (prev_ch > 0 && c.prev) { d.prev0 = c.pptr(in); d.prev_ch = prev_ch; }
+  set_out(d, c.ptr(out), out);
+  return uncl_conv_igemm(&d, c.s);
+}
+
+// decoder stage: ConvT2x2(s2) of `x1` -> up buffer; concat-ssr(skip, up) -> ConvT3x3 -> ConvT3x3
+int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int outbuf, int ch, int cout, int prev_ch,
+             void* final_out, const uncl_conv_desc* tail) {
+  int rc;
+  {
+    uncl_conv_desc d = base_desc(c, wi_up, 1, 0, ch, ch, UNCL_ACT_NONE);
+    set_src0(d, c, x1);
+    d.src_mode = UNCL_SRC_PLAIN;
+    d.H = kDims[x1].h == 1 ? 12 : kDims[x1].h;
+    d.W = kDims[x1].h == 1 ? 12 : kDims[x1].w;
+    if (prev_ch > 0 && c.prev) { d.prev0 = c.pptr(x1); d.prev_ch = prev_ch; }
+    d.z_mode = UNCL_Z_UP2X2;
+    set_out(d, c.ptr(upbuf), upbuf);
+    if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
+  }
+  {
+    uncl_conv_desc d = base_desc(c, wi_up + 1, 3, 2, 4 * ch, cout, c.w->act);
+    set_src0(d, c, skip);
+    d.src1 = c.ptr(upbuf);
+    d.src1_H = kDims[upbuf].h; d.src1_W = kDims[upbuf].w; d.src1_C = kDims[upbuf].c;
+    d.src_mode = UNCL_SRC_CONCAT_SSR;
+    d.H = kDims[skip].h; d.W = kDims[skip].w;
+    set_out(d, c.ptr(abuf), abuf);
+    if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
+  }
+  {
+    uncl_conv_desc d = base_desc(c, wi_up + 2, 3, 2, cout, cout, c.w->act);
+    set_src0(d, c, abuf);
+    d.src_mode = UNCL_SRC_PLAIN;
+    d.H = kDims[abuf].h; d.W = kDims[abuf].w;
+    set_out(d, final_out ? final_out : c.ptr(outbuf), outbuf);
+    if (tail) {
+      d.out1_w = tail->out1_w; d.out1_b = tail->out1_b; d.out1 = tail->out1; d.out1_act = tail->out1_act;
+      d.skip_main_store = tail->skip_main_store;
+    }
+    if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
+  }
+  return UNCL_OK;
+}
+
+int conv1(const Ctx& c, int wi, int in, int out, int cin, int cout, int act, const void* res, int res_b0,
+          const float* scale, int groups = 0) {
+  uncl_conv_desc d = base_desc(c, wi, 1, 0, groups ? cin / groups : cin, groups ? cout / groups : cout, act);
+  set_src0(d, c, in);
+  d.src_mode = UNCL_SRC_PLAIN;
+  d.H = 12; d.W = 12;
+  d.src0_H = 12; d.src0_W = 12;
+  d.res = res; d.res_batch_stride0 = res_b0; d.scale_n = scale;
+  if (groups) { d.z_mode = UNCL_Z_GROUPS; d.groups = groups; }
+  set_out(d, c.ptr(out), out);
+  d.out_H = 12; d.out_W = 12;
+  return uncl_conv_igemm(&d, c.s);
+}
+
+int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn_out, const float* drop0,
+              const float* drop1) {
+  const uncl_gen_weights* w = c.w;
+  int rc;
+#define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
+  // encoder
+  RUN(uncl_conv_in_c1(x, w->inc0_w, w->inc0_b, c.ptr(B_INC0), w->dtype, c.n, S_IN, S_IN, 32, w->act, c.s));
+  RUN(conv3(c, W_INC1, B_INC0, B_X0, 32, 32, 0, false));
+  RUN(conv3(c, W_D0A, B_X0, B_D0A, 32, 64, 0, true, 1));
+  RUN(conv3(c, W_D0B, B_D0A, B_X1, 64, 64, 0, false));
+  RUN(conv3(c, W_D1A, B_X1, B_D1A, 64, 128, 0, true, 2));
+  RUN(conv3(c, W_D1B, B_D1A, B_X2, 128, 128, 0, false));
+  RUN(conv3(c, W_D2A, B_X2, B_D2A, 128, 256, 0, true, 4));
+  RUN(conv3(c, W_D2B, B_D2A, B_X3, 256, 256, 0, false));
+  RUN(conv3(c, W_D3A, B_X3, B_D3A, 256, 256, 0, true, 8));
+  {
+    // transposed 3x3 back to 12x12, ReLU, then + pos_embed (Unet_singleFrame.py:94) fused as a broadcast residual
+    uncl_conv_desc d = base_desc(c, W_D3B, 3, 2, 256, 256, w->act);
+    set_src0(d, c, B_D3A);
+    d.H = S_D3A; d.W = S_D3A;
+    d.res = w->pos_embed; d.res_batch_stride0 = 1;
+    set_out(d, c.ptr(B_X4), B_X4);
+    RUN(uncl_conv_igemm(&d, c.s));
+  }
+  // graph block: Grapher (fc1 -> kNN -> max-relative -> grouped 1x1 + GELU -> fc2, residual) then FFN
+  RUN(conv1(c, W_GFC1, B_X4, B_GFC1, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
+  int32_t* knn = reinterpret_cast<int32_t*>(c.ptr(B_KNN));
+  RUN(uncl_gcn_knn(c.ptr(B_GFC1), w->dtype, w->relative_pos, knn, nullptr, c.n, NODES, 256, 9, nullptr, c.s));
+  if (knn_out && hipMemcpyAsync(knn_out, knn, (size_t)c.n * NODES * 9 * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+    return UNCL_ERR_LAUNCH;
+  RUN(uncl_gcn_maxrel(c.ptr(B_GFC1), knn, c.ptr(B_GMR), w->dtype, c.n, NODES, 256, 9, c.s));
+  RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_GELU, nullptr, 0, nullptr, 4));
+  RUN(conv1(c, W_GFC2, B_GGC, B_GX1, 512, 256, UNCL_ACT_NONE, c.ptr(B_X4), 0, drop0));
+  RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
+  RUN(conv1(c, W_FFC2, B_FH, B_GOUT, 256, 256, UNCL_ACT_NONE, c.ptr(B_GX1), 0, drop1));
+  // decoder
+  RUN(up_stage(c, W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128, 8, nullptr, nullptr));
+  RUN(up_stage(c, W_U1UP, B_U0, B_X2, B_U1UP, B_U1A, B_U1, 128, 64, 4, nullptr, nullptr));
+  RUN(up_stage(c, W_U2UP, B_U1, B_X1, B_U2UP, B_U2A, B_U2, 64, 32, 2, nullptr, nullptr));
+  uncl_conv_desc tail = {};
+  tail.out1_w = w->outc_w; tail.out1_b = w->outc_b; tail.out1 = out; tail.out1_act = w->last_act;
+  tail.skip_main_store = up_x == nullptr ? 1 : 0;
+  RUN(up_stage(c, W_U3UP, B_U2, B_X0, B_U3UP, B_U3A, B_UPX, 32, 32, 1, up_x, &tail));
+#undef RUN
+  return UNCL_OK;
+}
+
+}  // namespace
+
+extern "C" const char* uncl_gen_layer_name(int i) {
+  if (i < 0 || i >= UNCL_G_NUM_WEIGHTS) return nullptr;
+  return kNames[i];
+}
+
+extern "C" size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep_activations) {
+  if (N <= 0) return 0;
+  if (chunk <= 0 || chunk > N) chunk = N;
+  return make_layout(keep_activations ? N : chunk, dtype).total;
+}
+
+extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r, void* stream) {
+  if (!w || !r || !r->x || !r->out || !r->workspace || r->N <= 0) return UNCL_ERR_ARG;
+  if (w->dtype != UNCL_F32 && w->dtype != UNCL_BF16) return UNCL_ERR_ARG;
+  int chunk = r->chunk;
+  if (chunk <= 0 || chunk > r->N) chunk = r->N;
+  const int n_alloc = r->keep_activations ? r->N : chunk;
+  Layout L = make_layout(n_alloc, w->dtype);
+  if (r->workspace_bytes < L.total) return UNCL_ERR_ARG;
+  const size_t es = w->dtype == UNCL_BF16 ? 2 : 4;
+  for (int n0 = 0; n0 < r->N; n0 += chunk) {
+    Ctx c;
+    c.w = w;
+    c.L = L;
+    c.n = (r->N - n0 < chunk) ? r->N - n0 : chunk;
+    c.s = reinterpret_cast<hipStream_t>(stream);
+    // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
+    // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
+    Layout Lc = L;
+    if (r->keep_activations)
+      for (int b = 0; b < B_COUNT; ++b) Lc.off[b] = L.off[b] + L.per_n[b] * (size_t)n0;
+    c.L = Lc;
+    c.ws = reinterpret_cast<char*>(r->workspace);
+    c.prev = reinterpret_cast<const char*>(r->prev_workspace);
+    if (c.prev && !r->keep_activations) return UNCL_ERR_ARG;
+    void* up = r->up_x ? reinterpret_cast<char*>(r->up_x) + (size_t)n0 * 256 * 256 * 32 * es : nullptr;
+    int rc = run_chunk(c, r->x + (size_t)n0 * 256 * 256, r->out + (size_t)n0 * 256 * 256, up,
+                       r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr,
+                       r->drop_scale ? r->drop_scale + n0 : nullptr,
+                       r->drop_scale ? r->drop_scale + r->N + n0 : nullptr);
+    if (rc != UNCL_OK) return rc;
+  }
+  return UNCL_OK;
+}

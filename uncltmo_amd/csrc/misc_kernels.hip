@@ -1,0 +1,378 @@
+// Bandwidth-bound helpers of the generator forward: weight re-layout, the 1-channel first layer, the graph
+// block's kNN / max-relative gather, and the overlap-tile gather / cross-fade.  gfx950 only.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int Cout, int Cin, int kk,
+                                   int transposed, int flip) {
+  const size_t total = (size_t)kk * Cout * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int tap = (int)(i / ((size_t)Cin * Cout));
+    const int ts = flip ? (kk - 1 - tap) : tap;
+    const size_t s = transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
+    dst[i] = (T)src[s];
+  }
+}
+
+extern "C" int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int Cout, int Cin, int k,
+                                     int transposed, int flip, void* stream) {
+  if (src == nullptr || dst == nullptr || Cout <= 0 || Cin <= 0 || k <= 0) return UNCL_ERR_ARG;
+  const size_t total = (size_t)k * k * Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == UNCL_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, src, (bf16_t*)dst, Cout, Cin, k * k,
+                       transposed, flip);
+  else if (dtype == UNCL_F32)
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, Cout, Cin, k * k,
+                       transposed, flip);
+  else
+    return UNCL_ERR_ARG;
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// first layer: Conv2d(1 -> Cout, 3x3 valid) + bias + act; one thread = one pixel x 8 output channels
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, T* __restrict__ out, int N, int H,
+                                                         int W, int Cout, int act) {
+  extern __shared__ float sw[];  // Cout*9 weights + Cout biases
+  for (int i = threadIdx.x; i < Cout * 9; i += blockDim.x) sw[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[Cout * 9 + i] = b ? b[i] : 0.f;
+  __syncthreads();
+  const int Ho = H - 2, Wo = W - 2, G = Cout / 8;
+  const size_t total = (size_t)N * Ho * Wo * G;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    const size_t p = i / G;
+    const int ox = (int)(p % Wo);
+    const int oy = (int)((p / Wo) % Ho);
+    const int n = (int)(p / ((size_t)Wo * Ho));
+    float in[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) in[t] = x[((size_t)n * H + oy + t / 3) * W + ox + t % 3];
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* wc = sw + (g * 8 + c) * 9;
+      float s = sw[Cout * 9 + g * 8 + c];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) s = fmaf(in[t], wc[t], s);
+      v[c] = uncl_act(s, act);
+    }
+    T* o = out + p * Cout + g * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (T)v[c];
+  }
+}
+
+extern "C" int uncl_conv_in_c1(const float* x, const float* w, const float* b, void* out, int dtype, int N, int H,
+                               int W, int Cout, int act, void* stream) {
+  if (!x || !w || !out || N <= 0 || H < 3 || W < 3 || Cout % 8 != 0) return UNCL_ERR_ARG;
+  const size_t total = (size_t)N * (H - 2) * (W - 2) * (Cout / 8);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const size_t lds = (size_t)Cout * 10 * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == UNCL_BF16)
+    hipLaunchKernelGGL(conv_in_c1_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, x, w, b, (bf16_t*)out, N, H, W, Cout,
+                       act);
+  else if (dtype == UNCL_F32)
+    hipLaunchKernelGGL(conv_in_c1_kernel<float>, dim3(blocks), dim3(256), lds, s, x, w, b, (float*)out, N, H, W, Cout,
+                       act);
+  else
+    return UNCL_ERR_ARG;
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// kNN graph on the bottleneck: one workgroup (16 waves) per sample, the whole normalised sample in LDS (fp32)
+// ------------------------------------------------------------------------------------------------------
+#define KNN_MAX_NODES 144
+#define KNN_C 256
+#define KNN_LD (KNN_C + 4)  // padded row: consecutive rows shift one 16-byte slot -> conflict-free b128 reads
+
+template <typename T>
+__global__ __launch_bounds__(1024) void gcn_knn_kernel(const T* __restrict__ x, const float* __restrict__ rel,
+                                                       int32_t* __restrict__ idx, float* __restrict__ dist_out, int n,
+                                                       int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sx = reinterpret_cast<float*>(smem);  // [n][KNN_LD]
+  float* ssq = sx + (size_t)n * KNN_LD;        // [n]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const T* xs = x + (size_t)blockIdx.x * n * KNN_C;
+  // L2-normalise each node over channels (F.normalize: x / max(|x|, 1e-12)), keep |xn|^2
+  for (int i = wave; i < n; i += nw) {
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = (float)xs[(size_t)i * KNN_C + lane * 4 + t];
+    float ss = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] *= inv;
+    *reinterpret_cast<f32x4*>(sx + (size_t)i * KNN_LD + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    float s2 = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    if (lane == 0) ssq[i] = s2;
+  }
+  __syncthreads();
+  for (int i = wave; i < n; i += nw) {
+    const float* xi = sx + (size_t)i * KNN_LD;
+    float d[3];
+    int jj[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = lane + 64 * t;
+      jj[t] = j;
+      d[t] = INFINITY;
+      if (j < n) {
+        const float* xj = sx + (size_t)j * KNN_LD;
+        float dot = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < KNN_C; c += 4) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(xi + c);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(xj + c);
+          dot = fmaf(a[0], b[0], dot);
+          dot = fmaf(a[1], b[1], dot);
+          dot = fmaf(a[2], b[2], dot);
+          dot = fmaf(a[3], b[3], dot);
+        }
+        // same association as the reference: (|xi|^2 + (-2 xi.xj)) + |xj|^2, then + relative_pos
+        float dd = (ssq[i] + (-2.f * dot)) + ssq[j];
+        if (rel != nullptr) dd += rel[(size_t)i * n + j];
+        d[t] = dd;
+        if (dist_out != nullptr) dist_out[((size_t)blockIdx.x * n + i) * n + j] = dd;
+      }
+    }
+    // k rounds of wave-wide arg-min; ties go to the lower node index
+    for (int r = 0; r < k; ++r) {
+      float bv = d[0];
+      int bj = jj[0];
+#pragma unroll
+      for (int t = 1; t < 3; ++t)
+        if (d[t] < bv) { bv = d[t]; bj = jj[t]; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oj = __shfl_xor(bj, o, 64);
+        if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (jj[t] == bj) d[t] = INFINITY;
+      if (lane == 0) idx[((size_t)blockIdx.x * n + i) * k + r] = bj;
+    }
+  }
+}
+
+extern "C" size_t uncl_gcn_knn_workspace_bytes(int N, int n, int C) {
+  (void)N; (void)n; (void)C;
+  return 0;  // the sample lives in LDS
+}
+
+extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos, int32_t* idx, float* dist_out, int N,
+                            int n, int C, int k, void* workspace, void* stream) {
+  (void)workspace;
+  if (!x || !idx || N <= 0 || n <= 0 || n > KNN_MAX_NODES || C != KNN_C || k <= 0 || k > n) return UNCL_ERR_ARG;
+  const size_t lds = ((size_t)n * KNN_LD + n) * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static bool attr[2] = {false, false};
+  if (dtype == UNCL_BF16) {
+    if (!attr[1]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_kernel<bf16_t>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
+      attr[1] = true;
+    }
+    hipLaunchKernelGGL(gcn_knn_kernel<bf16_t>, dim3(N), dim3(1024), lds, s, (const bf16_t*)x, relative_pos, idx, dist_out,
+                       n, k);
+  } else if (dtype == UNCL_F32) {
+    if (!attr[0]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_kernel<float>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
+      attr[0] = true;
+    }
+    hipLaunchKernelGGL(gcn_knn_kernel<float>, dim3(N), dim3(1024), lds, s, (const float*)x, relative_pos, idx, dist_out, n,
+                       k);
+  } else {
+    return UNCL_ERR_ARG;
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// max-relative features, channels interleaved [x_c, max_k(x_c[nbr] - x_c)]
+template <typename T>
+__global__ __launch_bounds__(256) void gcn_maxrel_kernel(const T* __restrict__ x, const int32_t* __restrict__ idx,
+                                                         T* __restrict__ out, int N, int n, int C, int k) {
+  using E = Elem<T>;
+  using vec = typename E::vec;
+  constexpr int EPV = E::EPV;
+  const int VC = C / EPV;
+  const size_t total = (size_t)N * n * VC;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(t % VC);
+    const size_t node = t / VC;  // b*n + i
+    const size_t b = node / n;
+    float xi[EPV], m[EPV];
+    E::unpack(*reinterpret_cast<const vec*>(x + node * C + cv * EPV), xi);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) m[e] = -INFINITY;
+    for (int r = 0; r < k; ++r) {
+      const int j = idx[node * k + r];
+      float xj[EPV];
+      E::unpack(*reinterpret_cast<const vec*>(x + (b * n + j) * C + cv * EPV), xj);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) m[e] = fmaxf(m[e], xj[e] - xi[e]);
+    }
+    float o[2 * EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      o[2 * e] = xi[e];
+      o[2 * e + 1] = m[e];
+    }
+    T* op = out + node * 2 * C + (size_t)cv * 2 * EPV;
+    *reinterpret_cast<vec*>(op) = E::pack(o);
+    *reinterpret_cast<vec*>(op + EPV) = E::pack(o + EPV);
+  }
+}
+
+extern "C" int uncl_gcn_maxrel(const void* x, const int32_t* idx, void* out, int dtype, int N, int n, int C, int k,
+                               void* stream) {
+  if (!x || !idx || !out || N <= 0 || n <= 0 || C % 8 != 0 || k <= 0) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == UNCL_BF16) {
+    const size_t total = (size_t)N * n * (C / 8);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gcn_maxrel_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, idx, (bf16_t*)out, N, n,
+                       C, k);
+  } else if (dtype == UNCL_F32) {
+    const size_t total = (size_t)N * n * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gcn_maxrel_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, idx, (float*)out, N, n, C,
+                       k);
+  } else {
+    return UNCL_ERR_ARG;
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// overlap tiler: 256^2 tiles, stride 192, sequential linear cross-fade along x then along y
+// ------------------------------------------------------------------------------------------------------
+#define TILE 256
+#define TILE_OVERLAP 64
+#define TILE_MAX_AXIS 48
+
+struct AxisPlan {
+  int count;
+  int start[TILE_MAX_AXIS];
+  int blend[TILE_MAX_AXIS];
+};
+
+static int make_axis_plan(int L, AxisPlan* p) {
+  if (L <= TILE) return UNCL_ERR_ARG;  // the reference's loop is undefined there (model_save_util.py:417-441)
+  int c = 0;
+  for (int idx = 1; TILE * idx - TILE_OVERLAP * (idx - 1) < L; ++idx) {
+    if (c >= TILE_MAX_AXIS - 1) return UNCL_ERR_ARG;
+    p->start[c] = (TILE - TILE_OVERLAP) * (idx - 1);
+    p->blend[c] = idx == 1 ? 0 : TILE_OVERLAP;
+    ++c;
+  }
+  const int end_last = p->start[c - 1] + TILE;
+  p->start[c] = L - TILE;
+  p->blend[c] = end_last - (L - TILE);
+  p->count = c + 1;
+  return UNCL_OK;
+}
+
+extern "C" int uncl_tile_count(int H, int W) {
+  AxisPlan py, px;
+  if (make_axis_plan(H, &py) != UNCL_OK || make_axis_plan(W, &px) != UNCL_OK) return UNCL_ERR_ARG;
+  return py.count * px.count;
+}
+
+__global__ __launch_bounds__(256) void tile_gather_kernel(const float* __restrict__ frames, float* __restrict__ tiles,
+                                                          int H, int W, AxisPlan py, AxisPlan px) {
+  // grid: (tile rows of 4 px-quads, tiles per frame, frames)
+  const int t = blockIdx.y, f = blockIdx.z;
+  const int ty = t / px.count, tx = t - ty * px.count;
+  const int y0 = py.start[ty], x0 = px.start[tx];
+  const float* src = frames + (size_t)f * H * W;
+  float* dst = tiles + ((size_t)f * gridDim.y + t) * TILE * TILE;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < TILE * TILE; i += gridDim.x * blockDim.x) {
+    const int y = i >> 8, x = i & 255;
+    dst[i] = src[(size_t)(y0 + y) * W + x0 + x];
+  }
+}
+
+__device__ __forceinline__ float fold1(float acc, float piece, int i, int blend, bool first) {
+  if (first || i >= blend) return piece;
+  // same fp32 association as the reference: acc*(b-1-i)/(b-1) + piece*i/(b-1)
+  const float bm1 = (float)(blend - 1);
+  return (acc * (float)(blend - 1 - i)) / bm1 + (piece * (float)i) / bm1;
+}
+
+__global__ __launch_bounds__(256) void tile_blend_kernel(const float* __restrict__ tiles, float* __restrict__ frames,
+                                                         int H, int W, AxisPlan py, AxisPlan px) {
+  const int f = blockIdx.y;
+  const int T = py.count * px.count;
+  const float* tf = tiles + (size_t)f * T * TILE * TILE;
+  float* dst = frames + (size_t)f * H * W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    float acc = 0.f;
+    for (int sy = 0; sy < py.count; ++sy) {
+      const int ly = y - py.start[sy];
+      if (ly < 0 || ly >= TILE) continue;
+      float strip = 0.f;
+      for (int sx = 0; sx < px.count; ++sx) {
+        const int lx = x - px.start[sx];
+        if (lx < 0 || lx >= TILE) continue;
+        const float piece = tf[((size_t)(sy * px.count + sx) * TILE + ly) * TILE + lx];
+        strip = fold1(strip, piece, lx, px.blend[sx], sx == 0);
+      }
+      acc = fold1(acc, strip, ly, py.blend[sy], sy == 0);
+    }
+    dst[i] = acc;
+  }
+}
+
+extern "C" int uncl_tile_gather(const float* frames, float* tiles, int F, int H, int W, void* stream) {
+  AxisPlan py, px;
+  if (!frames || !tiles || F <= 0) return UNCL_ERR_ARG;
+  if (make_axis_plan(H, &py) != UNCL_OK || make_axis_plan(W, &px) != UNCL_OK) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(tile_gather_kernel, dim3(32, py.count * px.count, F), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), frames, tiles, H, W, py, px);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_tile_blend(const float* tiles, float* frames, int F, int H, int W, void* stream) {
+  AxisPlan py, px;
+  if (!frames || !tiles || F <= 0) return UNCL_ERR_ARG;
+  if (make_axis_plan(H, &py) != UNCL_OK || make_axis_plan(W, &px) != UNCL_OK) return UNCL_ERR_ARG;
+  const int blocks = (H * W + 255) / 256 < 4096 ? (H * W + 255) / 256 : 4096;
+  hipLaunchKernelGGL(tile_blend_kernel, dim3(blocks, F), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tiles,
+                     frames, H, W, py, px);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_version(void) { return 1; }
+
+extern "C" int uncl_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+  const char* a = p.gcnArchName;
+  return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}

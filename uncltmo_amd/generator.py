@@ -1,0 +1,280 @@
+"""Generators of UnCLTMO, MI355X-native: same constructor / forward() signatures and state_dict keys as the
+reference's `models/unet_multi_filters/Unet_singleFrame.py:UNet` (image) and `Unet.py:UNet` (video), with
+the arithmetic done by hand-written gfx950 kernels behind the C ABI of include/uncltmo_hip.h.
+
+The module only owns parameters (fp32 masters, reference layout); `forward` packs them once per parameter
+version into the kernels' layout and enqueues the whole network with one C call (uncl_gen_forward).
+There is no eager / CPU fallback: on a host tensor or without the built library, forward raises.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _hip, params
+from .state_spec import generator_spec
+
+
+def sincos_relative_pos(embed_dim=256, grid=12):
+    """Fixed buffer `relative_pos` = -(2 P P^T / D) for the 2-D sin/cos table P (columns first).
+    Reference: gcn_lib/pos_embed.py:21-83, gcn_lib/torch_vertex.py:203-209 (the bicubic resize to (n, n) is
+    the identity at reduce ratio 1)."""
+    quarter = embed_dim // 4
+    omega = 1.0 / 10000 ** (np.arange(quarter, dtype=np.float64) / quarter)
+    gy, gx = np.meshgrid(np.arange(grid, dtype=np.float64), np.arange(grid, dtype=np.float64), indexing="ij")
+
+    def enc(pos):
+        ang = pos.reshape(-1, 1) * omega[None, :]
+        return np.concatenate([np.sin(ang), np.cos(ang)], axis=1)
+
+    table = np.concatenate([enc(gx), enc(gy)], axis=1)
+    rel = 2.0 * (table @ table.T) / table.shape[1]
+    return -torch.from_numpy(rel.astype(np.float32)).unsqueeze(0)
+
+
+def _attach(root, dotted, tensor, as_param):
+    """Create plain container modules along a dotted state_dict key and register the leaf tensor."""
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    if as_param is None:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=as_param))
+
+
+_ACT = {"relu": _hip.ACT_RELU, "leakyrelu": _hip.ACT_LRELU}
+_LAST = {"sigmoid": _hip.ACT_SIGMOID, "none": _hip.ACT_NONE}
+
+
+class _GeneratorBase(nn.Module):
+    """Parameter container + packing cache shared by the image and video generators."""
+
+    def __init__(self, n_channels, output_dim, last_layer, depth, layer_factor, con_operator, filters, bilinear,
+                 network, dilation, to_crop, unet_norm, stretch_g, activation, doubleConvTranspose,
+                 padding_mode, convtranspose_kernel, up_mode=True, recurrent_ch_ratio=1 / 32,
+                 compute_dtype="fp32", chunk=0):
+        super().__init__()
+        # The 12x12 learned pos_embed hard-wires the topology (Unet_singleFrame.py:66,94): only the published
+        # configuration can produce a 12x12 bottleneck from a 256x256 input.
+        unsupported = []
+        if network != params.unet_network:
+            assert 0, "Unsupported network request: {}".format(network)
+        if activation not in _ACT:
+            assert 0, "Unsupported activation: {%s}" % (activation)
+        if con_operator not in (params.square_and_square_root,):
+            unsupported.append("con_operator=%s" % con_operator)
+        if depth != 4 or filters != 32 or layer_factor != 4:
+            unsupported.append("depth/filters/layer_factor=%s/%s/%s" % (depth, filters, layer_factor))
+        if not doubleConvTranspose or up_mode or bilinear or convtranspose_kernel != 2:
+            unsupported.append("decoder must be doubleConvTranspose=1, up_mode=0, bilinear=0, convtranspose_kernel=2")
+        if n_channels != 1 or output_dim != 1:
+            unsupported.append("n_channels/output_dim must be 1")
+        if unet_norm not in ("none", None):
+            unsupported.append("unet_norm=%s (HIP path covers 'none')" % unet_norm)
+        if last_layer not in _LAST:
+            unsupported.append("last_layer=%s" % last_layer)
+        if stretch_g not in ("none", None):
+            unsupported.append("stretch_g=%s" % stretch_g)
+        if unsupported:
+            raise NotImplementedError("generator configuration outside the published topology: " + "; ".join(unsupported))
+        self.to_crop = to_crop
+        self.con_operator = con_operator
+        self.network = network
+        self.depth = depth
+        self.activation = activation
+        self.last_layer = last_layer
+        self.recurrent_ch_ratio = recurrent_ch_ratio
+        self.compute_dtype = compute_dtype
+        self.chunk = chunk
+        self.drop_path_prob = 0.05          # dpr = linspace(0.05, 0.1, 1)[0] (Unet_singleFrame.py:62)
+        self.forced_drop_keep = None        # optional (2, N) 0/1 keep flags for deterministic train-mode runs
+        for key, shape, kind in generator_spec(filters, layer_factor):
+            if kind == "buffer":
+                _attach(self, key, sincos_relative_pos(), False)
+            elif kind == "embed":
+                _attach(self, key, torch.zeros(shape), True)
+            else:
+                _attach(self, key, torch.empty(shape), True)
+        self.reset_parameters()
+        self._pack_key = None
+        self._packed = None
+        self._ws = {}
+
+    # --- initialisation: what `create_G_net*` + `set_parallel_net(use_xaviar=True)` leave behind
+    def reset_parameters(self):
+        """Conv2d: xavier_normal(gain sqrt 2), zero bias (model_save_util.py:41-47); the class-name test there does
+        not match ConvTranspose2d, which keeps PyTorch's default init; the graph block re-inits its convs with
+        kaiming_normal / zero bias first (Unet_singleFrame.py:83-90) and xavier then overrides them."""
+        for key, shape, kind in generator_spec():
+            t = dict(self.named_parameters()).get(key)
+            if t is None:
+                continue
+            with torch.no_grad():
+                if kind == "conv":
+                    fan_in = shape[1] * shape[2] * shape[3]
+                    fan_out = shape[0] * shape[2] * shape[3]
+                    t.normal_(0.0, math.sqrt(2.0) * math.sqrt(2.0 / (fan_in + fan_out)))
+                elif kind == "convT":
+                    fan_in = shape[1] * shape[2] * shape[3]     # torch computes fan_in from dim 1 for any weight
+                    bound = 1.0 / math.sqrt(fan_in)             # kaiming_uniform(a=sqrt 5) == U(-1/sqrt(fan_in), ..)
+                    t.uniform_(-bound, bound)
+                elif kind == "bias":
+                    wkey = key[:-4] + "weight"
+                    wshape = dict((k, s) for k, s, _ in generator_spec())[wkey]
+                    wkind = dict((k, kd) for k, _, kd in generator_spec())[wkey]
+                    if wkind == "conv":
+                        t.zero_()
+                    else:
+                        bound = 1.0 / math.sqrt(wshape[1] * wshape[2] * wshape[3])
+                        t.uniform_(-bound, bound)
+
+    # --- packing
+    def _dtype_code(self):
+        return _hip.dtype_code(self.compute_dtype)
+
+    def _packed_weights(self):
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        code = self._dtype_code()
+        key = (code,) + tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        if key == self._pack_key:
+            return self._packed
+        lib = _hip.lib()
+        dev = sd["outc.conv.weight"].device
+        if dev.type != "cuda":
+            raise _hip.HipError("generator parameters live on %s; move the module to the MI355X (.cuda()) first" % dev)
+        tdt = _hip.torch_dtype(code)
+        spec = {k: (shape, kind) for k, shape, kind in generator_spec()}
+        keep = []          # tensors that must stay alive as long as the struct
+        gw = _hip.GenWeights()
+        gw.dtype = code
+        st = _hip.stream_ptr()
+
+        def f32(name):
+            t = sd[name].detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        gw.inc0_w, gw.inc0_b = f32("inc.conv.conv.weight"), f32("inc.conv.conv.bias")
+        for i in range(_hip.G_NUM_WEIGHTS):
+            name = lib.uncl_gen_layer_name(i).decode()
+            shape, kind = spec[name + ".weight"]
+            transposed = kind == "convT"
+            k = shape[2]
+            cout, cin = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
+            src = sd[name + ".weight"].detach().float().contiguous()
+            dst = torch.empty(k * k * cout * cin, dtype=tdt, device=dev)
+            flip = 1 if (transposed and k == 3) else 0
+            _hip.check(lib.uncl_pack_conv_weight(src.data_ptr(), dst.data_ptr(), code, cout, cin, k, int(transposed),
+                                                 flip, st), "uncl_pack_conv_weight(%s)" % name)
+            keep += [src, dst]
+            gw.w[i] = dst.data_ptr()
+            gw.b[i] = f32(name + ".bias")
+        pe = sd["gcn.pos_embed"].detach().reshape(256, 144).t().contiguous().to(tdt)    # (144,256) NHWC
+        keep.append(pe)
+        gw.pos_embed = pe.data_ptr()
+        gw.relative_pos = f32("gcn.module.0.0.relative_pos")
+        gw.outc_w, gw.outc_b = f32("outc.conv.weight"), f32("outc.conv.bias")
+        gw.act = _ACT[self.activation]
+        gw.last_act = _LAST[self.last_layer]
+        self._packed = (gw, keep)
+        self._pack_key = key
+        return self._packed
+
+    def _workspace(self, n, chunk, keep_act, dev, slot=0):
+        lib = _hip.lib()
+        code = self._dtype_code()
+        nbytes = lib.uncl_gen_workspace_bytes(n, chunk, code, int(keep_act))
+        k = (slot, dev)
+        ws = self._ws.get(k)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws[k] = ws
+        return ws, nbytes
+
+    def _drop_scale(self, n, dev):
+        """(2, N) multipliers keep/keep_prob of the two DropPath sites, or None in eval mode."""
+        if not self.training or self.drop_path_prob == 0.0:
+            return None
+        keep_prob = 1.0 - self.drop_path_prob
+        if self.forced_drop_keep is not None:
+            keep = torch.as_tensor(self.forced_drop_keep, dtype=torch.float32, device=dev).reshape(2, n)
+        else:
+            keep = torch.empty(2, n, device=dev).bernoulli_(keep_prob)
+        return (keep / keep_prob).contiguous()
+
+    def _run(self, x_flat, need_feat, prev_ws=None, keep_act=False, slot=0, want_knn=False):
+        """x_flat: (N,256,256) fp32 on the GPU.  Returns (out (N,1,256,256) fp32, up_x NHWC or None, knn or None, ws)."""
+        lib = _hip.lib()
+        gw, _keep = self._packed_weights()
+        n = x_flat.shape[0]
+        dev = x_flat.device
+        chunk = self.chunk if self.chunk and self.chunk > 0 else 0
+        ws, nbytes = self._workspace(n, chunk, keep_act, dev, slot)
+        out = torch.empty(n, 1, 256, 256, dtype=torch.float32, device=dev)
+        up = torch.empty(n, 256, 256, 32, dtype=_hip.torch_dtype(gw.dtype), device=dev) if need_feat else None
+        knn = torch.empty(n, 144, 9, dtype=torch.int32, device=dev) if want_knn else None
+        ds = self._drop_scale(n, dev)
+        run = _hip.GenRun()
+        run.N, run.chunk, run.keep_activations = n, chunk, int(keep_act)
+        run.x, run.out = x_flat.data_ptr(), out.data_ptr()
+        run.up_x = up.data_ptr() if up is not None else None
+        run.knn_idx = knn.data_ptr() if knn is not None else None
+        run.drop_scale = ds.data_ptr() if ds is not None else None
+        run.workspace, run.workspace_bytes = ws.data_ptr(), nbytes
+        run.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
+        _hip.check(lib.uncl_gen_forward(C.byref(gw), C.byref(run), _hip.stream_ptr()), "uncl_gen_forward")
+        return out, up, knn, ws
+
+    @staticmethod
+    def _check_input(x, hdim):
+        if x.shape[hdim] != params.input_size or x.shape[hdim + 1] != params.input_size:
+            # the reference fails with a RuntimeError at `inputs + self.pos_embed` (Unet_singleFrame.py:94)
+            raise ValueError("the generator only accepts %dx%d inputs (12x12 pos_embed); got %s. Use "
+                             "uncltmo_amd.tiler.test_big_size_image2 for larger frames."
+                             % (params.input_size, params.input_size, tuple(x.shape)))
+        if not x.is_cuda:
+            raise _hip.HipError("generator input is on %s; the HIP path needs it on the MI355X" % x.device)
+
+    @staticmethod
+    def _crop(x_out, diffY, diffX):
+        """utils/data_loader_util.py:165-172 (centre crop)."""
+        h, w = x_out.shape[-2], x_out.shape[-1]
+        th, tw = h - diffY, w - diffX
+        i, j = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))
+        return x_out[..., i:i + th, j:j + tw]
+
+
+class UNet(_GeneratorBase):
+    """Image generator.  forward(x[N,1,256,256]) -> (x_out[N,1,256,256] fp32, up_x[N,32,256,256])
+    (reference: Unet_singleFrame.py:177-213).  `up_x` is returned as a channels-last view in the compute dtype."""
+
+    def forward(self, x, apply_crop=True, diffY=0, diffX=0):
+        self._check_input(x, 2)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self._needs_autograd(x):
+            from .autograd import generator_image_apply
+            x_out, up_x = generator_image_apply(self, x)
+        else:
+            xf = x.detach().reshape(-1, 256, 256).float().contiguous()
+            x_out, up, _, _ = self._run(xf, need_feat=True)
+            up_x = up.permute(0, 3, 1, 2)
+        if apply_crop and self.to_crop:
+            x_out = self._crop(x_out, diffY, diffX)
+        return x_out, up_x
+
+    def _needs_autograd(self, x):
+        return True
+
+    @torch.no_grad()
+    def infer(self, x, want_knn=False):
+        """Inference entry used by the tiler: (N,1,256,256) -> (N,1,256,256); skips writing up_x to HBM."""
+        self._check_input(x, 2)
+        xf = x.reshape(-1, 256, 256).float().contiguous()
+        out, _, knn, _ = self._run(xf, need_feat=False, want_knn=want_knn)
+        return (out, knn) if want_knn else out

@@ -1,0 +1,79 @@
+"""Overlap-tile inference for frames larger than the generator's 256x256 window.
+
+Drop-in for `utils/model_save_util.py:test_big_size_image2` (4-D, :409-486) and `test_big_size_image` (5-D,
+:488-565): 256^2 patches, stride 192, linear cross-fade along x then y, edge-aligned final tile per axis.
+Instead of one batch-1 model call per tile and 64 tiny blend kernels per seam, all tiles of all frames are
+gathered by one kernel, run through the generator as ONE batch, and cross-faded by one kernel.
+"""
+import torch
+
+from . import _hip
+
+
+def _check_geometry(patch_h, patch_w, patch_h_overlap, patch_w_overlap):
+    if (patch_h, patch_w, patch_h_overlap, patch_w_overlap) != (256, 256, 64, 64):
+        raise NotImplementedError("the HIP tiler is built for 256x256 patches with overlap 64 (the published "
+                                  "setting, model_save_util.py:305)")
+
+
+def tile_count(H, W):
+    n = _hip.lib().uncl_tile_count(int(H), int(W))
+    if n < 0:
+        # the reference's loops leave w_end / h_end undefined for H or W <= 256 and crash (model_save_util.py:417-441)
+        raise ValueError("tiler needs H > 256 and W > 256 (got %dx%d)" % (H, W))
+    return n
+
+
+def gather_tiles(frames):
+    """frames (F,H,W) fp32 cuda -> tiles (F*T, 1, 256, 256)."""
+    F, H, W = frames.shape
+    T = tile_count(H, W)
+    tiles = torch.empty(F * T, 1, 256, 256, dtype=torch.float32, device=frames.device)
+    _hip.check(_hip.lib().uncl_tile_gather(_hip.ptr(frames), _hip.ptr(tiles), F, H, W, _hip.stream_ptr()),
+               "uncl_tile_gather")
+    return tiles
+
+
+def blend_tiles(tiles, F, H, W):
+    """tiles (F*T,1,256,256) fp32 cuda -> frames (F,H,W)."""
+    out = torch.empty(F, H, W, dtype=torch.float32, device=tiles.device)
+    _hip.check(_hip.lib().uncl_tile_blend(_hip.ptr(tiles), _hip.ptr(out), F, H, W, _hip.stream_ptr()),
+               "uncl_tile_blend")
+    return out
+
+
+def _run_model(model, tiles, apply_crop, diffY, diffX):
+    with torch.no_grad():
+        if hasattr(model, "infer"):
+            return model.infer(tiles)
+        out, _ = model(tiles, apply_crop=apply_crop, diffY=diffY, diffX=diffX)
+        return out
+
+
+def test_big_size_image2(input_data, model, apply_crop, diffY, diffX, patch_h=256, patch_w=256,
+                         patch_h_overlap=64, patch_w_overlap=64):
+    """input_data (N,1,H,W) -> (N,1,H,W).  Reference: utils/model_save_util.py:409-486."""
+    _check_geometry(patch_h, patch_w, patch_h_overlap, patch_w_overlap)
+    N, Cc, H, W = input_data.shape
+    if Cc != 1:
+        raise ValueError("tiler expects single-channel frames")
+    frames = input_data.reshape(N, H, W).float().contiguous()
+    tiles = gather_tiles(frames)
+    out = _run_model(model, tiles, apply_crop, diffY, diffX).float().contiguous()
+    return blend_tiles(out, N, H, W).reshape(N, 1, H, W)
+
+
+def test_big_size_image(input_data, model, apply_crop, diffY, diffX, patch_h=256, patch_w=256,
+                        patch_h_overlap=64, patch_w_overlap=64):
+    """input_data (B,T,1,H,W) -> (B,T,1,H,W).  Reference: utils/model_save_util.py:488-565.  Every tile
+    position is a clip of T frames that the (recurrent) video generator consumes in order."""
+    _check_geometry(patch_h, patch_w, patch_h_overlap, patch_w_overlap)
+    B, T, Cc, H, W = input_data.shape
+    frames = input_data.reshape(B * T, H, W).float().contiguous()
+    tiles = gather_tiles(frames)                                   # (B*T*nt, 1, 256, 256), frame-major
+    nt = tiles.shape[0] // (B * T)
+    clips = tiles.reshape(B, T, nt, 1, 256, 256).permute(0, 2, 1, 3, 4, 5).reshape(B * nt, T, 1, 256, 256).contiguous()
+    with torch.no_grad():
+        out, _ = model(clips, apply_crop=apply_crop, diffY=diffY, diffX=diffX)
+    out = out.reshape(B, nt, T, 1, 256, 256).permute(0, 2, 1, 3, 4, 5).reshape(B * T * nt, 1, 256, 256).float().contiguous()
+    return blend_tiles(out, B * T, H, W).reshape(B, T, 1, H, W)
