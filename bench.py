@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py — HDR frames/s of the tone-mapping generator on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
+    8 x 1024^2 log-compressed HDR frames -> 25 overlapping 256^2 tiles each (200 tiles) -> generator forward
+    (bf16 MFMA) -> cross-fade back to 8 x 1024^2          [BASELINE.json configs[1]]
+`value` is whole-job frames/s (all ranks); with --gpus N every rank runs its own 8 frames (weak scaling, the
+tiles are independent so there is no data-path collective) and the slowest rank's time is used.
+
+Extra objects on the JSON line:
+  roofline     dense-bf16 MFMA roofline of the dominant kernel (the implicit-GEMM conv of up_path.3.conv.conv,
+               25.6 % of the generator's FLOPs): algorithmic FLOPs per launch / mean launch duration measured
+               with HIP events inside the timed steps.
+  cpu_baseline the CPU oracle (a port, not the reference's own code) timed on this box's host cores on a bounded
+               sample of the same workload (generator forward over 256^2 tiles), reported in the same unit.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GFLOP_PER_TILE = 18.2858            # 2*MAC of the 27 conv layers, one 256^2 tile
+DOM_LAYER = 24                      # packed-weight index of up_path.3.conv.conv
+DOM_GFLOP_PER_TILE = 4.6820         # 64516 x 32 x 1152 x 2
+PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3
+FRAMES, H, W, TILES_PER_FRAME = 8, 1024, 1024, 25
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("UNCL_CHUNK", "0")))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """Oracle generator forward on the host cores, fp32, bounded to ~`seconds` of work."""
+    from oracle.state import generator_state
+    from oracle.generator import unet_image_forward
+    from uncltmo_amd import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = generator_state("g0")
+    x = synth.smooth_hdr_frames(4, salt="cpu")
+    with torch.no_grad():
+        unet_image_forward(sd, x[:1])                      # warm-up
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            unet_image_forward(sd, x)
+            done += x.shape[0]
+        dt = time.perf_counter() - t0
+    tiles_per_s = done / dt
+    return {"value": tiles_per_s / TILES_PER_FRAME, "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "%d 256x256 tile forwards of the fp32 CPU oracle in %.1f s (%.2f tiles/s); "
+                                      "one 1024x1024 frame = 25 tiles" % (done, dt, tiles_per_s)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = world > 1
+    torch.cuda.set_device(local_rank)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from uncltmo_amd import _hip, synth, tiler
+    from uncltmo_amd.generator import UNet
+
+    lib = _hip.lib()
+    assert lib.uncl_device_ok() == 1, "bench needs an MI355X (gfx950)"
+    net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+               "replicate", 2, 0, compute_dtype=a.dtype, chunk=a.chunk)
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().eval()
+    # synthetic frames (seeded, heavy-tailed log-compressed radiance), resident in HBM before timing starts
+    frames = synth.hdr_frames(FRAMES, H, W, salt="bench%d" % rank).cuda()
+
+    def step():
+        return tiler.test_big_size_image2(frames, net, 0, 0, 0)
+
+    for _ in range(a.warmup):
+        step()
+    lib.uncl_prof_enable(DOM_LAYER, 4096)
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    dt = time.perf_counter() - t0
+    # per-launch durations of the dominant kernel, recorded by HIP events on the launch stream during the steps
+    buf = (ctypes.c_float * 4096)()
+    nrec = lib.uncl_prof_read(buf, 4096)
+    lib.uncl_prof_enable(-1, 0)
+    dom_ms = sum(buf[i] for i in range(nrec)) / max(nrec, 1)
+    tiles_per_launch = FRAMES * TILES_PER_FRAME * a.steps / max(nrec, 1)
+    if dist:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        ms = dt / a.steps * 1e3
+        fps = world * FRAMES * a.steps / dt
+        dom_tflops = DOM_GFLOP_PER_TILE * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
+        fwd_tflops = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / ms          # per GPU
+        line = {
+            "metric": "HDR frames/sec (1024x1024 generator forward, tiled)", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "UNet generator forward, batch 8 x 1024x1024 synthetic HDR -> 200 overlap tiles "
+                                   "of 256x256 per GPU, eval mode, random-init weights (BASELINE.json configs[1])",
+                       "frames_per_step_per_gpu": FRAMES, "tiles_per_frame": TILES_PER_FRAME, "chunk": a.chunk,
+                       "parallelism": "frame-parallel x%d, no collective" % world},
+            "roofline": {"bound": "mfma", "achieved": dom_tflops, "peak": peak, "unit": "TFLOP/s",
+                         "frac": dom_tflops / peak, "traffic": None,
+                         "kernel": "conv_igemm_kernel<%s,3,8,1,1> @ up_path.3.conv.conv" % a.dtype,
+                         "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
+                         "gflop_per_tile": DOM_GFLOP_PER_TILE},
+            "forward_mfma": {"achieved": fwd_tflops, "peak": peak, "unit": "TFLOP/s", "frac": fwd_tflops / peak,
+                             "gflop_per_tile": GFLOP_PER_TILE, "note": "whole step incl. tiler, per GPU"},
+        }
+        if world == 1 and not a.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

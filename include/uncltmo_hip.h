@@ -95,6 +95,12 @@ typedef struct uncl_conv_desc {
 
 int uncl_conv_igemm(const uncl_conv_desc* d, void* stream);
 
+/* Pipelined bf16 variant for the 3x3 layers (persistent workgroups, register prefetch, LDS-transposed stores).
+ * Same descriptor (src_mode PLAIN / CONCAT_*, no z_mode, no scale_n); `pool_out`, if not NULL, also receives
+ * maxpool2x2(out) as NHWC (N, Hout/2, Wout/2, Cout) — the MaxPool2d of the next encoder stage
+ * (unet_parts.py:212,233) fused into the producer. */
+int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
+
 /* Re-layout one reference-format weight for uncl_conv_igemm.
  * src: fp32, Conv2d layout (Cout, Cin, k, k) or, if transposed != 0, ConvTranspose2d layout (Cin, Cout, k, k).
  * dst: [tap][Cout][Cin] in dtype; for a transposed stride-1 3x3 the taps are flipped (tap' = 8 - tap) so that
@@ -157,6 +163,12 @@ typedef struct uncl_gen_run {
 } uncl_gen_run;
 
 const char* uncl_gen_layer_name(int i); /* state_dict prefix of packed weight i, NULL past the end */
+
+/* Measurement aid (bench.py roofline leg): record HIP events around every launch of packed-weight layer `layer`
+ * inside uncl_gen_forward, on the stream the kernels run on.  layer < 0 disables.  uncl_prof_read waits for the
+ * recorded launches, writes their durations (ms) to a HOST array, resets the counter and returns how many. */
+int uncl_prof_enable(int layer, int max_records);
+int uncl_prof_read(float* ms_host, int max_n);
 size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep_activations);
 int uncl_gen_forward(const uncl_gen_weights* wts, const uncl_gen_run* run, void* stream);
 

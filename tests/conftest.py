@@ -44,15 +44,8 @@ def golden():
 
 def synth_state(spec, salt):
     """state dict (plain tensors) for a spec from uncltmo_amd.state_spec, via the hash generator."""
-    from uncltmo_amd import synth
-    from oracle.generator import sincos_relative_pos
-    sd = {}
-    for k, shape, kind in spec:
-        if kind == "buffer":
-            sd[k] = sincos_relative_pos()
-        else:
-            sd[k] = synth.synth_tensor(k, shape, salt)
-    return sd
+    from oracle.state import synth_state as _s
+    return _s(spec, salt)
 
 
 def check_summary(t, g, key, rtol=1e-4, atol=1e-5):

@@ -39,6 +39,19 @@ def run_conv(**kw):
     torch.cuda.synchronize()
 
 
+def run_pipe(pool_out=None, **kw):
+    d = _hip.ConvDesc()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(d, k, v)
+    _hip.check(_hip.lib().uncl_conv3x3_pipe(C.byref(d), pool_out.data_ptr() if pool_out is not None else None,
+                                            _hip.stream_ptr()), "uncl_conv3x3_pipe")
+    torch.cuda.synchronize()
+
+
 def rel_l2(a, b):
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hip_util import from_nhwc, pack_weight, rel_l2, run_conv, to_nhwc
+from hip_util import from_nhwc, pack_weight, rel_l2, run_conv, run_pipe, to_nhwc
 from uncltmo_amd import _hip
 
 pytestmark = pytest.mark.gpu
@@ -132,6 +132,58 @@ def test_conv_fused_outc_sigmoid_and_broadcast_residual(code):
              out1_act=_hip.ACT_SIGMOID, out1=out1)
     assert rel_l2(from_nhwc(out), up) < TOL[code]
     assert rel_l2(out1.cpu().unsqueeze(1), ref1) < TOL[code]
+
+
+# ---- pipelined bf16 kernel (the hot one): every mode, ragged sizes, many tiles per workgroup
+BF = _hip.BF16
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(32, 32, 52, 70, 3), (64, 64, 21, 37, 2), (128, 128, 11, 9, 2),
+                                            (32, 64, 40, 33, 1), (256, 256, 12, 12, 5), (32, 32, 256, 256, 2)])
+def test_pipe_valid_with_fused_pool(cin, cout, h, w, n):
+    x, wt, b = q(rnd(n, cin, h, w, seed=31), BF), q(rnd(cout, cin, 3, 3, seed=32, scale=0.1), BF), rnd(cout, seed=33)
+    ref = F.relu(F.conv2d(x, wt, b))
+    out = torch.zeros(n, h - 2, w - 2, cout, dtype=torch.bfloat16, device="cuda")
+    pool = torch.zeros(n, (h - 2) // 2, (w - 2) // 2, cout, dtype=torch.bfloat16, device="cuda")
+    run_pipe(pool_out=pool, dtype=BF, ksize=3, pad=0, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout,
+             src0=to_nhwc(x, BF), src0_H=h, src0_W=w, src0_C=cin, weight=pack_weight(wt, BF), bias=b.cuda(),
+             act=_hip.ACT_RELU, out=out, out_H=h - 2, out_W=w - 2, out_C=cout)
+    assert rel_l2(from_nhwc(out), ref) < TOL[BF]
+    # the pooled copy must be exactly the max-pool of what was stored (bf16 max is a selection)
+    assert torch.equal(from_nhwc(pool), F.max_pool2d(from_nhwc(out), 2))
+
+
+def test_pipe_transposed_concat_ssr_and_tail():
+    c, h, w = 32, 37, 45
+    x2 = q(rnd(2, c, h, w, seed=34).abs(), BF)
+    x1 = q(rnd(2, c, h - 1, w - 1, seed=35), BF)
+    wt, b = q(rnd(4 * c, 32, 3, 3, seed=36, scale=0.05), BF), rnd(32, seed=37)
+    cat = torch.cat([x2, F.pad(x1, (0, 1, 0, 1), mode="replicate"), x2 ** 2, (x2 + 1e-8) ** 0.5], 1)
+    ref = F.relu(F.conv_transpose2d(cat, wt, b))
+    w1, b1 = rnd(1, 32, 1, 1, seed=38), rnd(1, seed=39)
+    out = torch.zeros(2, h + 2, w + 2, 32, dtype=torch.bfloat16, device="cuda")
+    out1 = torch.zeros(2, h + 2, w + 2, dtype=torch.float32, device="cuda")
+    run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR, N=2, H=h, W=w, Cin=4 * c, Cout=32,
+             src0=to_nhwc(x2, BF), src0_H=h, src0_W=w, src0_C=c, src1=to_nhwc(x1, BF), src1_H=h - 1, src1_W=w - 1,
+             src1_C=c, weight=pack_weight(wt, BF, transposed=True, flip=True), bias=b.cuda(), act=_hip.ACT_RELU,
+             out=out, out_H=h + 2, out_W=w + 2, out_C=32, out1_w=w1.reshape(32).cuda(), out1_b=b1.cuda(),
+             out1_act=_hip.ACT_SIGMOID, out1=out1)
+    assert rel_l2(from_nhwc(out), ref) < 2e-2
+    ref1 = torch.sigmoid(F.conv2d(from_nhwc(out), w1, b1))       # the tail reads the stored (bf16) features
+    assert rel_l2(out1.cpu().unsqueeze(1), ref1) < 1e-4
+
+
+def test_pipe_broadcast_residual_and_skip_store():
+    cin, cout, h = 256, 256, 10
+    x, wt, b = q(rnd(3, cin, h, h, seed=40), BF), q(rnd(cin, cout, 3, 3, seed=41, scale=0.05), BF), rnd(cout, seed=42)
+    pe = q(rnd(1, cout, h + 2, h + 2, seed=43), BF)
+    ref = F.relu(F.conv_transpose2d(x, wt, b)) + pe
+    out = torch.zeros(3, h + 2, h + 2, cout, dtype=torch.bfloat16, device="cuda")
+    run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_PLAIN, N=3, H=h, W=h, Cin=cin, Cout=cout,
+             src0=to_nhwc(x, BF), src0_H=h, src0_W=h, src0_C=cin,
+             weight=pack_weight(wt, BF, transposed=True, flip=True), bias=b.cuda(), act=_hip.ACT_RELU,
+             res=to_nhwc(pe, BF), res_batch_stride0=1, out=out, out_H=h + 2, out_W=h + 2, out_C=cout)
+    assert rel_l2(from_nhwc(out), ref) < TOL[BF]
 
 
 def test_bad_arguments_are_refused():

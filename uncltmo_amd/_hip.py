@@ -65,6 +65,7 @@ SIGNATURES = {
     "uncl_version": (C.c_int, []),
     "uncl_device_ok": (C.c_int, []),
     "uncl_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "uncl_conv3x3_pipe": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p]),
     "uncl_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
     "uncl_conv_in_c1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -75,6 +76,8 @@ SIGNATURES = {
     "uncl_gcn_maxrel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
     "uncl_gen_layer_name": (C.c_char_p, [C.c_int]),
+    "uncl_prof_enable": (C.c_int, [C.c_int, C.c_int]),
+    "uncl_prof_read": (C.c_int, [C.c_void_p, C.c_int]),
     "uncl_gen_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "uncl_gen_forward": (C.c_int, [C.POINTER(GenWeights), C.POINTER(GenRun), C.c_void_p]),
     "uncl_tile_count": (C.c_int, [C.c_int, C.c_int]),

@@ -21,7 +21,7 @@ enum Buf {
   B_INC0, B_X0, B_D0A, B_X1, B_D1A, B_X2, B_D2A, B_X3, B_D3A, B_X4,
   B_GFC1, B_GMR, B_GGC, B_GX1, B_FH, B_GOUT,
   B_U0UP, B_U0A, B_U0, B_U1UP, B_U1A, B_U1, B_U2UP, B_U2A, B_U2, B_U3UP, B_U3A, B_UPX,
-  B_KNN, B_COUNT
+  B_KNN, B_X0P, B_X1P, B_X2P, B_X3P, B_COUNT
 };
 
 struct BufDim { int h, w, c; };
@@ -31,7 +31,8 @@ const BufDim kDims[B_COUNT] = {
     {1, 144, 256},  {1, 144, 512},  {1, 144, 512},  {1, 144, 256},  {1, 144, 256}, {1, 144, 256},
     {24, 24, 256},  {26, 26, 128},  {28, 28, 128},  {56, 56, 128},  {59, 59, 64},  {61, 61, 64},
     {122, 122, 64}, {124, 124, 32}, {126, 126, 32}, {252, 252, 32}, {254, 254, 32}, {256, 256, 32},
-    {1, 144, 9}};
+    {1, 144, 9},
+    {126, 126, 32}, {61, 61, 64}, {28, 28, 128}, {12, 12, 256}};
 
 struct Layout {
   size_t off[B_COUNT];
@@ -73,6 +74,25 @@ enum W {
   W_U0UP, W_U0A, W_U0B, W_U1UP, W_U1A, W_U1B, W_U2UP, W_U2A, W_U2B, W_U3UP, W_U3A, W_U3B
 };
 
+// Optional per-layer timing (bench.py's roofline leg): HIP events around every launch of ONE packed-weight
+// layer, on the stream the kernels run on.  Off unless uncl_prof_enable() was called.
+struct Prof {
+  int layer = -1;
+  int cap = 0, count = 0;
+  hipEvent_t* ev = nullptr;  // 2*cap events
+} g_prof;
+
+struct ProfScope {
+  bool on;
+  hipStream_t s;
+  ProfScope(int layer, hipStream_t st) : on(layer == g_prof.layer && g_prof.count < g_prof.cap), s(st) {
+    if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.count], s);
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(g_prof.ev[2 * g_prof.count + 1], s); ++g_prof.count; }
+  }
+};
+
 struct Ctx {
   const uncl_gen_weights* w;
   char* ws;          // workspace base for this chunk's activations
@@ -107,16 +127,29 @@ void set_out(uncl_conv_desc& d, void* p, int b) {
   d.out_H = kDims[b].h; d.out_W = kDims[b].w; d.out_C = kDims[b].c;
 }
 
-// 3x3 conv (valid or full) reading buffer `in` (optionally through a 2x2 max-pool) into buffer `out`
-int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, bool pool, int prev_ch = 0) {
+// bf16 runs the pipelined kernel (producer-side pooling); fp32 the generic one (loader-side pooling)
+inline bool use_pipe(const Ctx& c) { return c.w->dtype == UNCL_BF16; }
+
+int run3(const Ctx& c, int wi, uncl_conv_desc& d, void* pool_out) {
+  ProfScope ps(wi, c.s);
+  if (use_pipe(c)) return uncl_conv3x3_pipe(&d, pool_out, c.s);
+  return uncl_conv_igemm(&d, c.s);
+}
+
+// 3x3 conv (valid or full) reading buffer `in` (through a 2x2 max-pool if `pool`) into buffer `out`;
+// `pooled` >= 0 names the buffer that holds / receives the pooled copy in the bf16 path
+int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, bool pool, int prev_ch = 0,
+          int in_pooled = -1, int out_pooled = -1) {
   uncl_conv_desc d = base_desc(c, wi, 3, pad, cin, cout, c.w->act);
-  set_src0(d, c, in);
-  d.src_mode = pool ? UNCL_SRC_MAXPOOL2 : UNCL_SRC_PLAIN;
+  const bool pipe = use_pipe(c);
+  const int src = (pool && pipe) ? in_pooled : in;
+  set_src0(d, c, src);
+  d.src_mode = (pool && !pipe) ? UNCL_SRC_MAXPOOL2 : UNCL_SRC_PLAIN;
   d.H = pool ? kDims[in].h / 2 : kDims[in].h;
   d.W = pool ? kDims[in].w / 2 : kDims[in].w;
-  if (prev_ch > 0 && c.prev) { d.prev0 = c.pptr(in); d.prev_ch = prev_ch; }
+  if (prev_ch > 0 && c.prev) { d.prev0 = c.pptr(src); d.prev_ch = prev_ch; }
   set_out(d, c.ptr(out), out);
-  return uncl_conv_igemm(&d, c.s);
+  return run3(c, wi, d, (pipe && out_pooled >= 0) ? c.ptr(out_pooled) : nullptr);
 }
 
 // decoder stage: ConvT2x2(s2) of `x1` -> up buffer; concat-ssr(skip, up) -> ConvT3x3 -> ConvT3x3
@@ -132,6 +165,7 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
     if (prev_ch > 0 && c.prev) { d.prev0 = c.pptr(x1); d.prev_ch = prev_ch; }
     d.z_mode = UNCL_Z_UP2X2;
     set_out(d, c.ptr(upbuf), upbuf);
+    ProfScope ps(wi_up, c.s);
     if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
   }
   {
@@ -142,7 +176,7 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
     d.src_mode = UNCL_SRC_CONCAT_SSR;
     d.H = kDims[skip].h; d.W = kDims[skip].w;
     set_out(d, c.ptr(abuf), abuf);
-    if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
+    if ((rc = run3(c, wi_up + 1, d, nullptr)) != UNCL_OK) return rc;
   }
   {
     uncl_conv_desc d = base_desc(c, wi_up + 2, 3, 2, cout, cout, c.w->act);
@@ -154,7 +188,7 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
       d.out1_w = tail->out1_w; d.out1_b = tail->out1_b; d.out1 = tail->out1; d.out1_act = tail->out1_act;
       d.skip_main_store = tail->skip_main_store;
     }
-    if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
+    if ((rc = run3(c, wi_up + 2, d, nullptr)) != UNCL_OK) return rc;
   }
   return UNCL_OK;
 }
@@ -180,14 +214,14 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
 #define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
   // encoder
   RUN(uncl_conv_in_c1(x, w->inc0_w, w->inc0_b, c.ptr(B_INC0), w->dtype, c.n, S_IN, S_IN, 32, w->act, c.s));
-  RUN(conv3(c, W_INC1, B_INC0, B_X0, 32, 32, 0, false));
-  RUN(conv3(c, W_D0A, B_X0, B_D0A, 32, 64, 0, true, 1));
-  RUN(conv3(c, W_D0B, B_D0A, B_X1, 64, 64, 0, false));
-  RUN(conv3(c, W_D1A, B_X1, B_D1A, 64, 128, 0, true, 2));
-  RUN(conv3(c, W_D1B, B_D1A, B_X2, 128, 128, 0, false));
-  RUN(conv3(c, W_D2A, B_X2, B_D2A, 128, 256, 0, true, 4));
-  RUN(conv3(c, W_D2B, B_D2A, B_X3, 256, 256, 0, false));
-  RUN(conv3(c, W_D3A, B_X3, B_D3A, 256, 256, 0, true, 8));
+  RUN(conv3(c, W_INC1, B_INC0, B_X0, 32, 32, 0, false, 0, -1, B_X0P));
+  RUN(conv3(c, W_D0A, B_X0, B_D0A, 32, 64, 0, true, 1, B_X0P));
+  RUN(conv3(c, W_D0B, B_D0A, B_X1, 64, 64, 0, false, 0, -1, B_X1P));
+  RUN(conv3(c, W_D1A, B_X1, B_D1A, 64, 128, 0, true, 2, B_X1P));
+  RUN(conv3(c, W_D1B, B_D1A, B_X2, 128, 128, 0, false, 0, -1, B_X2P));
+  RUN(conv3(c, W_D2A, B_X2, B_D2A, 128, 256, 0, true, 4, B_X2P));
+  RUN(conv3(c, W_D2B, B_D2A, B_X3, 256, 256, 0, false, 0, -1, B_X3P));
+  RUN(conv3(c, W_D3A, B_X3, B_D3A, 256, 256, 0, true, 8, B_X3P));
   {
     // transposed 3x3 back to 12x12, ReLU, then + pos_embed (Unet_singleFrame.py:94) fused as a broadcast residual
     uncl_conv_desc d = base_desc(c, W_D3B, 3, 2, 256, 256, w->act);
@@ -195,7 +229,7 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
     d.H = S_D3A; d.W = S_D3A;
     d.res = w->pos_embed; d.res_batch_stride0 = 1;
     set_out(d, c.ptr(B_X4), B_X4);
-    RUN(uncl_conv_igemm(&d, c.s));
+    RUN(run3(c, W_D3B, d, nullptr));
   }
   // graph block: Grapher (fc1 -> kNN -> max-relative -> grouped 1x1 + GELU -> fc2, residual) then FFN
   RUN(conv1(c, W_GFC1, B_X4, B_GFC1, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
@@ -221,6 +255,29 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
 }
 
 }  // namespace
+
+extern "C" int uncl_prof_enable(int layer, int max_records) {
+  for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+  delete[] g_prof.ev;
+  g_prof = Prof();
+  if (layer < 0 || max_records <= 0) return UNCL_OK;
+  g_prof.ev = new hipEvent_t[2 * max_records];
+  for (int i = 0; i < 2 * max_records; ++i)
+    if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return UNCL_ERR_LAUNCH;
+  g_prof.layer = layer;
+  g_prof.cap = max_records;
+  return UNCL_OK;
+}
+
+extern "C" int uncl_prof_read(float* ms_host, int max_n) {
+  int n = g_prof.count < max_n ? g_prof.count : max_n;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return UNCL_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms_host[i], g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return UNCL_ERR_LAUNCH;
+  }
+  g_prof.count = 0;
+  return n;
+}
 
 extern "C" const char* uncl_gen_layer_name(int i) {
   if (i < 0 || i >= UNCL_G_NUM_WEIGHTS) return nullptr;
