@@ -3,10 +3,12 @@
 // Same GEMM orientation and LDS images as conv_igemm.hip (D[cout][pixel] = W[cout][k] X[k][pixel], 64-byte
 // K-chunks, XOR-swizzled 16-byte slots) with three structural changes that matter on MI355X:
 //
-//  * persistent workgroups + register prefetch: a workgroup walks a list of (tile, K-chunk) steps; the global
-//    loads of step s+1 are issued before the MFMAs of step s and land in VGPRs while the matrix pipe is busy,
-//    then are written to the single LDS buffer after a barrier (HBM/L2 latency hides under MFMA, two
-//    workgroups per CU cover the LDS write / barrier bubbles);
+//  * persistent workgroups + register prefetch: a workgroup walks a contiguous range of tiles, each a list of
+//    K-chunk steps; the global loads of step s+1 are issued before the MFMAs of step s and land in VGPRs while
+//    the matrix pipe is busy, then are written to the single LDS buffer after a barrier (HBM/L2 latency hides
+//    under MFMA; two workgroups per CU cover the LDS-write / barrier bubbles).  All per-slot addressing is
+//    precomputed once (32-bit offsets from a wave-uniform sample base), loads are unconditional (clamped, then
+//    masked) so the compiler can issue them back to back;
 //  * sliding-window fragment reuse: a wave owns MPW consecutive output rows, so the activation fragment of
 //    input row r serves output rows r, r-1, r-2 for the three vertical taps: (MPW+2)*3*2 instead of MPW*9*2
 //    LDS reads per chunk;
@@ -19,198 +21,251 @@
 namespace {
 
 struct PipeArgs {
-  const void* src0;
-  const void* src1;
-  const void* prev0;
-  const void* weight;
+  const bf16_t* src0;
+  const bf16_t* src1;
+  const bf16_t* prev0;
+  const bf16_t* weight;
   const float* bias;
-  const void* res;
-  void* out;
-  void* pool_out;
+  const bf16_t* res;
+  bf16_t* out;
+  bf16_t* pool_out;
   const float* out1_w;
   const float* out1_b;
   float* out1;
-  int N, H, W, Cin, Cout, pad, src_mode;
+  int H, W, Cin, Cout, pad;
   int s0H, s0W, s0C, s1H, s1W, s1C, prev_ch;
-  int act, res_b0;
+  float slope;  // activation as max(t,0) + slope*min(t,0): 0 relu, 0.2 leaky, 1 identity
+  int res_b0;
   int Hout, Wout, oC;
-  int pH, pW;  // pooled output extent (floor(Hout/2), floor(Wout/2))
-  int tiles_x, tiles_y, n_ct, total_tiles, nk;
+  int pH, pW;
+  int tiles_x, tiles_y, n_ct, total_tiles, tiles_per_wg, nk;
   int out1_act, skip_main;
 };
 
-struct Step {
-  int n, y0, x0, cout0, kc;
-};
+__device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-template <typename T>
-__device__ __forceinline__ typename Elem<T>::vec ldv(const void* base, size_t elem_off) {
-  return *reinterpret_cast<const typename Elem<T>::vec*>(reinterpret_cast<const T*>(base) + elem_off);
-}
-
-__device__ __forceinline__ f32x16 mma_bf16(const bf16x8& a, const bf16x8& b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-template <int NT, int MPW, int WAVES>
+// MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1]
+template <int NT, int MPW, int WAVES, int MODE, bool PREV>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeArgs a) {
-  using T = bf16_t;
-  using E = Elem<T>;
-  using vec = E::vec;
-  constexpr int KC = E::KC, EPV = E::EPV;
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  static_assert(WAVES == 4, "staging pattern below is written for 256 threads");
   constexpr int NTHR = WAVES * 64;
   constexpr int TH = MPW * WAVES, TW = 32;
   constexpr int HH = TH + 2, HW = TW + 2;
   constexpr int NPIX = HH * HW;
   constexpr int CT = NT * 32;
-  constexpr int XV = (NPIX * 4 + NTHR - 1) / NTHR;     // 16-byte vectors of the input tile per thread
-  constexpr int WVN = (9 * CT * 4 + NTHR - 1) / NTHR;  // ... of the weight chunk per thread
-  constexpr int SLOTS = CT / 8;                        // 16-byte slots per output pixel
-  static_assert(TH * TW * CT * 2 <= NPIX * 64 + 9 * CT * 64, "epilogue image must fit in the staging LDS");
+  static_assert(HH % 2 == 0, "two halo rows per staging pass");
+  constexpr int RS = HH / 2;   // regular slots: 32 columns x 2 rows x 4 vectors per pass
+  constexpr int XV = RS + 1;   // + one slot for the two extra halo columns
+  constexpr int WROWS = 9 * CT;
+  constexpr int WVN = (WROWS + 63) / 64;
+  constexpr bool W_RAGGED = WROWS % 64 != 0;
+  constexpr int SLOTS = CT / 8;
+  static_assert(TH * TW * CT * 2 <= NPIX * 64 + WROWS * 64, "epilogue image must fit in the staging LDS");
+  constexpr bool W_CLOBBERED = TH * TW * CT * 2 > NPIX * 64;  // epilogue image reaches into sW
+  constexpr int ST_IT = (TH * TW * SLOTS) / NTHR;             // main-store passes
+  constexpr int ROWS_PER_IT = NTHR / (TW * SLOTS);            // output rows covered per pass
+  static_assert(ROWS_PER_IT * TW * SLOTS == NTHR, "store pass must cover whole rows");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
   char* sW = smem + NPIX * 64;
-  char* sO = smem;  // epilogue image [TH*TW][CT] bf16, reuses the staging area
+  char* sO = smem;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
 
-  const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  if (my_tiles <= 0) return;
-  const int nsteps = my_tiles * a.nk;
-  // weights stay in LDS across tiles when there is one K-chunk, one Cout tile, and the epilogue image does not
-  // reach into sW
-  const bool w_static = (a.nk == 1 && a.n_ct == 1) && (TH * TW * CT * 2 <= NPIX * 64);
+  int tile = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile + a.tiles_per_wg, a.total_tiles);
+  if (tile >= tile_end) return;
+  const bool w_static = (a.nk == 1 && a.n_ct == 1) && !W_CLOBBERED;
 
-  auto decode = [&](int s) {
-    Step st;
-    const int ti = (int)blockIdx.x + (s / a.nk) * (int)gridDim.x;
-    st.kc = s - (s / a.nk) * a.nk;
-    int r = ti;
-    const int ct = r % a.n_ct; r /= a.n_ct;
-    const int tx = r % a.tiles_x; r /= a.tiles_x;
-    const int ty = r % a.tiles_y; r /= a.tiles_y;
-    st.n = r;
-    st.y0 = ty * TH;
-    st.x0 = tx * TW;
-    st.cout0 = ct * CT;
-    return st;
-  };
+  // ---- per-thread constants of the staging pattern (identical for every step)
+  // regular slot j: halo pixel (hy0 + 2j, hx), vector ch; extra slot: halo pixel (ey, 32 + ec), vector ch
+  const int ch = tid & 3, p0 = tid >> 2;
+  const int hx = p0 & 31, hy0 = p0 >> 5;
+  const int ey = tid >> 3, ec = (tid >> 2) & 1;
+  const bool e_on = tid < HH * 8;
+  const int row_el = a.s0W * a.s0C;                          // elements per source row
+  const int xoff_r = (hy0 * a.s0W + hx) * a.s0C + ch * 8;    // + j * 2 * row_el
+  const int xoff_e = (ey * a.s0W + 32 + ec) * a.s0C + ch * 8;
+  const int pix_r0 = hy0 * HW + hx;                          // + j * 2 * HW
+  const int pix_e = ey * HW + 32 + ec;
+  const int lds_w0 = p0 * 64 + ((ch ^ ((p0 >> 2) & 3)) << 4);  // + j * 4096
+  const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;  // + j * (64 / CT) * Cout * Cin
+
+  // ---- tile cursor (contiguous range per workgroup, carried without divisions)
+  int t_ct, t_tx, t_ty, t_n;
+  {
+    int r = tile;
+    t_ct = r % a.n_ct; r /= a.n_ct;
+    t_tx = r % a.tiles_x; r /= a.tiles_x;
+    t_ty = r % a.tiles_y; r /= a.tiles_y;
+    t_n = r;
+  }
+  int c_n = t_n, c_y0 = t_ty * TH, c_x0 = t_tx * TW, c_co = t_ct * CT, c_kc = 0;
+  int n_n = 0, n_y0 = 0, n_x0 = 0, n_co = 0, n_kc = 0;
 
   vec xr[XV];
   vec wr[WVN];
   unsigned xvalid = 0;
   int g_pending = 0;
 
-  // issue the global loads of one step into registers
-  auto load_regs = [&](const Step& st, bool with_w) {
-    const int c_log0 = st.kc * KC;
-    int g = 0, cbase = c_log0;
-    if (a.src_mode != UNCL_SRC_PLAIN) {
-      g = c_log0 / a.s0C;
-      cbase = c_log0 - g * a.s0C;
+  auto load_regs = [&](int n, int y0, int x0, int cout0, int kc, bool with_w) {
+    int g = 0, cbase = kc * 32;
+    if (MODE != 0) {
+      g = cbase / a.s0C;
+      cbase -= g * a.s0C;
     }
     g_pending = g;
-    xvalid = 0;
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    if (MODE != 0 && g == 1) {
+      // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
+      const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
+      const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
+      unsigned valid = 0;
+      const int ix = ix0 + hx;
+      const bool xok = (unsigned)ix < (unsigned)a.W;
+      const int sx = min(max(ix - dx, 0), a.s1W - 1);
 #pragma unroll
-    for (int j = 0; j < XV; ++j) {
-      const int idx = tid + j * NTHR;
-      xr[j] = E::zero();
-      if (idx < NPIX * 4) {
-        const int pix = idx >> 2, ch = idx & 3;
-        const int hy = pix / HW, hx = pix - hy * HW;
-        const int iy = st.y0 + hy - a.pad, ix = st.x0 + hx - a.pad;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-          xvalid |= 1u << j;
-          const int c = cbase + ch * EPV;
-          if (g == 1) {
-            const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
-            const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
-            xr[j] = ldv<T>(a.src1, (((size_t)st.n * a.s1H + sy) * a.s1W + sx) * a.s1C + c);
+      for (int j = 0; j < RS; ++j) {
+        const int iy = iy0 + hy0 + 2 * j;
+        const bool ok = xok && (unsigned)iy < (unsigned)a.H;
+        const int sy = min(max(iy - dy, 0), a.s1H - 1);
+        valid |= (ok ? 1u : 0u) << j;
+        xr[j] = ld16(base + (unsigned)((sy * a.s1W + sx) * a.s1C));
+      }
+      {
+        const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
+        const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
+        const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
+        valid |= (ok ? 1u : 0u) << RS;
+        xr[RS] = ld16(base + (unsigned)((sy * a.s1W + sxe) * a.s1C));
+      }
+      xvalid = valid;
+    } else {
+      const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
+      if (interior && !PREV) {
+        // the whole halo tile is inside the image: one scalar base, a constant stride between slots
+        const bf16_t* base = a.src0 + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
+#pragma unroll
+        for (int j = 0; j < RS; ++j) xr[j] = ld16(base + (unsigned)(xoff_r + j * 2 * row_el));
+        xr[RS] = ld16(base + (unsigned)(e_on ? xoff_e : 0));
+        xvalid = 0xffffffffu;
+      } else {
+        const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+        const int toff = (iy0 * a.s0W + ix0) * a.s0C;  // may be negative on the border; masked below
+        unsigned valid = 0;
+        const bool xok = (unsigned)(ix0 + hx) < (unsigned)a.W;
+#pragma unroll
+        for (int j = 0; j <= RS; ++j) {
+          bool ok;
+          int eoff;
+          if (j < RS) {
+            ok = xok && (unsigned)(iy0 + hy0 + 2 * j) < (unsigned)a.H;
+            eoff = xoff_r + j * 2 * row_el;
           } else {
-            const size_t off = (((size_t)st.n * a.s0H + iy) * a.s0W + ix) * a.s0C + c;
-            vec v = ldv<T>(a.src0, off);
-            if (a.prev0 != nullptr && c < a.prev_ch) {
-              const vec p = ldv<T>(a.prev0, off);
+            ok = e_on && (unsigned)(iy0 + ey) < (unsigned)a.H && (unsigned)(ix0 + 32 + ec) < (unsigned)a.W;
+            eoff = xoff_e;
+          }
+          valid |= (ok ? 1u : 0u) << j;
+          const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
+          xr[j] = ld16(base + off);
+          if (PREV) {
+            const int c = cbase + ch * 8;
+            if (c < a.prev_ch) {
+              const vec p = ld16(a.prev0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase + off);
 #pragma unroll
-              for (int i = 0; i < EPV; ++i)
-                if (c + i < a.prev_ch) v[i] = p[i];
+              for (int i = 0; i < 8; ++i)
+                if (c + i < a.prev_ch) xr[j][i] = p[i];
             }
-            xr[j] = v;
           }
         }
+        xvalid = valid;
       }
     }
     if (with_w) {
+      const bf16_t* wb = a.weight + (size_t)cout0 * a.Cin + kc * 32;
+      const int wstride = (64 / CT) * a.Cout * a.Cin;  // CT = 32: two taps per pass, CT = 64: one
 #pragma unroll
       for (int j = 0; j < WVN; ++j) {
-        const int idx = tid + j * NTHR;
-        if (idx < 9 * CT * 4) {
-          const int row = idx >> 2, ch = idx & 3;
-          const int tap = row / CT, co = row - tap * CT;
-          wr[j] = ldv<T>(a.weight, ((size_t)(tap * a.Cout + st.cout0 + co)) * a.Cin + st.kc * KC + ch * EPV);
-        }
+        unsigned off = (unsigned)(woff0 + j * wstride);
+        if (W_RAGGED && j == WVN - 1) off = (p0 + 64 * j < WROWS) ? off : 0u;
+        wr[j] = ld16(wb + off);
       }
     }
   };
 
-  // registers -> LDS (applying the concat operator's x^2 / sqrt(x + 1e-8) on the way)
   auto write_lds = [&](bool with_w) {
+    const bool all_ok = xvalid == 0xffffffffu;  // wave-uniform in practice (interior tiles)
 #pragma unroll
-    for (int j = 0; j < XV; ++j) {
-      const int idx = tid + j * NTHR;
-      if (idx < NPIX * 4) {
-        const int pix = idx >> 2, ch = idx & 3;
-        vec v = xr[j];
-        if (a.src_mode == UNCL_SRC_CONCAT_SSR && g_pending >= 2 && ((xvalid >> j) & 1u)) {
-          float f[EPV];
-          E::unpack(v, f);
-          if (g_pending == 2) {
+    for (int j = 0; j <= RS; ++j) {
+      if (j == RS && !e_on) continue;
+      vec v = xr[j];
+      if (MODE == 1 && g_pending >= 2) {
+        float f[8];
+        E::unpack(v, f);
+        if (g_pending == 2) {
 #pragma unroll
-            for (int i = 0; i < EPV; ++i) f[i] = f[i] * f[i];
-          } else {
+          for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
+        } else {
 #pragma unroll
-            for (int i = 0; i < EPV; ++i) f[i] = sqrtf(f[i] + 1e-8f);
-          }
-          v = E::pack(f);
+          for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f);
         }
-        *reinterpret_cast<vec*>(sX + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = v;
+        v = E::pack(f);
       }
+      if (!all_ok && !((xvalid >> j) & 1u)) v = E::zero();
+      const int pix = j < RS ? pix_r0 + j * 2 * HW : pix_e;
+      *reinterpret_cast<vec*>(sX + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = v;
     }
     if (with_w) {
 #pragma unroll
       for (int j = 0; j < WVN; ++j) {
-        const int idx = tid + j * NTHR;
-        if (idx < 9 * CT * 4) {
-          const int row = idx >> 2, ch = idx & 3;
-          *reinterpret_cast<vec*>(sW + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4)) = wr[j];
-        }
+        if (W_RAGGED && j == WVN - 1 && p0 + 64 * j >= WROWS) continue;
+        *reinterpret_cast<vec*>(sW + lds_w0 + j * 4096) = wr[j];
       }
     }
+  };
+
+  // advance the (tile, kc) cursor by one step; returns false past the end of this workgroup's range
+  auto advance = [&]() {
+    n_n = c_n; n_y0 = c_y0; n_x0 = c_x0; n_co = c_co; n_kc = c_kc + 1;
+    if (n_kc < a.nk) return true;
+    n_kc = 0;
+    if (++tile >= tile_end) return false;
+    if (++t_ct == a.n_ct) {
+      t_ct = 0;
+      if (++t_tx == a.tiles_x) {
+        t_tx = 0;
+        if (++t_ty == a.tiles_y) { t_ty = 0; ++t_n; }
+      }
+    }
+    n_n = t_n; n_y0 = t_ty * TH; n_x0 = t_tx * TW; n_co = t_ct * CT;
+    return true;
   };
 
   f32x16 acc[MPW][NT];
+  f32x16 zero16;
 #pragma unroll
-  for (int m = 0; m < MPW; ++m)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][nt][i] = 0.f;
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
 
-  Step cur = decode(0);
-  load_regs(cur, true);
+  // epilogue addressing that does not change between tiles
+  const int sw_e = (lr >> 1) & (SLOTS - 1);                            // swizzle of this lane's pixel column
+  const int eo_base = (wave * MPW * TW + lr) * (CT * 2) + (lh << 3);   // + m*TW*CT*2 + ((slot ^ sw_e) << 4)
+  const int st_pl = tid / SLOTS, st_sl = tid - st_pl * SLOTS;          // main store: pixel / slot of pass 0
+  const int st_row = st_pl / TW, st_col = st_pl - st_row * TW;
+  const int st_lds = st_pl * (CT * 2) + ((st_sl ^ ((st_pl >> 1) & (SLOTS - 1))) << 4);
+
+  load_regs(c_n, c_y0, c_x0, c_co, c_kc, true);
   write_lds(true);
   __syncthreads();
 
-  for (int s = 0; s < nsteps; ++s) {
-    const bool has_next = (s + 1 < nsteps);
-    Step nxt = cur;
-    if (has_next) {
-      nxt = decode(s + 1);
-      load_regs(nxt, !w_static);
-    }
+  bool more = true;
+  while (more) {
+    more = advance();
+    if (more) load_regs(n_n, n_y0, n_x0, n_co, n_kc, !w_static);
     // ---- MFMA phase over the staged chunk
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -230,70 +285,101 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
           const int pix = (wave * MPW + r) * HW + lr + tx;
           B[r] = *reinterpret_cast<const vec*>(sX + pix * 64 + ((chunk ^ ((pix >> 2) & 3)) << 4));
         }
+        if (ks == 0 && tx == 0) {
+          // first tap of the chunk: on the first chunk of a tile the accumulation starts from zero (inline C = 0)
+          if (c_kc == 0) {
 #pragma unroll
-        for (int m = 0; m < MPW; ++m)
+            for (int m = 0; m < MPW; ++m)
 #pragma unroll
-          for (int ty = 0; ty < 3; ++ty)
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][nt], B[m], zero16, 0, 0, 0);
+          } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma_bf16(A[ty][nt], B[m + ty], acc[m][nt]);
+            for (int m = 0; m < MPW; ++m)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][nt], B[m], acc[m][nt], 0, 0, 0);
+          }
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 1; ty < 3; ++ty)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ty][nt], B[m + ty], acc[m][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ty][nt], B[m + ty], acc[m][nt], 0, 0, 0);
+        }
       }
     }
     // ---- tile finished: epilogue through LDS
-    if (cur.kc == a.nk - 1) {
+    if (c_kc == a.nk - 1) {
       __syncthreads();  // every wave is done reading sX / sW
 #pragma unroll
-      for (int m = 0; m < MPW; ++m) {
-        const int prow = wave * MPW + m;
-        const int pl = prow * TW + lr;  // pixel index inside the tile
-        const int oy = cur.y0 + prow, ox = cur.x0 + lr;
+      for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c_co + nt * 32 + 8 * q + 4 * lh)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cl = nt * 32 + 8 * q + 4 * lh;  // channel inside the CT tile
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float t = acc[m][nt][4 * q + r];
-              if (a.bias != nullptr) t += a.bias[cur.cout0 + cl + r];
-              v[r] = uncl_act(t, a.act);
-              acc[m][nt][4 * q + r] = 0.f;
-            }
-            if (a.res != nullptr && oy < a.Hout && ox < a.Wout) {
-              const size_t rp = (a.res_b0 ? 0 : (size_t)cur.n * a.Hout * a.Wout) + (size_t)oy * a.Wout + ox;
-              const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const T*>(a.res) + rp * a.oC +
-                                                                 cur.cout0 + cl);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
+          for (int m = 0; m < MPW; ++m) {
             bf16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-            const int slot = (cl >> 3) ^ ((pl >> 1) & (SLOTS - 1));
-            *reinterpret_cast<bf16x4*>(sO + pl * (CT * 2) + slot * 16 + (lh << 3)) = o;
+            for (int r = 0; r < 4; ++r) {
+              const float t = acc[m][nt][4 * q + r] + b[r];
+              o[r] = (bf16_t)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+            }
+            *reinterpret_cast<bf16x4*>(sO + eo_base + m * (TW * CT * 2) + (((nt * 4 + q) ^ sw_e) << 4)) = o;
           }
         }
       }
       __syncthreads();
-      // main NHWC store: consecutive threads -> consecutive 16-byte slots -> 1 KiB per wave instruction
       if (!a.skip_main) {
-        for (int v = tid; v < TH * TW * SLOTS; v += NTHR) {
-          const int pl = v / SLOTS, sl = v - pl * SLOTS;
-          const int prow = pl / TW, pcol = pl - prow * TW;
-          const int oy = cur.y0 + prow, ox = cur.x0 + pcol;
-          if (oy < a.Hout && ox < a.Wout) {
-            const vec val = *reinterpret_cast<const vec*>(sO + pl * (CT * 2) + ((sl ^ ((pl >> 1) & (SLOTS - 1))) << 4));
-            *reinterpret_cast<vec*>(reinterpret_cast<T*>(a.out) +
-                                    (((size_t)cur.n * a.Hout + oy) * a.Wout + ox) * a.oC + cur.cout0 + sl * 8) = val;
+        const int ox = c_x0 + st_col;
+        if (ox < a.Wout) {
+          const size_t pix0 = (size_t)(c_y0 + st_row) * a.Wout + ox;
+          bf16_t* ob = a.out + ((size_t)c_n * a.Hout * a.Wout + pix0) * a.oC + c_co + st_sl * 8;
+          const int rows_left = a.Hout - (c_y0 + st_row);  // passes with it*ROWS_PER_IT < rows_left are in range
+          const unsigned row_stride = (unsigned)(ROWS_PER_IT * a.Wout * a.oC);
+          if (a.res == nullptr) {
+#pragma unroll
+            for (int it = 0; it < ST_IT; ++it) {
+              if (it * ROWS_PER_IT < rows_left) {
+                const vec val = *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2));
+                *reinterpret_cast<vec*>(ob + it * row_stride) = val;
+              }
+            }
+          } else {
+            // residual (pos_embed, Unet_singleFrame.py:94) is added to the stored bf16 features in fp32
+            const bf16_t* rb = a.res + ((a.res_b0 ? 0 : (size_t)c_n * a.Hout * a.Wout) + pix0) * a.oC + c_co + st_sl * 8;
+#pragma unroll
+            for (int it = 0; it < ST_IT; ++it) {
+              if (it * ROWS_PER_IT < rows_left) {
+                const vec val = *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2));
+                const vec rv = ld16(rb + it * row_stride);
+                float f[8], g[8];
+                E::unpack(val, f);
+                E::unpack(rv, g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] += g[i];
+                *reinterpret_cast<vec*>(ob + it * row_stride) = E::pack(f);
+              }
+            }
           }
         }
       }
-      // fused 2x2 max-pool copy for the next encoder stage
       if (a.pool_out != nullptr) {
+        bf16_t* pb = a.pool_out + (size_t)c_n * a.pH * a.pW * a.oC + c_co;
         for (int v = tid; v < (TH / 2) * (TW / 2) * SLOTS; v += NTHR) {
           const int pp = v / SLOTS, sl = v - pp * SLOTS;
           const int py = pp / (TW / 2), px = pp - py * (TW / 2);
-          const int gy = (cur.y0 >> 1) + py, gx = (cur.x0 >> 1) + px;
+          const int gy = (c_y0 >> 1) + py, gx = (c_x0 >> 1) + px;
           if (gy < a.pH && gx < a.pW) {
             float m[8];
 #pragma unroll
@@ -305,16 +391,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
 #pragma unroll
               for (int i = 0; i < 8; ++i) m[i] = qd == 0 ? f[i] : fmaxf(m[i], f[i]);
             }
-            *reinterpret_cast<vec*>(reinterpret_cast<T*>(a.pool_out) +
-                                    (((size_t)cur.n * a.pH + gy) * a.pW + gx) * a.oC + cur.cout0 + sl * 8) = E::pack(m);
+            *reinterpret_cast<vec*>(pb + (unsigned)((gy * a.pW + gx) * a.oC + sl * 8)) = E::pack(m);
           }
         }
       }
-      // fused trailing 1x1 -> one channel (+ sigmoid)
       if (a.out1_w != nullptr) {
         for (int pl = tid; pl < TH * TW; pl += NTHR) {
           const int prow = pl / TW, pcol = pl - prow * TW;
-          const int oy = cur.y0 + prow, ox = cur.x0 + pcol;
+          const int oy = c_y0 + prow, ox = c_x0 + pcol;
           if (oy < a.Hout && ox < a.Wout) {
             float sum = a.out1_b[0];
 #pragma unroll
@@ -325,25 +409,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
 #pragma unroll
               for (int i = 0; i < 8; ++i) sum = fmaf(f[i], a.out1_w[sl * 8 + i], sum);
             }
-            a.out1[((size_t)cur.n * a.Hout + oy) * a.Wout + ox] = uncl_act(sum, a.out1_act);
+            a.out1[((size_t)c_n * a.Hout + oy) * a.Wout + ox] = uncl_act(sum, a.out1_act);
           }
         }
       }
     }
     __syncthreads();
-    if (has_next) {
+    if (more) {
       write_lds(!w_static);
       __syncthreads();
-      cur = nxt;
+      c_n = n_n; c_y0 = n_y0; c_x0 = n_x0; c_co = n_co; c_kc = n_kc;
     }
   }
 }
 
-template <int NT, int MPW, int WAVES>
-int launch_pipe(const PipeArgs& a, hipStream_t s) {
+template <int NT, int MPW, int WAVES, int MODE, bool PREV>
+int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
   constexpr size_t lds = (size_t)(TH + 2) * 34 * 64 + (size_t)9 * NT * 32 * 64;
-  auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES>;
+  auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV>;
   static bool attr_done = false;
   static int max_blocks = 0;
   if (!attr_done) {
@@ -354,6 +438,7 @@ int launch_pipe(const PipeArgs& a, hipStream_t s) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WAVES * 64, lds) !=
             hipSuccess || per_cu <= 0)
       per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
     hipDeviceProp_t p;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -361,10 +446,19 @@ int launch_pipe(const PipeArgs& a, hipStream_t s) {
     max_blocks = per_cu * p.multiProcessorCount;
     attr_done = true;
   }
-  const int grid = a.total_tiles < max_blocks ? a.total_tiles : max_blocks;
+  int grid = a.total_tiles < max_blocks ? a.total_tiles : max_blocks;
+  a.tiles_per_wg = (a.total_tiles + grid - 1) / grid;
+  grid = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
+}
+
+template <int NT, int MPW>
+int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
+  if (mode == UNCL_SRC_PLAIN) return prev ? launch_pipe<NT, MPW, 4, 0, true>(a, s) : launch_pipe<NT, MPW, 4, 0, false>(a, s);
+  if (mode == UNCL_SRC_CONCAT_SSR) return launch_pipe<NT, MPW, 4, 1, false>(a, s);
+  return launch_pipe<NT, MPW, 4, 2, false>(a, s);
 }
 
 }  // namespace
@@ -377,40 +471,46 @@ extern "C" int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* 
   if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_CONCAT2) return UNCL_ERR_ARG;
   if (d->Cin <= 0 || d->Cin % 32 != 0 || d->Cout <= 0 || d->Cout % 32 != 0) return UNCL_ERR_ARG;
   if (d->z_mode != UNCL_Z_NONE || d->scale_n != nullptr) return UNCL_ERR_ARG;
+  if (d->act != UNCL_ACT_NONE && d->act != UNCL_ACT_RELU && d->act != UNCL_ACT_LRELU) return UNCL_ERR_ARG;
   if (d->src0 == nullptr || d->weight == nullptr) return UNCL_ERR_ARG;
   if (d->out == nullptr && !(d->skip_main_store && d->out1 != nullptr)) return UNCL_ERR_ARG;
   if (d->src_mode != UNCL_SRC_PLAIN) {
-    if (d->src1 == nullptr || d->src0_C != d->src1_C || d->src0_C % 32 != 0) return UNCL_ERR_ARG;
+    if (d->src1 == nullptr || d->src0_C != d->src1_C || d->src0_C % 32 != 0 || d->prev0 != nullptr) return UNCL_ERR_ARG;
     const int groups = d->src_mode == UNCL_SRC_CONCAT_SSR ? 4 : 2;
     if (d->Cin != groups * d->src0_C) return UNCL_ERR_ARG;
     if (d->src1_H > d->src0_H || d->src1_W > d->src0_W) return UNCL_ERR_ARG;
   }
   if (d->out1_w != nullptr && (d->Cout != 32 || d->out1 == nullptr)) return UNCL_ERR_ARG;
+  // 32-bit element offsets inside one sample
+  if ((long long)d->src0_H * d->src0_W * d->src0_C >= (1LL << 31)) return UNCL_ERR_ARG;
   PipeArgs a;
-  a.src0 = d->src0; a.src1 = d->src1; a.prev0 = d->prev0; a.weight = d->weight; a.bias = d->bias; a.res = d->res;
-  a.out = d->out; a.pool_out = pool_out; a.out1_w = d->out1_w; a.out1_b = d->out1_b; a.out1 = d->out1;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.pad = d->pad; a.src_mode = d->src_mode;
+  a.src0 = (const bf16_t*)d->src0; a.src1 = (const bf16_t*)d->src1; a.prev0 = (const bf16_t*)d->prev0;
+  a.weight = (const bf16_t*)d->weight; a.bias = d->bias; a.res = (const bf16_t*)d->res;
+  a.out = (bf16_t*)d->out; a.pool_out = (bf16_t*)pool_out; a.out1_w = d->out1_w; a.out1_b = d->out1_b; a.out1 = d->out1;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.pad = d->pad;
   a.s0H = d->src0_H; a.s0W = d->src0_W; a.s0C = d->src0_C;
   a.s1H = d->src1_H; a.s1W = d->src1_W; a.s1C = d->src1_C; a.prev_ch = d->prev_ch;
-  a.act = d->act; a.res_b0 = d->res_batch_stride0;
+  a.slope = d->act == UNCL_ACT_RELU ? 0.f : (d->act == UNCL_ACT_LRELU ? 0.2f : 1.f);
+  a.res_b0 = d->res_batch_stride0;
   a.Hout = d->H + 2 * d->pad - 2; a.Wout = d->W + 2 * d->pad - 2; a.oC = d->out_C;
   if (a.Hout <= 0 || a.Wout <= 0) return UNCL_ERR_ARG;
   if (d->out != nullptr && (d->out_H != a.Hout || d->out_W != a.Wout)) return UNCL_ERR_ARG;
   a.pH = a.Hout / 2; a.pW = a.Wout / 2;
   a.out1_act = d->out1_act; a.skip_main = d->skip_main_store;
   a.nk = d->Cin / 32;
+  const bool prev = d->prev0 != nullptr && d->prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->Cout == 32) {
     constexpr int TH = 16;
     a.n_ct = 1;
     a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
     a.total_tiles = d->N * a.tiles_x * a.tiles_y;
-    return launch_pipe<1, 4, 4>(a, s);
+    return dispatch_mode<1, 4>(a, d->src_mode, prev, s);
   }
   if (d->Cout % 64 != 0) return UNCL_ERR_ARG;
   constexpr int TH = 8;
   a.n_ct = d->Cout / 64;
   a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
   a.total_tiles = d->N * a.tiles_x * a.tiles_y * a.n_ct;
-  return launch_pipe<2, 2, 4>(a, s);
+  return dispatch_mode<2, 2>(a, d->src_mode, prev, s);
 }
