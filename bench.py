@@ -52,7 +52,9 @@ def cpu_baseline(seconds):
     from oracle.state import generator_state
     from oracle.generator import unet_image_forward
     from uncltmo_amd import synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    # one thread per physical core of one socket at most: oversubscribing the small convolutions with every SMT
+    # thread of the box (256 on the MI355X hosts) is >50x slower than 64 threads
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("UNCL_CPU_THREADS", "64"))))
     sd = generator_state("g0")
     x = synth.smooth_hdr_frames(4, salt="cpu")
     with torch.no_grad():
@@ -134,7 +136,8 @@ def main():
                        "parallelism": "frame-parallel x%d, no collective" % world},
             "roofline": {"bound": "mfma", "achieved": dom_tflops, "peak": peak, "unit": "TFLOP/s",
                          "frac": dom_tflops / peak, "traffic": None,
-                         "kernel": "conv_igemm_kernel<%s,3,8,1,1> @ up_path.3.conv.conv" % a.dtype,
+                         "kernel": ("conv3x3_pipe_kernel<1,4,4,1,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
+                                   + " @ up_path.3.conv.conv",
                          "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
                          "gflop_per_tile": DOM_GFLOP_PER_TILE},
             "forward_mfma": {"achieved": fwd_tflops, "peak": peak, "unit": "TFLOP/s", "frac": fwd_tflops / peak,

@@ -101,6 +101,13 @@ int uncl_conv_igemm(const uncl_conv_desc* d, void* stream);
  * (unet_parts.py:212,233) fused into the producer. */
 int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
 
+/* ConvTranspose2d(k2, s2) + bias, bf16, HBM-bound layout (whole output-row runs per store).
+ * Replaces `self.up(x1)` in up.forward (unet_parts.py:269,288).  x: NHWC (N,H,W,C); w: packed [4][Cout][C]
+ * (uncl_pack_conv_weight with transposed=1, flip=0); out: NHWC (N,2H,2W,Cout).  `prev`/`prev_ch`: the video
+ * generator's channel hand-off (Unet.py:270), NULL/0 otherwise. */
+int uncl_upconv2x2(const void* x, const void* prev, int prev_ch, const void* w, const float* bias, void* out, int N,
+                   int H, int W, int C, int Cout, void* stream);
+
 /* Re-layout one reference-format weight for uncl_conv_igemm.
  * src: fp32, Conv2d layout (Cout, Cin, k, k) or, if transposed != 0, ConvTranspose2d layout (Cin, Cout, k, k).
  * dst: [tap][Cout][Cin] in dtype; for a transposed stride-1 3x3 the taps are flipped (tap' = 8 - tap) so that

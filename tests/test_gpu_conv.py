@@ -186,6 +186,18 @@ def test_pipe_broadcast_residual_and_skip_store():
     assert rel_l2(from_nhwc(out), ref) < TOL[BF]
 
 
+@pytest.mark.parametrize("c,h,w,n", [(32, 9, 13, 3), (64, 61, 61, 2), (128, 28, 28, 2), (256, 12, 12, 3)])
+def test_upconv2x2_bf16(c, h, w, n):
+    x, wt, b = q(rnd(n, c, h, w, seed=51), BF), q(rnd(c, c, 2, 2, seed=52, scale=0.1), BF), rnd(c, seed=53)
+    ref = F.conv_transpose2d(x, wt, b, stride=2)
+    out = torch.zeros(n, 2 * h, 2 * w, c, dtype=torch.bfloat16, device="cuda")
+    xd, wd, bd = to_nhwc(x, BF), pack_weight(wt, BF, transposed=True), b.cuda()      # keep the operands alive
+    _hip.check(_hip.lib().uncl_upconv2x2(xd.data_ptr(), None, 0, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), n, h, w,
+                                         c, c, _hip.stream_ptr()), "upconv")
+    torch.cuda.synchronize()
+    assert rel_l2(from_nhwc(out), ref) < TOL[BF]
+
+
 def test_bad_arguments_are_refused():
     d = _hip.ConvDesc()
     import ctypes as C

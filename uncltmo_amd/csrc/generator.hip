@@ -156,7 +156,14 @@ int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, boo
 int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int outbuf, int ch, int cout, int prev_ch,
              void* final_out, const uncl_conv_desc* tail) {
   int rc;
-  {
+  if (use_pipe(c)) {
+    ProfScope ps(wi_up, c.s);
+    const int h = kDims[x1].h == 1 ? 12 : kDims[x1].h, w = kDims[x1].h == 1 ? 12 : kDims[x1].w;
+    const bool pv = prev_ch > 0 && c.prev;
+    if ((rc = uncl_upconv2x2(c.ptr(x1), pv ? c.pptr(x1) : nullptr, pv ? prev_ch : 0, c.w->w[wi_up], c.w->b[wi_up],
+                             c.ptr(upbuf), c.n, h, w, ch, ch, c.s)) != UNCL_OK)
+      return rc;
+  } else {
     uncl_conv_desc d = base_desc(c, wi_up, 1, 0, ch, ch, UNCL_ACT_NONE);
     set_src0(d, c, x1);
     d.src_mode = UNCL_SRC_PLAIN;

@@ -69,8 +69,12 @@ __global__ __launch_bounds__(256) void conv_in_c1_kernel(const float* __restrict
       v[c] = uncl_act(s, act);
     }
     T* o = out + p * Cout + g * 8;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = (T)v[c];
+    if constexpr (sizeof(T) == 2) {
+      *reinterpret_cast<bf16x8*>(o) = Elem<bf16_t>::pack(v);
+    } else {
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
   }
 }
 
@@ -98,6 +102,7 @@ extern "C" int uncl_conv_in_c1(const float* x, const float* w, const float* b, v
 // ------------------------------------------------------------------------------------------------------
 #define KNN_MAX_NODES 144
 #define KNN_C 256
+#define KNN_SPLIT 3        // workgroups per sample (144 rows -> 48 each, 3 per wave)
 #define KNN_LD (KNN_C + 4)  // padded row: consecutive rows shift one 16-byte slot -> conflict-free b128 reads
 
 template <typename T>
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(1024) void gcn_knn_kernel(const T* __restrict__ x, 
     if (lane == 0) ssq[i] = s2;
   }
   __syncthreads();
-  for (int i = wave; i < n; i += nw) {
+  // rows are dealt round-robin to the gridDim.y workgroups of this sample (each re-normalises the sample: cheap)
+  for (int i = wave * gridDim.y + blockIdx.y; i < n; i += nw * gridDim.y) {
     const float* xi = sx + (size_t)i * KNN_LD;
     float d[3];
     int jj[3];
@@ -190,7 +196,7 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
       attr[1] = true;
     }
-    hipLaunchKernelGGL(gcn_knn_kernel<bf16_t>, dim3(N), dim3(1024), lds, s, (const bf16_t*)x, relative_pos, idx, dist_out,
+    hipLaunchKernelGGL(gcn_knn_kernel<bf16_t>, dim3(N, KNN_SPLIT), dim3(1024), lds, s, (const bf16_t*)x, relative_pos, idx, dist_out,
                        n, k);
   } else if (dtype == UNCL_F32) {
     if (!attr[0]) {
@@ -198,7 +204,7 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
       attr[0] = true;
     }
-    hipLaunchKernelGGL(gcn_knn_kernel<float>, dim3(N), dim3(1024), lds, s, (const float*)x, relative_pos, idx, dist_out, n,
+    hipLaunchKernelGGL(gcn_knn_kernel<float>, dim3(N, KNN_SPLIT), dim3(1024), lds, s, (const float*)x, relative_pos, idx, dist_out, n,
                        k);
   } else {
     return UNCL_ERR_ARG;

@@ -1,0 +1,178 @@
+// ConvTranspose2d(k=2, s=2) + bias for gfx950 (bf16), the `up` of every decoder stage (unet_parts.py:269,288).
+//
+// out[n, 2y+dy, 2x+dx, co] = b[co] + sum_ci x[n, y, x, ci] * W[ci, co, dy, dx]
+//
+// This is a skinny GEMM (K = Cin <= 256, N = 4*Cout) that reads each input pixel once and writes four output
+// pixels: 25 FLOP per byte at C = 32, i.e. HBM-bound.  The kernel is therefore built around its memory access
+// pattern, not the MFMA rate:
+//   * activations go straight from global memory to MFMA B-fragments (each pixel is used by exactly one wave);
+//   * the packed weights [tap][cout][cin] are one [4*Cout][Cin] matrix; a workgroup keeps a 128-row slice in LDS
+//     (XOR-swizzled 16-byte slots) for all the pixel tiles it walks;
+//   * the 128 pixels x 128 virtual channels result tile is transposed through LDS so that every store
+//     instruction writes whole 2*Cout-element runs of an output row (a wave writes contiguous KiBs), instead of
+//     8-byte pieces scattered at a 2-pixel stride.
+#include "common.h"
+
+namespace {
+
+struct UpArgs {
+  const bf16_t* x;
+  const bf16_t* prev;
+  const bf16_t* w;      // [4*Cout][Cin]
+  const float* bias;    // [Cout]
+  bf16_t* out;          // (N, 2H, 2W, Cout)
+  int H, W, C, Cout, prev_ch;
+  int M;                // N*H*W input pixels
+  int n_tiles;          // ceil(M / 128)
+};
+
+template <int CIN, bool PREV>
+__global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int KS = CIN / 16;           // MFMA k-steps
+  constexpr int S = CIN / 8;             // 16-byte slots per weight row
+  constexpr int CT = 128;                // virtual output channels (tap-major) per workgroup
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;                       // [CT][CIN] bf16, swizzled
+  char* sO = smem + CT * CIN * 2;        // [128 pixels][CT] bf16, swizzled
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ct = blockIdx.y;             // which 128-wide slice of the 4*Cout virtual channels
+
+  auto wswz = [](int row, int slot) {
+    const int f = S == 4 ? ((row >> 2) & 3) : (S == 8 ? ((row >> 1) & 7) : (row & 15));
+    return slot ^ f;
+  };
+  // stage this slice of the weights once
+  for (int v = tid; v < CT * S; v += 256) {
+    const int row = v / S, slot = v - row * S;
+    const vec wv = *reinterpret_cast<const vec*>(a.w + ((size_t)(ct * CT + row)) * CIN + slot * 8);
+    *reinterpret_cast<vec*>(sW + row * (CIN * 2) + (wswz(row, slot) << 4)) = wv;
+  }
+  // bias of this lane's channels: virtual channel c' = ct*128 + nt*32 + 8q + 4lh + r  ->  co = c' % Cout
+  float bv[4][16];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = (ct * CT + nt * 32 + 8 * q + 4 * lh) % a.Cout;
+      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[nt][4 * q + r] = b[r];
+    }
+  __syncthreads();
+
+  f32x16 zero16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+
+  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const int m0 = t * 128;
+    // ---- B fragments: pixel m0 + wave*32 + lr, channels 16*ks + 8*lh .. +7
+    const int mp = min(m0 + wave * 32 + lr, a.M - 1);
+    vec B[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const size_t off = (size_t)mp * CIN + ks * 16 + lh * 8;
+      B[ks] = *reinterpret_cast<const vec*>(a.x + off);
+      if (PREV && ks * 16 + lh * 8 < a.prev_ch) {
+        const vec p = *reinterpret_cast<const vec*>(a.prev + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (ks * 16 + lh * 8 + i < a.prev_ch) B[ks][i] = p[i];
+      }
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = nt * 32 + lr;
+        const vec A = *reinterpret_cast<const vec*>(sW + row * (CIN * 2) + (wswz(row, 2 * ks + lh) << 4));
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[ks], ks == 0 ? zero16 : acc[nt], 0, 0, 0);
+      }
+    }
+    // ---- transpose through LDS: image [pixel (128)][virtual channel (128)], 16-byte slots XOR pixel
+    __syncthreads();  // previous tile's readers are done with sO
+    const int pl = wave * 32 + lr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[nt][4 * q + r] + bv[nt][4 * q + r]);
+        *reinterpret_cast<bf16x4*>(sO + pl * 256 + (((nt * 4 + q) ^ (pl & 15)) << 4) + (lh << 3)) = o;
+      }
+    __syncthreads();
+    // ---- coalesced stores.  A run = the channels of one (pixel, tap-row) that are contiguous in the output:
+    // RUN virtual channels = min(128, 2*Cout) -> RUN/8 slots; runs of consecutive pixels are adjacent in memory.
+    const int run = min(CT, 2 * a.Cout);          // virtual channels per contiguous run
+    const int rs = run >> 3;                      // slots per run
+    const int runs_per_px = CT / run;             // 2 (Cout=32), 1 otherwise
+    for (int v = tid; v < 128 * 16; v += 256) {
+      // order: [run index within pixel][pixel][slot in run]
+      const int sl = v % rs;
+      const int p = (v / rs) % 128;
+      const int ri = v / (rs * 128);
+      if (ri >= runs_per_px) continue;
+      const int m = m0 + p;
+      if (m >= a.M) continue;
+      const int slot = ri * rs + sl;              // slot inside the 128-channel tile
+      const int cv = ct * CT + slot * 8;          // virtual channel
+      const int tap = cv / a.Cout, co = cv - tap * a.Cout;
+      const int n = m / (a.H * a.W), rem = m - n * (a.H * a.W);
+      const int y = rem / a.W, x = rem - y * a.W;
+      const size_t opix = ((size_t)n * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1);
+      const vec val = *reinterpret_cast<const vec*>(sO + p * 256 + ((slot ^ (p & 15)) << 4));
+      *reinterpret_cast<vec*>(a.out + opix * a.Cout + co) = val;
+    }
+  }
+}
+
+template <int CIN>
+int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
+  constexpr size_t lds = (size_t)128 * CIN * 2 + 128 * 256;
+  static bool attr_done[2] = {false, false};
+  auto k0 = upconv2x2_kernel<CIN, false>;
+  auto k1 = upconv2x2_kernel<CIN, true>;
+  const void* kp = prev ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0);
+  if (!attr_done[prev]) {
+    if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UNCL_ERR_LAUNCH;
+    attr_done[prev] = true;
+  }
+  const int n_ct = 4 * a.Cout / 128;
+  const int gx = a.n_tiles < 2048 ? a.n_tiles : 2048;
+  if (prev)
+    hipLaunchKernelGGL(k1, dim3(gx, n_ct), dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL(k0, dim3(gx, n_ct), dim3(256), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+}  // namespace
+
+// x: (N,H,W,C) bf16; w: packed [4][Cout][C] bf16 (uncl_pack_conv_weight, transposed=1, flip=0); out: (N,2H,2W,Cout).
+// prev / prev_ch: video recurrence (first prev_ch input channels come from `prev`, Unet.py:270).
+extern "C" int uncl_upconv2x2(const void* x, const void* prev, int prev_ch, const void* w, const float* bias, void* out,
+                              int N, int H, int W, int C, int Cout, void* stream) {
+  if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0) return UNCL_ERR_ARG;
+  if (Cout % 32 != 0 || (C != 32 && C != 64 && C != 128 && C != 256)) return UNCL_ERR_ARG;
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL / 256) return UNCL_ERR_ARG;
+  UpArgs a;
+  a.x = (const bf16_t*)x; a.prev = (const bf16_t*)prev; a.w = (const bf16_t*)w; a.bias = bias; a.out = (bf16_t*)out;
+  a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.prev_ch = prev_ch; a.M = (int)M; a.n_tiles = (int)((M + 127) / 128);
+  const bool pv = prev != nullptr && prev_ch > 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (C) {
+    case 32: return launch_up<32>(a, pv, s);
+    case 64: return launch_up<64>(a, pv, s);
+    case 128: return launch_up<128>(a, pv, s);
+    default: return launch_up<256>(a, pv, s);
+  }
+}
