@@ -180,6 +180,16 @@ size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep_activation
 int uncl_gen_forward(const uncl_gen_weights* wts, const uncl_gen_run* run, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Window statistics.
+ * ---------------------------------------------------------------------------------------------------- */
+/* Per (sample, channel): mean(x) and the mean of the 11x11 sigma-1.5 Gaussian local variance G*(x^2)-(G*x)^2 over
+ * the 'valid' region.  x: NHWC (N,H,W,C) in dtype, C == 1 (fp32 image) or C % 8 == 0; W <= 256.  out: fp32 (N,2,C).
+ * Replaces ContrastExtracter + adaptive_avg_pool2d / mean (Unet.py:101-123,274-278; Discriminator.py:50-83,122-124;
+ * GanTrainerImg.py:24-56,308-313,361-367).  Deterministic two-stage reduction. */
+size_t uncl_gauss_stats_workspace_bytes(int N, int H, int C);
+int uncl_gauss_stats(const void* x, int dtype, float* out, int N, int H, int W, int C, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Overlap-tile inference (256^2 tiles, stride 192, linear cross-fade).
  * Replaces test_big_size_image2 / test_big_size_image (utils/model_save_util.py:409-486, :488-565).
  * ---------------------------------------------------------------------------------------------------- */

@@ -8,7 +8,7 @@ from hip_util import rel_l2
 from oracle import generator as OG
 from oracle import tiler as OT
 from uncltmo_amd import synth, tiler
-from uncltmo_amd.generator import UNet
+from uncltmo_amd.generator import UNet, UNetVideo, gauss_stats
 
 pytestmark = pytest.mark.gpu
 
@@ -86,6 +86,53 @@ def test_generator_rejects_other_sizes_and_host_tensors():
             net(torch.zeros(1, 1, *hw, device="cuda"))
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 1, 256, 256))
+
+
+def make_gv(dtype):
+    g = UNetVideo(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+                  "replicate", 2, 0, compute_dtype=dtype)
+    synth.fill_state_dict(g, "g0")
+    return g.cuda().eval()
+
+
+def test_gauss_stats_vs_torch():
+    import torch.nn.functional as F
+    x = synth.ldr_frames(3, 62, 70, salt="gs")                      # (3,1,62,70)
+    win = OG.gauss_window()
+    mu = F.conv2d(x, win)
+    var = F.conv2d(x * x, win) - mu ** 2
+    st = gauss_stats(x.reshape(3, 62, 70).cuda(), 3, 62, 70, 1).cpu()
+    np.testing.assert_allclose(st[:, 0, 0].numpy(), x.mean(dim=(1, 2, 3)).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(st[:, 1, 0].numpy(), var.mean(dim=(1, 2, 3)).numpy(), rtol=2e-4)
+    xc = torch.rand(2, 16, 40, 256, generator=torch.Generator().manual_seed(3))
+    mu = F.conv2d(xc.reshape(32, 1, 40, 256), win)
+    var = (F.conv2d(xc.reshape(32, 1, 40, 256) ** 2, win) - mu ** 2).reshape(2, 16, -1).mean(-1)
+    st = gauss_stats(xc.permute(0, 2, 3, 1).contiguous().cuda(), 2, 40, 256, 16).cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), xc.mean(dim=(2, 3)).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(st[:, 1].numpy(), var.numpy(), rtol=2e-4)
+
+
+def test_video_generator_fp32_matches_reference_golden(golden):
+    g = golden("video")
+    net = make_gv("fp32")
+    x = torch.cat([synth.smooth_hdr_frames(1, salt="v%d" % t) for t in range(3)], 0).unsqueeze(0).cuda()
+    with torch.no_grad():
+        y, f = net(x)
+    assert y.shape == (1, 3, 1, 256, 256) and f.shape == (1, 3, 64, 1, 1)
+    for t in range(3):
+        check_summary(y[:, t].cpu(), g, "v_eval.frame%d" % t, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(f.cpu().numpy(), g["v_eval.feats"], rtol=2e-3, atol=1e-6)
+
+
+def test_video_generator_bf16_vs_oracle_batch2():
+    net = make_gv("bf16")
+    x = torch.stack([torch.cat([synth.smooth_hdr_frames(1, salt="w%d_%d" % (b, t)) for t in range(2)], 0)
+                     for b in range(2)], 0)
+    with torch.no_grad():
+        y, f = net(x.cuda())
+        y_ref, f_ref = OG.unet_video_forward(cpu_sd(net), x)
+    assert rel_l2(y.cpu(), y_ref) < 3e-2
+    assert rel_l2(f.cpu(), f_ref) < 5e-2
 
 
 def _standin(p, **kw):

@@ -82,6 +82,9 @@ SIGNATURES = {
     "uncl_prof_read": (C.c_int, [C.c_void_p, C.c_int]),
     "uncl_gen_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "uncl_gen_forward": (C.c_int, [C.POINTER(GenWeights), C.POINTER(GenRun), C.c_void_p]),
+    "uncl_gauss_stats_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "uncl_gauss_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p]),
     "uncl_tile_count": (C.c_int, [C.c_int, C.c_int]),
     "uncl_tile_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_tile_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

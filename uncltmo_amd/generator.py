@@ -278,3 +278,46 @@ class UNet(_GeneratorBase):
         xf = x.reshape(-1, 256, 256).float().contiguous()
         out, _, knn, _ = self._run(xf, need_feat=False, want_knn=want_knn)
         return (out, knn) if want_knn else out
+
+
+def gauss_stats(x_nhwc, n, h, w, c):
+    """[mean(x), mean(Gaussian local variance)] per (sample, channel): fp32 (n, 2, c).  x_nhwc is a contiguous
+    NHWC tensor (or an (n,h,w) fp32 image when c == 1).  Reference: Unet.py:112-123,274-278."""
+    lib = _hip.lib()
+    code = _hip.BF16 if x_nhwc.dtype == torch.bfloat16 else _hip.F32
+    ws = torch.empty(lib.uncl_gauss_stats_workspace_bytes(n, h, c), dtype=torch.uint8, device=x_nhwc.device)
+    out = torch.empty(n, 2, c, dtype=torch.float32, device=x_nhwc.device)
+    _hip.check(lib.uncl_gauss_stats(_hip.ptr(x_nhwc), code, out.data_ptr(), n, h, w, c, ws.data_ptr(), _hip.stream_ptr()),
+               "uncl_gauss_stats")
+    return out
+
+
+class UNetVideo(_GeneratorBase):
+    """Video generator (reference class `UNet` of models/unet_multi_filters/Unet.py:136-289).
+    forward(x[B,T,1,256,256]) -> (frames[B,T,1,256,256] fp32, feats[B,T,64,1,1] fp32).
+
+    Frames of a clip are sequential: from the second frame on, the first C/32 channels entering every down / up
+    stage are read from the previous frame's activations (kept in that frame's workspace), Unet.py:244,270.
+    feats = [mean(up_x), mean(Gaussian local variance of up_x)] per channel (Unet.py:274-278)."""
+
+    def forward(self, x, apply_crop=True, diffY=0, diffX=0):
+        if x.dim() != 5:
+            raise ValueError("video generator expects (B,T,1,H,W)")
+        self._check_input(x, 3)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("uncltmo_amd: the generator's HIP backward kernels are not built yet; run the "
+                                      "forward under torch.no_grad()")
+        B, T = x.shape[0], x.shape[1]
+        outs, feats = [], []
+        prev_ws = None
+        for t in range(T):
+            xf = x[:, t].detach().reshape(B, 256, 256).float().contiguous()
+            out, up, _, ws = self._run(xf, need_feat=True, prev_ws=prev_ws, keep_act=True, slot=t)
+            st = gauss_stats(up, B, 256, 256, 32)                      # (B,2,32)
+            feats.append(st.reshape(B, 1, 64, 1, 1))
+            outs.append(out.reshape(B, 1, 1, 256, 256))
+            prev_ws = ws
+        x_out = torch.cat(outs, 1)
+        if apply_crop and self.to_crop:
+            x_out = self._crop(x_out, diffY, diffX)
+        return x_out, torch.cat(feats, 1)
