@@ -190,6 +190,60 @@ size_t uncl_gauss_stats_workspace_bytes(int N, int H, int C);
 int uncl_gauss_stats(const void* x, int dtype, float* out, int N, int H, int W, int C, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Structural loss (models/struct_loss.py:23-104): 5x5 box-normalised windows, MSE, bicubic-halved pyramid.
+ * fake, hdr: fp32 (N,H,W) device.  weights_host: HOST array of `levels` pyramid weights.  loss_out: device fp32
+ * scalar = sum_l w_l * MSE_l.  grad_fake (optional): d loss / d fake, multiplied by upstream[0] if upstream != NULL.
+ * ---------------------------------------------------------------------------------------------------- */
+size_t uncl_struct_loss_workspace_bytes(int N, int H, int W, int levels);
+int uncl_struct_loss(const float* fake, const float* hdr, const float* weights_host, int levels, float* loss_out,
+                     float* grad_fake, const float* upstream, int N, int H, int W, void* workspace, void* stream);
+/* F.interpolate(x, scale_factor=0.5, mode='bicubic', align_corners=False) on fp32 (N,H,W) (struct_loss.py:52-53) */
+int uncl_bicubic_half(const float* in, float* out, int N, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * SimpleDiscriminator (models/Discriminator.py:87-126), fp32: forward (logit + [mean, variance] feature) and
+ * backward (parameter gradients and/or input gradient).  Parameters in reference layout.
+ * ---------------------------------------------------------------------------------------------------- */
+size_t uncl_simple_d_workspace_bytes(int N);
+int uncl_simple_d_forward(const float* x, const float* w0, const float* b0, const float* w2, const float* b2,
+                          const float* w4, const float* b4, const float* wl, float* out, float* fea_final, int N,
+                          void* workspace, void* gs_workspace, void* stream);
+int uncl_simple_d_backward(const float* x, const float* w0, const float* w2, const float* w4, const float* wl,
+                           const float* g_out, const float* g_f1, const float* g_var, float* gw0, float* gb0, float* gw2,
+                           float* gb2, float* gw4, float* gb4, float* gwl, float* g_x, int accumulate, int N,
+                           void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Loss heads.  Each returns the weighted loss (written or accumulated into a device fp32 scalar) and, where
+ * pointers are given, its input gradients.
+ * ---------------------------------------------------------------------------------------------------- */
+/* w * (half(real,fake) + half(-fake,-real)), half = cross-entropy of [t1_i, t2_*] vs class 0 (GanTrainerImg.py:219-229) */
+int uncl_cgan_loss(const float* real, const float* fake, int N, float w, float* loss, float* g_real, float* g_fake,
+                   int accumulate_loss, void* stream);
+/* w * mean_n CE([s(a,p), s(a,q)], 0), s(a,b) = mean_hw sum_c a b / (c + k|a-b|) (GanTrainerImg.py:410-439); pos/neg may be
+ * one row shared by all samples (infoNCE2, :401-402).  E = elements per sample, hw = spatial positions. */
+size_t uncl_nce_workspace_bytes(int N);
+int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
+                  int neg_shared, float k, float c, float w, float* loss, float* g_anchor, float* g_pos, float* g_neg,
+                  int accumulate_loss, int accumulate_grad, void* workspace, void* stream);
+/* w * mean_n |a_n - b_n| over strided per-sample scalars (nn.L1Loss on per-frame means, GanTrainerImg.py:308-313) */
+int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss, float* g_a,
+                  float* g_b, int accumulate_loss, void* stream);
+/* TMQI statistical naturalness in fp64 (TMQI.py:210-242) of every h x w patch of fp32 frames scaled by `scale` (255);
+ * best_worst (optional int32[2]): first arg-max / arg-min (GanTrainerImg.py:357-359, 398-402) */
+int uncl_tmqi_naturalness(const float* x, int F, int frame_h, int frame_w, int h, int w, float scale, double* scores,
+                          int32_t* best_worst, void* stream);
+/* gx[n] (+)= gscale[n] * d mean(Gaussian local variance of x[n]) / dx */
+int uncl_gauss_var_backward(const float* x, const float* gscale, float* gx, int N, int H, int W, int accumulate, void* stream);
+int uncl_add_per_sample_const(float* g, const float* scale, long long per, int N, float mul, int accumulate, void* stream);
+/* w * L_TV(x) (GanTrainer.py:669-682) and its gradient; workspace: 1024 floats */
+int uncl_tv_loss(const float* x, int N, int H, int W, float w, float* loss, float* gx, int accumulate_loss,
+                 int accumulate_grad, void* workspace, void* stream);
+/* torch.optim.Adam step over `count` tensors (HOST arrays of device pointers) */
+int uncl_adam_step(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int* numel,
+                   int count, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Overlap-tile inference (256^2 tiles, stride 192, linear cross-fade).
  * Replaces test_big_size_image2 / test_big_size_image (utils/model_save_util.py:409-486, :488-565).
  * ---------------------------------------------------------------------------------------------------- */

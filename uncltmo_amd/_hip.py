@@ -85,6 +85,29 @@ SIGNATURES = {
     "uncl_gauss_stats_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "uncl_gauss_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),
+    "uncl_struct_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "uncl_struct_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_bicubic_half": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uncl_simple_d_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "uncl_simple_d_forward": (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uncl_simple_d_backward": (C.c_int, [C.c_void_p] * 16 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_cgan_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p]),
+    "uncl_nce_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "uncl_nce_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_l1_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_void_p]),
+    "uncl_tmqi_naturalness": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "uncl_gauss_var_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uncl_add_per_sample_const": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "uncl_tv_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p]),
+    "uncl_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "uncl_tile_count": (C.c_int, [C.c_int, C.c_int]),
     "uncl_tile_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_tile_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -1,0 +1,489 @@
+// Loss heads of the GanTrainer step (GanTrainerImg.py:219-229, 341-439; GanTrainer.py:669-682), the TMQI
+// naturalness score used for sample selection (TMQI.py:210-242), the Gaussian-variance backward, and fused Adam.
+// All are tiny or HBM-bound; each "loss" kernel returns the weighted loss AND its input gradients in one pass
+// (the weights are constants of the step), fp32 with fp64 where the reference is fp64.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// contrastive GAN loss: half(t1,t2) = CE([t1_i, t2_0..t2_{N-1}], 0);  L = w * (half(r, f) + half(-f, -r))
+// ------------------------------------------------------------------------------------------------------
+__global__ void cgan_kernel(const float* __restrict__ r, const float* __restrict__ f, int N, float w, float* loss,
+                            float* g_r, float* g_f, int accumulate_loss) {
+  // single workgroup; N <= 4096.  Deterministic: every output element is produced by one thread in a fixed order.
+  extern __shared__ float sh[];  // lse0[N] (rows [r_i, f_*]), lse1[N] (rows [-f_i, -r_*])
+  float* lse0 = sh;
+  float* lse1 = sh + N;
+  __shared__ double part[256];
+  double lsum = 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    float mx0 = r[i], mx1 = -f[i];
+    for (int j = 0; j < N; ++j) { mx0 = fmaxf(mx0, f[j]); mx1 = fmaxf(mx1, -r[j]); }
+    float s0 = expf(r[i] - mx0), s1 = expf(-f[i] - mx1);
+    for (int j = 0; j < N; ++j) { s0 += expf(f[j] - mx0); s1 += expf(-r[j] - mx1); }
+    lse0[i] = mx0 + logf(s0);
+    lse1[i] = mx1 + logf(s1);
+    lsum += (double)(lse0[i] - r[i]) + (double)(lse1[i] + f[i]);
+  }
+  part[threadIdx.x] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)blockDim.x; ++i) t += part[i];
+    loss[0] = (accumulate_loss ? loss[0] : 0.f) + (float)(t * (double)w / (double)N);
+  }
+  const float s = w / (float)N;
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    // d/dr_j: own row of half 0 (p0 - 1) and column j of every row of half 1 (logit -r_j)
+    float gr = s * (expf(r[j] - lse0[j]) - 1.f);
+    float gf = -s * (expf(-f[j] - lse1[j]) - 1.f);
+    for (int i = 0; i < N; ++i) {
+      gr -= s * expf(-r[j] - lse1[i]);
+      gf += s * expf(f[j] - lse0[i]);
+    }
+    if (g_r) g_r[j] = gr;
+    if (g_f) g_f[j] = gf;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// NCE similarity  s(a,b) = (1/HW) sum_e a*b / (c + k|a-b|)   and the 2-way InfoNCE built on it
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p, size_t i) { return (float)p[i]; }
+
+// pass 1: per-sample partial sums of the two similarities.  grid (blocks, N)
+template <typename T>
+__global__ __launch_bounds__(256) void nce_sim_kernel(const T* __restrict__ a, const T* __restrict__ p, const T* __restrict__ q,
+                                                      size_t E, size_t p_stride, size_t q_stride, float k, float c,
+                                                      float* __restrict__ partial) {
+  __shared__ float red[4][2];
+  const int n = blockIdx.y;
+  const T* an = a + (size_t)n * E;
+  const T* pn = p + (size_t)n * p_stride;
+  const T* qn = q + (size_t)n * q_stride;
+  float sp = 0.f, sq = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (size_t)gridDim.x * 256) {
+    const float av = ldf(an, e), pv = ldf(pn, e), qv = ldf(qn, e);
+    sp += av * pv * (1.f / (c + k * fabsf(av - pv)));
+    sq += av * qv * (1.f / (c + k * fabsf(av - qv)));
+  }
+  sp = wave_sum(sp); sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sp; red[threadIdx.x >> 6][1] = sq; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    partial[((size_t)n * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// pass 2: finish the sums, the 2-way cross-entropy and d loss / d s_pos, d loss / d s_neg.  single block
+__global__ void nce_ce_kernel(const float* __restrict__ partial, int blocks, int N, double inv_hw, float w, float* loss,
+                              float* __restrict__ gs /* [N][2] */, int accumulate_loss) {
+  __shared__ double sl;
+  if (threadIdx.x == 0) sl = 0.0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    double sp = 0.0, sq = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+      sp += (double)partial[((size_t)n * blocks + b) * 2];
+      sq += (double)partial[((size_t)n * blocks + b) * 2 + 1];
+    }
+    const float fp = (float)(sp * inv_hw), fq = (float)(sq * inv_hw);
+    const float mx = fmaxf(fp, fq);
+    const float lse = mx + logf(expf(fp - mx) + expf(fq - mx));
+    atomicAdd(&sl, (double)(lse - fp));
+    gs[2 * n] = w / (float)N * (expf(fp - lse) - 1.f);
+    gs[2 * n + 1] = w / (float)N * expf(fq - lse);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (accumulate_loss ? loss[0] : 0.f) + (float)(sl * (double)w / (double)N);
+}
+
+// pass 3: gradients.  One thread per element e, looping over the samples, so that a positive / negative that is
+// ONE row shared by every sample (stride 0, GanTrainerImg.py:401-402) gets its summed gradient without atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void nce_grad_kernel(const T* __restrict__ a, const T* __restrict__ p, const T* __restrict__ q,
+                                                       size_t E, size_t p_stride, size_t q_stride, int N, float k, float c,
+                                                       float inv_hw, const float* __restrict__ gs, float* __restrict__ g_a,
+                                                       float* __restrict__ g_p, float* __restrict__ g_q, int accumulate) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (size_t)gridDim.x * 256) {
+    float accp = 0.f, accq = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float av = ldf(a, (size_t)n * E + e), pv = ldf(p, (size_t)n * p_stride + e), qv = ldf(q, (size_t)n * q_stride + e);
+      const float dp = av - pv, dq = av - qv;
+      const float ip = 1.f / (c + k * fabsf(dp)), iq = 1.f / (c + k * fabsf(dq));
+      const float sgp = dp > 0.f ? 1.f : (dp < 0.f ? -1.f : 0.f), sgq = dq > 0.f ? 1.f : (dq < 0.f ? -1.f : 0.f);
+      const float gp = gs[2 * n] * inv_hw, gq = gs[2 * n + 1] * inv_hw;
+      // d/da [a b / (c + k|a-b|)] = b i - a b k sgn i^2 ;  d/db = a i + a b k sgn i^2
+      const float tp = av * pv * k * sgp * ip * ip, tq = av * qv * k * sgq * iq * iq;
+      const float ga = gp * (pv * ip - tp) + gq * (qv * iq - tq);
+      if (g_a) { float* d = g_a + (size_t)n * E + e; *d = accumulate ? *d + ga : ga; }
+      const float gpp = gp * (av * ip + tp), gqq = gq * (av * iq + tq);
+      if (p_stride == 0) accp += gpp; else if (g_p) { float* d = g_p + (size_t)n * E + e; *d = accumulate ? *d + gpp : gpp; }
+      if (q_stride == 0) accq += gqq; else if (g_q) { float* d = g_q + (size_t)n * E + e; *d = accumulate ? *d + gqq : gqq; }
+    }
+    if (p_stride == 0 && g_p) { float* d = g_p + e; *d = accumulate ? *d + accp : accp; }
+    if (q_stride == 0 && g_q) { float* d = g_q + e; *d = accumulate ? *d + accq : accq; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// L1 between two per-sample scalars: L = w * mean_n |a_n - b_n| ; g_a = w sign / N
+// ------------------------------------------------------------------------------------------------------
+__global__ void l1_pairs_kernel(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss,
+                                float* g_a, float* g_b, int accumulate_loss) {
+  __shared__ double sl;
+  if (threadIdx.x == 0) sl = 0.0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const float d = a[(size_t)n * a_stride] - b[(size_t)n * b_stride];
+    atomicAdd(&sl, (double)fabsf(d));
+    const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (g_a) g_a[n] = w * s / (float)N;
+    if (g_b) g_b[n] = -w * s / (float)N;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (accumulate_loss ? loss[0] : 0.f) + (float)(sl * (double)w / (double)N);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TMQI statistical naturalness, fp64 (TMQI.py:210-242): u = mean(L), sig = mean over 11x11 blocks (zero padded to the
+// next multiple of 11, always at least one extra) of the population std; N = beta_pdf(sig/64.29)/C0 * gauss(u)
+// ------------------------------------------------------------------------------------------------------
+__device__ double beta_pdf(double x, double a, double b) {
+  if (x <= 0.0 || x >= 1.0) return 0.0;
+  return exp(lgamma(a + b) - lgamma(a) - lgamma(b) + (a - 1.0) * log(x) + (b - 1.0) * log1p(-x));
+}
+
+// one workgroup per image region; the image is x*scale with x fp32 in a (rows x row_stride) frame
+__global__ __launch_bounds__(256) void tmqi_n_kernel(const float* __restrict__ x, int n_per_frame, int h, int w, int frame_h,
+                                                     int frame_w, float scale, double* __restrict__ scores) {
+  // image id = blockIdx.x: frame = id / n_per_frame, patch = id % n_per_frame laid out row-major on a
+  // (frame_h/h) x (frame_w/w) grid of patches
+  __shared__ double red_s[4], red_sig[4];
+  const int id = blockIdx.x;
+  const int frame = id / n_per_frame, patch = id % n_per_frame;
+  const int ppr = frame_w / w;
+  const float* base = x + (size_t)frame * frame_h * frame_w + (size_t)(patch / ppr) * h * frame_w + (size_t)(patch % ppr) * w;
+  const int bh = (h + (11 - h % 11)) / 11, bw = (w + (11 - w % 11)) / 11;
+  double s_all = 0.0, s_sig = 0.0;
+  for (int b = threadIdx.x; b < bh * bw; b += 256) {
+    const int by = b / bw, bx = b % bw;
+    double s1 = 0.0, s2 = 0.0;
+    for (int dy = 0; dy < 11; ++dy) {
+      const int yy = by * 11 + dy;
+      if (yy >= h) continue;
+      for (int dx = 0; dx < 11; ++dx) {
+        const int xx = bx * 11 + dx;
+        if (xx >= w) continue;
+        const double v = (double)(base[(size_t)yy * frame_w + xx] * scale);
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    s_all += s1;
+    const double m = s1 / 121.0;
+    const double var = s2 / 121.0 - m * m;
+    s_sig += sqrt(var > 0.0 ? var : 0.0);
+  }
+  s_all = wave_sum_d(s_all); s_sig = wave_sum_d(s_sig);
+  if ((threadIdx.x & 63) == 0) { red_s[threadIdx.x >> 6] = s_all; red_sig[threadIdx.x >> 6] = s_sig; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double u = ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3])) / ((double)h * w);
+    const double sig = ((red_sig[0] + red_sig[1]) + (red_sig[2] + red_sig[3])) / ((double)bh * bw);
+    const double a = 4.4, bb = 10.1, mu = 115.94, sd = 27.99;
+    const double mode = (a - 1.0) / (a + bb - 2.0);
+    const double pc = beta_pdf(sig / 64.29, a, bb) / beta_pdf(mode, a, bb);
+    const double z = (u - mu) / sd;
+    scores[id] = exp(-0.5 * z * z) * pc;
+  }
+}
+
+// first-occurrence arg-max / arg-min (sorted()[-1] / [0] then list.index, GanTrainerImg.py:398-402)
+__global__ void argminmax_kernel(const double* __restrict__ s, int n, int32_t* __restrict__ out /* [2]: best, worst */) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int best = 0, worst = 0;
+  for (int i = 1; i < n; ++i) {
+    if (s[i] > s[best]) best = i;
+    if (s[i] < s[worst]) worst = i;
+  }
+  out[0] = best;
+  out[1] = worst;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward of mean(Gaussian local variance): d/dx_i = (2/P) (x_i Wc_i - (G^T mu)_i), times a per-image scale
+// ------------------------------------------------------------------------------------------------------
+constexpr int GW = 11, GT = 32, GM = GT + GW - 1 /*42 mu's*/, GI = GM + GW - 1 /*52 inputs*/;
+struct GaussW { float g[GW]; };
+
+__global__ __launch_bounds__(256) void gauss_var_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gscale,
+                                                            float* __restrict__ gx, int H, int W, int tiles_x, GaussW gw,
+                                                            int accumulate) {
+  __shared__ float sx[GI * GI];
+  __shared__ float sh[GI * GM];   // horizontal pass: rows GI, cols GM
+  __shared__ float smu[GM * GM];  // mu, zero outside the valid window range
+  __shared__ float sv[GM * GT];   // vertical back-projection: rows GT, cols GM
+  const int n = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * GT, x0 = tx * GT;
+  const int Ho = H - (GW - 1), Wo = W - (GW - 1);
+  const float* xn = x + (size_t)n * H * W;
+  // inputs [y0-10, y0+GT+10), windows o in [y0-10, y0+GT)
+  for (int i = threadIdx.x; i < GI * GI; i += 256) {
+    const int ly = i / GI, lx = i - ly * GI;
+    const int gy = y0 - 10 + ly, gxx = x0 - 10 + lx;
+    sx[i] = (gy >= 0 && gy < H && gxx >= 0 && gxx < W) ? xn[(size_t)gy * W + gxx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GI * GM; i += 256) {
+    const int ly = i / GM, lx = i - ly * GM;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < GW; ++t) s = fmaf(gw.g[t], sx[ly * GI + lx + t], s);
+    sh[i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GM * GM; i += 256) {
+    const int ly = i / GM, lx = i - ly * GM;
+    const int oy = y0 - 10 + ly, ox = x0 - 10 + lx;
+    float s = 0.f;
+    if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+#pragma unroll
+      for (int t = 0; t < GW; ++t) s = fmaf(gw.g[t], sh[(ly + t) * GM + lx], s);
+    }
+    smu[i] = s;
+  }
+  __syncthreads();
+  // (G^T mu)_i = sum_{dy,dx} w_dy w_dx mu[i - (dy,dx)]  (mu is zero outside the valid range)
+  for (int i = threadIdx.x; i < GT * GM; i += 256) {
+    const int ly = i / GM, lx = i - ly * GM;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < GW; ++t) s = fmaf(gw.g[t], smu[(ly + 10 - t) * GM + lx], s);
+    sv[i] = s;
+  }
+  __syncthreads();
+  const float sc = gscale[n] * 2.f / ((float)Ho * (float)Wo);
+  for (int i = threadIdx.x; i < GT * GT; i += 256) {
+    const int ly = i / GT, lx = i - ly * GT;
+    const int gy = y0 + ly, gxx = x0 + lx;
+    if (gy < H && gxx < W) {
+      float s = 0.f, wy = 0.f, wx = 0.f;
+#pragma unroll
+      for (int t = 0; t < GW; ++t) {
+        s = fmaf(gw.g[t], sv[ly * GM + lx + 10 - t], s);
+        if (gy - t >= 0 && gy - t < Ho) wy += gw.g[t];
+        if (gxx - t >= 0 && gxx - t < Wo) wx += gw.g[t];
+      }
+      const float g = sc * (sx[(ly + 10) * GI + lx + 10] * wy * wx - s);
+      float* d = gx + (size_t)n * H * W + (size_t)gy * W + gxx;
+      *d = accumulate ? *d + g : g;
+    }
+  }
+}
+
+// g[n][i] (+)= scale[n]  (gradient of a per-sample mean times a per-sample factor already divided by H*W)
+__global__ void add_const_kernel(float* __restrict__ g, const float* __restrict__ scale, size_t per, int N, float mul,
+                                 int accumulate) {
+  const size_t total = per * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const float v = scale[i / per] * mul;
+    g[i] = accumulate ? g[i] + v : v;
+  }
+}
+
+// total variation (GanTrainer.py:669-682): L = w * 2 (sum dh^2 / ((H-1) W) + sum dw^2 / (H (W-1))) / N
+__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ x, float* __restrict__ gx, float* __restrict__ partial,
+                                                 int N, int H, int W, float ch, float cw, int accumulate) {
+  __shared__ float red[4];
+  const size_t total = (size_t)N * H * W;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int xx = (int)(i % W), yy = (int)((i / W) % H);
+    const float v = x[i];
+    float g = 0.f;
+    if (yy + 1 < H) { const float d = x[i + W] - v; acc = fmaf(ch * d, d, acc); g -= 2.f * ch * d; }
+    if (yy > 0) g += 2.f * ch * (v - x[i - W]);
+    if (xx + 1 < W) { const float d = x[i + 1] - v; acc = fmaf(cw * d, d, acc); g -= 2.f * cw * d; }
+    if (xx > 0) g += 2.f * cw * (v - x[i - 1]);
+    if (gx) gx[i] = accumulate ? gx[i] + g : g;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void sum_f_kernel(const float* __restrict__ partial, int count, float* out, int accumulate) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 64) s += (double)partial[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fused multi-tensor Adam (torch.optim.Adam, no weight decay, no amsgrad; main_train_image.py:29-32)
+// ------------------------------------------------------------------------------------------------------
+constexpr int ADAM_MAX = 64;
+struct AdamTable {
+  float* p[ADAM_MAX];
+  const float* g[ADAM_MAX];
+  float* m[ADAM_MAX];
+  float* v[ADAM_MAX];
+  int n[ADAM_MAX];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float lr, float b1, float b2, float eps, float bc1, float bc2s) {
+  const int ti = blockIdx.y;
+  if (ti >= t.count) return;
+  float* p = t.p[ti];
+  const float* g = t.g[ti];
+  float* m = t.m[ti];
+  float* v = t.v[ti];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n[ti]; i += gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;       // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;          // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+    p[i] = p[i] - (lr / bc1) * (mi / denom);             // param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
+  }
+}
+
+}  // namespace
+
+extern "C" int uncl_cgan_loss(const float* real, const float* fake, int N, float w, float* loss, float* g_real, float* g_fake,
+                              int accumulate_loss, void* stream) {
+  if (!real || !fake || !loss || N <= 0 || N > 4096) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(cgan_kernel, dim3(1), dim3(256), 2 * N * sizeof(float), reinterpret_cast<hipStream_t>(stream), real, fake,
+                     N, w, loss, g_real, g_fake, accumulate_loss);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" size_t uncl_nce_workspace_bytes(int N) { return ((size_t)N * 256 * 2 + (size_t)N * 2) * sizeof(float); }
+
+// anchor (N,E) ; pos / neg (N,E) or a single row shared by all samples (stride_n = 0).  hw = spatial size the mean runs
+// over (E = C*hw).  loss (+)= w * mean_n CE([s(a,p), s(a,n)], 0).  Gradients (optional) are written or accumulated.
+extern "C" int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw,
+                             int pos_shared, int neg_shared, float k, float c, float w, float* loss, float* g_anchor,
+                             float* g_pos, float* g_neg, int accumulate_loss, int accumulate_grad, void* workspace,
+                             void* stream) {
+  if (!anchor || !pos || !neg || !loss || !workspace || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+  const int blocks = (int)((E + 255) / 256 < 256 ? (E + 255) / 256 : 256);
+  float* gs = partial + (size_t)N * 256 * 2;
+  const size_t ps = pos_shared ? 0 : (size_t)E, qs = neg_shared ? 0 : (size_t)E;
+  const bool need_grad = g_anchor || g_pos || g_neg;
+  const int gblocks = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
+  if (dtype == UNCL_F32) {
+    hipLaunchKernelGGL(nce_sim_kernel<float>, dim3(blocks, N), dim3(256), 0, st, (const float*)anchor, (const float*)pos,
+                       (const float*)neg, (size_t)E, ps, qs, k, c, partial);
+    hipLaunchKernelGGL(nce_ce_kernel, dim3(1), dim3(256), 0, st, partial, blocks, N, 1.0 / (double)hw, w, loss, gs, accumulate_loss);
+    if (need_grad)
+      hipLaunchKernelGGL(nce_grad_kernel<float>, dim3(gblocks), dim3(256), 0, st, (const float*)anchor, (const float*)pos,
+                         (const float*)neg, (size_t)E, ps, qs, N, k, c, 1.f / (float)hw, gs, g_anchor, g_pos, g_neg, accumulate_grad);
+  } else if (dtype == UNCL_BF16) {
+    hipLaunchKernelGGL(nce_sim_kernel<bf16_t>, dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)anchor, (const bf16_t*)pos,
+                       (const bf16_t*)neg, (size_t)E, ps, qs, k, c, partial);
+    hipLaunchKernelGGL(nce_ce_kernel, dim3(1), dim3(256), 0, st, partial, blocks, N, 1.0 / (double)hw, w, loss, gs, accumulate_loss);
+    if (need_grad)
+      hipLaunchKernelGGL(nce_grad_kernel<bf16_t>, dim3(gblocks), dim3(256), 0, st, (const bf16_t*)anchor, (const bf16_t*)pos,
+                         (const bf16_t*)neg, (size_t)E, ps, qs, N, k, c, 1.f / (float)hw, gs, g_anchor, g_pos, g_neg, accumulate_grad);
+  } else {
+    return UNCL_ERR_ARG;
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss, float* g_a,
+                             float* g_b, int accumulate_loss, void* stream) {
+  if (!a || !b || !loss || N <= 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(l1_pairs_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, a_stride, b, b_stride, N,
+                     w, loss, g_a, g_b, accumulate_loss);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// scores[f * n_per_frame + p] for the (frame_h/h) x (frame_w/w) patches of every frame; x fp32 (F, frame_h, frame_w)
+extern "C" int uncl_tmqi_naturalness(const float* x, int F, int frame_h, int frame_w, int h, int w, float scale, double* scores,
+                                     int32_t* best_worst, void* stream) {
+  if (!x || !scores || F <= 0 || h <= 0 || w <= 0 || frame_h % h != 0 || frame_w % w != 0) return UNCL_ERR_ARG;
+  const int npf = (frame_h / h) * (frame_w / w);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(tmqi_n_kernel, dim3(F * npf), dim3(256), 0, st, x, npf, h, w, frame_h, frame_w, scale, scores);
+  if (best_worst) hipLaunchKernelGGL(argminmax_kernel, dim3(1), dim3(64), 0, st, scores, F * npf, best_worst);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// gx[n] (+)= gscale[n] * d mean(local variance of x[n]) / dx      x, gx: fp32 (N,H,W)
+extern "C" int uncl_gauss_var_backward(const float* x, const float* gscale, float* gx, int N, int H, int W, int accumulate,
+                                       void* stream) {
+  if (!x || !gscale || !gx || N <= 0 || H < GW || W < GW) return UNCL_ERR_ARG;
+  GaussW gw;
+  double s = 0.0, g[GW];
+  for (int k = 0; k < GW; ++k) { g[k] = exp(-((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); s += g[k]; }
+  for (int k = 0; k < GW; ++k) gw.g[k] = (float)(g[k] / s);
+  const int tx = (W + GT - 1) / GT, ty = (H + GT - 1) / GT;
+  hipLaunchKernelGGL(gauss_var_bwd_kernel, dim3(tx * ty, N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gscale, gx,
+                     H, W, tx, gw, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_add_per_sample_const(float* g, const float* scale, long long per, int N, float mul, int accumulate,
+                                         void* stream) {
+  if (!g || !scale || per <= 0 || N <= 0) return UNCL_ERR_ARG;
+  const size_t total = (size_t)per * N;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(add_const_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, scale, (size_t)per, N,
+                     mul, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// loss (+)= w * TV(x); gx (+)= w * dTV/dx.  workspace: 1024 floats
+extern "C" int uncl_tv_loss(const float* x, int N, int H, int W, float w, float* loss, float* gx, int accumulate_loss,
+                            int accumulate_grad, void* workspace, void* stream) {
+  if (!x || !loss || !workspace || N <= 0 || H < 2 || W < 2) return UNCL_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t total = (size_t)N * H * W;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  const float ch = w * 2.f / ((float)(H - 1) * W) / N, cw = w * 2.f / ((float)H * (W - 1)) / N;
+  hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, st, x, gx, (float*)workspace, N, H, W, ch, cw, accumulate_grad);
+  hipLaunchKernelGGL(sum_f_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, blocks, loss, accumulate_loss);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// ptrs: HOST arrays of `count` device pointers (params, grads, exp_avg, exp_avg_sq) and element counts
+extern "C" int uncl_adam_step(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                              const int* numel, int count, float lr, float beta1, float beta2, float eps, int step,
+                              void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || count <= 0 || step <= 0) return UNCL_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  for (int base = 0; base < count; base += ADAM_MAX) {
+    AdamTable t;
+    t.count = count - base < ADAM_MAX ? count - base : ADAM_MAX;
+    int mx = 0;
+    for (int i = 0; i < t.count; ++i) {
+      t.p[i] = (float*)params[base + i]; t.g[i] = (const float*)grads[base + i];
+      t.m[i] = (float*)exp_avg[base + i]; t.v[i] = (float*)exp_avg_sq[base + i];
+      t.n[i] = numel[base + i];
+      if (t.n[i] > mx) mx = t.n[i];
+    }
+    const int bx = (mx + 255) / 256 < 1024 ? (mx + 255) / 256 : 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3(bx, t.count), dim3(256), 0, st, t, lr, beta1, beta2, eps, bc1, bc2s);
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}

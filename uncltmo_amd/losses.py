@@ -1,0 +1,163 @@
+"""Loss heads of the GanTrainer step as autograd Functions over the fused loss+gradient HIP kernels
+(csrc/loss_heads.hip, csrc/stats_kernels.hip).  Names follow the trainer methods they replace
+(GanTrainerImg.py:219-229 contrastive_D_loss, :410-439 nce, :341-408 pseudo_label_loss / infoNCE2,
+GanTrainer.py:669-682 L_TV)."""
+import torch
+
+from . import _hip
+from .generator import gauss_stats
+
+
+def _scalar(dev):
+    return torch.zeros(1, dtype=torch.float32, device=dev)
+
+
+class _CganFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real, fake):
+        n = real.numel()
+        r, f = real.detach().reshape(n).float().contiguous(), fake.detach().reshape(n).float().contiguous()
+        loss, gr, gf = _scalar(r.device), torch.empty_like(r), torch.empty_like(f)
+        _hip.check(_hip.lib().uncl_cgan_loss(r.data_ptr(), f.data_ptr(), n, 1.0, loss.data_ptr(), gr.data_ptr(), gf.data_ptr(),
+                                             0, _hip.stream_ptr()), "uncl_cgan_loss")
+        ctx.save_for_backward(gr, gf)
+        ctx.shapes = (real.shape, fake.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gr, gf = ctx.saved_tensors
+        return (gr * g).reshape(ctx.shapes[0]), (gf * g).reshape(ctx.shapes[1])
+
+
+def contrastive_D_loss(real_logits, fake_logits):
+    return _CganFn.apply(real_logits, fake_logits)
+
+
+class _NceFn(torch.autograd.Function):
+    """anchor / pos / neg: same shape (N, ...) contiguous in ANY common layout; `hw` = spatial positions averaged."""
+
+    @staticmethod
+    def forward(ctx, anchor, pos, neg, hw, k, c, pos_shared, neg_shared):
+        lib = _hip.lib()
+        n = anchor.shape[0]
+        E = anchor.numel() // n
+        code = _hip.BF16 if anchor.dtype == torch.bfloat16 else _hip.F32
+        a, p, q = anchor.detach().contiguous(), pos.detach().contiguous(), neg.detach().contiguous()
+        dev = a.device
+        ws = torch.empty(lib.uncl_nce_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        loss = _scalar(dev)
+        need = ctx.needs_input_grad
+        ga = torch.empty(a.shape, dtype=torch.float32, device=dev) if need[0] else None
+        gp = torch.empty(p.shape, dtype=torch.float32, device=dev) if need[1] else None
+        gq = torch.empty(q.shape, dtype=torch.float32, device=dev) if need[2] else None
+        P = lambda t: t.data_ptr() if t is not None else None
+        _hip.check(lib.uncl_nce_loss(a.data_ptr(), p.data_ptr(), q.data_ptr(), code, n, E, hw, int(pos_shared), int(neg_shared),
+                                     float(k), float(c), 1.0, loss.data_ptr(), P(ga), P(gp), P(gq), 0, 0, ws.data_ptr(),
+                                     _hip.stream_ptr()), "uncl_nce_loss")
+        ctx.g = (ga, gp, gq)
+        ctx.dt = (anchor.dtype, pos.dtype, neg.dtype)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        out = [None if t is None else (t * g).to(dt) for t, dt in zip(ctx.g, ctx.dt)]
+        return out[0], out[1], out[2], None, None, None, None, None
+
+
+def nce(anchor, positive, negative, k, c, hw=None):
+    """2-way InfoNCE with s(a,b) = mean_hw sum_c a b / (c + k|a-b|).  Tensors are (N,C,H,W)-shaped (any memory layout
+    shared by the three); `positive` / `negative` may have a leading dim of 1 (one row shared by all samples)."""
+    if hw is None:
+        hw = anchor.shape[-1] * anchor.shape[-2]
+    return _NceFn.apply(anchor, positive, negative, hw, k, c, positive.shape[0] == 1 and anchor.shape[0] != 1,
+                        negative.shape[0] == 1 and anchor.shape[0] != 1)
+
+
+class _FrameStatsFn(torch.autograd.Function):
+    """(N,1,H,W) fp32 -> (mean (N,), mean Gaussian local variance (N,)) with analytic backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, _, h, w = x.shape
+        xf = x.detach().reshape(n, h, w).float().contiguous()
+        st = gauss_stats(xf, n, h, w, 1)
+        ctx.save_for_backward(xf)
+        return st[:, 0, 0].contiguous(), st[:, 1, 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_mean, g_var):
+        (xf,) = ctx.saved_tensors
+        n, h, w = xf.shape
+        lib = _hip.lib()
+        gx = torch.empty_like(xf)
+        _hip.check(lib.uncl_add_per_sample_const(gx.data_ptr(), g_mean.float().contiguous().data_ptr(), h * w, n, 1.0 / (h * w), 0,
+                                                 _hip.stream_ptr()), "uncl_add_per_sample_const")
+        _hip.check(lib.uncl_gauss_var_backward(xf.data_ptr(), g_var.float().contiguous().data_ptr(), gx.data_ptr(), n, h, w, 1,
+                                               _hip.stream_ptr()), "uncl_gauss_var_backward")
+        return gx.reshape(n, 1, h, w)
+
+
+def frame_stats(x):
+    return _FrameStatsFn.apply(x)
+
+
+class _L1PairsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        n = a.numel()
+        af, bf = a.detach().reshape(n).float().contiguous(), b.detach().reshape(n).float().contiguous()
+        loss, ga, gb = _scalar(af.device), torch.empty_like(af), torch.empty_like(bf)
+        _hip.check(_hip.lib().uncl_l1_pairs(af.data_ptr(), 1, bf.data_ptr(), 1, n, 1.0, loss.data_ptr(), ga.data_ptr(),
+                                            gb.data_ptr(), 0, _hip.stream_ptr()), "uncl_l1_pairs")
+        ctx.save_for_backward(ga, gb)
+        ctx.shapes = (a.shape, b.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ga, gb = ctx.saved_tensors
+        return (ga * g).reshape(ctx.shapes[0]), (gb * g).reshape(ctx.shapes[1])
+
+
+def l1_mean(a, b):
+    """nn.L1Loss()(a, b) for per-sample scalars."""
+    return _L1PairsFn.apply(a, b)
+
+
+def tmqi_naturalness(frames, patch=None):
+    """fp64 naturalness scores of (N,1,H,W) frames scaled by 255 (TMQI.py:210-242), per frame or per patch x patch tile
+    (row-major within a frame).  Returns (scores float64 (N*tiles,), best_worst int32 (2,))."""
+    n, _, h, w = frames.shape
+    ph, pw = (h, w) if patch is None else (patch, patch)
+    xf = frames.detach().reshape(n, h, w).float().contiguous()
+    cnt = n * (h // ph) * (w // pw)
+    scores = torch.empty(cnt, dtype=torch.float64, device=xf.device)
+    bw = torch.empty(2, dtype=torch.int32, device=xf.device)
+    _hip.check(_hip.lib().uncl_tmqi_naturalness(xf.data_ptr(), n, h, w, ph, pw, 255.0, scores.data_ptr(), bw.data_ptr(),
+                                                _hip.stream_ptr()), "uncl_tmqi_naturalness")
+    return scores, bw
+
+
+class _TvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        xf = x.detach().reshape(n * c, h, w).float().contiguous()
+        loss, gx = _scalar(xf.device), torch.empty_like(xf)
+        ws = torch.empty(1024, dtype=torch.float32, device=xf.device)
+        # L_TV divides by the batch size (dim 0) only
+        _hip.check(_hip.lib().uncl_tv_loss(xf.data_ptr(), n * c, h, w, float(c), loss.data_ptr(), gx.data_ptr(), 0, 0,
+                                           ws.data_ptr(), _hip.stream_ptr()), "uncl_tv_loss")
+        ctx.save_for_backward(gx)
+        ctx.shape = x.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (gx,) = ctx.saved_tensors
+        return (gx * g).reshape(ctx.shape)
+
+
+def tv_loss(x):
+    return _TvFn.apply(x)
