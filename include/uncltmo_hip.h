@@ -108,6 +108,18 @@ int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
 int uncl_upconv2x2(const void* x, const void* prev, int prev_ch, const void* w, const float* bias, void* out, int N,
                    int H, int W, int C, int Cout, void* stream);
 
+/* Weight gradient of a 3x3 / 1x1 convolution (bf16 operands, fp32 accumulation, transposing LDS reads):
+ * dw_packed[tap][Cout][Cin] += sum_p gy[p][co] * X[p + tap][ci].  Descriptor: ksize, pad, src_mode (PLAIN / CONCAT_SSR),
+ * N, H, W, Cin, Cout, src0/src1 (+dims); gy: (N,Hout,Wout,Cout) bf16.  dw_packed is accumulated with float atomics:
+ * zero it first.  Backward of the layers of uncl_conv3x3_pipe / the graph block's 1x1 convs. */
+int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* dw_packed, void* stream);
+/* packed fp32 gradient -> reference layout (inverse of uncl_pack_conv_weight), written or accumulated */
+int uncl_unpack_conv_wgrad(const float* packed, float* dst, int Cout, int Cin, int k, int transposed, int flip,
+                           int accumulate, void* stream);
+/* bias gradient: out[c] (+)= sum_rows x[row][c], x bf16 [rows][ld]; workspace uncl_colsum_workspace_bytes(C) */
+size_t uncl_colsum_workspace_bytes(int C);
+int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, float* out, int accumulate, void* workspace, void* stream);
+
 /* Re-layout one reference-format weight for uncl_conv_igemm.
  * src: fp32, Conv2d layout (Cout, Cin, k, k) or, if transposed != 0, ConvTranspose2d layout (Cin, Cout, k, k).
  * dst: [tap][Cout][Cin] in dtype; for a transposed stride-1 3x3 the taps are flipped (tap' = 8 - tap) so that

@@ -1,0 +1,332 @@
+// Weight-gradient GEMM for the 3x3 (and 1x1) convolutions, bf16 operands, fp32 accumulation, gfx950.
+//
+//   dW[tap][co][ci] = sum over output pixels p of  gY[p][co] * X[p + tap][ci]
+//
+// The reduction runs over PIXELS, which is the strided dimension of both NHWC operands.  Both tiles are staged
+// into LDS in their natural [pixel][32 channels] (64-byte rows, XOR-swizzled 16-byte slots) and read back with
+// the transposing LDS read of CDNA4 (ds_read_b64_tr_b16): a 16-lane group fetches a 4-pixel x 16-channel block and
+// each lane receives 4 consecutive pixels of ONE channel — exactly the K-contiguous fragment the 32x32x16 MFMA
+// wants (A = gY^T: rows = co, k = pixel; B = X: k = pixel, cols = ci).  Lane mapping verified on hardware.
+//
+// Work split: blockIdx.y = vertical tap ty (three accumulators, tx = 0..2, per wave), blockIdx.z = (ci chunk,
+// co chunk) pair, blockIdx.x = group of 16x32 pixel tiles walked persistently with register prefetch.  Waves split
+// the tile's rows; partial sums are combined through LDS and added to the packed fp32 gradient with one float
+// atomic per element per workgroup.  The input tile supports the same synthesised sources as the forward kernel
+// (skip concat [x2, x1, x2^2, sqrt(x2+1e-8)] with replicate padding).
+#include "common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgArgs {
+  const bf16_t* src0;   // X source (skip x2 in concat mode)
+  const bf16_t* src1;   // upsampled x1 in concat mode
+  const bf16_t* gy;     // (N, Hout, Wout, Cout) gradient w.r.t. the conv output (already through the activation)
+  float* dw;            // packed [taps][Cout][Cin] fp32, accumulated with atomics
+  int H, W, Cin, Cout, pad, ks;  // ks = 3 or 1
+  int s0H, s0W, s0C, s1H, s1W, s1C;
+  int Hout, Wout;
+  int tiles_x, tiles_y, total_tiles, tiles_per_wg, nci;
+  long long M;          // ks == 1: number of valid flattened pixels (rows of 32)
+};
+
+__device__ __forceinline__ bf16x8 ld16g(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds_row0_base, int pix0, int c0, int lane) {
+  // 8 consecutive pixels (pix0 + 8h' ... handled by caller) x one channel per lane: two 4-pixel transposed reads
+  const int li = lane & 15, q = li >> 2, pp = li & 3;
+  bf16x8 out;
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int p = pix0 + 4 * rd + q;
+    const int slot = (c0 >> 3) + (pp >> 1);
+    const char* addr = lds_row0_base + p * 64 + ((slot ^ ((p >> 2) & 3)) << 4) + ((pp & 1) << 3);
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)addr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[4 * rd + i] = __builtin_bit_cast(bf16_t, (short)v[i]);
+  }
+  return out;
+}
+
+// MODE: 0 plain, 1 concat-ssr.  KS: 3 (three horizontal taps per workgroup) or 1
+template <int MODE, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int TH = 16, TW = 32;
+  constexpr int XW = TW + KS - 1;            // staged input columns
+  constexpr int NX = TH * XW;                // staged input pixels (one vertical tap: no vertical halo)
+  constexpr int NG = TH * TW;
+  constexpr int XV = (NX * 4 + 255) / 256, GV = (NG * 4) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;
+  char* sG = smem + NX * 64;
+  float* sR = reinterpret_cast<float*>(smem);  // [KS][32][32] cross-wave reduction (after the loop)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ty = blockIdx.y;                              // vertical tap handled by this workgroup
+  const int kc = blockIdx.z % a.nci, cc = blockIdx.z / a.nci;  // input / output channel chunk
+  int tile = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile + a.tiles_per_wg, a.total_tiles);
+  if (tile >= tile_end) return;
+
+  int g = 0, cbase = kc * 32;
+  if (MODE != 0) { g = cbase / a.s0C; cbase -= g * a.s0C; }
+  const int p0 = tid >> 2, ch = tid & 3;
+
+  vec xr[XV], gr[GV];
+  unsigned xvalid = 0;
+
+  auto load_tile = [&](int t) {
+    int r = t;
+    const int tx_ = r % a.tiles_x; r /= a.tiles_x;
+    const int ty_ = r % a.tiles_y; r /= a.tiles_y;
+    const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
+    const int iy0 = y0 + ty - a.pad, ix0 = x0 - a.pad;
+    unsigned valid = 0;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = p0 + j * 64;
+      const int hy = pix / XW, hx = pix - hy * XW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      bool ok = pix < NX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      if (KS == 1) ok = ok && ((long long)iy * 32 + ix < a.M);
+      valid |= (ok ? 1u : 0u) << j;
+      if (MODE != 0 && g == 1) {
+        const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
+        const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
+        xr[j] = ld16g(a.src1 + ((size_t)n * a.s1H * a.s1W + (size_t)sy * a.s1W + sx) * a.s1C + cbase + ch * 8);
+      } else {
+        const size_t off = ok ? ((size_t)n * a.s0H * a.s0W + (size_t)iy * a.s0W + ix) * a.s0C : 0;
+        xr[j] = ld16g(a.src0 + off + cbase + ch * 8);
+      }
+    }
+    xvalid = valid;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = p0 + j * 64;
+      const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
+      bool ok = gy_ < a.Hout && gx_ < a.Wout;
+      if (KS == 1) ok = ok && ((long long)gy_ * 32 + gx_ < a.M);
+      const size_t off = ok ? ((size_t)n * a.Hout * a.Wout + (size_t)gy_ * a.Wout + gx_) * a.Cout : 0;
+      vec v = ld16g(a.gy + off + cc * 32 + ch * 8);
+      if (!ok) v = E::zero();
+      gr[j] = v;
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = p0 + j * 64;
+      if (pix >= NX) continue;
+      vec v = xr[j];
+      if (MODE == 1 && g >= 2) {
+        float f[8];
+        E::unpack(v, f);
+        if (g == 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f);
+        }
+        v = E::pack(f);
+      }
+      if (!((xvalid >> j) & 1u)) v = E::zero();
+      *reinterpret_cast<vec*>(sX + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = p0 + j * 64;
+      *reinterpret_cast<vec*>(sG + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = gr[j];
+    }
+  };
+
+  f32x16 acc[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const int grp = lane >> 4;                  // 16-lane group
+  const int c0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
+
+  load_tile(tile);
+  write_lds();
+  __syncthreads();
+  while (true) {
+    const bool more = tile + 1 < tile_end;
+    if (more) load_tile(tile + 1);
+    // this wave's rows: 4*wave .. 4*wave+3; k-steps of 16 pixels (half rows)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 4 + r;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const vec A = tr_frag(sG, row * TW + half * 16 + kb, c0, lane);
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx) {
+          const vec B = tr_frag(sX, row * XW + half * 16 + tx + kb, c0, lane);
+          acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[tx], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (!more) break;
+    write_lds();
+    __syncthreads();
+    ++tile;
+  }
+  // ---- combine the four waves' partial sums through LDS, then one atomic per element
+  for (int i = tid; i < KS * 1024; i += 256) sR[i] = 0.f;
+  __syncthreads();
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = (i & 3) + 8 * (i >> 2) + 4 * lh;  // accumulator row
+      atomicAdd(&sR[(tx * 32 + co) * 32 + lr], acc[tx][i]);
+    }
+  __syncthreads();
+  for (int i = tid; i < KS * 1024; i += 256) {
+    const int tx = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+    const int tap = KS == 3 ? ty * 3 + tx : 0;
+    atomicAdd(a.dw + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
+  }
+}
+
+template <int MODE, int KS>
+int launch_wg(WgArgs& a, hipStream_t s) {
+  constexpr int XW = 32 + KS - 1;
+  constexpr size_t lds = (size_t)16 * XW * 64 + 512 * 64;
+  auto kern = wgrad_kernel<MODE, KS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int pairs = a.nci * (a.Cout / 32);
+  int groups = 2048 / (KS * pairs);
+  if (groups < 1) groups = 1;
+  if (groups > a.total_tiles) groups = a.total_tiles;
+  a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
+  groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  hipLaunchKernelGGL(kern, dim3(groups, KS, pairs), dim3(256), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// column sums of a [rows][C] bf16 matrix -> fp32 (bias gradients), deterministic two-stage
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, size_t rows, int C,
+                                                     int ld) {
+  // thread = (row lane, 8-channel vector); blockDim = 256 = (256 / (C/8)) rows x (C/8) vectors
+  const int VC = C / 8;
+  const int v = threadIdx.x % VC, rl = threadIdx.x / VC, rpb = 256 / VC;
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  for (size_t r = (size_t)blockIdx.x * rpb + rl; r < rows; r += (size_t)gridDim.x * rpb) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + r * ld + v * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] += (float)t[i];
+  }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = s[i];
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int vv = threadIdx.x / 8, ii = threadIdx.x % 8;
+    float t = 0.f;
+    for (int r = 0; r < rpb; ++r) t += red[(r * VC + vv) * 8 + ii];
+    partial[(size_t)blockIdx.x * C + threadIdx.x] = t;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += (double)partial[(size_t)b * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// packed fp32 [tap][Cout][Cin] gradient -> reference-layout fp32 gradient (inverse of uncl_pack_conv_weight)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int kk,
+                                    int transposed, int flip, int accumulate) {
+  const size_t total = (size_t)kk * Cout * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((size_t)Cin * Cout));
+    const int ts = flip ? (kk - 1 - tap) : tap;
+    const size_t d = transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
+    dst[d] = accumulate ? dst[d] + src[i] : src[i];
+  }
+}
+
+}  // namespace
+
+// dw_packed must be zeroed by the caller (it is accumulated with atomics).  Descriptor fields used: ksize (3 or 1),
+// pad, src_mode (PLAIN / CONCAT_SSR), N, H, W, Cin, Cout, src0/src1 (+dims); `gy` is (N, Hout, Wout, Cout) bf16.
+extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* dw_packed, void* stream) {
+  if (!d || !gy || !dw_packed || d->dtype != UNCL_BF16) return UNCL_ERR_ARG;
+  if (d->ksize != 3 && d->ksize != 1) return UNCL_ERR_ARG;
+  if (d->src_mode != UNCL_SRC_PLAIN && d->src_mode != UNCL_SRC_CONCAT_SSR) return UNCL_ERR_ARG;
+  if (d->Cin % 32 != 0 || d->Cout % 32 != 0 || d->src0 == nullptr) return UNCL_ERR_ARG;
+  if (d->src_mode == UNCL_SRC_CONCAT_SSR && (d->src1 == nullptr || d->Cin != 4 * d->src0_C)) return UNCL_ERR_ARG;
+  WgArgs a;
+  a.src0 = (const bf16_t*)d->src0; a.src1 = (const bf16_t*)d->src1; a.gy = (const bf16_t*)gy; a.dw = dw_packed;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.pad = d->ksize == 3 ? d->pad : 0; a.ks = d->ksize;
+  a.s0H = d->src0_H; a.s0W = d->src0_W; a.s0C = d->src0_C; a.s1H = d->src1_H; a.s1W = d->src1_W; a.s1C = d->src1_C;
+  if (d->ksize == 1) {
+    // flatten: one row of M pixels
+    const long long M = (long long)d->N * d->H * d->W;
+    if (M > 0x7fffffffLL) return UNCL_ERR_ARG;
+    const int rows = (int)((M + 31) / 32);  // a (rows x 32) image with a ragged last row
+    a.H = rows; a.W = 32; a.s0H = rows; a.s0W = 32;
+    a.Hout = rows; a.Wout = 32;
+    a.M = M;
+    a.tiles_x = 1; a.tiles_y = (rows + 15) / 16;
+    a.total_tiles = a.tiles_y;
+  } else {
+    a.Hout = d->H + 2 * d->pad - 2; a.Wout = d->W + 2 * d->pad - 2;
+    a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + 15) / 16;
+    a.total_tiles = d->N * a.tiles_x * a.tiles_y;
+  }
+  a.nci = d->Cin / 32;
+  if (d->ksize == 3) a.M = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d->ksize == 3) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg<0, 3>(a, s) : launch_wg<1, 3>(a, s);
+  return launch_wg<0, 1>(a, s);
+}
+
+extern "C" size_t uncl_colsum_workspace_bytes(int C) { return (size_t)512 * C * sizeof(float); }
+
+// out[c] (+)= sum over rows of x[row][c]; x bf16 [rows][ld] (any ld >= C), C a multiple of 8 (bias gradients)
+extern "C" int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, float* out, int accumulate, void* workspace,
+                                void* stream) {
+  if (!x || !out || !workspace || rows <= 0 || C < 8 || C % 8 != 0 || ld < C) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int cw = C - c0 < 256 ? C - c0 : 256;
+    if (256 % (cw / 8) != 0) return UNCL_ERR_ARG;
+    const int rpb = 256 / (cw / 8);
+    const int blocks = (int)((rows + rpb - 1) / rpb < 512 ? (rows + rpb - 1) / rpb : 512);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x + c0, (float*)workspace, (size_t)rows, cw, ld);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cw + 63) / 64), dim3(64), 0, s, (const float*)workspace, blocks, cw, out + c0,
+                       accumulate);
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_unpack_conv_wgrad(const float* packed, float* dst, int Cout, int Cin, int k, int transposed, int flip,
+                                      int accumulate, void* stream) {
+  if (!packed || !dst || Cout <= 0 || Cin <= 0 || k <= 0) return UNCL_ERR_ARG;
+  const size_t total = (size_t)k * k * Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), packed, dst, Cout,
+                     Cin, k * k, transposed, flip, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
