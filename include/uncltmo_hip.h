@@ -120,6 +120,33 @@ int uncl_unpack_conv_wgrad(const float* packed, float* dst, int Cout, int Cin, i
 size_t uncl_colsum_workspace_bytes(int C);
 int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, float* out, int accumulate, void* workspace, void* stream);
 
+/* Data gradient of a 3x3 layer: uncl_conv3x3_pipe over re-packed weights with an identity activation; the stored
+ * gradient is multiplied by the activation derivative of the layer that produced the tensor it flows into
+ * (mask > 0 ? 1 : mask_slope; mask may be NULL) and optionally added to the gradient already in `out`. */
+int uncl_conv3x3_dgrad(const uncl_conv_desc* d, const void* mask, float mask_slope, int accumulate, void* stream);
+/* backward of uncl_upconv2x2: weight gradient (packed [4][Cout][C], zeroed by the caller) and data gradient
+ * (wt = the (Cin,Cout,2,2) weight packed as a Conv2d weight: [4][Cin][Cout]) */
+int uncl_upconv2x2_wgrad(const void* x, const void* gy, float* dw_packed, int N, int H, int W, int C, int Cout, void* stream);
+int uncl_upconv2x2_dgrad(const void* gy, const void* wt, const void* mask, float slope, void* gx, int N, int H, int W, int Cin,
+                         int Cout, void* stream);
+/* element-wise pieces of the generator backward (bf16 tensors, fp32 math); see csrc/backward_kernels.hip */
+int uncl_outc_backward(const float* g_out, const float* x_out, const void* g_upx, const void* up_x, const float* w, void* G_up,
+                       float* gw, float* gb, long long P, int last_act, float slope, int accumulate, void* workspace,
+                       void* stream);
+int uncl_ssr_backward(const void* g_cat, const void* x2, void* G_x2, void* G_x1, int N, int H, int W, int C, int H1, int W1,
+                      float slope, int accumulate_x2, void* stream);
+int uncl_pool_backward(const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope, int accumulate,
+                       void* stream);
+int uncl_gelu_forward(const void* z, void* h, long long n, void* stream);
+int uncl_gelu_backward(const void* g_h, const void* z, void* g_z, long long n, void* stream);
+int uncl_scale_rows(const void* x, const float* scale, void* y, int N, long long per, void* stream);
+int uncl_mask_minus(const void* g, const void* x, const void* pe, void* out, int N, long long per, float slope, void* stream);
+int uncl_sum_samples(const void* g, float* out, int N, long long per, void* stream);
+int uncl_gcn_maxrel_backward(const void* g_out, const void* x, const int32_t* idx, float* g_x_f32, void* g_x_bf16, int N, int n,
+                             int C, int k, void* stream);
+int uncl_conv_in_c1_wgrad(const void* G, const float* x, float* gw, float* gb, int N, int H, int W, int accumulate,
+                          void* workspace, void* stream);
+
 /* Re-layout one reference-format weight for uncl_conv_igemm.
  * src: fp32, Conv2d layout (Cout, Cin, k, k) or, if transposed != 0, ConvTranspose2d layout (Cin, Cout, k, k).
  * dst: [tap][Cout][Cin] in dtype; for a transposed stride-1 3x3 the taps are flipped (tap' = 8 - tap) so that
@@ -177,9 +204,35 @@ typedef struct uncl_gen_run {
   const float* drop_scale;    /* optional fp32 (2,N): DropPath keep/keep_prob for the two residual sites   */
   void* workspace;
   size_t workspace_bytes;
+  int save_preact;            /* 1: also keep the pre-GELU values of the graph block (needed by uncl_gen_backward)    */
   const void* prev_workspace; /* video: workspace of the previous frame (same N, keep_activations=1); the
                                  first C/32 channels entering every down/up stage come from it (Unet.py:244,270) */
 } uncl_gen_run;
+
+/* Backward of uncl_gen_forward (bf16, keep_activations = 1, save_preact = 1): gradients of every generator parameter
+ * from dL/dx_out (fp32) and optionally dL/dup_x (bf16 NHWC).  Weight gradients come out in the PACKED layout of the
+ * forward weights ([tap][Cout][Cin] fp32; uncl_unpack_conv_wgrad converts); `wd` are the weights re-packed for the
+ * data-gradient convolutions. */
+typedef struct uncl_gen_bwd {
+  int N;
+  const float* x;            /* generator input (N,256,256)                                */
+  const float* x_out;        /* forward output (N,256,256)                                 */
+  const float* g_out;        /* dL/dx_out (N,256,256)                                      */
+  const void* up_x;          /* forward up_x, NHWC bf16 (N,256,256,32)                     */
+  const void* g_upx;         /* dL/dup_x, NHWC bf16, or NULL                               */
+  const float* drop_scale;   /* the (2,N) DropPath multipliers of the forward, or NULL     */
+  void* workspace;           /* the forward's workspace                                    */
+  void* grad_workspace;      /* uncl_gen_backward_workspace_bytes(N)                       */
+  size_t grad_workspace_bytes;
+  const void* wd[UNCL_G_NUM_WEIGHTS];   /* data-gradient weights                           */
+  float* gw[UNCL_G_NUM_WEIGHTS];        /* packed fp32 weight gradients, ZEROED by caller  */
+  float* gb[UNCL_G_NUM_WEIGHTS];        /* bias gradients                                  */
+  float* g_inc0_w; float* g_inc0_b;     /* (32,1,3,3), (32)                                */
+  float* g_outc_w; float* g_outc_b;     /* (32), (1)                                       */
+  float* g_pos_embed;                   /* (144,256) NHWC fp32                             */
+} uncl_gen_bwd;
+size_t uncl_gen_backward_workspace_bytes(int N);
+int uncl_gen_backward(const uncl_gen_weights* wts, const uncl_gen_bwd* b, void* stream);
 
 const char* uncl_gen_layer_name(int i); /* state_dict prefix of packed weight i, NULL past the end */
 

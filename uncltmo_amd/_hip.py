@@ -54,7 +54,18 @@ class GenRun(C.Structure):
         ("N", C.c_int), ("chunk", C.c_int), ("keep_activations", C.c_int),
         ("x", C.c_void_p), ("out", C.c_void_p), ("up_x", C.c_void_p), ("knn_idx", C.c_void_p),
         ("drop_scale", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("prev_workspace", C.c_void_p),
+        ("save_preact", C.c_int), ("prev_workspace", C.c_void_p),
+    ]
+
+
+class GenBwd(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("x", C.c_void_p), ("x_out", C.c_void_p), ("g_out", C.c_void_p), ("up_x", C.c_void_p),
+        ("g_upx", C.c_void_p), ("drop_scale", C.c_void_p), ("workspace", C.c_void_p), ("grad_workspace", C.c_void_p),
+        ("grad_workspace_bytes", C.c_size_t),
+        ("wd", C.c_void_p * G_NUM_WEIGHTS), ("gw", C.c_void_p * G_NUM_WEIGHTS), ("gb", C.c_void_p * G_NUM_WEIGHTS),
+        ("g_inc0_w", C.c_void_p), ("g_inc0_b", C.c_void_p), ("g_outc_w", C.c_void_p), ("g_outc_b", C.c_void_p),
+        ("g_pos_embed", C.c_void_p),
     ]
 
 
@@ -73,6 +84,23 @@ SIGNATURES = {
                                          C.c_void_p]),
     "uncl_colsum_workspace_bytes": (C.c_size_t, [C.c_int]),
     "uncl_colsum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_conv3x3_dgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "uncl_upconv2x2_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    "uncl_upconv2x2_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p]),
+    "uncl_outc_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_longlong, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_ssr_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float, C.c_int, C.c_void_p]),
+    "uncl_pool_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
+    "uncl_gelu_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "uncl_gelu_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "uncl_scale_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
+    "uncl_mask_minus": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
+    "uncl_sum_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
+    "uncl_gcn_maxrel_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "uncl_conv_in_c1_wgrad": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
+    "uncl_gen_backward_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "uncl_gen_backward": (C.c_int, [C.POINTER(GenWeights), C.POINTER(GenBwd), C.c_void_p]),
     "uncl_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
     "uncl_conv_in_c1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -1,0 +1,413 @@
+// Element-wise / gather kernels of the generator's backward pass (bf16 activations and gradients, fp32 math).
+// Every gradient tensor that is stored is already multiplied by the activation derivative of the layer that
+// produced the corresponding activation ("pre-activation gradient"), so consumers never need a second mask pass.
+#include "common.h"
+
+namespace {
+
+using E8 = Elem<bf16_t>;
+__device__ __forceinline__ bf16x8 ldv8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void stv8(bf16_t* p, const float* f) { *reinterpret_cast<bf16x8*>(p) = E8::pack(f); }
+
+// ---- outconv (1x1 to one channel) + sigmoid backward (Unet_singleFrame.py:207-209)
+// g_pre[p] = g_out[p] s (1 - s);  G_up[p][c] = (g_upx[p][c] + g_pre[p] w[c]) * [up_x[p][c] > 0 ? 1 : slope]
+// partial[block][33] = sum_p g_pre[p] up_x[p][c] (c < 32), sum_p g_pre[p]
+__global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ x_out,
+                                                       const bf16_t* __restrict__ g_upx, const bf16_t* __restrict__ up_x,
+                                                       const float* __restrict__ w, bf16_t* __restrict__ G_up,
+                                                       float* __restrict__ partial, size_t P, int last_act, float slope) {
+  __shared__ float red[4][33];
+  float aw[32], ab = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) aw[c] = 0.f;
+  // thread = (pixel, 8-channel vector): 4 threads per pixel
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P * 4; i += (size_t)gridDim.x * 256) {
+    const size_t p = i >> 2;
+    const int v = (int)(i & 3);
+    const float s = x_out[p];
+    const float gp = last_act == UNCL_ACT_SIGMOID ? g_out[p] * s * (1.f - s) : g_out[p];
+    float u[8], gu[8], o[8];
+    E8::unpack(ldv8(up_x + p * 32 + v * 8), u);
+    if (g_upx) E8::unpack(ldv8(g_upx + p * 32 + v * 8), gu);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float t = (g_upx ? gu[c] : 0.f) + gp * w[v * 8 + c];
+      o[c] = u[c] > 0.f ? t : slope * t;
+      aw[v * 8 + c] = fmaf(gp, u[c], aw[v * 8 + c]);
+    }
+    if (v == 0) ab += gp;
+    stv8(G_up + p * 32 + v * 8, o);
+  }
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float t = wave_sum(aw[c]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = t;
+  }
+  const float tb = wave_sum(ab);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][32] = tb;
+  __syncthreads();
+  if (threadIdx.x < 33)
+    partial[(size_t)blockIdx.x * 33 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ partial, int rows, int cols, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * cols + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// ---- skip-concat backward (unet_parts.py:319-322, 292-298)
+// g_cat: (N,H,W,4C).  G_x2 = (g0 + 2 x2 g2 + g3 / (2 sqrt(x2 + eps))) * relu'(x2)   [written or accumulated]
+// G_x1 (N,H1,W1,C) = g1 with the replicate-padded border folded back (clamped positions accumulate)
+__global__ __launch_bounds__(256) void ssr_bwd_kernel(const bf16_t* __restrict__ g_cat, const bf16_t* __restrict__ x2,
+                                                      bf16_t* __restrict__ G_x2, bf16_t* __restrict__ G_x1, int N, int H, int W,
+                                                      int C, int H1, int W1, float slope, int accumulate_x2) {
+  const int VC = C / 8;
+  const size_t total = (size_t)N * H * W * VC;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int v = (int)(i % VC);
+    const size_t p = i / VC;
+    const bf16_t* gc = g_cat + p * 4 * C + v * 8;
+    float g0[8], g2[8], g3[8], xv[8], o[8];
+    E8::unpack(ldv8(gc), g0);
+    E8::unpack(ldv8(gc + 2 * C), g2);
+    E8::unpack(ldv8(gc + 3 * C), g3);
+    E8::unpack(ldv8(x2 + p * C + v * 8), xv);
+    if (accumulate_x2) E8::unpack(ldv8(G_x2 + p * C + v * 8), o);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float t = g0[c] + 2.f * xv[c] * g2[c] + g3[c] * 0.5f / sqrtf(xv[c] + 1e-8f);
+      const float m = xv[c] > 0.f ? t : slope * t;
+      o[c] = accumulate_x2 ? o[c] + m : m;
+    }
+    stv8(G_x2 + p * C + v * 8, o);
+  }
+  // x1 gradient: one thread per (x1 pixel, vector) gathers the skip-resolution pixels that were clamped onto it
+  const int dy = (H - H1) >> 1, dx = (W - W1) >> 1;
+  const size_t total1 = (size_t)N * H1 * W1 * VC;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total1; i += (size_t)gridDim.x * 256) {
+    const int v = (int)(i % VC);
+    size_t r = i / VC;
+    const int sx = (int)(r % W1); r /= W1;
+    const int sy = (int)(r % H1);
+    const int n = (int)(r / H1);
+    const int y_lo = sy == 0 ? 0 : sy + dy, y_hi = sy == H1 - 1 ? H - 1 : sy + dy;
+    const int x_lo = sx == 0 ? 0 : sx + dx, x_hi = sx == W1 - 1 ? W - 1 : sx + dx;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int y = y_lo; y <= y_hi; ++y)
+      for (int x = x_lo; x <= x_hi; ++x) {
+        float g1[8];
+        E8::unpack(ldv8(g_cat + (((size_t)n * H + y) * W + x) * 4 * C + C + v * 8), g1);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += g1[c];
+      }
+    stv8(G_x1 + (((size_t)n * H1 + sy) * W1 + sx) * C + v * 8, acc);
+  }
+}
+
+// ---- 2x2 max-pool backward: the gradient of each pooled pixel goes to the first maximum of its window
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const bf16_t* __restrict__ g_pool, const bf16_t* __restrict__ x,
+                                                       bf16_t* __restrict__ G_x, int N, int H, int W, int C, float slope,
+                                                       int accumulate) {
+  const int VC = C / 8, Hp = H / 2, Wp = W / 2;
+  const size_t total = (size_t)N * Hp * Wp * VC;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int v = (int)(i % VC);
+    size_t r = i / VC;
+    const int px = (int)(r % Wp); r /= Wp;
+    const int py = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    float g[8], xs[4][8];
+    E8::unpack(ldv8(g_pool + (((size_t)n * Hp + py) * Wp + px) * C + v * 8), g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      E8::unpack(ldv8(x + (((size_t)n * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + v * 8), xs[q]);
+    int best[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int b = 0;
+      float m = xs[0][c];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (xs[q][c] > m) { m = xs[q][c]; b = q; }
+      best[c] = b;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bf16_t* dst = G_x + (((size_t)n * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + v * 8;
+      float o[8];
+      if (accumulate) E8::unpack(ldv8(dst), o);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float t = best[c] == q ? (xs[q][c] > 0.f ? g[c] : slope * g[c]) : 0.f;
+        o[c] = accumulate ? o[c] + t : t;
+      }
+      stv8(dst, o);
+    }
+  }
+}
+
+// ---- GELU forward / backward on [rows][C] with an optional per-sample scale (DropPath) on the backward
+__global__ void gelu_fwd_kernel(const bf16_t* __restrict__ z, bf16_t* __restrict__ h, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float f[8];
+    E8::unpack(ldv8(z + i * 8), f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = uncl_gelu(f[c]);
+    stv8(h + i * 8, f);
+  }
+}
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ g_h, const bf16_t* __restrict__ z, bf16_t* __restrict__ g_z, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float g[8], f[8];
+    E8::unpack(ldv8(g_h + i * 8), g);
+    E8::unpack(ldv8(z + i * 8), f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float x = f[c];
+      const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+      g[c] *= cdf + x * pdf;
+    }
+    stv8(g_z + i * 8, g);
+  }
+}
+
+// y = x * scale[n] (per-sample DropPath factor) on [N][per] bf16; scale == NULL -> copy
+__global__ void scale_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale, bf16_t* __restrict__ y,
+                                  size_t per_vec, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float f[8];
+    E8::unpack(ldv8(x + i * 8), f);
+    const float s = scale ? scale[i / per_vec] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] *= s;
+    stv8(y + i * 8, f);
+  }
+}
+
+// G = g * [(x - pe) > 0 ? 1 : slope]   (x = relu(v) + pos_embed, Unet_singleFrame.py:94); pe broadcast over samples
+__global__ void mask_minus_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ pe,
+                                  bf16_t* __restrict__ out, size_t per_vec, size_t nvec, float slope) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float gg[8], xx[8], pp[8];
+    E8::unpack(ldv8(g + i * 8), gg);
+    E8::unpack(ldv8(x + i * 8), xx);
+    E8::unpack(ldv8(pe + (i % per_vec) * 8), pp);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) gg[c] = (xx[c] - pp[c]) > 0.f ? gg[c] : slope * gg[c];
+    stv8(out + i * 8, gg);
+  }
+}
+
+// sum over samples: out[e] = sum_n g[n][e]   (pos_embed gradient), fp32 out
+__global__ void sum_samples_kernel(const bf16_t* __restrict__ g, float* __restrict__ out, int N, size_t per) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += (float)g[(size_t)n * per + e];
+    out[e] = s;
+  }
+}
+
+// ---- max-relative backward (torch_vertex.py:22-29): out[2c] = x_c, out[2c+1] = max_k (x_c[nbr_k] - x_c)
+// g_x[i][c] = g[i][2c] - g[i][2c+1];  g_x[nbr*(i,c)][c] += g[i][2c+1]   (fp32 atomics into a zeroed fp32 buffer)
+__global__ __launch_bounds__(256) void maxrel_bwd_kernel(const bf16_t* __restrict__ g_out, const bf16_t* __restrict__ x,
+                                                         const int32_t* __restrict__ idx, float* __restrict__ g_x, int N, int n,
+                                                         int C, int k) {
+  const int VC = C / 8;
+  const size_t total = (size_t)N * n * VC;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+    const int cv = (int)(t % VC);
+    const size_t node = t / VC;
+    const size_t b = node / n;
+    float xi[8], m[8], g0[16];
+    int arg[8];
+    E8::unpack(ldv8(x + node * C + cv * 8), xi);
+    E8::unpack(ldv8(g_out + node * 2 * C + (size_t)cv * 16), g0);
+    E8::unpack(ldv8(g_out + node * 2 * C + (size_t)cv * 16 + 8), g0 + 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; arg[e] = 0; }
+    for (int r = 0; r < k; ++r) {
+      const int j = idx[node * k + r];
+      float xj[8];
+      E8::unpack(ldv8(x + (b * n + j) * C + cv * 8), xj);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = xj[e] - xi[e];
+        if (d > m[e]) { m[e] = d; arg[e] = j; }   // first maximum, like torch.max
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gx = g0[2 * e], gr = g0[2 * e + 1];
+      atomicAdd(g_x + node * C + cv * 8 + e, gx - gr);
+      atomicAdd(g_x + (b * n + arg[e]) * C + cv * 8 + e, gr);
+    }
+  }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = (bf16_t)x[i];
+}
+
+// ---- first layer (Cin = 1) weight / bias gradient: dw[co][tap] = sum_p G[p][co] x[p + tap]
+__global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const bf16_t* __restrict__ G, const float* __restrict__ x,
+                                                            float* __restrict__ partial, int N, int H, int W) {
+  // G: (N, H-2, W-2, 32).  thread = (pixel, 8-channel vector); partial[block][32*10]
+  __shared__ float red[4][320];
+  const int Ho = H - 2, Wo = W - 2;
+  float acc[8][10];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[c][t] = 0.f;
+  const int v = threadIdx.x & 3;
+  const size_t P = (size_t)N * Ho * Wo;
+  for (size_t p = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); p < P; p += (size_t)gridDim.x * 64) {
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((size_t)Wo * Ho));
+    float g[8];
+    E8::unpack(ldv8(G + p * 32 + v * 8), g);
+    float in[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) in[t] = x[((size_t)n * H + oy + t / 3) * W + ox + t % 3];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(g[c], in[t], acc[c][t]);
+      acc[c][9] += g[c];
+    }
+  }
+  // lanes with equal v hold the same channels: reduce over the 16 pixel-lanes of a wave sharing v (stride 4)
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      float s = acc[c][t];
+#pragma unroll
+      for (int o = 32; o >= 4; o >>= 1) s += __shfl_xor(s, o, 64);
+      if ((threadIdx.x & 63) < 4) red[threadIdx.x >> 6][(v * 8 + c) * 10 + t] = s;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 320; i += 256)
+    partial[(size_t)blockIdx.x * 320 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+__global__ void conv_in_final_kernel(const float* __restrict__ tot, float* __restrict__ gw, float* __restrict__ gb, int accumulate) {
+  const int i = threadIdx.x + blockIdx.x * blockDim.x;
+  if (i >= 320) return;
+  const int co = i / 10, t = i % 10;
+  float* dst = t < 9 ? gw + co * 9 + t : gb + co;
+  *dst = accumulate ? *dst + tot[i] : tot[i];
+}
+
+inline int nblocks(size_t n, int cap = 4096) { return (int)((n + 255) / 256 < (size_t)cap ? (n + 255) / 256 : cap); }
+
+}  // namespace
+
+extern "C" int uncl_outc_backward(const float* g_out, const float* x_out, const void* g_upx, const void* up_x, const float* w,
+                                  void* G_up, float* gw, float* gb, long long P, int last_act, float slope, int accumulate,
+                                  void* workspace /* 1024*33 floats */, void* stream) {
+  if (!g_out || !x_out || !up_x || !w || !G_up || !gw || !gb || !workspace || P <= 0) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = nblocks((size_t)P * 4, 1024);
+  hipLaunchKernelGGL(outc_bwd_kernel, dim3(blocks), dim3(256), 0, s, g_out, x_out, (const bf16_t*)g_upx, (const bf16_t*)up_x, w,
+                     (bf16_t*)G_up, (float*)workspace, (size_t)P, last_act, slope);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, blocks, 33, (float*)workspace + 1024 * 33,
+                     0);
+  // split the 33 sums into gw[32], gb[1]
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace + 1024 * 33, 1, 32, gw, accumulate);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace + 1024 * 33 + 32, 1, 1, gb, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_ssr_backward(const void* g_cat, const void* x2, void* G_x2, void* G_x1, int N, int H, int W, int C, int H1,
+                                 int W1, float slope, int accumulate_x2, void* stream) {
+  if (!g_cat || !x2 || !G_x2 || !G_x1 || C % 8 != 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(ssr_bwd_kernel, dim3(nblocks((size_t)N * H * W * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)g_cat, (const bf16_t*)x2, (bf16_t*)G_x2, (bf16_t*)G_x1, N, H, W, C, H1, W1, slope, accumulate_x2);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_pool_backward(const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope,
+                                  int accumulate, void* stream) {
+  if (!g_pool || !x || !G_x || C % 8 != 0) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!accumulate && ((H & 1) || (W & 1))) {
+    // odd sizes: the last row / column is outside every window and must read as zero
+    if (hipMemsetAsync(G_x, 0, (size_t)N * H * W * C * 2, s) != hipSuccess) return UNCL_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(nblocks((size_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, s, (const bf16_t*)g_pool,
+                     (const bf16_t*)x, (bf16_t*)G_x, N, H, W, C, slope, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_gelu_forward(const void* z, void* h, long long n, void* stream) {
+  if (!z || !h || n <= 0 || n % 8 != 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(nblocks((size_t)n / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)z, (bf16_t*)h, (size_t)n / 8);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+extern "C" int uncl_gelu_backward(const void* g_h, const void* z, void* g_z, long long n, void* stream) {
+  if (!g_h || !z || !g_z || n <= 0 || n % 8 != 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nblocks((size_t)n / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)g_h, (const bf16_t*)z, (bf16_t*)g_z, (size_t)n / 8);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+extern "C" int uncl_scale_rows(const void* x, const float* scale, void* y, int N, long long per, void* stream) {
+  if (!x || !y || N <= 0 || per <= 0 || per % 8 != 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(nblocks((size_t)N * per / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)x, scale, (bf16_t*)y, (size_t)per / 8, (size_t)N * per / 8);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+extern "C" int uncl_mask_minus(const void* g, const void* x, const void* pe, void* out, int N, long long per, float slope,
+                               void* stream) {
+  if (!g || !x || !pe || !out || per % 8 != 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(mask_minus_kernel, dim3(nblocks((size_t)N * per / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)pe, (bf16_t*)out, (size_t)per / 8, (size_t)N * per / 8, slope);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+extern "C" int uncl_sum_samples(const void* g, float* out, int N, long long per, void* stream) {
+  if (!g || !out || N <= 0 || per <= 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(sum_samples_kernel, dim3(nblocks((size_t)per)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)g, out, N, (size_t)per);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+// g_x_f32 must be zeroed; g_x_bf16 receives the converted result
+extern "C" int uncl_gcn_maxrel_backward(const void* g_out, const void* x, const int32_t* idx, float* g_x_f32, void* g_x_bf16, int N,
+                                        int n, int C, int k, void* stream) {
+  if (!g_out || !x || !idx || !g_x_f32 || !g_x_bf16 || C % 8 != 0) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(maxrel_bwd_kernel, dim3(nblocks((size_t)N * n * (C / 8))), dim3(256), 0, s, (const bf16_t*)g_out, (const bf16_t*)x,
+                     idx, g_x_f32, N, n, C, k);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(nblocks((size_t)N * n * C)), dim3(256), 0, s, g_x_f32, (bf16_t*)g_x_bf16, (size_t)N * n * C);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+// G: (N,H-2,W-2,32) bf16 masked gradient of inc.conv.conv's output; gw: (32,1,3,3), gb: (32).  workspace: 512*320+320 floats
+extern "C" int uncl_conv_in_c1_wgrad(const void* G, const float* x, float* gw, float* gb, int N, int H, int W, int accumulate,
+                                     void* workspace, void* stream) {
+  if (!G || !x || !gw || !gb || !workspace) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t P = (size_t)N * (H - 2) * (W - 2);
+  const int blocks = (int)((P + 63) / 64 < 512 ? (P + 63) / 64 : 512);
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(conv_in_wgrad_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)G, x, part, N, H, W);
+  float* tot = part + (size_t)512 * 320;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(5), dim3(64), 0, s, (const float*)part, blocks, 320, tot, 0);
+  hipLaunchKernelGGL(conv_in_final_kernel, dim3(5), dim3(64), 0, s, (const float*)tot, gw, gb, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}

@@ -27,6 +27,9 @@ struct PipeArgs {
   const bf16_t* weight;
   const float* bias;
   const bf16_t* res;
+  const bf16_t* mask;   // backward: stored value is zeroed where mask <= 0 (ReLU of the layer that produced `mask`)
+  int accumulate;       // backward: add to what `out` already holds
+  float mask_slope;     // backward: derivative on the non-positive side (0 ReLU, 0.2 LeakyReLU)
   bf16_t* out;
   bf16_t* pool_out;
   const float* out1_w;
@@ -347,12 +350,36 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
           bf16_t* ob = a.out + ((size_t)c_n * a.Hout * a.Wout + pix0) * a.oC + c_co + st_sl * 8;
           const int rows_left = a.Hout - (c_y0 + st_row);  // passes with it*ROWS_PER_IT < rows_left are in range
           const unsigned row_stride = (unsigned)(ROWS_PER_IT * a.Wout * a.oC);
-          if (a.res == nullptr) {
+          if (a.res == nullptr && a.mask == nullptr && !a.accumulate) {
 #pragma unroll
             for (int it = 0; it < ST_IT; ++it) {
               if (it * ROWS_PER_IT < rows_left) {
                 const vec val = *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2));
                 *reinterpret_cast<vec*>(ob + it * row_stride) = val;
+              }
+            }
+          } else if (a.res == nullptr) {
+            // gradient store: ReLU mask of the producing layer and / or accumulation into an existing gradient
+            const bf16_t* mb = a.mask ? a.mask + ((size_t)c_n * a.Hout * a.Wout + pix0) * a.oC + c_co + st_sl * 8 : nullptr;
+#pragma unroll
+            for (int it = 0; it < ST_IT; ++it) {
+              if (it * ROWS_PER_IT < rows_left) {
+                const vec val = *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2));
+                float f[8];
+                E::unpack(val, f);
+                if (mb) {
+                  float m[8];
+                  E::unpack(ld16(mb + it * row_stride), m);
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) f[i] = m[i] > 0.f ? f[i] : a.mask_slope * f[i];
+                }
+                if (a.accumulate) {
+                  float o[8];
+                  E::unpack(ld16(ob + it * row_stride), o);
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) f[i] += o[i];
+                }
+                *reinterpret_cast<vec*>(ob + it * row_stride) = E::pack(f);
               }
             }
           } else {
@@ -465,7 +492,8 @@ int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
 
 // Same descriptor as uncl_conv_igemm; handles bf16 3x3 with src_mode PLAIN / CONCAT_SSR / CONCAT2.
 // `pool_out` (optional) receives maxpool2x2(out) as NHWC (N, Hout/2, Wout/2, Cout).
-extern "C" int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream) {
+static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void* mask, float mask_slope, int accumulate,
+                             void* stream) {
   if (d == nullptr || d->dtype != UNCL_BF16 || d->ksize != 3) return UNCL_ERR_ARG;
   if (d->pad != 0 && d->pad != 2) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_CONCAT2) return UNCL_ERR_ARG;
@@ -486,11 +514,15 @@ extern "C" int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* 
   PipeArgs a;
   a.src0 = (const bf16_t*)d->src0; a.src1 = (const bf16_t*)d->src1; a.prev0 = (const bf16_t*)d->prev0;
   a.weight = (const bf16_t*)d->weight; a.bias = d->bias; a.res = (const bf16_t*)d->res;
+  a.mask = (const bf16_t*)mask; a.accumulate = accumulate; a.mask_slope = mask_slope;
   a.out = (bf16_t*)d->out; a.pool_out = (bf16_t*)pool_out; a.out1_w = d->out1_w; a.out1_b = d->out1_b; a.out1 = d->out1;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.pad = d->pad;
   a.s0H = d->src0_H; a.s0W = d->src0_W; a.s0C = d->src0_C;
   a.s1H = d->src1_H; a.s1W = d->src1_W; a.s1C = d->src1_C; a.prev_ch = d->prev_ch;
   a.slope = d->act == UNCL_ACT_RELU ? 0.f : (d->act == UNCL_ACT_LRELU ? 0.2f : 1.f);
+  if (mask != nullptr) {
+    if (d->act != UNCL_ACT_NONE || d->res != nullptr) return UNCL_ERR_ARG;  // gradient mode: identity epilogue
+  }
   a.res_b0 = d->res_batch_stride0;
   a.Hout = d->H + 2 * d->pad - 2; a.Wout = d->W + 2 * d->pad - 2; a.oC = d->out_C;
   if (a.Hout <= 0 || a.Wout <= 0) return UNCL_ERR_ARG;
@@ -513,4 +545,15 @@ extern "C" int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* 
   a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
   a.total_tiles = d->N * a.tiles_x * a.tiles_y * a.n_ct;
   return dispatch_mode<2, 2>(a, d->src_mode, prev, s);
+}
+
+extern "C" int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream) {
+  return conv3x3_pipe_impl(d, pool_out, nullptr, 0.f, 0, stream);
+}
+
+// Data gradient of a 3x3 layer = the same kernel over re-packed weights (see uncl_pack_conv_weight), identity
+// activation; the stored gradient is multiplied by the activation derivative of the layer that produced the tensor it
+// flows into (mask > 0 ? 1 : mask_slope) and optionally added to the gradient already there (skip connections).
+extern "C" int uncl_conv3x3_dgrad(const uncl_conv_desc* d, const void* mask, float mask_slope, int accumulate, void* stream) {
+  return conv3x3_pipe_impl(d, nullptr, mask, mask_slope, accumulate, stream);
 }

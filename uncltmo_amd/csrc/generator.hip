@@ -21,7 +21,7 @@ enum Buf {
   B_INC0, B_X0, B_D0A, B_X1, B_D1A, B_X2, B_D2A, B_X3, B_D3A, B_X4,
   B_GFC1, B_GMR, B_GGC, B_GX1, B_FH, B_GOUT,
   B_U0UP, B_U0A, B_U0, B_U1UP, B_U1A, B_U1, B_U2UP, B_U2A, B_U2, B_U3UP, B_U3A, B_UPX,
-  B_KNN, B_X0P, B_X1P, B_X2P, B_X3P, B_COUNT
+  B_KNN, B_X0P, B_X1P, B_X2P, B_X3P, B_GGCZ, B_FHZ, B_COUNT
 };
 
 struct BufDim { int h, w, c; };
@@ -32,7 +32,8 @@ const BufDim kDims[B_COUNT] = {
     {24, 24, 256},  {26, 26, 128},  {28, 28, 128},  {56, 56, 128},  {59, 59, 64},  {61, 61, 64},
     {122, 122, 64}, {124, 124, 32}, {126, 126, 32}, {252, 252, 32}, {254, 254, 32}, {256, 256, 32},
     {1, 144, 9},
-    {126, 126, 32}, {61, 61, 64}, {28, 28, 128}, {12, 12, 256}};
+    {126, 126, 32}, {61, 61, 64}, {28, 28, 128}, {12, 12, 256},
+    {1, 144, 512}, {1, 144, 256}};
 
 struct Layout {
   size_t off[B_COUNT];
@@ -99,6 +100,7 @@ struct Ctx {
   const char* prev;  // previous frame's workspace base (video) or NULL
   Layout L;
   int n;             // tiles in this chunk
+  int save_preact;   // keep pre-GELU values (training)
   hipStream_t s;
   void* ptr(int b) const { return ws + L.off[b]; }
   const void* pptr(int b) const { return prev ? prev + L.off[b] : nullptr; }
@@ -245,9 +247,19 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   if (knn_out && hipMemcpyAsync(knn_out, knn, (size_t)c.n * NODES * 9 * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
     return UNCL_ERR_LAUNCH;
   RUN(uncl_gcn_maxrel(c.ptr(B_GFC1), knn, c.ptr(B_GMR), w->dtype, c.n, NODES, 256, 9, c.s));
-  RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_GELU, nullptr, 0, nullptr, 4));
+  if (c.save_preact && use_pipe(c)) {
+    RUN(conv1(c, W_GGC, B_GMR, B_GGCZ, 512, 512, UNCL_ACT_NONE, nullptr, 0, nullptr, 4));
+    RUN(uncl_gelu_forward(c.ptr(B_GGCZ), c.ptr(B_GGC), (long long)c.n * NODES * 512, c.s));
+  } else {
+    RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_GELU, nullptr, 0, nullptr, 4));
+  }
   RUN(conv1(c, W_GFC2, B_GGC, B_GX1, 512, 256, UNCL_ACT_NONE, c.ptr(B_X4), 0, drop0));
-  RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
+  if (c.save_preact && use_pipe(c)) {
+    RUN(conv1(c, W_FFC1, B_GX1, B_FHZ, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
+    RUN(uncl_gelu_forward(c.ptr(B_FHZ), c.ptr(B_FH), (long long)c.n * NODES * 256, c.s));
+  } else {
+    RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
+  }
   RUN(conv1(c, W_FFC2, B_FH, B_GOUT, 256, 256, UNCL_ACT_NONE, c.ptr(B_GX1), 0, drop1));
   // decoder
   RUN(up_stage(c, W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128, 8, nullptr, nullptr));
@@ -257,6 +269,188 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   tail.out1_w = w->outc_w; tail.out1_b = w->outc_b; tail.out1 = out; tail.out1_act = w->last_act;
   tail.skip_main_store = up_x == nullptr ? 1 : 0;
   RUN(up_stage(c, W_U3UP, B_U2, B_X0, B_U3UP, B_U3A, B_UPX, 32, 32, 1, up_x, &tail));
+#undef RUN
+  return UNCL_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward pass (bf16).  G(b) = gradient buffer of activation buffer b (same layout in the gradient workspace);
+// every stored gradient already carries the activation derivative of the layer that produced b.
+// ------------------------------------------------------------------------------------------------------------------
+struct BwdScratch {
+  char* gcat;    // (N,252,252,128) bf16: gradient of a decoder stage's concat input
+  char* gpool;   // (N,126,126,32) bf16: gradient of a pooled encoder input
+  char* tA;      // (N,144,512) bf16 x 4 temporaries of the graph block
+  char* tB;
+  char* tC;
+  char* tD;
+  float* f32;    // (N,144,256) fp32 max-relative scatter target
+  float* misc;   // colsum / outc / conv_in partial sums
+};
+
+size_t bwd_scratch_bytes(int N) {
+  size_t b = 0;
+  b += (size_t)N * 252 * 252 * 128 * 2;
+  b += (size_t)N * 126 * 126 * 32 * 2;
+  b += 4 * (size_t)N * 144 * 512 * 2;
+  b += (size_t)N * 144 * 256 * 4;
+  b += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
+  return b + 4096;
+}
+
+struct BCtx {
+  const uncl_gen_weights* w;
+  const uncl_gen_bwd* b;
+  char* fws;   // forward workspace
+  char* gws;   // gradient arena (same layout)
+  Layout L;
+  BwdScratch sc;
+  int n;
+  float slope;
+  hipStream_t s;
+  void* F(int buf) const { return fws + L.off[buf]; }
+  void* G(int buf) const { return gws + L.off[buf]; }
+};
+
+uncl_conv_desc bdesc(const BCtx& c, int ks, int pad, int h, int w, int cin, int cout) {
+  uncl_conv_desc d = {};
+  d.dtype = UNCL_BF16; d.ksize = ks; d.pad = pad; d.N = c.n; d.H = h; d.W = w; d.Cin = cin; d.Cout = cout;
+  d.src_mode = UNCL_SRC_PLAIN; d.act = UNCL_ACT_NONE;
+  return d;
+}
+
+// weight + bias gradient of a 3x3 layer whose input is buffer `xin` (plain) and whose output gradient is gy
+int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const void* gy, int oh, int ow) {
+  uncl_conv_desc d = bdesc(c, 3, pad, kDims[xin].h, kDims[xin].w, cin, cout);
+  d.src0 = c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
+  int rc = uncl_conv_wgrad(&d, gy, c.b->gw[wi], c.s);
+  if (rc != UNCL_OK) return rc;
+  return uncl_colsum_bf16(gy, (long long)c.n * oh * ow, cout, cout, c.b->gb[wi], 0, c.sc.misc, c.s);
+}
+
+// data gradient of a 3x3 layer: gy (N,gh,gw,gc) -> out buffer (cout_d channels), pad_d = 2 - pad_fwd
+int dgrad3(const BCtx& c, int wi, const void* gy, int gh, int gw, int gc, int pad_d, int cout_d, void* out, int oh, int ow,
+           const void* mask, int accumulate) {
+  uncl_conv_desc d = bdesc(c, 3, pad_d, gh, gw, gc, cout_d);
+  d.src0 = gy; d.src0_H = gh; d.src0_W = gw; d.src0_C = gc;
+  d.weight = c.b->wd[wi];
+  d.out = out; d.out_H = oh; d.out_W = ow; d.out_C = cout_d;
+  return uncl_conv3x3_dgrad(&d, mask, c.slope, accumulate, c.s);
+}
+
+// 1x1 conv on the 144-node graph tensors: weight gradient / data gradient
+int wgrad1(const BCtx& c, int wi, const void* x, int xc_total, int cin, const void* gy, int gy_total, int cout, float* gw,
+           bool bias) {
+  uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, cin, cout);
+  d.src0 = x; d.src0_H = 12; d.src0_W = 12; d.src0_C = xc_total;
+  d.out_C = gy_total;  // leading dimension of gy
+  int rc = uncl_conv_wgrad(&d, gy, gw, c.s);
+  if (rc != UNCL_OK || !bias) return rc;
+  return uncl_colsum_bf16(gy, (long long)c.n * NODES, gy_total, gy_total, c.b->gb[wi], 0, c.sc.misc, c.s);
+}
+int dgrad1(const BCtx& c, int wi, const void* gy, int cin_d, int cout_d, void* out, const void* res, int groups = 0) {
+  uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, groups ? cin_d / groups : cin_d, groups ? cout_d / groups : cout_d);
+  d.src0 = gy; d.src0_H = 12; d.src0_W = 12; d.src0_C = cin_d;
+  d.weight = c.b->wd[wi];
+  d.res = res;
+  d.out = out; d.out_H = 12; d.out_W = 12; d.out_C = cout_d;
+  if (groups) { d.z_mode = UNCL_Z_GROUPS; d.groups = groups; }
+  return uncl_conv_igemm(&d, c.s);
+}
+
+int backward_all(const BCtx& c) {
+  const uncl_gen_bwd* b = c.b;
+  int rc;
+#define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
+  // ---- tail: outconv + sigmoid
+  RUN(uncl_outc_backward(b->g_out, b->x_out, b->g_upx, b->up_x, c.w->outc_w, c.G(B_UPX), b->g_outc_w, b->g_outc_b,
+                         (long long)c.n * 256 * 256, c.w->last_act, c.slope, 0, c.sc.misc, c.s));
+  // ---- decoder stages 3..0
+  struct Stage { int wi, x1, skip, up, a, out, ch, cout; };
+  const Stage st[4] = {{W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128},
+                       {W_U1UP, B_U0, B_X2, B_U1UP, B_U1A, B_U1, 128, 64},
+                       {W_U2UP, B_U1, B_X1, B_U2UP, B_U2A, B_U2, 64, 32},
+                       {W_U3UP, B_U2, B_X0, B_U3UP, B_U3A, B_UPX, 32, 32}};
+  for (int i = 3; i >= 0; --i) {
+    const Stage& q = st[i];
+    const int oh = kDims[q.out].h, ow = kDims[q.out].w, ah = kDims[q.a].h, aw = kDims[q.a].w;
+    const int sh = kDims[q.skip].h, sw = kDims[q.skip].w, uh = kDims[q.up].h, uw = kDims[q.up].w;
+    // conv b (ConvT 3x3, cout -> cout): input = buffer a
+    RUN(wgrad3(c, q.wi + 2, q.a, 2, q.cout, q.cout, c.G(q.out), oh, ow));
+    RUN(dgrad3(c, q.wi + 2, c.G(q.out), oh, ow, q.cout, 0, q.cout, c.G(q.a), ah, aw, c.F(q.a), 0));
+    // conv a (ConvT 3x3 on the concat, 4ch -> cout)
+    {
+      uncl_conv_desc d = bdesc(c, 3, 2, sh, sw, 4 * q.ch, q.cout);
+      d.src_mode = UNCL_SRC_CONCAT_SSR;
+      d.src0 = c.F(q.skip); d.src0_H = sh; d.src0_W = sw; d.src0_C = q.ch;
+      d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
+      RUN(uncl_conv_wgrad(&d, c.G(q.a), b->gw[q.wi + 1], c.s));
+      RUN(uncl_colsum_bf16(c.G(q.a), (long long)c.n * ah * aw, q.cout, q.cout, b->gb[q.wi + 1], 0, c.sc.misc, c.s));
+    }
+    RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
+    RUN(uncl_ssr_backward(c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
+    // up (ConvT 2x2 s2, ch -> ch): input x1
+    const int xh = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].h, xw = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].w;
+    RUN(uncl_upconv2x2_wgrad(c.F(q.x1), c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
+    RUN(uncl_colsum_bf16(c.G(q.up), (long long)c.n * uh * uw, q.ch, q.ch, b->gb[q.wi], 0, c.sc.misc, c.s));
+    RUN(uncl_upconv2x2_dgrad(c.G(q.up), b->wd[q.wi], i == 0 ? nullptr : c.F(q.x1), c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
+                             c.s));
+  }
+  // ---- graph block
+  const float* drop0 = b->drop_scale;
+  const float* drop1 = b->drop_scale ? b->drop_scale + c.n : nullptr;
+  const long long per256 = (long long)NODES * 256, per512 = (long long)NODES * 512;
+  // FFN: GOUT = drop1 * fc2(gelu(fc1(GX1))) + GX1
+  RUN(uncl_scale_rows(c.G(B_GOUT), drop1, c.sc.tA, c.n, per256, c.s));
+  RUN(wgrad1(c, W_FFC2, c.F(B_FH), 256, 256, c.sc.tA, 256, 256, b->gw[W_FFC2], true));
+  RUN(dgrad1(c, W_FFC2, c.sc.tA, 256, 256, c.sc.tB, nullptr));
+  RUN(uncl_gelu_backward(c.sc.tB, c.F(B_FHZ), c.sc.tB, (long long)c.n * per256, c.s));
+  RUN(wgrad1(c, W_FFC1, c.F(B_GX1), 256, 256, c.sc.tB, 256, 256, b->gw[W_FFC1], true));
+  RUN(dgrad1(c, W_FFC1, c.sc.tB, 256, 256, c.G(B_GX1), c.G(B_GOUT)));
+  // Grapher: GX1 = drop0 * fc2(gelu(gconv(maxrel(fc1(X4))))) + X4
+  RUN(uncl_scale_rows(c.G(B_GX1), drop0, c.sc.tA, c.n, per256, c.s));
+  RUN(wgrad1(c, W_GFC2, c.F(B_GGC), 512, 512, c.sc.tA, 256, 256, b->gw[W_GFC2], true));
+  RUN(dgrad1(c, W_GFC2, c.sc.tA, 256, 512, c.sc.tC, nullptr));
+  RUN(uncl_gelu_backward(c.sc.tC, c.F(B_GGCZ), c.sc.tC, (long long)c.n * per512, c.s));
+  for (int g = 0; g < 4; ++g)  // grouped 1x1: four independent 128 -> 128 blocks
+    RUN(wgrad1(c, W_GGC, (const bf16_t*)c.F(B_GMR) + g * 128, 512, 128, (const bf16_t*)c.sc.tC + g * 128, 512, 128,
+               b->gw[W_GGC] + (size_t)g * 128 * 128, false));
+  RUN(uncl_colsum_bf16(c.sc.tC, (long long)c.n * NODES, 512, 512, b->gb[W_GGC], 0, c.sc.misc, c.s));
+  RUN(dgrad1(c, W_GGC, c.sc.tC, 512, 512, c.sc.tD, nullptr, 4));
+  if (hipMemsetAsync(c.sc.f32, 0, (size_t)c.n * per256 * 4, c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
+  RUN(uncl_gcn_maxrel_backward(c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, c.sc.tB, c.n, NODES,
+                               256, 9, c.s));
+  RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, c.sc.tB, 256, 256, b->gw[W_GFC1], true));
+  RUN(dgrad1(c, W_GFC1, c.sc.tB, 256, 256, c.G(B_X4), c.G(B_GX1)));
+  RUN(uncl_sum_samples(c.G(B_X4), b->g_pos_embed, c.n, per256, c.s));
+  RUN(uncl_mask_minus(c.G(B_X4), c.F(B_X4), c.w->pos_embed, c.sc.tA, c.n, per256, c.slope, c.s));
+  // ---- encoder
+  // down3: conv (valid, pooled X3 -> D3A), ConvT (D3A -> X4)
+  RUN(wgrad3(c, W_D3B, B_D3A, 2, 256, 256, c.sc.tA, 12, 12));
+  RUN(dgrad3(c, W_D3B, c.sc.tA, 12, 12, 256, 0, 256, c.G(B_D3A), 10, 10, c.F(B_D3A), 0));
+  struct Enc { int wa, wb, xin, pooled, mid, out, cin, cout; };
+  // second conv of each level first (its output gradient is complete), then the first conv + pool backward
+  const Enc en[3] = {{W_D2A, W_D2B, B_X2, B_X2P, B_D2A, B_X3, 128, 256},
+                     {W_D1A, W_D1B, B_X1, B_X1P, B_D1A, B_X2, 64, 128},
+                     {W_D0A, W_D0B, B_X0, B_X0P, B_D0A, B_X1, 32, 64}};
+  // down3's first conv reads pooled X3
+  RUN(wgrad3(c, W_D3A, B_X3P, 0, 256, 256, c.G(B_D3A), 10, 10));
+  RUN(dgrad3(c, W_D3A, c.G(B_D3A), 10, 10, 256, 2, 256, c.sc.gpool, 12, 12, nullptr, 0));
+  RUN(uncl_pool_backward(c.sc.gpool, c.F(B_X3), c.G(B_X3), c.n, 24, 24, 256, c.slope, 1, c.s));
+  for (int i = 0; i < 3; ++i) {
+    const Enc& e = en[i];
+    const int oh = kDims[e.out].h, mh = kDims[e.mid].h, ph = kDims[e.pooled].h, xh = kDims[e.xin].h;
+    RUN(wgrad3(c, e.wb, e.mid, 0, e.cout, e.cout, c.G(e.out), oh, oh));
+    RUN(dgrad3(c, e.wb, c.G(e.out), oh, oh, e.cout, 2, e.cout, c.G(e.mid), mh, mh, c.F(e.mid), 0));
+    RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh));
+    RUN(dgrad3(c, e.wa, c.G(e.mid), mh, mh, e.cout, 2, e.cin, c.sc.gpool, ph, ph, nullptr, 0));
+    RUN(uncl_pool_backward(c.sc.gpool, c.F(e.xin), c.G(e.xin), c.n, xh, xh, e.cin, c.slope, 1, c.s));
+  }
+  // inc: conv1 (INC0 -> X0), conv (image -> INC0)
+  RUN(wgrad3(c, W_INC1, B_INC0, 0, 32, 32, c.G(B_X0), 252, 252));
+  RUN(dgrad3(c, W_INC1, c.G(B_X0), 252, 252, 32, 2, 32, c.G(B_INC0), 254, 254, c.F(B_INC0), 0));
+  RUN(uncl_conv_in_c1_wgrad(c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, 0, c.sc.misc, c.s));
 #undef RUN
   return UNCL_OK;
 }
@@ -311,6 +505,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.w = w;
     c.L = L;
     c.n = (r->N - n0 < chunk) ? r->N - n0 : chunk;
+    c.save_preact = r->save_preact;
     c.s = reinterpret_cast<hipStream_t>(stream);
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
@@ -329,4 +524,36 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     if (rc != UNCL_OK) return rc;
   }
   return UNCL_OK;
+}
+
+extern "C" size_t uncl_gen_backward_workspace_bytes(int N) {
+  if (N <= 0) return 0;
+  return make_layout(N, UNCL_BF16).total + bwd_scratch_bytes(N);
+}
+
+extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* b, void* stream) {
+  if (!w || !b || w->dtype != UNCL_BF16 || b->N <= 0) return UNCL_ERR_ARG;
+  if (!b->x || !b->x_out || !b->g_out || !b->up_x || !b->workspace || !b->grad_workspace) return UNCL_ERR_ARG;
+  if (b->grad_workspace_bytes < uncl_gen_backward_workspace_bytes(b->N)) return UNCL_ERR_ARG;
+  for (int i = 0; i < UNCL_G_NUM_WEIGHTS; ++i)
+    if (!b->wd[i] || !b->gw[i] || !b->gb[i]) return UNCL_ERR_ARG;
+  if (!b->g_inc0_w || !b->g_inc0_b || !b->g_outc_w || !b->g_outc_b || !b->g_pos_embed) return UNCL_ERR_ARG;
+  BCtx c;
+  c.w = w; c.b = b; c.n = b->N;
+  c.L = make_layout(b->N, UNCL_BF16);
+  c.fws = reinterpret_cast<char*>(b->workspace);
+  c.gws = reinterpret_cast<char*>(b->grad_workspace);
+  c.slope = w->act == UNCL_ACT_LRELU ? 0.2f : 0.f;
+  c.s = reinterpret_cast<hipStream_t>(stream);
+  char* p = c.gws + c.L.total;
+  const int N = b->N;
+  c.sc.gcat = p; p += (size_t)N * 252 * 252 * 128 * 2;
+  c.sc.gpool = p; p += (size_t)N * 126 * 126 * 32 * 2;
+  c.sc.tA = p; p += (size_t)N * 144 * 512 * 2;
+  c.sc.tB = p; p += (size_t)N * 144 * 512 * 2;
+  c.sc.tC = p; p += (size_t)N * 144 * 512 * 2;
+  c.sc.tD = p; p += (size_t)N * 144 * 512 * 2;
+  c.sc.f32 = reinterpret_cast<float*>(p); p += (size_t)N * 144 * 256 * 4;
+  c.sc.misc = reinterpret_cast<float*>(p);
+  return backward_all(c);
 }

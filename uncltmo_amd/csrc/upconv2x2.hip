@@ -176,3 +176,144 @@ extern "C" int uncl_upconv2x2(const void* x, const void* prev, int prev_ch, cons
     default: return launch_up<256>(a, pv, s);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Data gradient of ConvTranspose2d(k2, s2):  g_x[n,y,x,ci] = sum_{dy,dx,co} g_up[n,2y+dy,2x+dx,co] * W[ci,co,dy,dx]
+// Same skinny-GEMM structure as the forward with the roles of the channel dimensions swapped: K = Cout per tap (four
+// taps accumulate into the same tile), weights re-packed as [tap][ci][co].  The stored gradient is multiplied by the
+// activation derivative of the layer that produced x (mask > 0 ? 1 : slope) when a mask is given.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct UpBwdArgs {
+  const bf16_t* gy;     // (N, 2H, 2W, Cout)
+  const bf16_t* wt;     // [4][Cin][Cout]
+  const bf16_t* mask;   // (N,H,W,Cin) or NULL
+  bf16_t* gx;           // (N,H,W,Cin)
+  int H, W, Cin, M, n_tiles, rows;  // rows = min(Cin, 128) handled per workgroup
+  float slope;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void upconv2x2_dgrad_kernel(const UpBwdArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int KS = COUT / 16, S = COUT / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;                        // [rows][COUT] bf16, swizzled
+  char* sO = smem + 128 * COUT * 2;       // [128 pixels][rows] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ct = blockIdx.y;              // 128-row slice of Cin
+  const int NTI = a.rows / 32;            // N-tiles (ci) per workgroup: 1..4
+  auto wswz = [](int row, int slot) {
+    const int f = S == 4 ? ((row >> 2) & 3) : (S == 8 ? ((row >> 1) & 7) : (row & 15));
+    return slot ^ f;
+  };
+  f32x16 zero16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+  const int slots_o = a.rows / 8;         // 16-byte slots per output pixel
+
+  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const int m0 = t * 128;
+    const int mp = min(m0 + wave * 32 + lr, a.M - 1);
+    const int n = mp / (a.H * a.W), rem = mp - n * (a.H * a.W);
+    const int y = rem / a.W, x = rem - y * a.W;
+    f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = zero16;
+    for (int tap = 0; tap < 4; ++tap) {
+      __syncthreads();  // previous tap's (or tile's) readers are done with sW / sO
+      for (int v = tid; v < a.rows * S; v += 256) {
+        const int row = v / S, slot = v - row * S;
+        const vec wv = *reinterpret_cast<const vec*>(a.wt + ((size_t)tap * a.Cin + ct * 128 + row) * COUT + slot * 8);
+        *reinterpret_cast<vec*>(sW + row * (COUT * 2) + (wswz(row, slot) << 4)) = wv;
+      }
+      const size_t gp = (((size_t)n * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1)) * COUT;
+      vec B[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) B[ks] = *reinterpret_cast<const vec*>(a.gy + gp + ks * 16 + lh * 8);
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (nt < NTI) {
+            const int row = nt * 32 + lr;
+            const vec A = *reinterpret_cast<const vec*>(sW + row * (COUT * 2) + (wswz(row, 2 * ks + lh) << 4));
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[ks], acc[nt], 0, 0, 0);
+          }
+    }
+    // transpose through LDS: [pixel][rows] bf16
+    const int pl = wave * 32 + lr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      if (nt < NTI) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[nt][4 * q + r];
+          *reinterpret_cast<bf16x4*>(sO + pl * (a.rows * 2) + (((nt * 4 + q) ^ (pl & (slots_o - 1))) << 4) + (lh << 3)) = o;
+        }
+      }
+    __syncthreads();
+    for (int v = tid; v < 128 * slots_o; v += 256) {
+      const int p = v / slots_o, sl = v - p * slots_o;
+      const int m = m0 + p;
+      if (m >= a.M) continue;
+      vec val = *reinterpret_cast<const vec*>(sO + p * (a.rows * 2) + ((sl ^ (p & (slots_o - 1))) << 4));
+      const size_t off = (size_t)m * a.Cin + ct * 128 + sl * 8;
+      if (a.mask != nullptr) {
+        float f[8], mk[8];
+        E::unpack(val, f);
+        E::unpack(*reinterpret_cast<const vec*>(a.mask + off), mk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = mk[i] > 0.f ? f[i] : a.slope * f[i];
+        val = E::pack(f);
+      }
+      *reinterpret_cast<vec*>(a.gx + off) = val;
+    }
+  }
+}
+
+template <int COUT>
+int launch_up_bwd(const UpBwdArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)128 * COUT * 2 + 128 * 256;
+  auto kern = upconv2x2_dgrad_kernel<COUT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int n_ct = (a.Cin + 127) / 128;
+  const int gx = a.n_tiles < 2048 ? a.n_tiles : 2048;
+  hipLaunchKernelGGL(kern, dim3(gx, n_ct), dim3(256), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+}  // namespace
+
+// gy: (N,2H,2W,Cout) bf16; wt: packed [4][Cin][Cout] bf16 (uncl_pack_conv_weight on the (Cin,Cout,2,2) weight with
+// transposed=0, i.e. treating it as a Conv2d weight); gx: (N,H,W,Cin).  mask (optional): the activation x itself.
+extern "C" int uncl_upconv2x2_dgrad(const void* gy, const void* wt, const void* mask, float slope, void* gx, int N, int H, int W,
+                                    int Cin, int Cout, void* stream) {
+  if (!gy || !wt || !gx || N <= 0 || Cin % 32 != 0) return UNCL_ERR_ARG;
+  if (Cout != 32 && Cout != 64 && Cout != 128 && Cout != 256) return UNCL_ERR_ARG;
+  if (Cin > 128 && Cin % 128 != 0) return UNCL_ERR_ARG;
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL / 256) return UNCL_ERR_ARG;
+  UpBwdArgs a;
+  a.gy = (const bf16_t*)gy; a.wt = (const bf16_t*)wt; a.mask = (const bf16_t*)mask; a.gx = (bf16_t*)gx;
+  a.H = H; a.W = W; a.Cin = Cin; a.M = (int)M; a.n_tiles = (int)((M + 127) / 128); a.rows = Cin < 128 ? Cin : 128; a.slope = slope;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (Cout) {
+    case 32: return launch_up_bwd<32>(a, s);
+    case 64: return launch_up_bwd<64>(a, s);
+    case 128: return launch_up_bwd<128>(a, s);
+    default: return launch_up_bwd<256>(a, s);
+  }
+}

@@ -29,6 +29,9 @@ struct WgArgs {
   int Hout, Wout;
   int tiles_x, tiles_y, total_tiles, tiles_per_wg, nci;
   long long M;          // ks == 1: number of valid flattened pixels (rows of 32)
+  int gy_ld;            // elements between consecutive pixels of gy (>= Cout; grouped convs pass the full width)
+  int up_tap, upH, upW; // ks == 1, up_tap >= 0: gy is the (N,2*upH,2*upW,Cout) output gradient of a 2x2 stride-2
+                        // transposed conv and pixel m=(n,y,x) pairs with gy pixel (n, 2y+dy, 2x+dx)
 };
 
 __device__ __forceinline__ bf16x8 ld16g(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -109,7 +112,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
       const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
       bool ok = gy_ < a.Hout && gx_ < a.Wout;
       if (KS == 1) ok = ok && ((long long)gy_ * 32 + gx_ < a.M);
-      const size_t off = ok ? ((size_t)n * a.Hout * a.Wout + (size_t)gy_ * a.Wout + gx_) * a.Cout : 0;
+      size_t off = ok ? ((size_t)n * a.Hout * a.Wout + (size_t)gy_ * a.Wout + gx_) * a.gy_ld : 0;
+      if (KS == 1 && a.up_tap >= 0 && ok) {
+        const long long m = (long long)gy_ * 32 + gx_;
+        const int hw = a.upH * a.upW;
+        const int nn = (int)(m / hw), rem = (int)(m - (long long)nn * hw);
+        const int yy = rem / a.upW, xx = rem - yy * a.upW;
+        off = (((size_t)nn * 2 * a.upH + 2 * yy + (a.up_tap >> 1)) * (2 * a.upW) + 2 * xx + (a.up_tap & 1)) * a.gy_ld;
+      }
       vec v = ld16g(a.gy + off + cc * 32 + ch * 8);
       if (!ok) v = E::zero();
       gr[j] = v;
@@ -295,9 +305,35 @@ extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* d
   }
   a.nci = d->Cin / 32;
   if (d->ksize == 3) a.M = 0;
+  a.up_tap = -1; a.upH = a.upW = 0;
+  a.gy_ld = d->out_C > 0 ? d->out_C : d->Cout;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->ksize == 3) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg<0, 3>(a, s) : launch_wg<1, 3>(a, s);
   return launch_wg<0, 1>(a, s);
+}
+
+// Weight gradient of ConvTranspose2d(k2, s2): dw_packed[tap][Cout][C] += sum_p gy[(n,2y+dy,2x+dx)][co] * x[(n,y,x)][ci].
+// x: (N,H,W,C) bf16, gy: (N,2H,2W,Cout) bf16; dw_packed zeroed by the caller.
+extern "C" int uncl_upconv2x2_wgrad(const void* x, const void* gy, float* dw_packed, int N, int H, int W, int C, int Cout,
+                                    void* stream) {
+  if (!x || !gy || !dw_packed || C % 32 != 0 || Cout % 32 != 0) return UNCL_ERR_ARG;
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int tap = 0; tap < 4; ++tap) {
+    WgArgs a;
+    a.src0 = (const bf16_t*)x; a.src1 = nullptr; a.gy = (const bf16_t*)gy; a.dw = dw_packed + (size_t)tap * Cout * C;
+    a.Cin = C; a.Cout = Cout; a.pad = 0; a.ks = 1;
+    a.s0C = C; a.s1H = a.s1W = a.s1C = 0;
+    const int rows = (int)((M + 31) / 32);
+    a.H = rows; a.W = 32; a.s0H = rows; a.s0W = 32; a.Hout = rows; a.Wout = 32; a.M = M;
+    a.tiles_x = 1; a.tiles_y = (rows + 15) / 16; a.total_tiles = a.tiles_y;
+    a.nci = C / 32;
+    a.up_tap = tap; a.upH = H; a.upW = W; a.gy_ld = Cout;
+    const int rc = launch_wg<0, 1>(a, s);
+    if (rc != UNCL_OK) return rc;
+  }
+  return UNCL_OK;
 }
 
 extern "C" size_t uncl_colsum_workspace_bytes(int C) { return (size_t)512 * C * sizeof(float); }

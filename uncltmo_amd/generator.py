@@ -176,6 +176,33 @@ class _GeneratorBase(nn.Module):
             keep += [src, dst]
             gw.w[i] = dst.data_ptr()
             gw.b[i] = f32(name + ".bias")
+        # weights re-packed for the data-gradient convolutions (bf16 training path only)
+        wd = []
+        if code == _hip.BF16:
+            for i in range(_hip.G_NUM_WEIGHTS):
+                name = lib.uncl_gen_layer_name(i).decode()
+                shape, kind = spec[name + ".weight"]
+                src = sd[name + ".weight"].detach().float().contiguous()
+                k = shape[2]
+                dst = torch.empty(src.numel(), dtype=tdt, device=dev)
+                if kind == "convT" and k == 3:      # dgrad = valid conv with the weight read as a Conv2d weight
+                    args = [(src, dst, shape[0], shape[1], 3, 0, 0)]
+                elif kind == "convT":                # 2x2 stride 2: [4][Cin][Cout]
+                    args = [(src, dst, shape[0], shape[1], 2, 0, 0)]
+                elif name.endswith("graph_conv.gconv.nn.0"):   # grouped 1x1: transpose every 128x128 block
+                    g, blk = 4, shape[1]
+                    args = [(src[j * blk:(j + 1) * blk], dst[j * blk * blk:(j + 1) * blk * blk], blk, blk, 1, 1, 0)
+                            for j in range(g)]
+                else:                                # Conv2d (Cout,Cin,k,k): read as a ConvTranspose2d weight, flipped for 3x3
+                    args = [(src, dst, shape[1], shape[0], k, 1, 1 if k == 3 else 0)]
+                for (a_src, a_dst, co, ci, kk, tr, fl) in args:
+                    a_src = a_src.contiguous()
+                    keep.append(a_src)
+                    _hip.check(lib.uncl_pack_conv_weight(a_src.data_ptr(), a_dst.data_ptr(), code, co, ci, kk, tr, fl, st),
+                               "uncl_pack_conv_weight(dgrad %s)" % name)
+                keep += [src, dst]
+                wd.append(dst)
+        self._wd = wd
         pe = sd["gcn.pos_embed"].detach().reshape(256, 144).t().contiguous().to(tdt)    # (144,256) NHWC
         keep.append(pe)
         gw.pos_embed = pe.data_ptr()
@@ -209,7 +236,8 @@ class _GeneratorBase(nn.Module):
             keep = torch.empty(2, n, device=dev).bernoulli_(keep_prob)
         return (keep / keep_prob).contiguous()
 
-    def _run(self, x_flat, need_feat, prev_ws=None, keep_act=False, slot=0, want_knn=False):
+    def _run(self, x_flat, need_feat, prev_ws=None, keep_act=False, slot=0, want_knn=False, save_preact=False,
+             return_drop=False):
         """x_flat: (N,256,256) fp32 on the GPU.  Returns (out (N,1,256,256) fp32, up_x NHWC or None, knn or None, ws)."""
         lib = _hip.lib()
         gw, _keep = self._packed_weights()
@@ -229,7 +257,10 @@ class _GeneratorBase(nn.Module):
         run.drop_scale = ds.data_ptr() if ds is not None else None
         run.workspace, run.workspace_bytes = ws.data_ptr(), nbytes
         run.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
+        run.save_preact = int(save_preact)
         _hip.check(lib.uncl_gen_forward(C.byref(gw), C.byref(run), _hip.stream_ptr()), "uncl_gen_forward")
+        if return_drop:
+            return out, up, knn, ws, ds
         return out, up, knn, ws
 
     @staticmethod
