@@ -1,0 +1,44 @@
+"""torch.optim.Adam semantics (no weight decay / amsgrad) with the update done by one fused HIP launch per step
+(uncl_adam_step).  Drop-in for the `optim.Adam(net.parameters(), lr=..., betas=(0.5, 0.999))` the reference builds in
+main_train_image.py:29-32; works with torch.optim.lr_scheduler.StepLR (it only edits param_groups[...]['lr'])."""
+import ctypes as C
+
+import torch
+
+from . import _hip
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = _hip.lib()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if not p.is_cuda:
+                    raise _hip.HipError("uncltmo_amd.optim.Adam needs CUDA(HIP) parameters")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+                st["step"] += 1
+            step = self.state[ps[0]]["step"]
+            grads = [p.grad.float().contiguous() for p in ps]
+            arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            n = (C.c_int * len(ps))(*[p.numel() for p in ps])
+            b1, b2 = group["betas"]
+            _hip.check(lib.uncl_adam_step(arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
+                                          arr([self.state[p]["exp_avg_sq"] for p in ps]), n, len(ps), float(group["lr"]),
+                                          float(b1), float(b2), float(group["eps"]), int(step), _hip.stream_ptr()),
+                       "uncl_adam_step")
+            for p in ps:
+                p._version  # noqa: B018  (parameters were updated in place by the kernel)
+                p.add_(0)   # bump the autograd version counter so cached weight packs are rebuilt
+        return loss

@@ -1,0 +1,186 @@
+"""Image GAN trainer, MI355X-native.  Same constructor / method signatures and side-effect attributes as the reference's
+`GanTrainerImg.GanTrainer` (GanTrainerImg.py:58-339, 341-461); every tensor op of the step runs in this package's HIP
+kernels (generator / discriminator forward+backward, loss heads, TMQI selection, Adam), PyTorch autograd only routes
+gradient tensors between the custom Functions.
+
+Differences that are stated, not hidden:
+ * the reference wraps every step in autograd.detect_anomaly(), prints tensor statistics and calls .item() three times
+   per step (host syncs); this trainer keeps the losses on the device (`errD`, `errG_d`, `errG_struct` are 0-dim tensors)
+   and appends them to the same lists without syncing;
+ * the two generator backward passes (errG_d with retain_graph, then errG_struct, GanTrainerImg.py:338,460) are summed
+   into ONE backward pass: identical gradient up to fp32 summation order, half the backward work;
+ * `netD(real_ldr_neg)` in train_D is computed and discarded upstream (GanTrainerImg.py:237); it is skipped here;
+ * dataset construction (opt.dataset_properties) is out of scope: pass `data_loaders=(hdr, ldr_pos, ldr_neg)` iterables
+   yielding the reference's dict batches, or call train_D / train_G directly.
+"""
+import torch
+
+from . import losses as L
+from . import params
+from .struct_loss import StructLoss, crop_input_hdr_batch
+
+
+def _flat(t):
+    return t.reshape(-1, t.shape[2], t.shape[3], t.shape[4])
+
+
+class GanTrainer:
+    def __init__(self, opt, t_netG, t_netD, t_optimizerG, t_optimizerD, lr_scheduler_G, lr_scheduler_D, data_loaders=None):
+        self.device = opt.device
+        self.batch_size = getattr(opt, "batch_size", None)
+        self.num_epochs = getattr(opt, "num_epochs", 1)
+        self.netG, self.netD = t_netG, t_netD
+        self.optimizerG, self.optimizerD = t_optimizerG, t_optimizerD
+        self.lr_scheduler_G, self.lr_scheduler_D = lr_scheduler_G, lr_scheduler_D
+        self.epoch, self.num_iter = 0, 0
+        self.d_model = getattr(opt, "d_model", "simpleD")
+        self.d_pretrain_epochs = getattr(opt, "d_pretrain_epochs", 0)
+        self.pre_train_mode = False
+        self.manual_d_training = getattr(opt, "manual_d_training", 0)
+        self.train_with_D = getattr(opt, "train_with_D", 1)
+        self.pyramid_weight_list = opt.pyramid_weight_list
+        self.struct_loss_factor = opt.ssim_loss_factor
+        if opt.ssim_loss_factor:
+            self.struct_loss = StructLoss(window_size=opt.ssim_window_size, pyramid_weight_list=opt.pyramid_weight_list,
+                                          pyramid_pow=False, use_c3=False, struct_method=opt.struct_method,
+                                          crop_input=opt.add_frame, final_shape_addition=opt.final_shape_addition)
+        self.loss_g_d_factor = opt.loss_g_d_factor
+        self.adv_weight_list = opt.adv_weight_list
+        self.final_shape_addition = opt.final_shape_addition
+        self.to_crop = opt.add_frame
+        self.errG_d = self.errG_struct = self.errD = None
+        self.G_loss_struct, self.G_loss_d, self.D_losses = [], [], []
+        self.epoch_step1, self.epoch_step2 = 6, 9          # GanTrainerImg.py:111-112
+        self.data_loaders = data_loaders
+
+    # ---------------------------------------------------------------- loop (GanTrainerImg.py:141-198)
+    def train(self):
+        for epoch in range(self.epoch, self.num_epochs):
+            self.epoch += 1
+            self.train_epoch(epoch)
+            self.lr_scheduler_G.step()
+            if self.train_with_D:
+                self.lr_scheduler_D.step()
+
+    def train_epoch(self, epoch):
+        if self.data_loaders is None:
+            raise RuntimeError("no data loaders were given; dataset construction is outside the hot path")
+        for data_hdr, data_ldr_pos, data_ldr_neg in zip(*self.data_loaders):
+            self.num_iter += 1
+            real_ldr_pos = data_ldr_pos[params.gray_input_image_key].to(self.device)
+            real_ldr_neg = data_ldr_neg[params.gray_input_image_key].to(self.device)
+            hdr_input = self.get_hdr_input(data_hdr)
+            hdr_original_gray_norm = data_hdr[params.original_gray_norm_key].to(self.device)
+            if self.train_with_D:
+                self.train_D(hdr_input, real_ldr_pos, real_ldr_neg, epoch)
+            if not self.pre_train_mode:
+                self.train_G(hdr_input, hdr_original_gray_norm, real_ldr_pos, real_ldr_neg, epoch)
+
+    def get_hdr_input(self, data_hdr):
+        return data_hdr[params.gray_input_image_key].to(self.device)
+
+    # ---------------------------------------------------------------- D step (GanTrainerImg.py:200-260)
+    def train_D(self, hdr_input, real_ldr_pos, real_ldr_neg, epoch):
+        self.netD.zero_grad()
+        self.D_real_fake_pass(real_ldr_pos.float(), real_ldr_neg.float(), hdr_input.float(), epoch)
+        self.optimizerD.step()
+        self.D_losses.append(self.errD.detach())
+
+    def contrastive_D_loss(self, real_logits, fake_logits):
+        return L.contrastive_D_loss(real_logits, fake_logits)
+
+    def D_real_fake_pass(self, real_ldr_pos, real_ldr_neg, hdr_input, epoch):
+        d_real_pos, _ = self.netD(_flat(real_ldr_pos))
+        if not self.pre_train_mode:
+            with torch.no_grad():
+                fake, _ = self.netG(_flat(hdr_input), diffY=self.final_shape_addition, diffX=self.final_shape_addition)
+        else:
+            fake = _flat(hdr_input)
+            if self.to_crop:
+                fake = crop_input_hdr_batch(fake, self.final_shape_addition, self.final_shape_addition)
+        d_fake, _ = self.netD(fake.detach())
+        scale = 1.0 if epoch <= self.epoch_step1 else 1e-6
+        self.errD = float(self.adv_weight_list[0]) * scale * self.contrastive_D_loss(d_real_pos, d_fake)
+        self.errD.backward()
+
+    # ---------------------------------------------------------------- G step (GanTrainerImg.py:262-339, 452-461)
+    def train_G(self, hdr_input, hdr_original_gray_norm, real_ldr_pos, real_ldr_neg, epoch):
+        self.netG.zero_grad()
+        hdr_flat = _flat(hdr_input.float())
+        fake, fea_fake = self.netG(hdr_flat, diffY=self.final_shape_addition, diffX=self.final_shape_addition)
+        total = None
+        if self.train_with_D:
+            # D's own parameters get no gradient here (the reference accumulates and then discards it)
+            d_params = [p for p in self.netD.parameters()]
+            req = [p.requires_grad for p in d_params]
+            for p in d_params:
+                p.requires_grad_(False)
+            try:
+                d_fake_bp, d_fea_fake = self.netD(fake.float())
+                with torch.no_grad():
+                    d_real_pos_bp, d_fea_real_pos = self.netD(_flat(real_ldr_pos))
+                    _, d_fea_real_neg = self.netD(_flat(real_ldr_neg))
+                    _, d_fea_input = self.netD(hdr_flat)
+                self.update_g_d_loss(d_fake_bp, d_real_pos_bp, None, d_fea_fake, d_fea_real_pos, d_fea_real_neg, d_fea_input,
+                                     fea_fake, fake, hdr_flat, _flat(real_ldr_pos), _flat(real_ldr_neg), epoch)
+            finally:
+                for p, r in zip(d_params, req):
+                    p.requires_grad_(r)
+            total = self.errG_d
+        self.update_struct_loss(hdr_flat, _flat(hdr_original_gray_norm), fake)
+        if self.struct_loss_factor:
+            total = self.errG_struct if total is None else total + self.errG_struct
+        total.backward()
+        self.optimizerG.step()
+
+    def update_g_d_loss(self, d_fake_bp, d_real_pos_bp, d_real_neg_bp, d_fea_fake, d_fea_real_pos, d_fea_real_neg, d_fea_input,
+                        fea_fake, fake, hdr_input, ldr_pos, ldr_neg, epoch):
+        f = self.loss_g_d_factor
+        cgan = self.contrastive_D_loss(d_fake_bp, d_real_pos_bp)
+        if epoch <= self.epoch_step2:
+            first = epoch <= self.epoch_step1
+            err = f * (1.0 if first else 1e-6) * cgan
+            err = err + f * 0.5 * self.infoNCE(d_fea_fake, d_fea_real_pos, d_fea_input, fake, hdr_input, "InfoNCE", 1, 1e-2)
+            err = err + f * 0.5 * (0.2 * self.infoNCE(d_fea_fake, d_fea_real_pos, d_fea_real_neg, fake, hdr_input, "InfoNCE",
+                                                       1e3, 2))
+            n2 = self.infoNCE2(fea_fake, fake, hdr_input, "InfoNCE", 1, 1e-2)
+            err = err + (f * 1e-6 * n2 if first else f * 0.1 * (5 * n2))
+            m_f, v_f = L.frame_stats(fake)
+            with torch.no_grad():
+                m_p, v_p = L.frame_stats(ldr_pos)
+            lm, lc = L.l1_mean(m_f, m_p), L.l1_mean(v_f, v_p)
+            err = err + (f * 1e-6 * lm if first else f * 0.5 * (1e2 * lm))
+            err = err + (f * 1e-6 * lc if first else f * 0.5 * (2 * lc))
+            err = err + f * 1e-6 * self.pseudo_label_loss(fake, hdr_input)
+        else:
+            # GanTrainerImg.py:332-335 references an undefined L_TV: reproduced on purpose
+            raise NameError("name 'L_TV' is not defined")
+        self.errG_d = err
+        self.G_loss_d.append(err.detach())
+
+    def pseudo_label_loss(self, fake, hdr_input):
+        n = fake.shape[0]
+        scores, bw = L.tmqi_naturalness(fake, patch=128)
+        patches = fake.reshape(n, 1, 2, 128, 2, 128).permute(0, 2, 4, 1, 3, 5).reshape(4 * n, 1, 128, 128)
+        m, v = L.frame_stats(patches)
+        best = bw[0].long()
+        return L.l1_mean(m, m[best].expand_as(m)) + L.l1_mean(v, v[best].expand_as(v))
+
+    def infoNCE(self, fea_fake, fea_real, fea_neg, fake, hdr_input, cl_loss_type, k, constant):
+        return self.nce(fea_fake, [fea_real], [fea_neg], cl_loss_type, k, constant)
+
+    def infoNCE2(self, fea_fake, fake, hdr_input, cl_loss_type, k, constant):
+        _, bw = L.tmqi_naturalness(fake)
+        best, worst = int(bw[0]), int(bw[1])      # one small host read, as the reference's list.index() implies
+        return self.nce(fea_fake, [fea_fake[best:best + 1]], [fea_fake[worst:worst + 1]], cl_loss_type, k, constant)
+
+    def nce(self, fea_anchor, feas_positive, feas_negative, cl_loss_type, k, constant):
+        if cl_loss_type != "InfoNCE" or len(feas_positive) != 1 or len(feas_negative) != 1:
+            raise NotImplementedError("HIP nce covers the published InfoNCE form with one positive and one negative")
+        return L.nce(fea_anchor, feas_positive[0], feas_negative[0], k, constant)
+
+    def update_struct_loss(self, hdr_input, hdr_input_original_gray_norm, fake):
+        if self.struct_loss_factor:
+            self.errG_struct = self.struct_loss_factor * self.struct_loss(fake, hdr_input_original_gray_norm, hdr_input,
+                                                                          self.pyramid_weight_list)
+            self.G_loss_struct.append(self.errG_struct.detach())
