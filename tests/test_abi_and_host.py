@@ -1,0 +1,124 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/uncltmo_hip.h declares, the
+ctypes mirror covers the header, module state_dicts match the reference's key/shape contract, the product path refuses
+to run without a GPU instead of falling back, and the data-parallel gradient exchange is correct under gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "uncltmo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(uncl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    lib = ctypes.CDLL(ge.LIB)
+    names = header_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), "libuncltmo_hip.so does not export %s" % n
+    assert lib.uncl_version() >= 1
+
+
+def test_ctypes_mirror_covers_the_header():
+    from uncltmo_amd import _hip
+    assert sorted(_hip.SIGNATURES) == header_functions()
+    _hip.lib()          # resolves every symbol with its signature
+
+
+def test_struct_layouts_match_the_c_side():
+    """sizeof() of the ctypes mirrors must equal the C structs (compiled here with the host compiler)."""
+    from uncltmo_amd import _hip
+    code = '#include <stdio.h>\n#include "uncltmo_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(uncl_conv_desc), ' \
+           'sizeof(uncl_gen_weights), sizeof(uncl_gen_run), sizeof(uncl_gen_bwd));return 0;}\n'
+    src = os.path.join(ROOT, "build", "abi_sizes.c")
+    os.makedirs(os.path.dirname(src), exist_ok=True)
+    open(src, "w").write(code)
+    exe = src[:-2]
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+    sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(_hip.ConvDesc), ctypes.sizeof(_hip.GenWeights), ctypes.sizeof(_hip.GenRun),
+                     ctypes.sizeof(_hip.GenBwd)]
+
+
+def test_state_dict_contract_and_no_cpu_fallback():
+    from uncltmo_amd import _hip, state_spec
+    from uncltmo_amd.discriminator import SimpleDiscriminator
+    from uncltmo_amd.generator import UNet, UNetVideo
+    args = (1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
+    for cls in (UNet, UNetVideo):
+        g = cls(*args)
+        sd = g.state_dict()
+        assert [(k, tuple(s)) for k, s, _ in state_spec.generator_spec()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        assert sum(v.numel() for v in sd.values()) == 4941281
+        assert sum(p.numel() for p in g.parameters() if p.requires_grad) == 4920545
+        with pytest.raises(RuntimeError):                      # host tensor: HipError, never an eager fallback
+            g(torch.zeros(1, 1, 256, 256) if cls is UNet else torch.zeros(1, 2, 1, 256, 256))
+    d = SimpleDiscriminator(256, 1, 16, "none", "none", 0, 0)
+    assert sum(p.numel() for p in d.parameters()) == 12373
+    with pytest.raises(RuntimeError):
+        d(torch.zeros(1, 1, 256, 256))
+    with pytest.raises(NotImplementedError):
+        UNet(1, 1, "sigmoid", 5, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
+    # a reference-format checkpoint loads with strict=True (also through a DataParallel 'module.' prefix)
+    g = UNet(*args)
+    from oracle.state import generator_state
+    g.load_state_dict(generator_state("g0"), strict=True)
+
+
+def test_relative_pos_buffer_matches_reference_golden(golden):
+    from uncltmo_amd.generator import sincos_relative_pos
+    np.testing.assert_allclose(sincos_relative_pos().numpy(), golden("generator")["relative_pos"], rtol=0, atol=1e-6)
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from uncltmo_amd.distributed import allreduce_gradients, shard_range
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    x = torch.randn(8, 7)
+    lo, hi = shard_range(8, rank, world)
+    net(x[lo:hi]).pow(2).mean().backward()
+    allreduce_gradients(net.parameters(), bucket_bytes=64)      # tiny buckets: exercise the bucketing
+    q.put((rank, [p.grad.clone() for p in net.parameters()]))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_gradient_allreduce_equals_mean_of_rank_gradients():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    x = torch.randn(8, 7)
+    ref = []
+    for r in range(2):
+        net.zero_grad()
+        net(x[4 * r:4 * r + 4]).pow(2).mean().backward()
+        ref.append([p.grad.clone() for p in net.parameters()])
+    mean = [(a + b) / 2 for a, b in zip(*ref)]
+    for r in range(2):
+        for g_, m in zip(got[r], mean):
+            np.testing.assert_allclose(g_.numpy(), m.numpy(), rtol=1e-6, atol=1e-8)
