@@ -70,6 +70,7 @@ class GenBwd(C.Structure):
 
 
 _lib = None
+PARAM_EPOCH = [0]   # bumped by uncltmo_amd.optim.Adam after its in-place kernel update
 
 # name -> (restype, argtypes); every symbol include/uncltmo_hip.h declares
 SIGNATURES = {

@@ -222,90 +222,91 @@ __global__ __launch_bounds__(256) void d_conv2_dgrad_kernel(const float* __restr
   }
 }
 
-// conv2 weight / bias gradient: one workgroup per (co, ci-quad); threads sweep the output pixels
+// conv2 weight / bias gradient.  Workgroup = one 8x8 block of output pixels of one frame; thread = one (tap, ci) column
+// (256 of them) accumulating all 32 output channels; partial sums per workgroup, reduced in a fixed order afterwards.
 __global__ __launch_bounds__(256) void d_conv2_wgrad_kernel(const float* __restrict__ g_h2pre, const float* __restrict__ h1,
-                                                            float* __restrict__ gw2, float* __restrict__ gb2, int N,
-                                                            int accumulate) {
-  // grid: (C2, C1/4).  acc[4 ci][16 taps]
-  __shared__ float red[4][65];
-  const int co = blockIdx.x, ci0 = blockIdx.y * 4;
-  float acc[4][16];
-  float bsum = 0.f;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
-  const size_t total = (size_t)N * H2 * H2;
-  for (size_t i = threadIdx.x; i < total; i += 256) {
-    const int ox = (int)(i % H2), oy = (int)((i / H2) % H2), n = (int)(i / ((size_t)H2 * H2));
-    const float gv = g_h2pre[i * C2 + co];
-    bsum += gv;
-    const float* hp = h1 + (((size_t)n * H1 + 2 * oy) * H1 + 2 * ox) * C1 + ci0;
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx) {
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + ((size_t)ky * H1 + kx) * C1);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a][ky * 4 + kx] = fmaf(gv, hv[a], acc[a][ky * 4 + kx]);
-      }
+                                                            float* __restrict__ partial /* [wg][8192 + 32] */) {
+  __shared__ float sg[64 * C2];          // [pixel][co]
+  __shared__ float sa[C1 * 324];         // [ci][18*18]
+  const int n = blockIdx.y;
+  const int ty = blockIdx.x / 8, tx = blockIdx.x % 8;
+  const int y0 = ty * 8, x0 = tx * 8;
+  for (int i = threadIdx.x; i < 64 * C2; i += 256) {
+    const int p = i / C2, co = i % C2;
+    const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
+    sg[i] = (oy < H2 && ox < H2) ? g_h2pre[(((size_t)n * H2 + oy) * H2 + ox) * C2 + co] : 0.f;
   }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const float s = wave_sum(acc[a][t]);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][a * 16 + t] = s;
-    }
-  const float bs = wave_sum(bsum);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][64] = bs;
+  for (int i = threadIdx.x; i < C1 * 324; i += 256) {
+    const int ci = i / 324, r = i % 324, ly = r / 18, lx = r % 18;
+    const int gy = min(2 * y0 + ly, H1 - 1), gx = min(2 * x0 + lx, H1 - 1);
+    sa[i] = h1[(((size_t)n * H1 + gy) * H1 + gx) * C1 + ci];
+  }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const int a = threadIdx.x >> 4, t = threadIdx.x & 15;
-    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float* dst = gw2 + (co * C1 + ci0 + a) * 16 + t;
-    *dst = accumulate ? *dst + s : s;
+  const int tap = threadIdx.x >> 4, ci = threadIdx.x & 15;
+  const int ky = tap >> 2, kx = tap & 3;
+  float acc[C2];
+#pragma unroll
+  for (int c = 0; c < C2; ++c) acc[c] = 0.f;
+  for (int p = 0; p < 64; ++p) {
+    const float a = sa[ci * 324 + (2 * (p >> 3) + ky) * 18 + 2 * (p & 7) + kx];
+#pragma unroll
+    for (int c = 0; c < C2; c += 4) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(sg + p * C2 + c);
+      acc[c] = fmaf(a, gv[0], acc[c]); acc[c + 1] = fmaf(a, gv[1], acc[c + 1]);
+      acc[c + 2] = fmaf(a, gv[2], acc[c + 2]); acc[c + 3] = fmaf(a, gv[3], acc[c + 3]);
+    }
   }
-  if (threadIdx.x == 64 && blockIdx.y == 0) {
-    const float s = (red[0][64] + red[1][64]) + (red[2][64] + red[3][64]);
-    gb2[co] = accumulate ? gb2[co] + s : s;
+  float* out = partial + ((size_t)n * 64 + blockIdx.x) * (8192 + 32);
+#pragma unroll
+  for (int c = 0; c < C2; ++c) out[(c * C1 + ci) * 16 + tap] = acc[c];   // reference layout (co, ci, 4, 4)
+  if (threadIdx.x < C2) {
+    float b = 0.f;
+    for (int p = 0; p < 64; ++p) b += sg[p * C2 + threadIdx.x];
+    out[8192 + threadIdx.x] = b;
   }
 }
 
-// conv1 weight / bias gradient (one workgroup per output channel) and optional data gradient
+// conv1 weight / bias gradient.  Workgroup = 16x32 output pixels of one frame; thread = (tap, co).
 __global__ __launch_bounds__(256) void d_conv1_wgrad_kernel(const float* __restrict__ g_h1pre, const float* __restrict__ x,
-                                                            float* __restrict__ gw0, float* __restrict__ gb0, int N,
-                                                            int accumulate) {
-  __shared__ float red[4][17];
-  const int co = blockIdx.x;
-  float acc[16];
-  float bsum = 0.f;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-  const size_t total = (size_t)N * H1 * H1;
-  for (size_t i = threadIdx.x; i < total; i += 256) {
-    const int ox = (int)(i % H1), oy = (int)((i / H1) % H1), n = (int)(i / ((size_t)H1 * H1));
-    const float gv = g_h1pre[i * C1 + co];
-    bsum += gv;
-    const float* xp = x + ((size_t)n * H0 + 2 * oy) * H0 + 2 * ox;
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx) acc[ky * 4 + kx] = fmaf(gv, xp[ky * H0 + kx], acc[ky * 4 + kx]);
+                                                            float* __restrict__ partial /* [wg][256 + 16] */) {
+  __shared__ float sx[34 * 66];
+  __shared__ float sg[512 * 17];         // [pixel][co], padded row
+  const int n = blockIdx.y;
+  const int ty = blockIdx.x / 4, tx = blockIdx.x % 4;
+  const int y0 = ty * 16, x0 = tx * 32;
+  for (int i = threadIdx.x; i < 34 * 66; i += 256) {
+    const int ly = i / 66, lx = i % 66;
+    const int gy = min(2 * y0 + ly, H0 - 1), gx = min(2 * x0 + lx, H0 - 1);
+    sx[i] = x[((size_t)n * H0 + gy) * H0 + gx];
   }
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const float s = wave_sum(acc[t]);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s;
+  for (int i = threadIdx.x; i < 512 * C1; i += 256) {
+    const int p = i / C1, co = i % C1;
+    const int oy = y0 + (p >> 5), ox = x0 + (p & 31);
+    sg[p * 17 + co] = (oy < H1 && ox < H1) ? g_h1pre[(((size_t)n * H1 + oy) * H1 + ox) * C1 + co] : 0.f;
   }
-  const float bs = wave_sum(bsum);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][16] = bs;
   __syncthreads();
-  if (threadIdx.x < 17) {
-    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float* dst = threadIdx.x < 16 ? gw0 + co * 16 + threadIdx.x : gb0 + co;
-    *dst = accumulate ? *dst + s : s;
+  const int tap = threadIdx.x >> 4, co = threadIdx.x & 15;
+  const int ky = tap >> 2, kx = tap & 3;
+  float acc = 0.f, bsum = 0.f;
+  for (int p = 0; p < 512; ++p) {
+    const float gv = sg[p * 17 + co];
+    acc = fmaf(gv, sx[(2 * (p >> 5) + ky) * 66 + 2 * (p & 31) + kx], acc);
+    bsum += gv;
   }
+  float* out = partial + ((size_t)n * 32 + blockIdx.x) * (256 + 16);
+  out[co * 16 + tap] = acc;
+  if (tap == 0) out[256 + co] = bsum;
+}
+
+// out[j] (+)= sum over `count` partial rows of width `width` (fixed order)
+__global__ void d_partial_sum_kernel(const float* __restrict__ partial, int count, int width, int off0, int n0, float* __restrict__ dst0,
+                                     int n1, float* __restrict__ dst1, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n0 + n1) return;
+  double s = 0.0;
+  for (int r = 0; r < count; ++r) s += (double)partial[(size_t)r * width + off0 + j];
+  float* d = j < n0 ? dst0 + j : dst1 + (j - n0);
+  *d = accumulate ? *d + (float)s : (float)s;
 }
 
 // g_x[n][y][x] = sum_{ky,kx,co} g_h1pre[(y-ky)/2][(x-kx)/2][co] w0[co][ky][kx]
@@ -349,13 +350,14 @@ __global__ void d_w4_final_kernel(const float* __restrict__ partial, int blocks,
 extern "C" size_t uncl_simple_d_workspace_bytes(int N) {
   // h1, h2, fea, partial(fwd), g_h2pre, g_h1pre, head partials
   const size_t f = (size_t)N * H1 * H1 * C1 + (size_t)N * H2 * H2 * C2 + (size_t)N * H2 * H2 + (size_t)N * 64 * 2;
-  const size_t b = (size_t)N * H2 * H2 * C2 + (size_t)N * H1 * H1 * C1 + (size_t)256 * (C2 + 1);
+  const size_t b = (size_t)N * H2 * H2 * C2 + (size_t)N * H1 * H1 * C1 + (size_t)256 * (C2 + 1) +
+                   (size_t)N * 64 * (8192 + 32) + (size_t)N * 32 * (256 + 16);
   return (f + b) * sizeof(float) + 1024;
 }
 
 namespace {
 struct DBufs {
-  float *h1, *h2, *fea, *partial, *g_h2pre, *g_h1pre, *w4part;
+  float *h1, *h2, *fea, *partial, *g_h2pre, *g_h1pre, *w4part, *w2part, *w0part;
 };
 DBufs d_bufs(void* workspace, int N) {
   DBufs b;
@@ -366,7 +368,9 @@ DBufs d_bufs(void* workspace, int N) {
   b.partial = p; p += (size_t)N * 64 * 2;
   b.g_h2pre = p; p += (size_t)N * H2 * H2 * C2;
   b.g_h1pre = p; p += (size_t)N * H1 * H1 * C1;
-  b.w4part = p;
+  b.w4part = p; p += (size_t)256 * (C2 + 1);
+  b.w2part = p; p += (size_t)N * 64 * (8192 + 32);
+  b.w0part = p;
   return b;
 }
 }  // namespace
@@ -423,11 +427,16 @@ extern "C" int uncl_simple_d_backward(const float* x, const float* w0, const flo
       hipLaunchKernelGGL(d_wl_bwd_kernel, dim3((H2 * H2 + 255) / 256), dim3(256), 0, st, g_out, b.fea, gwl, N, accumulate);
     else if (!accumulate)
       (void)hipMemsetAsync(gwl, 0, H2 * H2 * sizeof(float), st);
-    hipLaunchKernelGGL(d_conv2_wgrad_kernel, dim3(C2, C1 / 4), dim3(256), 0, st, b.g_h2pre, b.h1, gw2, gb2, N, accumulate);
+    hipLaunchKernelGGL(d_conv2_wgrad_kernel, dim3(64, N), dim3(256), 0, st, b.g_h2pre, b.h1, b.w2part);
+    hipLaunchKernelGGL(d_partial_sum_kernel, dim3((8192 + 32 + 255) / 256), dim3(256), 0, st, b.w2part, N * 64, 8192 + 32, 0, 8192, gw2,
+                       32, gb2, accumulate);
   }
   hipLaunchKernelGGL(d_conv2_dgrad_kernel, dim3((unsigned)((t1 + 255) / 256 < 4096 ? (t1 + 255) / 256 : 4096)), dim3(256), 0,
                      st, b.g_h2pre, w2, b.h1, b.g_h1pre, N);
-  if (params) hipLaunchKernelGGL(d_conv1_wgrad_kernel, dim3(C1), dim3(256), 0, st, b.g_h1pre, x, gw0, gb0, N, accumulate);
+  if (params) {
+    hipLaunchKernelGGL(d_conv1_wgrad_kernel, dim3(32, N), dim3(256), 0, st, b.g_h1pre, x, b.w0part);
+    hipLaunchKernelGGL(d_partial_sum_kernel, dim3(2), dim3(256), 0, st, b.w0part, N * 32, 256 + 16, 0, 256, gw0, 16, gb0, accumulate);
+  }
   if (g_x != nullptr)
     hipLaunchKernelGGL(d_conv1_dgrad_kernel, dim3((unsigned)((t0 + 255) / 256 < 4096 ? (t0 + 255) / 256 : 4096)), dim3(256), 0,
                        st, b.g_h1pre, w0, g_x, N, 0);

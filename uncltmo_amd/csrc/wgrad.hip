@@ -347,7 +347,7 @@ extern "C" int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, fl
     const int cw = C - c0 < 256 ? C - c0 : 256;
     if (256 % (cw / 8) != 0) return UNCL_ERR_ARG;
     const int rpb = 256 / (cw / 8);
-    const int blocks = (int)((rows + rpb - 1) / rpb < 512 ? (rows + rpb - 1) / rpb : 512);
+    const int blocks = (int)((rows + rpb - 1) / rpb < 96 ? (rows + rpb - 1) / rpb : 96);
     hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x + c0, (float*)workspace, (size_t)rows, cw, ld);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((cw + 63) / 64), dim3(64), 0, s, (const float*)workspace, blocks, cw, out + c0,
                        accumulate);

@@ -38,7 +38,5 @@ class Adam(torch.optim.Optimizer):
                                           arr([self.state[p]["exp_avg_sq"] for p in ps]), n, len(ps), float(group["lr"]),
                                           float(b1), float(b2), float(group["eps"]), int(step), _hip.stream_ptr()),
                        "uncl_adam_step")
-            for p in ps:
-                p._version  # noqa: B018  (parameters were updated in place by the kernel)
-                p.add_(0)   # bump the autograd version counter so cached weight packs are rebuilt
+            _hip.PARAM_EPOCH[0] += 1    # parameters changed behind autograd's back: invalidate cached weight packs
         return loss
