@@ -1,7 +1,7 @@
 // Pipelined 3x3 implicit-GEMM convolution for gfx950 — the generator's hot kernel (bf16).
 //
-// Same GEMM orientation and LDS images as conv_igemm.hip (D[cout][pixel] = W[cout][k] X[k][pixel], 64-byte
-// K-chunks, XOR-swizzled 16-byte slots) with three structural changes that matter on MI355X:
+// Same GEMM orientation as conv_igemm.hip (D[cout][pixel] = W[cout][k] X[k][pixel], 64-byte K-chunks; LDS rows padded
+// to 80 bytes instead of swizzled) with three structural changes that matter on MI355X:
 //
 //  * persistent workgroups + register prefetch: a workgroup walks a contiguous range of tiles, each a list of
 //    K-chunk steps; the global loads of step s+1 are issued before the MFMAs of step s and land in VGPRs while
@@ -46,6 +46,10 @@ struct PipeArgs {
 };
 
 __device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// wave-uniform base + 32-bit per-lane BYTE offset: lowers to global_load_dwordx4 v, v_off, s[base] (no address VGPR pair)
+__device__ __forceinline__ bf16x8 ld16o(const bf16_t* base, unsigned byte_off) {
+  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1]
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
@@ -65,15 +69,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
   constexpr int WVN = (WROWS + 63) / 64;
   constexpr bool W_RAGGED = WROWS % 64 != 0;
   constexpr int SLOTS = CT / 8;
-  static_assert(TH * TW * CT * 2 <= NPIX * 64 + WROWS * 64, "epilogue image must fit in the staging LDS");
-  constexpr bool W_CLOBBERED = TH * TW * CT * 2 > NPIX * 64;  // epilogue image reaches into sW
+  static_assert(TH * TW * CT * 2 <= NPIX * 80 + WROWS * 80, "epilogue image must fit in the staging LDS");
+  constexpr bool W_CLOBBERED = TH * TW * CT * 2 > NPIX * 80;  // epilogue image reaches into sW
   constexpr int ST_IT = (TH * TW * SLOTS) / NTHR;             // main-store passes
   constexpr int ROWS_PER_IT = NTHR / (TW * SLOTS);            // output rows covered per pass
   static_assert(ROWS_PER_IT * TW * SLOTS == NTHR, "store pass must cover whole rows");
 
+  // LDS rows are padded from 64 to 80 bytes: 16 consecutive rows then start on 16 distinct 16-byte slots of the
+  // 256-byte bank row (20*p mod 64 covers every multiple of 4), so ds_read_b128 is conflict-free with NO swizzle and
+  // every fragment address is "lane base + compile-time immediate" (zero address arithmetic in the MFMA loop).
+  constexpr int RP = 80;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
-  char* sW = smem + NPIX * 64;
+  char* sW = smem + NPIX * RP;
   char* sO = smem;
 
   const int tid = threadIdx.x;
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
   const int xoff_e = (ey * a.s0W + 32 + ec) * a.s0C + ch * 8;
   const int pix_r0 = hy0 * HW + hx;                          // + j * 2 * HW
   const int pix_e = ey * HW + 32 + ec;
-  const int lds_w0 = p0 * 64 + ((ch ^ ((p0 >> 2) & 3)) << 4);  // + j * 4096
+  const int lds_w0 = p0 * 80 + (ch << 4);  // + j * 64 * 80
   const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;  // + j * (64 / CT) * Cout * Cin
 
   // ---- tile cursor (contiguous range per workgroup, carried without divisions)
@@ -138,14 +146,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
         const bool ok = xok && (unsigned)iy < (unsigned)a.H;
         const int sy = min(max(iy - dy, 0), a.s1H - 1);
         valid |= (ok ? 1u : 0u) << j;
-        xr[j] = ld16(base + (unsigned)((sy * a.s1W + sx) * a.s1C));
+        xr[j] = ld16o(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
       }
       {
         const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
         const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
         valid |= (ok ? 1u : 0u) << RS;
-        xr[RS] = ld16(base + (unsigned)((sy * a.s1W + sxe) * a.s1C));
+        xr[RS] = ld16o(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
       }
       xvalid = valid;
     } else {
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
         // the whole halo tile is inside the image: one scalar base, a constant stride between slots
         const bf16_t* base = a.src0 + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
 #pragma unroll
-        for (int j = 0; j < RS; ++j) xr[j] = ld16(base + (unsigned)(xoff_r + j * 2 * row_el));
-        xr[RS] = ld16(base + (unsigned)(e_on ? xoff_e : 0));
+        for (int j = 0; j < RS; ++j) xr[j] = ld16o(base, (unsigned)(xoff_r + j * 2 * row_el) * 2u);
+        xr[RS] = ld16o(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
         xvalid = 0xffffffffu;
       } else {
         const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
           }
           valid |= (ok ? 1u : 0u) << j;
           const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
-          xr[j] = ld16(base + off);
+          xr[j] = ld16o(base, off * 2u);
           if (PREV) {
             const int c = cbase + ch * 8;
             if (c < a.prev_ch) {
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
       for (int j = 0; j < WVN; ++j) {
         unsigned off = (unsigned)(woff0 + j * wstride);
         if (W_RAGGED && j == WVN - 1) off = (p0 + 64 * j < WROWS) ? off : 0u;
-        wr[j] = ld16(wb + off);
+        wr[j] = ld16o(wb, off * 2u);
       }
     }
   };
@@ -221,13 +229,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
       }
       if (!all_ok && !((xvalid >> j) & 1u)) v = E::zero();
       const int pix = j < RS ? pix_r0 + j * 2 * HW : pix_e;
-      *reinterpret_cast<vec*>(sX + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = v;
+      *reinterpret_cast<vec*>(sX + pix * RP + (ch << 4)) = v;
     }
     if (with_w) {
 #pragma unroll
       for (int j = 0; j < WVN; ++j) {
         if (W_RAGGED && j == WVN - 1 && p0 + 64 * j >= WROWS) continue;
-        *reinterpret_cast<vec*>(sW + lds_w0 + j * 4096) = wr[j];
+        *reinterpret_cast<vec*>(sW + lds_w0 + j * 64 * RP) = wr[j];
       }
     }
   };
@@ -281,12 +289,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int row = (ty * 3 + tx) * CT + nt * 32 + lr;
-            A[ty][nt] = *reinterpret_cast<const vec*>(sW + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+            A[ty][nt] = *reinterpret_cast<const vec*>(sW + row * RP + (chunk << 4));
           }
 #pragma unroll
         for (int r = 0; r < MPW + 2; ++r) {
           const int pix = (wave * MPW + r) * HW + lr + tx;
-          B[r] = *reinterpret_cast<const vec*>(sX + pix * 64 + ((chunk ^ ((pix >> 2) & 3)) << 4));
+          B[r] = *reinterpret_cast<const vec*>(sX + pix * RP + (chunk << 4));
         }
         if (ks == 0 && tx == 0) {
           // first tap of the chunk: on the first chunk of a tile the accumulation starts from zero (inline C = 0)
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
 int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
-  constexpr size_t lds = (size_t)(TH + 2) * 34 * 64 + (size_t)9 * NT * 32 * 64;
+  constexpr size_t lds = (size_t)(TH + 2) * 34 * 80 + (size_t)9 * NT * 32 * 80;
   auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV>;
   static bool attr_done = false;
   static int max_blocks = 0;
