@@ -48,7 +48,38 @@ struct PipeArgs {
 __device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 // wave-uniform base + 32-bit per-lane BYTE offset: lowers to global_load_dwordx4 v, v_off, s[base] (no address VGPR pair)
 __device__ __forceinline__ bf16x8 ld16o(const bf16_t* base, unsigned byte_off) {
+  // The empty asm keeps the zero-extension of the offset next to the load: hoisted out of the loop it turns the access
+  // into a 64-bit VGPR address that the compiler builds inside the destination registers, and the write-after-write
+  // hazard check then waits (vmcnt) for every load issued so far before the next one can go out.
+  asm volatile("" : "+v"(byte_off));
   return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// Phase timing (measurement builds only, -DUNCL_PIPE_TIMING; tools/pipe_phase_timing.py): wave 0 of every workgroup
+// accumulates s_memtime deltas per loop phase into g_pipe_t[]; the product library compiles all of this away.
+#ifdef UNCL_PIPE_TIMING
+__device__ unsigned long long g_pipe_t[16];
+__device__ __forceinline__ unsigned long long pt_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define PT_DECL unsigned long long pt_acc[12] = {}; unsigned long long pt_last = pt_now();
+#define PT(i) { const unsigned long long pt_t = pt_now(); pt_acc[i] += pt_t - pt_last; pt_last = pt_t; }
+#define PT_FLUSH() if (threadIdx.x == 0) { for (int i = 0; i < 12; ++i) atomicAdd(&g_pipe_t[i], pt_acc[i]); atomicAdd(&g_pipe_t[15], 1ull); }
+#else
+#define PT_DECL
+#define PT(i)
+#define PT_FLUSH()
+#endif
+
+template <int V>
+struct IntTag { static constexpr int value = V; };
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off) {
+  asm volatile("" : "+v"(byte_off));
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1]
@@ -74,6 +105,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
   constexpr int ST_IT = (TH * TW * SLOTS) / NTHR;             // main-store passes
   constexpr int ROWS_PER_IT = NTHR / (TW * SLOTS);            // output rows covered per pass
   static_assert(ROWS_PER_IT * TW * SLOTS == NTHR, "store pass must cover whole rows");
+  static_assert(ST_IT % 4 == 0, "main-store passes are issued in groups of four");
 
   // LDS rows are padded from 64 to 80 bytes: 16 consecutive rows then start on 16 distinct 16-byte slots of the
   // 256-byte bank row (20*p mod 64 covers every multiple of 4), so ds_read_b128 is conflict-free with NO swizzle and
@@ -82,6 +114,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
   char* sW = smem + NPIX * RP;
+  char* sB = sW + WROWS * RP;  // CT fp32 biases of the current cout tile (outside the epilogue image)
   char* sO = smem;
 
   const int tid = threadIdx.x;
@@ -121,18 +154,34 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
 
   vec xr[XV];
   vec wr[WVN];
+  f32x4 br = {0.f, 0.f, 0.f, 0.f};
   unsigned xvalid = 0;
   int g_pending = 0;
+  bool b_pending = false;
 
+  // K-chunk order.  MODE 1 walks each 32-channel slice of the skip as [x1, x2, x2^2, sqrt(x2)]: the x2 registers loaded
+  // for the second step are kept and re-staged (squared, then square-rooted) for the third and fourth, so the skip is
+  // read from memory once instead of three times; `wk` is the chunk's position in the weight's K layout
+  // [x2 | x1 | x2^2 | sqrt] (unet_parts.py:319-322).
   auto load_regs = [&](int n, int y0, int x0, int cout0, int kc, bool with_w) {
-    int g = 0, cbase = kc * 32;
-    if (MODE != 0) {
+    int g = 0, cbase = kc * 32, wk = kc;
+    bool reuse = false;
+    if (MODE == 1) {
+      const int ph = kc & 3;
+      cbase = (kc >> 2) * 32;
+      g = ph == 0 ? 1 : (ph == 1 ? 0 : ph);
+      wk = g * (a.s0C >> 5) + (kc >> 2);
+      reuse = ph >= 2;
+    } else if (MODE == 2) {
       g = cbase / a.s0C;
       cbase -= g * a.s0C;
     }
     g_pending = g;
+    b_pending = kc == 0;
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
-    if (MODE != 0 && g == 1) {
+    if (reuse) {
+      // xr / xvalid still hold this tile's x2 slice
+    } else if (MODE != 0 && g == 1) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
       const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
       const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
@@ -161,8 +210,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
       if (interior && !PREV) {
         // the whole halo tile is inside the image: one scalar base, a constant stride between slots
         const bf16_t* base = a.src0 + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
+        // the stride between slots goes into the scalar base, so one offset VGPR serves all regular slots
 #pragma unroll
-        for (int j = 0; j < RS; ++j) xr[j] = ld16o(base, (unsigned)(xoff_r + j * 2 * row_el) * 2u);
+        for (int j = 0; j < RS; ++j) xr[j] = ld16o(base + j * 2 * row_el, (unsigned)xoff_r * 2u);
         xr[RS] = ld16o(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
         xvalid = 0xffffffffu;
       } else {
@@ -198,15 +248,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
       }
     }
     if (with_w) {
-      const bf16_t* wb = a.weight + (size_t)cout0 * a.Cin + kc * 32;
+      const bf16_t* wb = a.weight + (size_t)cout0 * a.Cin + wk * 32;
       const int wstride = (64 / CT) * a.Cout * a.Cin;  // CT = 32: two taps per pass, CT = 64: one
 #pragma unroll
       for (int j = 0; j < WVN; ++j) {
-        unsigned off = (unsigned)(woff0 + j * wstride);
+        unsigned off = (unsigned)woff0;
         if (W_RAGGED && j == WVN - 1) off = (p0 + 64 * j < WROWS) ? off : 0u;
-        wr[j] = ld16o(wb, off * 2u);
+        wr[j] = ld16o(wb + j * wstride, off * 2u);
       }
     }
+    // last on purpose: the alternative x paths above are laid out one after the other, and the hazard check of a later
+    // one waits for whatever an earlier one might have issued -- with the bias load in front that wait was real
+    if (b_pending && tid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)tid * 16u);
   };
 
   auto write_lds = [&](bool with_w) {
@@ -238,6 +291,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
         *reinterpret_cast<vec*>(sW + lds_w0 + j * 64 * RP) = wr[j];
       }
     }
+    if (b_pending && tid < CT / 4) *reinterpret_cast<f32x4*>(sB + tid * 16) = br;
+    // Name every prefetch register as consumed on every path.  The waitcnt insertion is path-insensitive: a register
+    // that one path leaves unread (weights of a static layer, the extra-column slot of idle lanes) counts as still in
+    // flight at the loop head, and the next step's loads would each wait for the ones issued just before them.
+#pragma unroll
+    for (int j = 0; j < XV; ++j) asm volatile("" ::"v"(xr[j]));
+#pragma unroll
+    for (int j = 0; j < WVN; ++j) asm volatile("" ::"v"(wr[j]));
+    asm volatile("" ::"v"(br));
   };
 
   // advance the (tile, kc) cursor by one step; returns false past the end of this workgroup's range
@@ -269,15 +331,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
   const int st_row = st_pl / TW, st_col = st_pl - st_row * TW;
   const int st_lds = st_pl * (CT * 2) + ((st_sl ^ ((st_pl >> 1) & (SLOTS - 1))) << 4);
 
-  load_regs(c_n, c_y0, c_x0, c_co, c_kc, true);
-  write_lds(true);
-  __syncthreads();
-
-  bool more = true;
-  while (more) {
-    more = advance();
-    if (more) load_regs(n_n, n_y0, n_x0, n_co, n_kc, !w_static);
-    // ---- MFMA phase over the staged chunk
+  // ---- MFMA phase over the staged chunk
+  auto mfma_phase = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = 2 * ks + lh;
@@ -329,52 +384,83 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
         }
       }
     }
+  };
+
+  load_regs(c_n, c_y0, c_x0, c_co, c_kc, true);
+  write_lds(true);
+  __syncthreads();
+
+  PT_DECL
+  for (;;) {
+    const bool more = advance();
+    if (more) load_regs(n_n, n_y0, n_x0, n_co, n_kc, !w_static);
+    PT(0)  // cursor + prefetch issue
+    mfma_phase();
+    PT(1)  // MFMA phase (LDS fragment reads + matrix pipe)
     // ---- tile finished: epilogue through LDS
     if (c_kc == a.nk - 1) {
       __syncthreads();  // every wave is done reading sX / sW
+      PT(2)  // barrier: slowest wave's MFMA phase
+      // ACT 0: ReLU, applied to the rounded bf16 pair as a signed 16-bit max against zero (one packed op per two
+      // values; rounding is sign-symmetric, so relu(round(t)) == round(relu(t))); ACT 1: identity (gradient mode);
+      // ACT 2: general max(t,0) + slope*min(t,0).
+      auto transpose_out = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c_co + nt * 32 + 8 * q + 4 * lh)
-                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sB + (nt * 32 + 8 * q + 4 * lh) * 4);
 #pragma unroll
-          for (int m = 0; m < MPW; ++m) {
-            bf16x4 o;
+            for (int m = 0; m < MPW; ++m) {
+              bf16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float t = acc[m][nt][4 * q + r] + b[r];
-              o[r] = (bf16_t)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+              for (int r = 0; r < 4; ++r) {
+                const float t = acc[m][nt][4 * q + r] + b[r];
+                o[r] = (bf16_t)(ACT == 2 ? fmaxf(t, 0.f) + a.slope * fminf(t, 0.f) : t);
+              }
+              if (ACT == 0) {
+                s16x4 si = __builtin_bit_cast(s16x4, o);
+                si = __builtin_elementwise_max(si, s16x4{0, 0, 0, 0});
+                o = __builtin_bit_cast(bf16x4, si);
+              }
+              *reinterpret_cast<bf16x4*>(sO + eo_base + m * (TW * CT * 2) + (((nt * 4 + q) ^ sw_e) << 4)) = o;
             }
-            *reinterpret_cast<bf16x4*>(sO + eo_base + m * (TW * CT * 2) + (((nt * 4 + q) ^ sw_e) << 4)) = o;
           }
         }
-      }
+      };
+      if (a.slope == 0.f) transpose_out(IntTag<0>{});
+      else if (a.slope == 1.f) transpose_out(IntTag<1>{});
+      else transpose_out(IntTag<2>{});
       __syncthreads();
+      PT(3)  // bias/activation, transposing LDS writes, barrier
       if (!a.skip_main) {
         const int ox = c_x0 + st_col;
-        if (ox < a.Wout) {
+        if (ox < a.Wout && c_y0 + st_row < a.Hout) {
           const size_t pix0 = (size_t)(c_y0 + st_row) * a.Wout + ox;
           bf16_t* ob = a.out + ((size_t)c_n * a.Hout * a.Wout + pix0) * a.oC + c_co + st_sl * 8;
           const int rows_left = a.Hout - (c_y0 + st_row);  // passes with it*ROWS_PER_IT < rows_left are in range
           const unsigned row_stride = (unsigned)(ROWS_PER_IT * a.Wout * a.oC);
+          // LDS reads of the image in groups of four ahead of their (conditional) stores: one LDS latency per group
+          auto VAL = [&](int it) { return *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2)); };
           if (a.res == nullptr && a.mask == nullptr && !a.accumulate) {
 #pragma unroll
-            for (int it = 0; it < ST_IT; ++it) {
-              if (it * ROWS_PER_IT < rows_left) {
-                const vec val = *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2));
-                *reinterpret_cast<vec*>(ob + it * row_stride) = val;
-              }
+            for (int it = 0; it < ST_IT; it += 4) {
+              const vec v0 = VAL(it), v1 = VAL(it + 1), v2 = VAL(it + 2), v3 = VAL(it + 3);
+              if (it * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + it * row_stride) = v0;
+              if ((it + 1) * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + (it + 1) * row_stride) = v1;
+              if ((it + 2) * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + (it + 2) * row_stride) = v2;
+              if ((it + 3) * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + (it + 3) * row_stride) = v3;
             }
           } else if (a.res == nullptr) {
             // gradient store: ReLU mask of the producing layer and / or accumulation into an existing gradient
             const bf16_t* mb = a.mask ? a.mask + ((size_t)c_n * a.Hout * a.Wout + pix0) * a.oC + c_co + st_sl * 8 : nullptr;
+            // rows past the end are clamped to the last valid one for the loads, so they issue back to back
 #pragma unroll
             for (int it = 0; it < ST_IT; ++it) {
               if (it * ROWS_PER_IT < rows_left) {
-                const vec val = *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2));
                 float f[8];
-                E::unpack(val, f);
+                E::unpack(VAL(it), f);
                 if (mb) {
                   float m[8];
                   E::unpack(ld16(mb + it * row_stride), m);
@@ -396,11 +482,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
 #pragma unroll
             for (int it = 0; it < ST_IT; ++it) {
               if (it * ROWS_PER_IT < rows_left) {
-                const vec val = *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2));
-                const vec rv = ld16(rb + it * row_stride);
                 float f[8], g[8];
-                E::unpack(val, f);
-                E::unpack(rv, g);
+                E::unpack(VAL(it), f);
+                E::unpack(ld16(rb + it * row_stride), g);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) f[i] += g[i];
                 *reinterpret_cast<vec*>(ob + it * row_stride) = E::pack(f);
@@ -449,19 +533,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeA
         }
       }
     }
+    PT(4)  // global stores issued (main, pooled copy, fused 1x1 tail)
     __syncthreads();
-    if (more) {
-      write_lds(!w_static);
-      __syncthreads();
-      c_n = n_n; c_y0 = n_y0; c_x0 = n_x0; c_co = n_co; c_kc = n_kc;
-    }
+    PT(5)  // end-of-step barrier
+    // All prefetched registers are needed from here on.  The explicit vmcnt(0) sits BEFORE the exit test on purpose: the
+    // compiler routes the exit through the loop latch, and its (path-insensitive) waitcnt insertion would otherwise see a
+    // path "loads issued -> staging skipped -> loop head" and make every load of the next step wait for its predecessors.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
+    if (!more) break;
+    PT(6)  // wait for the prefetched registers (and everything older in the vmcnt queue)
+    write_lds(!w_static);
+    PT(7)  // LDS staging writes
+    __syncthreads();
+    PT(8)  // barrier after staging
+    c_n = n_n; c_y0 = n_y0; c_x0 = n_x0; c_co = n_co; c_kc = n_kc;
   }
+  PT_FLUSH()
 }
 
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
 int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
-  constexpr size_t lds = (size_t)(TH + 2) * 34 * 80 + (size_t)9 * NT * 32 * 80;
+  constexpr size_t lds = (size_t)(TH + 2) * 34 * 80 + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4;
   auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV>;
   static bool attr_done = false;
   static int max_blocks = 0;
@@ -554,6 +647,18 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   a.total_tiles = d->N * a.tiles_x * a.tiles_y * a.n_ct;
   return dispatch_mode<2, 2>(a, d->src_mode, prev, s);
 }
+
+#ifdef UNCL_PIPE_TIMING
+// measurement builds only: copy (and optionally clear) the per-phase cycle counters
+extern "C" int uncl_pipe_timing_read(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pipe_t), sizeof(unsigned long long) * 16) != hipSuccess) return UNCL_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_t), z, sizeof(z)) != hipSuccess) return UNCL_ERR_LAUNCH;
+  }
+  return UNCL_OK;
+}
+#endif
 
 extern "C" int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream) {
   return conv3x3_pipe_impl(d, pool_out, nullptr, 0.f, 0, stream);
