@@ -50,6 +50,27 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(dtype):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected separately over this same command, gfx950 correction applied; profiles/*_pmc_traffic.json).  bench.py
+    cannot run the counters itself, so the value is the recorded one; None when there is no record for this dtype."""
+    if dtype != "bf16":
+        return None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        doc = json.load(open(files[-1]))
+        dom = doc["dominant"]
+        for k in doc["kernels"]:
+            if k["grid_x"] == dom["grid_x"] and "pipe_kernel<1, 4, 4, 1" in k["kernel"]:
+                return int(k["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def cpu_baseline(seconds):
     """Oracle generator forward on the host cores, fp32, bounded to ~`seconds` of work."""
     from oracle.state import generator_state
@@ -198,6 +219,7 @@ def main():
         fps = world * FRAMES * a.steps / dt
         dom_tflops = DOM_GFLOP_PER_TILE * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
         fwd_tflops = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / ms          # per GPU
+        traffic, traffic_src = pmc_traffic(a.dtype)
         line = {
             "metric": "HDR frames/sec (1024x1024 generator forward, tiled)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -207,7 +229,10 @@ def main():
                        "frames_per_step_per_gpu": FRAMES, "tiles_per_frame": TILES_PER_FRAME, "chunk": a.chunk,
                        "parallelism": "frame-parallel x%d, no collective" % world},
             "roofline": {"bound": "mfma", "achieved": dom_tflops, "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom_tflops / peak, "traffic": None,
+                         "frac": dom_tflops / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes": int(FRAMES * TILES_PER_FRAME * (2 * 252 * 252 + 254 * 254) * 64),
+                         "hbm_gbps": (traffic / dom_ms / 1e6 if traffic and dom_ms > 0 else None),
                          "kernel": ("conv3x3_pipe_kernel<1,4,4,1,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
                                    + " @ up_path.3.conv.conv",
                          "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
