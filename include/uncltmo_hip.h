@@ -141,7 +141,16 @@ int uncl_gelu_forward(const void* z, void* h, long long n, void* stream);
 int uncl_gelu_backward(const void* g_h, const void* z, void* g_z, long long n, void* stream);
 int uncl_scale_rows(const void* x, const float* scale, void* y, int N, long long per, void* stream);
 int uncl_mask_minus(const void* g, const void* x, const void* pe, void* out, int N, long long per, float slope, void* stream);
-int uncl_sum_samples(const void* g, float* out, int N, long long per, void* stream);
+int uncl_sum_samples(const void* g, float* out, int N, long long per, int accumulate, void* stream);
+/* Recurrent hand-off of the video generator (Unet.py:244,270), backward side.  g: bf16 (npix, C) gradient of the MIXED input
+ * of a down / up stage.  For c < prev_ch (= C/32 <= 8): carry_out[pix][c] = g[pix][c], g[pix][c] = 0 (the head gradient
+ * belongs to the previous frame; carry_out NULL on the first frame) and then g[pix][c] += carry_in[pix][c] (what the next
+ * frame's consumer sent back; NULL on the last frame).  If mask != NULL every channel is then multiplied by the activation
+ * derivative of the layer that produced this frame's tensor (mask > 0 ? 1 : slope).  Carries are bf16 (npix, prev_ch). */
+int uncl_head_handoff(void* g, const void* mask, float slope, const void* carry_in, void* carry_out, long long npix, int C,
+                      int prev_ch, void* stream);
+/* out = x with the first prev_ch channels of every pixel taken from prev: the mixed tensor a stage of frame k > 0 read */
+int uncl_mix_heads(const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream);
 int uncl_gcn_maxrel_backward(const void* g_out, const void* x, const int32_t* idx, float* g_x_f32, void* g_x_bf16, int N, int n,
                              int C, int k, void* stream);
 int uncl_conv_in_c1_wgrad(const void* G, const float* x, float* gw, float* gb, int N, int H, int W, int accumulate,
@@ -230,8 +239,14 @@ typedef struct uncl_gen_bwd {
   float* g_inc0_w; float* g_inc0_b;     /* (32,1,3,3), (32)                                */
   float* g_outc_w; float* g_outc_b;     /* (32), (1)                                       */
   float* g_pos_embed;                   /* (144,256) NHWC fp32                             */
+  /* video clips (Unet.py:213-289), backward through time, frames visited last to first:                    */
+  int accumulate;            /* != 0: bias / inc / outc / pos_embed gradients are added to, not overwritten   */
+  const void* prev_workspace;/* forward workspace of frame k-1 (NULL for the first frame of a clip)           */
+  const void* carry_in;      /* uncl_gen_carry_bytes(N): head gradients sent back by frame k+1, or NULL        */
+  void* carry_out;           /* receives the head gradients of frame k-1; required iff prev_workspace != NULL */
 } uncl_gen_bwd;
 size_t uncl_gen_backward_workspace_bytes(int N);
+size_t uncl_gen_carry_bytes(int N);
 int uncl_gen_backward(const uncl_gen_weights* wts, const uncl_gen_bwd* b, void* stream);
 
 const char* uncl_gen_layer_name(int i); /* state_dict prefix of packed weight i, NULL past the end */
@@ -300,6 +315,10 @@ int uncl_tmqi_naturalness(const float* x, int F, int frame_h, int frame_w, int h
                           int32_t* best_worst, void* stream);
 /* gx[n] (+)= gscale[n] * d mean(Gaussian local variance of x[n]) / dx */
 int uncl_gauss_var_backward(const float* x, const float* gscale, float* gx, int N, int H, int W, int accumulate, void* stream);
+/* Backward of uncl_gauss_stats for NHWC tensors (the video generator's per-frame features, Unet.py:274-278):
+ * gx[n,y,x,c] (+)= g_stats[n][0][c] / (H*W) + g_stats[n][1][c] * d mean(local variance) / dx.  x, gx in dtype. */
+int uncl_gauss_stats_backward(const void* x, int dtype, const float* g_stats, void* gx, int N, int H, int W, int C, int accumulate,
+                              void* stream);
 int uncl_add_per_sample_const(float* g, const float* scale, long long per, int N, float mul, int accumulate, void* stream);
 /* w * L_TV(x) (GanTrainer.py:669-682) and its gradient; workspace: 1024 floats */
 int uncl_tv_loss(const float* x, int N, int H, int W, float w, float* loss, float* gx, int accumulate_loss,

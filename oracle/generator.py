@@ -252,14 +252,16 @@ def unet_image_forward(sd, x, con_operator="square_and_square_root", last_layer=
 
 
 def unet_video_forward(sd, x, con_operator="square_and_square_root", last_layer="sigmoid", activation="relu",
-                       unet_norm="none", training=False, drop_keep=None, ratio=1.0 / 32, want=None):
+                       unet_norm="none", training=False, drop_keep=None, ratio=1.0 / 32, want=None,
+                       detach_handoff=False):
     """Video generator: (B,T,1,256,256) -> (frames (B,T,1,256,256), feats (B,T,64,1,1)).
 
     Unet.py:213-289.  From the second frame on, the first int(C*ratio) channels of the *input* of every
     down/up stage are replaced by the same channels of the previous frame's corresponding stage output
     (not detached: gradients flow back through time).  feats = [mean(up_x), mean(local variance of
     up_x under an 11x11 sigma-1.5 Gaussian)] per channel (Unet.py:274-278).
-    drop_keep, if given, is (T, 2, B).
+    drop_keep, if given, is (T, 2, B).  detach_handoff is a TEST knob (not in the reference): it cuts the gradient
+    through time so that a test can show how much of a gradient travels through the hand-off.
     """
     a, n = activation, unet_norm
     outs, fts, last = [], [], None
@@ -296,5 +298,5 @@ def unet_video_forward(sd, x, con_operator="square_and_square_root", last_layer=
         f2 = local_variance(up, win).mean(dim=(2, 3), keepdim=True)
         fts.append(torch.cat([f1, f2], dim=1).unsqueeze(1))
         outs.append(_last_act(F.conv2d(up, sd["outc.conv.weight"], sd["outc.conv.bias"]), last_layer).unsqueeze(1))
-        last = cur
+        last = [h.detach() for h in cur] if detach_handoff else cur
     return torch.cat(outs, 1), torch.cat(fts, 1)

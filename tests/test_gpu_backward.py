@@ -209,3 +209,102 @@ def test_ssr_and_pool_backward():
     _hip.check(_hip.lib().uncl_pool_backward(gpd.data_ptr(), xpd.data_ptr(), G.data_ptr(), n, h, h, c, 0.0, 1, _hip.stream_ptr()), "pool")
     torch.cuda.synchronize()
     assert rel_l2(from_nhwc(G), xp.grad + prior) < 1e-2
+
+
+# ---- video generator: backward through the recurrent hand-off (Unet.py:244,270) --------------------------------
+def test_head_handoff_and_mix_kernels():
+    npix, c, pc = 7 * 5 * 3, 64, 2
+    g = q(rnd(npix, c, seed=61)).cuda().to(torch.bfloat16)
+    mask = q(rnd(npix, c, seed=62)).cuda().to(torch.bfloat16)
+    cin = q(rnd(npix, pc, seed=63)).cuda().to(torch.bfloat16)
+    cout = torch.zeros(npix, pc, dtype=torch.bfloat16, device="cuda")
+    ref = g.float().clone()
+    ref_out = ref[:, :pc].clone()
+    ref[:, :pc] = cin.float()
+    ref = torch.where(mask.float() > 0, ref, 0.2 * ref)
+    g2 = g.clone()
+    _hip.check(_hip.lib().uncl_head_handoff(g2.data_ptr(), mask.data_ptr(), 0.2, cin.data_ptr(), cout.data_ptr(), npix, c, pc,
+                                            _hip.stream_ptr()), "handoff")
+    torch.cuda.synchronize()
+    assert torch.equal(cout.float(), ref_out)
+    assert rel_l2(g2.float().cpu(), ref.cpu()) < 4e-3
+    # first frame of a clip: nothing leaves, the next frame's head gradient is ADDED to this frame's own; no mask
+    g3 = g.clone()
+    _hip.check(_hip.lib().uncl_head_handoff(g3.data_ptr(), None, 0.0, cin.data_ptr(), None, npix, c, pc, _hip.stream_ptr()), "handoff")
+    ref3 = g.float().clone()
+    ref3[:, :pc] += cin.float()
+    assert rel_l2(g3.float().cpu(), ref3.cpu()) < 4e-3
+    mixed = torch.empty_like(g)
+    _hip.check(_hip.lib().uncl_mix_heads(g.data_ptr(), mask.data_ptr(), mixed.data_ptr(), npix, c, pc, _hip.stream_ptr()), "mix")
+    refm = g.clone()
+    refm[:, :pc] = mask[:, :pc]
+    assert torch.equal(mixed, refm)
+
+
+def test_gauss_stats_backward_vs_autograd():
+    n, h, c = 2, 40, 16
+    x = q(rnd(n, c, h, h, seed=64).abs()).requires_grad_(True)
+    gst = rnd(n, 2, c, seed=65)
+    win = OG.gauss_window()
+    f1 = x.mean(dim=(2, 3))
+    f2 = OG.local_variance(x, win).mean(dim=(2, 3))
+    ((f1 * gst[:, 0]).sum() + (f2 * gst[:, 1]).sum()).backward()
+    xd = to_nhwc(x.detach(), BF)
+    gx = torch.empty_like(xd)
+    _hip.check(_hip.lib().uncl_gauss_stats_backward(xd.data_ptr(), BF, gst.cuda().data_ptr(), gx.data_ptr(), n, h, h, c, 0,
+                                                    _hip.stream_ptr()), "gsb")
+    assert rel_l2(from_nhwc(gx), x.grad) < 1e-2
+
+
+def test_video_generator_backward_through_time_vs_oracle_autograd():
+    from uncltmo_amd.generator import UNetVideo
+    net = UNetVideo(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+                    "replicate", 2, 0, compute_dtype="bf16")
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().eval()
+    B, T = 1, 3
+    x = synth.smooth_hdr_frames(B * T, salt="vbw").reshape(B, T, 1, 256, 256)
+    wy = (0.5 + synth.smooth_hdr_frames(B * T, salt="vbwy")).reshape(B, T, 1, 256, 256)
+    wf = torch.from_numpy(synth.hash_uniform("vbwf", 64).copy()).reshape(1, 1, 64, 1, 1) * 10.0
+    y, ft = net(x.cuda())
+    assert y.shape == (B, T, 1, 256, 256) and ft.shape == (B, T, 64, 1, 1)
+    ((y * wy.cuda()).sum() + (ft * wf.cuda()).sum()).backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(not k.endswith("relative_pos")) for k, v in net.state_dict().items()}
+    yo, fo = OG.unet_video_forward(sd, x)
+    ((yo * wy).sum() + (fo * wf).sum()).backward()
+    errs = {k: rel_l2(p.grad.cpu(), sd[k].grad) for k, p in net.named_parameters() if p.requires_grad}
+    for k, r in errs.items():
+        print("%-45s %.4f" % (k, r))
+    bad = {k: r for k, r in errs.items() if not r < (0.3 if k == "gcn.pos_embed" else 6e-2)}
+    assert not bad, bad
+
+
+def test_video_backward_last_frame_loss_travels_through_the_handoff():
+    """Loss on the LAST frame only: everything the earlier frames contribute to the parameter gradients arrives through the
+    head-channel carries.  The HIP gradient must match the oracle's full backward-through-time much more closely than the
+    oracle's own gradient with the hand-off cut."""
+    from uncltmo_amd.generator import UNetVideo
+    net = UNetVideo(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+                    "replicate", 2, 0, compute_dtype="bf16")
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().eval()
+    B, T = 1, 3
+    x = synth.smooth_hdr_frames(B * T, salt="vbl").reshape(B, T, 1, 256, 256)
+    wy = (0.5 + synth.smooth_hdr_frames(B, salt="vbly")).reshape(B, 1, 256, 256)
+    y, _ = net(x.cuda())
+    (y[:, T - 1] * wy.cuda()).sum().backward()
+    grads = {}
+    for cut in (False, True):
+        sd = {k: v.detach().cpu().clone().requires_grad_(not k.endswith("relative_pos")) for k, v in net.state_dict().items()}
+        yo, _ = OG.unet_video_forward(sd, x, detach_handoff=cut)
+        (yo[:, T - 1] * wy).sum().backward()
+        grads[cut] = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    keys = ["inc.conv.conv1.weight", "down_path.0.mpconv.1.conv.weight", "down_path.3.mpconv.1.conv1.weight",
+            "up_path.0.conv.conv.weight", "up_path.2.conv.conv1.weight"]
+    named = dict(net.named_parameters())
+    for k in keys:
+        through_time = rel_l2(grads[True][k], grads[False][k])          # what cutting the hand-off changes
+        err = rel_l2(named[k].grad.cpu(), grads[False][k])
+        print("%-40s hand-off share %.4f   HIP error %.4f" % (k, through_time, err))
+        assert err < 6e-2
+        assert err < 0.5 * through_time, (k, err, through_time)

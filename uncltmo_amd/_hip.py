@@ -66,6 +66,7 @@ class GenBwd(C.Structure):
         ("wd", C.c_void_p * G_NUM_WEIGHTS), ("gw", C.c_void_p * G_NUM_WEIGHTS), ("gb", C.c_void_p * G_NUM_WEIGHTS),
         ("g_inc0_w", C.c_void_p), ("g_inc0_b", C.c_void_p), ("g_outc_w", C.c_void_p), ("g_outc_b", C.c_void_p),
         ("g_pos_embed", C.c_void_p),
+        ("accumulate", C.c_int), ("prev_workspace", C.c_void_p), ("carry_in", C.c_void_p), ("carry_out", C.c_void_p),
     ]
 
 
@@ -97,7 +98,13 @@ SIGNATURES = {
     "uncl_gelu_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "uncl_scale_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
     "uncl_mask_minus": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
-    "uncl_sum_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
+    "uncl_sum_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
+    "uncl_head_handoff": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int,
+                                    C.c_void_p]),
+    "uncl_mix_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    "uncl_gen_carry_bytes": (C.c_size_t, [C.c_int]),
+    "uncl_gauss_stats_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p]),
     "uncl_gcn_maxrel_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "uncl_conv_in_c1_wgrad": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "uncl_gen_backward_workspace_bytes": (C.c_size_t, [C.c_int]),

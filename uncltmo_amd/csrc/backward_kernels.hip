@@ -206,11 +206,65 @@ __global__ void mask_minus_kernel(const bf16_t* __restrict__ g, const bf16_t* __
 }
 
 // sum over samples: out[e] = sum_n g[n][e]   (pos_embed gradient), fp32 out
-__global__ void sum_samples_kernel(const bf16_t* __restrict__ g, float* __restrict__ out, int N, size_t per) {
+__global__ void sum_samples_kernel(const bf16_t* __restrict__ g, float* __restrict__ out, int N, size_t per, int accumulate) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) {
-    float s = 0.f;
+    float s = accumulate ? out[e] : 0.f;
     for (int n = 0; n < N; ++n) s += (float)g[(size_t)n * per + e];
     out[e] = s;
+  }
+}
+
+// ---- recurrent hand-off of the video generator (Unet.py:244,270): from the second frame on, the first pc = C/32
+// channels entering a down / up stage are the previous frame's.  Backward, for the gradient g of such a mixed input:
+//   carry_out[pix][c] = g[pix][c], g[pix][c] = 0      (c < pc; the head gradient belongs to the previous frame)
+//   g[pix][c] += carry_in[pix][c]                      (c < pc; what the NEXT frame's consumer sent back to this frame)
+// and then, if mask is given, the activation derivative of the layer that produced this frame's tensor on all channels.
+__global__ void head_handoff_kernel(bf16_t* __restrict__ g, const bf16_t* __restrict__ mask, float slope,
+                                    const bf16_t* __restrict__ cin, bf16_t* __restrict__ cout, size_t npix, int C, int pc) {
+  const int VC = mask ? C / 8 : 1;  // without a mask only the first vector of every pixel changes
+  const size_t total = npix * VC;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+    const size_t pix = t / VC;
+    const int v = (int)(t - pix * VC);
+    float f[8];
+    E8::unpack(ldv8(g + pix * C + v * 8), f);
+    if (v == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < pc) {
+          float x = f[c];
+          if (cout) { cout[pix * pc + c] = (bf16_t)x; x = 0.f; }
+          if (cin) x += (float)cin[pix * pc + c];
+          f[c] = x;
+        }
+      }
+    }
+    if (mask) {
+      float m[8];
+      E8::unpack(ldv8(mask + pix * C + v * 8), m);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) f[c] = m[c] > 0.f ? f[c] : slope * f[c];
+    }
+    stv8(g + pix * C + v * 8, f);
+  }
+}
+
+// out = x with the first pc channels of every pixel taken from prev (the mixed tensor a stage of frame k > 0 consumed)
+__global__ void mix_heads_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ prev, bf16_t* __restrict__ out,
+                                 size_t npix, int C, int pc) {
+  const int VC = C / 8;
+  const size_t total = npix * VC;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+    const size_t pix = t / VC;
+    const int v = (int)(t - pix * VC);
+    bf16x8 a = ldv8(x + pix * C + v * 8);
+    if (v == 0) {
+      const bf16x8 b = ldv8(prev + pix * C);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < pc) a[c] = b[c];
+    }
+    *reinterpret_cast<bf16x8*>(out + pix * C + v * 8) = a;
   }
 }
 
@@ -378,10 +432,27 @@ extern "C" int uncl_mask_minus(const void* g, const void* x, const void* pe, voi
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
-extern "C" int uncl_sum_samples(const void* g, float* out, int N, long long per, void* stream) {
+extern "C" int uncl_sum_samples(const void* g, float* out, int N, long long per, int accumulate, void* stream) {
   if (!g || !out || N <= 0 || per <= 0) return UNCL_ERR_ARG;
   hipLaunchKernelGGL(sum_samples_kernel, dim3(nblocks((size_t)per)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const bf16_t*)g, out, N, (size_t)per);
+                     (const bf16_t*)g, out, N, (size_t)per, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+extern "C" int uncl_head_handoff(void* g, const void* mask, float slope, const void* carry_in, void* carry_out, long long npix,
+                                 int C, int prev_ch, void* stream) {
+  if (!g || npix <= 0 || C % 8 != 0 || prev_ch <= 0 || prev_ch > 8 || prev_ch > C) return UNCL_ERR_ARG;
+  if (!mask && !carry_in && !carry_out) return UNCL_OK;
+  const size_t total = (size_t)npix * (mask ? C / 8 : 1);
+  hipLaunchKernelGGL(head_handoff_kernel, dim3(nblocks(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (bf16_t*)g,
+                     (const bf16_t*)mask, slope, (const bf16_t*)carry_in, (bf16_t*)carry_out, (size_t)npix, C, prev_ch);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+extern "C" int uncl_mix_heads(const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream) {
+  if (!x || !prev || !out || npix <= 0 || C % 8 != 0 || prev_ch <= 0 || prev_ch > 8) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(mix_heads_kernel, dim3(nblocks((size_t)npix * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)x, (const bf16_t*)prev, (bf16_t*)out, (size_t)npix, C, prev_ch);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

@@ -286,8 +286,19 @@ struct BwdScratch {
   char* tC;
   char* tD;
   float* f32;    // (N,144,256) fp32 max-relative scatter target
+  char* mix;     // (N,126,126,32) bf16: a stage input with the previous frame's head channels (video)
   float* misc;   // colsum / outc / conv_in partial sums
 };
+
+// carry arena of the recurrent hand-off: head-channel gradients of the eight mixed stage inputs, bf16 (N, pixels, C/32)
+struct CarrySlot { int buf, pix, pc; };
+const CarrySlot kCarry[8] = {{B_X0P, 126 * 126, 1}, {B_X1P, 61 * 61, 2}, {B_X2P, 28 * 28, 4}, {B_X3P, 12 * 12, 8},
+                             {B_GOUT, 144, 8},      {B_U0, 28 * 28, 4},  {B_U1, 61 * 61, 2},  {B_U2, 126 * 126, 1}};
+size_t carry_off(int slot, int N) {
+  size_t o = 0;
+  for (int i = 0; i < slot; ++i) o += ((size_t)N * kCarry[i].pix * kCarry[i].pc * 2 + 255) & ~(size_t)255;
+  return o;
+}
 
 size_t bwd_scratch_bytes(int N) {
   size_t b = 0;
@@ -295,6 +306,7 @@ size_t bwd_scratch_bytes(int N) {
   b += (size_t)N * 126 * 126 * 32 * 2;
   b += 4 * (size_t)N * 144 * 512 * 2;
   b += (size_t)N * 144 * 256 * 4;
+  b += (size_t)N * 126 * 126 * 32 * 2;
   b += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
   return b + 4096;
 }
@@ -303,6 +315,7 @@ struct BCtx {
   const uncl_gen_weights* w;
   const uncl_gen_bwd* b;
   char* fws;   // forward workspace
+  const char* pws;  // previous frame's forward workspace (video, frame > 0) or NULL
   char* gws;   // gradient arena (same layout)
   Layout L;
   BwdScratch sc;
@@ -311,6 +324,21 @@ struct BCtx {
   hipStream_t s;
   void* F(int buf) const { return fws + L.off[buf]; }
   void* G(int buf) const { return gws + L.off[buf]; }
+  bool video() const { return b->carry_in != nullptr || b->carry_out != nullptr; }
+  const void* cin(int slot) const { return b->carry_in ? (const char*)b->carry_in + carry_off(slot, n) : nullptr; }
+  void* cout(int slot) const { return b->carry_out ? (char*)b->carry_out + carry_off(slot, n) : nullptr; }
+  // the tensor a hand-off stage actually read: this frame's buffer with the previous frame's head channels
+  const void* mixed(int slot) const {
+    const CarrySlot& k = kCarry[slot];
+    if (!pws) return F(k.buf);
+    if (uncl_mix_heads(F(k.buf), pws + L.off[k.buf], sc.mix, (long long)n * k.pix, kDims[k.buf].c, k.pc, s) != UNCL_OK) return nullptr;
+    return sc.mix;
+  }
+  int handoff(int slot, void* g, const void* mask) const {
+    if (!video()) return UNCL_OK;
+    const CarrySlot& k = kCarry[slot];
+    return uncl_head_handoff(g, mask, slope, cin(slot), cout(slot), (long long)n * k.pix, kDims[k.buf].c, k.pc, s);
+  }
 };
 
 uncl_conv_desc bdesc(const BCtx& c, int ks, int pad, int h, int w, int cin, int cout) {
@@ -321,12 +349,13 @@ uncl_conv_desc bdesc(const BCtx& c, int ks, int pad, int h, int w, int cin, int 
 }
 
 // weight + bias gradient of a 3x3 layer whose input is buffer `xin` (plain) and whose output gradient is gy
-int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const void* gy, int oh, int ow) {
+int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const void* gy, int oh, int ow,
+           const void* src = nullptr) {
   uncl_conv_desc d = bdesc(c, 3, pad, kDims[xin].h, kDims[xin].w, cin, cout);
-  d.src0 = c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
+  d.src0 = src ? src : c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
   int rc = uncl_conv_wgrad(&d, gy, c.b->gw[wi], c.s);
   if (rc != UNCL_OK) return rc;
-  return uncl_colsum_bf16(gy, (long long)c.n * oh * ow, cout, cout, c.b->gb[wi], 0, c.sc.misc, c.s);
+  return uncl_colsum_bf16(gy, (long long)c.n * oh * ow, cout, cout, c.b->gb[wi], c.b->accumulate, c.sc.misc, c.s);
 }
 
 // data gradient of a 3x3 layer: gy (N,gh,gw,gc) -> out buffer (cout_d channels), pad_d = 2 - pad_fwd
@@ -347,7 +376,7 @@ int wgrad1(const BCtx& c, int wi, const void* x, int xc_total, int cin, const vo
   d.out_C = gy_total;  // leading dimension of gy
   int rc = uncl_conv_wgrad(&d, gy, gw, c.s);
   if (rc != UNCL_OK || !bias) return rc;
-  return uncl_colsum_bf16(gy, (long long)c.n * NODES, gy_total, gy_total, c.b->gb[wi], 0, c.sc.misc, c.s);
+  return uncl_colsum_bf16(gy, (long long)c.n * NODES, gy_total, gy_total, c.b->gb[wi], c.b->accumulate, c.sc.misc, c.s);
 }
 int dgrad1(const BCtx& c, int wi, const void* gy, int cin_d, int cout_d, void* out, const void* res, int groups = 0) {
   uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, groups ? cin_d / groups : cin_d, groups ? cout_d / groups : cout_d);
@@ -365,7 +394,7 @@ int backward_all(const BCtx& c) {
 #define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
   // ---- tail: outconv + sigmoid
   RUN(uncl_outc_backward(b->g_out, b->x_out, b->g_upx, b->up_x, c.w->outc_w, c.G(B_UPX), b->g_outc_w, b->g_outc_b,
-                         (long long)c.n * 256 * 256, c.w->last_act, c.slope, 0, c.sc.misc, c.s));
+                         (long long)c.n * 256 * 256, c.w->last_act, c.slope, b->accumulate, c.sc.misc, c.s));
   // ---- decoder stages 3..0
   struct Stage { int wi, x1, skip, up, a, out, ch, cout; };
   const Stage st[4] = {{W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128},
@@ -386,16 +415,23 @@ int backward_all(const BCtx& c) {
       d.src0 = c.F(q.skip); d.src0_H = sh; d.src0_W = sw; d.src0_C = q.ch;
       d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
       RUN(uncl_conv_wgrad(&d, c.G(q.a), b->gw[q.wi + 1], c.s));
-      RUN(uncl_colsum_bf16(c.G(q.a), (long long)c.n * ah * aw, q.cout, q.cout, b->gb[q.wi + 1], 0, c.sc.misc, c.s));
+      RUN(uncl_colsum_bf16(c.G(q.a), (long long)c.n * ah * aw, q.cout, q.cout, b->gb[q.wi + 1], b->accumulate, c.sc.misc, c.s));
     }
     RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
     RUN(uncl_ssr_backward(c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
     // up (ConvT 2x2 s2, ch -> ch): input x1
     const int xh = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].h, xw = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].w;
-    RUN(uncl_upconv2x2_wgrad(c.F(q.x1), c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
-    RUN(uncl_colsum_bf16(c.G(q.up), (long long)c.n * uh * uw, q.ch, q.ch, b->gb[q.wi], 0, c.sc.misc, c.s));
-    RUN(uncl_upconv2x2_dgrad(c.G(q.up), b->wd[q.wi], i == 0 ? nullptr : c.F(q.x1), c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
+    const int slot = 4 + i;  // hand-off slot of this stage's input (video): GOUT, U0, U1, U2
+    const void* x1m = c.mixed(slot);
+    if (!x1m) return UNCL_ERR_LAUNCH;
+    RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
+    RUN(uncl_colsum_bf16(c.G(q.up), (long long)c.n * uh * uw, q.ch, q.ch, b->gb[q.wi], b->accumulate, c.sc.misc, c.s));
+    // the ReLU derivative of the layer that produced x1 is applied by the dgrad kernel (single frames) or, for clips,
+    // by the hand-off kernel after the head channels have been exchanged between frames
+    const void* x1mask = i == 0 ? nullptr : c.F(q.x1);
+    RUN(uncl_upconv2x2_dgrad(c.G(q.up), b->wd[q.wi], c.video() ? nullptr : x1mask, c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
                              c.s));
+    RUN(c.handoff(slot, c.G(q.x1), x1mask));
   }
   // ---- graph block
   const float* drop0 = b->drop_scale;
@@ -416,14 +452,14 @@ int backward_all(const BCtx& c) {
   for (int g = 0; g < 4; ++g)  // grouped 1x1: four independent 128 -> 128 blocks
     RUN(wgrad1(c, W_GGC, (const bf16_t*)c.F(B_GMR) + g * 128, 512, 128, (const bf16_t*)c.sc.tC + g * 128, 512, 128,
                b->gw[W_GGC] + (size_t)g * 128 * 128, false));
-  RUN(uncl_colsum_bf16(c.sc.tC, (long long)c.n * NODES, 512, 512, b->gb[W_GGC], 0, c.sc.misc, c.s));
+  RUN(uncl_colsum_bf16(c.sc.tC, (long long)c.n * NODES, 512, 512, b->gb[W_GGC], b->accumulate, c.sc.misc, c.s));
   RUN(dgrad1(c, W_GGC, c.sc.tC, 512, 512, c.sc.tD, nullptr, 4));
   if (hipMemsetAsync(c.sc.f32, 0, (size_t)c.n * per256 * 4, c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
   RUN(uncl_gcn_maxrel_backward(c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, c.sc.tB, c.n, NODES,
                                256, 9, c.s));
   RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, c.sc.tB, 256, 256, b->gw[W_GFC1], true));
   RUN(dgrad1(c, W_GFC1, c.sc.tB, 256, 256, c.G(B_X4), c.G(B_GX1)));
-  RUN(uncl_sum_samples(c.G(B_X4), b->g_pos_embed, c.n, per256, c.s));
+  RUN(uncl_sum_samples(c.G(B_X4), b->g_pos_embed, c.n, per256, b->accumulate, c.s));
   RUN(uncl_mask_minus(c.G(B_X4), c.F(B_X4), c.w->pos_embed, c.sc.tA, c.n, per256, c.slope, c.s));
   // ---- encoder
   // down3: conv (valid, pooled X3 -> D3A), ConvT (D3A -> X4)
@@ -435,22 +471,30 @@ int backward_all(const BCtx& c) {
                      {W_D1A, W_D1B, B_X1, B_X1P, B_D1A, B_X2, 64, 128},
                      {W_D0A, W_D0B, B_X0, B_X0P, B_D0A, B_X1, 32, 64}};
   // down3's first conv reads pooled X3
-  RUN(wgrad3(c, W_D3A, B_X3P, 0, 256, 256, c.G(B_D3A), 10, 10));
+  {
+    const void* xm = c.mixed(3);
+    if (!xm) return UNCL_ERR_LAUNCH;
+    RUN(wgrad3(c, W_D3A, B_X3P, 0, 256, 256, c.G(B_D3A), 10, 10, xm));
+  }
   RUN(dgrad3(c, W_D3A, c.G(B_D3A), 10, 10, 256, 2, 256, c.sc.gpool, 12, 12, nullptr, 0));
+  RUN(c.handoff(3, c.sc.gpool, nullptr));
   RUN(uncl_pool_backward(c.sc.gpool, c.F(B_X3), c.G(B_X3), c.n, 24, 24, 256, c.slope, 1, c.s));
   for (int i = 0; i < 3; ++i) {
     const Enc& e = en[i];
     const int oh = kDims[e.out].h, mh = kDims[e.mid].h, ph = kDims[e.pooled].h, xh = kDims[e.xin].h;
     RUN(wgrad3(c, e.wb, e.mid, 0, e.cout, e.cout, c.G(e.out), oh, oh));
     RUN(dgrad3(c, e.wb, c.G(e.out), oh, oh, e.cout, 2, e.cout, c.G(e.mid), mh, mh, c.F(e.mid), 0));
-    RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh));
+    const void* xm = c.mixed(2 - i);
+    if (!xm) return UNCL_ERR_LAUNCH;
+    RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh, xm));
     RUN(dgrad3(c, e.wa, c.G(e.mid), mh, mh, e.cout, 2, e.cin, c.sc.gpool, ph, ph, nullptr, 0));
+    RUN(c.handoff(2 - i, c.sc.gpool, nullptr));
     RUN(uncl_pool_backward(c.sc.gpool, c.F(e.xin), c.G(e.xin), c.n, xh, xh, e.cin, c.slope, 1, c.s));
   }
   // inc: conv1 (INC0 -> X0), conv (image -> INC0)
   RUN(wgrad3(c, W_INC1, B_INC0, 0, 32, 32, c.G(B_X0), 252, 252));
   RUN(dgrad3(c, W_INC1, c.G(B_X0), 252, 252, 32, 2, 32, c.G(B_INC0), 254, 254, c.F(B_INC0), 0));
-  RUN(uncl_conv_in_c1_wgrad(c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, 0, c.sc.misc, c.s));
+  RUN(uncl_conv_in_c1_wgrad(c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, b->accumulate, c.sc.misc, c.s));
 #undef RUN
   return UNCL_OK;
 }
@@ -531,6 +575,11 @@ extern "C" size_t uncl_gen_backward_workspace_bytes(int N) {
   return make_layout(N, UNCL_BF16).total + bwd_scratch_bytes(N);
 }
 
+extern "C" size_t uncl_gen_carry_bytes(int N) {
+  if (N <= 0) return 0;
+  return carry_off(8, N);
+}
+
 extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* b, void* stream) {
   if (!w || !b || w->dtype != UNCL_BF16 || b->N <= 0) return UNCL_ERR_ARG;
   if (!b->x || !b->x_out || !b->g_out || !b->up_x || !b->workspace || !b->grad_workspace) return UNCL_ERR_ARG;
@@ -538,10 +587,12 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   for (int i = 0; i < UNCL_G_NUM_WEIGHTS; ++i)
     if (!b->wd[i] || !b->gw[i] || !b->gb[i]) return UNCL_ERR_ARG;
   if (!b->g_inc0_w || !b->g_inc0_b || !b->g_outc_w || !b->g_outc_b || !b->g_pos_embed) return UNCL_ERR_ARG;
+  if ((b->prev_workspace != nullptr) != (b->carry_out != nullptr)) return UNCL_ERR_ARG;
   BCtx c;
   c.w = w; c.b = b; c.n = b->N;
   c.L = make_layout(b->N, UNCL_BF16);
   c.fws = reinterpret_cast<char*>(b->workspace);
+  c.pws = reinterpret_cast<const char*>(b->prev_workspace);
   c.gws = reinterpret_cast<char*>(b->grad_workspace);
   c.slope = w->act == UNCL_ACT_LRELU ? 0.2f : 0.f;
   c.s = reinterpret_cast<hipStream_t>(stream);
@@ -554,6 +605,7 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   c.sc.tC = p; p += (size_t)N * 144 * 512 * 2;
   c.sc.tD = p; p += (size_t)N * 144 * 512 * 2;
   c.sc.f32 = reinterpret_cast<float*>(p); p += (size_t)N * 144 * 256 * 4;
+  c.sc.mix = p; p += (size_t)N * 126 * 126 * 32 * 2;
   c.sc.misc = reinterpret_cast<float*>(p);
   return backward_all(c);
 }

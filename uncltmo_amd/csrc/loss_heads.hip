@@ -285,6 +285,75 @@ __global__ __launch_bounds__(256) void gauss_var_bwd_kernel(const float* __restr
   }
 }
 
+// Backward of uncl_gauss_stats for NHWC tensors: gx[n,y,x,c] (+)= g[n][0][c] / (H*W) + g[n][1][c] * d mean(local var) / dx.
+// One (32x32 tile, channel) per workgroup; the channel's pixels are strided by C in memory, neighbouring channels'
+// workgroups read the same lines out of L2.
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_stats_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gst,
+                                                              T* __restrict__ gx, int H, int W, int C, int tiles_x, GaussW gw,
+                                                              int accumulate) {
+  __shared__ float sx[GI * GI];
+  __shared__ float sh[GI * GM];
+  __shared__ float smu[GM * GM];
+  __shared__ float sv[GM * GT];
+  const int n = blockIdx.y, ch = blockIdx.z;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * GT, x0 = tx * GT;
+  const int Ho = H - (GW - 1), Wo = W - (GW - 1);
+  const T* xn = x + (size_t)n * H * W * C + ch;
+  for (int i = threadIdx.x; i < GI * GI; i += 256) {
+    const int ly = i / GI, lx = i - ly * GI;
+    const int gy = y0 - 10 + ly, gxx = x0 - 10 + lx;
+    sx[i] = (gy >= 0 && gy < H && gxx >= 0 && gxx < W) ? (float)xn[((size_t)gy * W + gxx) * C] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GI * GM; i += 256) {
+    const int ly = i / GM, lx = i - ly * GM;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < GW; ++t) s = fmaf(gw.g[t], sx[ly * GI + lx + t], s);
+    sh[i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GM * GM; i += 256) {
+    const int ly = i / GM, lx = i - ly * GM;
+    const int oy = y0 - 10 + ly, ox = x0 - 10 + lx;
+    float s = 0.f;
+    if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+#pragma unroll
+      for (int t = 0; t < GW; ++t) s = fmaf(gw.g[t], sh[(ly + t) * GM + lx], s);
+    }
+    smu[i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GT * GM; i += 256) {
+    const int ly = i / GM, lx = i - ly * GM;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < GW; ++t) s = fmaf(gw.g[t], smu[(ly + 10 - t) * GM + lx], s);
+    sv[i] = s;
+  }
+  __syncthreads();
+  const float gm = gst[((size_t)n * 2 + 0) * C + ch] / ((float)H * (float)W);
+  const float sc = gst[((size_t)n * 2 + 1) * C + ch] * 2.f / ((float)Ho * (float)Wo);
+  for (int i = threadIdx.x; i < GT * GT; i += 256) {
+    const int ly = i / GT, lx = i - ly * GT;
+    const int gy = y0 + ly, gxx = x0 + lx;
+    if (gy < H && gxx < W) {
+      float s = 0.f, wy = 0.f, wx = 0.f;
+#pragma unroll
+      for (int t = 0; t < GW; ++t) {
+        s = fmaf(gw.g[t], sv[ly * GM + lx + 10 - t], s);
+        if (gy - t >= 0 && gy - t < Ho) wy += gw.g[t];
+        if (gxx - t >= 0 && gxx - t < Wo) wx += gw.g[t];
+      }
+      const float g = gm + sc * (sx[(ly + 10) * GI + lx + 10] * wy * wx - s);
+      T* d = gx + ((size_t)n * H * W + (size_t)gy * W + gxx) * C + ch;
+      *d = (T)(accumulate ? (float)*d + g : g);
+    }
+  }
+}
+
 // g[n][i] (+)= scale[n]  (gradient of a per-sample mean times a per-sample factor already divided by H*W)
 __global__ void add_const_kernel(float* __restrict__ g, const float* __restrict__ scale, size_t per, int N, float mul,
                                  int accumulate) {
@@ -435,6 +504,27 @@ extern "C" int uncl_gauss_var_backward(const float* x, const float* gscale, floa
   const int tx = (W + GT - 1) / GT, ty = (H + GT - 1) / GT;
   hipLaunchKernelGGL(gauss_var_bwd_kernel, dim3(tx * ty, N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gscale, gx,
                      H, W, tx, gw, accumulate);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// x, gx: NHWC (N,H,W,C) in dtype; g_stats: fp32 (N,2,C) = [d/d mean, d/d mean-local-variance] per (sample, channel)
+extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* g_stats, void* gx, int N, int H, int W, int C,
+                                         int accumulate, void* stream) {
+  if (!x || !g_stats || !gx || N <= 0 || C <= 0 || H < GW || W < GW) return UNCL_ERR_ARG;
+  if (dtype != UNCL_BF16 && dtype != UNCL_F32) return UNCL_ERR_ARG;
+  GaussW gw;
+  double s = 0.0, g[GW];
+  for (int k = 0; k < GW; ++k) { g[k] = exp(-((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); s += g[k]; }
+  for (int k = 0; k < GW; ++k) gw.g[k] = (float)(g[k] / s);
+  const int tx = (W + GT - 1) / GT, ty = (H + GT - 1) / GT;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == UNCL_BF16)
+    hipLaunchKernelGGL(gauss_stats_bwd_kernel<bf16_t>, dim3(tx * ty, N, C), dim3(256), 0, st, (const bf16_t*)x, g_stats, (bf16_t*)gx,
+                       H, W, C, tx, gw, accumulate);
+  else
+    hipLaunchKernelGGL(gauss_stats_bwd_kernel<float>, dim3(tx * ty, N, C), dim3(256), 0, st, (const float*)x, g_stats, (float*)gx, H,
+                       W, C, tx, gw, accumulate);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

@@ -336,8 +336,11 @@ class UNetVideo(_GeneratorBase):
             raise ValueError("video generator expects (B,T,1,H,W)")
         self._check_input(x, 3)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("uncltmo_amd: the generator's HIP backward kernels are not built yet; run the "
-                                      "forward under torch.no_grad()")
+            from .autograd import generator_video_apply
+            x_out, feats = generator_video_apply(self, x)
+            if apply_crop and self.to_crop:
+                x_out = self._crop(x_out, diffY, diffX)
+            return x_out, feats
         B, T = x.shape[0], x.shape[1]
         outs, feats = [], []
         prev_ws = None
