@@ -82,3 +82,53 @@ def test_train_d_only_matches_golden_exactly_enough(golden):
         np.testing.assert_allclose(p.grad.double().norm().item(), g["img_step_e0.gradD." + k], rtol=5e-2, atol=1e-6, err_msg=k)  # model.4.bias: analytically 0
     np.testing.assert_allclose(D.state_dict()["tail.1.weight"].cpu().numpy()[:, :64], g["img_step_e0.D_after.tail"], rtol=1e-3,
                                atol=1e-6)
+
+
+# ---- video trainer (GanTrainer.py): clip goes through the recurrent generator, backward through time ----------------
+def make_video_trainer():
+    from uncltmo_amd.trainer_vid import GanTrainer as VideoTrainer
+    dev = torch.device("cuda")
+    G = model_factory.create_G_net("unet", dev, False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, "none", "none", "relu",
+                                   True, 1, 1, 0, "replicate", 2, 0, compute_dtype="bf16")
+    D = model_factory.create_D_net(1, 16, dev, False, "none", True, "simpleD", 3, "none", 3, 0, 0, 0)
+    synth.fill_state_dict(G, "g0")
+    synth.fill_state_dict(D, "d0")
+    G.train()
+    G.drop_path_prob = 0.0
+    optG = Adam(G.parameters(), lr=1e-5, betas=(0.5, 0.999))
+    optD = Adam(D.parameters(), lr=1.5e-5, betas=(0.5, 0.999))
+    opt = types.SimpleNamespace(device=dev, pyramid_weight_list=torch.tensor([1.0, 1.0, 1.0]), ssim_loss_factor=1.0,
+                                ssim_window_size=5, struct_method="gamma_ssim", add_frame=0, final_shape_addition=0,
+                                loss_g_d_factor=0.1, adv_weight_list=torch.tensor([0.2, 0.2, 0.2]))
+    return VideoTrainer(opt, G, D, optG, optD, None, None), G, D
+
+
+@pytest.mark.parametrize("epoch", [0, 7, 10])
+def test_video_step_matches_reference_golden(golden, epoch):
+    g = golden("vid_step")
+    tag = "vid_step_e%d" % epoch
+    tr, G, D = make_video_trainer()
+    hdr, pos, neg = step_inputs()
+    tr.train_D(hdr, pos, neg, epoch)
+    np.testing.assert_allclose(tr.errD.item(), g[tag + ".errD"], rtol=2e-2)
+    tr.train_G(hdr, hdr.clone(), pos, neg, epoch)        # epoch 10: the L_TV regime the image trainer cannot reach
+    np.testing.assert_allclose(tr.errG_d.item(), g[tag + ".errG_d"], rtol=3e-2)
+    np.testing.assert_allclose(tr.errG_struct.item(), g[tag + ".errG_struct"], rtol=2e-2)
+    bad = {}
+    for k, p in G.named_parameters():
+        if p.grad is None:
+            continue
+        ref = float(g[tag + ".gradG." + k])
+        got = p.grad.double().norm().item()
+        tol = 0.3 if k == "gcn.pos_embed" else 0.1
+        if abs(got - ref) > tol * ref + 1e-12:
+            bad[k] = (got, ref)
+    assert not bad, bad
+    # parameters after the Adam step.  Adam's first step moves every element by ~lr * sign(grad), so a tensor's sum moves by
+    # lr * (#positive - #negative gradients); bf16 noise flips the sign of near-zero gradients, hence the bound is stated as
+    # a number of sign flips (5 % of the elements + 3, each worth 2*lr) rather than as a relative error of the sum.
+    for k, v in G.state_dict().items():
+        if k.endswith("relative_pos"):
+            continue
+        got, ref = v.double().sum().item(), float(g[tag + ".G_after." + k])
+        assert abs(got - ref) <= 2e-5 * (0.05 * v.numel() + 3) + 1e-6, (k, got, ref)

@@ -79,6 +79,15 @@ class GanTrainer:
     def get_hdr_input(self, data_hdr):
         return data_hdr[params.gray_input_image_key].to(self.device)
 
+    def _generate(self, hdr_input):
+        """Image trainer: the frames of the loader tensor (B,2,1,H,W) are flattened into the batch (GanTrainerImg.py:240,272).
+        Returns (fake (N,1,H,W), fea_fake (N,32,H,W))."""
+        return self.netG(_flat(hdr_input), diffY=self.final_shape_addition, diffX=self.final_shape_addition)
+
+    def _last_regime_loss(self, cgan, fake, ldr_pos, hdr_input):
+        # GanTrainerImg.py:332-335 references an undefined L_TV: reproduced on purpose
+        raise NameError("name 'L_TV' is not defined")
+
     # ---------------------------------------------------------------- D step (GanTrainerImg.py:200-260)
     def train_D(self, hdr_input, real_ldr_pos, real_ldr_neg, epoch):
         self.netD.zero_grad()
@@ -93,7 +102,7 @@ class GanTrainer:
         d_real_pos, _ = self.netD(_flat(real_ldr_pos))
         if not self.pre_train_mode:
             with torch.no_grad():
-                fake, _ = self.netG(_flat(hdr_input), diffY=self.final_shape_addition, diffX=self.final_shape_addition)
+                fake, _ = self._generate(hdr_input)
         else:
             fake = _flat(hdr_input)
             if self.to_crop:
@@ -107,7 +116,7 @@ class GanTrainer:
     def train_G(self, hdr_input, hdr_original_gray_norm, real_ldr_pos, real_ldr_neg, epoch):
         self.netG.zero_grad()
         hdr_flat = _flat(hdr_input.float())
-        fake, fea_fake = self.netG(hdr_flat, diffY=self.final_shape_addition, diffX=self.final_shape_addition)
+        fake, fea_fake = self._generate(hdr_input.float())
         total = None
         if self.train_with_D:
             # D's own parameters get no gradient here (the reference accumulates and then discards it)
@@ -153,8 +162,7 @@ class GanTrainer:
             err = err + (f * 1e-6 * lc if first else f * 0.5 * (2 * lc))
             err = err + f * 1e-6 * self.pseudo_label_loss(fake, hdr_input)
         else:
-            # GanTrainerImg.py:332-335 references an undefined L_TV: reproduced on purpose
-            raise NameError("name 'L_TV' is not defined")
+            err = self._last_regime_loss(cgan, fake, ldr_pos, hdr_input)
         self.errG_d = err
         self.G_loss_d.append(err.detach())
 
