@@ -42,9 +42,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("UNCL_CHUNK", "0")))
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "train_video"],
                     help="infer: BASELINE configs[1] (default, the headline metric); train: configs[2], one full "
-                         "GanTrainerImg step on 32 frames of 256x256 (reported for DESIGN.md, not the headline)")
+                         "GanTrainerImg step on 32 frames of 256x256; train_video: configs[3], one GanTrainer step on clips "
+                         "of T=5 (4 crops of 256x256 per 512x512 clip) -- both reported for DESIGN.md, not the headline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -95,15 +96,21 @@ def cpu_baseline(seconds):
 
 
 def train_bench(a, rank, world, dist):
-    """configs[2]: full image-trainer step (train_D + train_G, all losses, Adam) on N = 32 frames per rank."""
+    """configs[2]: full image-trainer step (train_D + train_G, all losses, Adam) on N = 32 frames per rank;
+    configs[3] (--mode train_video): the video trainer on 2 clips x 4 crops x T=5 = 40 frames per rank."""
     import types
     from uncltmo_amd import model_factory, synth
     from uncltmo_amd.distributed import DistributedOptimizer
     from uncltmo_amd.optim import Adam
-    from uncltmo_amd.trainer_img import GanTrainer
+    video = a.mode == "train_video"
+    if video:
+        from uncltmo_amd.trainer_vid import GanTrainer
+    else:
+        from uncltmo_amd.trainer_img import GanTrainer
     dev = torch.device("cuda", torch.cuda.current_device())
-    G = model_factory.create_G_net2("unet", dev, False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, "none", "none", "relu",
-                                    True, 1, 1, 0, "replicate", 2, 0, compute_dtype="bf16")
+    make_g = model_factory.create_G_net if video else model_factory.create_G_net2
+    G = make_g("unet", dev, False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, "none", "none", "relu",
+               True, 1, 1, 0, "replicate", 2, 0, compute_dtype="bf16")
     D = model_factory.create_D_net(1, 16, dev, False, "none", True, "simpleD", 3, "none", 3, 0, 0, 0)
     synth.fill_state_dict(G, "g0")
     synth.fill_state_dict(D, "d0")
@@ -115,7 +122,7 @@ def train_bench(a, rank, world, dist):
                                 ssim_window_size=5, struct_method="gamma_ssim", add_frame=0, final_shape_addition=0,
                                 loss_g_d_factor=0.1, adv_weight_list=torch.tensor([0.2, 0.2, 0.2]))
     tr = GanTrainer(opt, G, D, optG, optD, None, None)
-    B, T = 16, 2
+    B, T = (8, 5) if video else (16, 2)     # video: 2 clips of 512x512 -> 4 spatial 256x256 crops each
     hdr = synth.smooth_hdr_frames(B * T, salt="tr%d" % rank).reshape(B, T, 1, 256, 256).to(dev)
     pos = synth.ldr_frames(B * T, salt="trp%d" % rank).reshape(B, T, 1, 256, 256).to(dev)
     neg = (synth.ldr_frames(B * T, salt="trn%d" % rank) ** 2).reshape(B, T, 1, 256, 256).to(dev)
@@ -146,16 +153,20 @@ def train_bench(a, rank, world, dist):
         n = B * T
         # per frame: 2 generator forwards + 1 (summed) backward = 2*18.286 + 36.572 GFLOP (the reference runs 2 backwards)
         tfl = n * (2 * GFLOP_PER_TILE + 2 * GFLOP_PER_TILE) / ms
-        print(json.dumps({"metric": "HDR frames/sec (256x256 full GanTrainerImg step)", "value": world * n * a.steps / dt,
+        name = "GanTrainer (video, T=5)" if video else "GanTrainerImg"
+        print(json.dumps({"metric": "HDR frames/sec (256x256 full %s step)" % name, "value": world * n * a.steps / dt,
                           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": "GanTrainerImg step (train_D + train_G, all losses, Adam), 32 frames of 256x256 "
-                                                 "per GPU, epoch regime 0 (BASELINE.json configs[2])",
+                          "config": {"workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, "
+                                                  "Adam), 2 clips x 4 crops x 5 frames of 256x256 per GPU, epoch regime 0 "
+                                                  "(BASELINE.json configs[3])") if video else
+                                                 ("GanTrainerImg step (train_D + train_G, all losses, Adam), 32 frames of 256x256 "
+                                                  "per GPU, epoch regime 0 (BASELINE.json configs[2])"),
                                      "parallelism": "data-parallel x%d, gradient all-reduce" % world},
                           "generator_mfma": {"achieved": tfl, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                              "frac": tfl / PEAK_BF16_TFLOPS,
                                              "note": "2 fwd + 1 summed bwd of G per frame, whole step time"},
-                          "errD": float(tr.errD), "errG_d": float(tr.errG_d), "errG_struct": float(tr.errG_struct)}), flush=True)
+                          "errD": tr.errD.item(), "errG_d": tr.errG_d.item(), "errG_struct": tr.errG_struct.item()}), flush=True)
 
 
 def main():
@@ -170,7 +181,7 @@ def main():
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from uncltmo_amd import _hip, synth, tiler
     from uncltmo_amd.generator import UNet
-    if a.mode == "train":
+    if a.mode in ("train", "train_video"):
         train_bench(a, rank, world, dist)
         if dist:
             td.destroy_process_group()
