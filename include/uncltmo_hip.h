@@ -293,6 +293,17 @@ int uncl_simple_d_backward(const float* x, const float* w0, const float* w2, con
                            float* gb2, float* gw4, float* gb4, float* gwl, float* g_x, int accumulate, int N,
                            void* workspace, void* stream);
 
+/* PatchGAN discriminator forward (models/Discriminator.py:129-167 NLayerDiscriminator with Blocks.Conv2dBlock,
+ * models/Blocks.py:6-36, norm "instance_norm"): conv(4,2,1)+bias+LeakyReLU(0.2), (n_layers-1) x [conv(4,2,1) ->
+ * InstanceNorm(eps 1e-5) -> LeakyReLU], [conv(4,1,1) -> InstanceNorm -> LeakyReLU], conv(4,1,1)+bias.  fp32.
+ * x: (N,H,H) one-channel frames; w: HOST array of n_layers+2 device pointers to reference-layout weights (Cout,Cin,4,4);
+ * b_first (ndf), b_last (1); out: (N,Ho,Ho) with Ho = uncl_patch_d_out_size(H, n_layers) (30 for 256 / 3 layers).
+ * Forward-parity module: the reference's trainers never build it. */
+size_t uncl_patch_d_workspace_bytes(int N, int H, int ndf, int n_layers);
+int uncl_patch_d_out_size(int H, int n_layers);
+int uncl_patch_d_forward(const float* x, const float* const* w, const float* b_first, const float* b_last, float* out, int N, int H,
+                         int ndf, int n_layers, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Loss heads.  Each returns the weighted loss (written or accumulated into a device fp32 scalar) and, where
  * pointers are given, its input gradients.

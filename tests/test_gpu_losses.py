@@ -206,3 +206,25 @@ def test_adam_step_matches_torch():
         torch.cuda.synchronize()
     for r, d in zip(ref, dev):
         np.testing.assert_allclose(d.cpu().numpy(), r.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+# ---- PatchGAN (forward-parity module) ------------------------------------------------------
+def test_patch_d_forward_matches_reference_golden(golden):
+    from uncltmo_amd import model_factory
+    g = golden("disc")
+    p = model_factory.create_D_net(1, 16, torch.device("cuda"), False, "instance_norm", False, "patchD", 3, "none", 1, 0, 0, 0)
+    assert [k for k, _, _ in state_spec.patch_d_spec()] == list(p.state_dict().keys())
+    synth.fill_state_dict(p, "p0")
+    x = torch.cat([synth.ldr_frames(2, salt="dA"), synth.smooth_hdr_frames(1, salt="dB")], 0).cuda()
+    with torch.no_grad():
+        o = p(x)
+    assert o.shape == (3, 1, 30, 30)
+    assert rel_l2(o.cpu(), torch.from_numpy(g["patchd.output"])) < 1e-4
+    # other sizes / batch: against the oracle
+    x2 = synth.smooth_hdr_frames(2, 144, 144, salt="dP").cuda()
+    with torch.no_grad():
+        o2 = p(x2)
+    ref = OD.patch_d_forward({k: v.cpu() for k, v in p.state_dict().items()}, x2.cpu())
+    assert o2.shape == ref.shape and rel_l2(o2.cpu(), ref) < 1e-4
+    with pytest.raises(NotImplementedError):
+        p(x)                                     # gradients enabled: no backward kernels for this module

@@ -3,7 +3,7 @@ MI355X-native modules.  `weights_init_xavier` is folded into the modules' reset_
 import torch
 
 from . import params
-from .discriminator import SimpleDiscriminator
+from .discriminator import NLayerDiscriminator, SimpleDiscriminator
 from .generator import UNet, UNetVideo
 
 
@@ -44,10 +44,14 @@ def create_G_net2(model, device_, is_checkpoint, input_dim_, last_layer, filters
 
 def create_D_net(input_dim_, down_dim, device_, is_checkpoint, norm, use_xaviar, d_model, d_nlayers, last_activation, num_D,
                  d_fully_connected, simpleD_maxpool, d_padding):
-    """reference: model_save_util.py:101-118; only the published `simpleD` is on the HIP path."""
-    if d_model != "simpleD":
+    """reference: model_save_util.py:101-118; `simpleD` (the published trainer's D, forward + backward) and `patchD`
+    (forward-parity PatchGAN) are on the HIP path."""
+    if d_model == "patchD":
+        net = NLayerDiscriminator(input_dim_, ndf=down_dim, n_layers=d_nlayers, norm_layer=norm, last_activation=last_activation)
+    elif d_model == "simpleD":
+        net = SimpleDiscriminator(params.input_size, input_dim_, down_dim, norm, last_activation, simpleD_maxpool, d_padding)
+    else:
         assert 0, "Unsupported d model request: {}".format(d_model)
-    net = SimpleDiscriminator(params.input_size, input_dim_, down_dim, norm, last_activation, simpleD_maxpool, d_padding)
     if use_xaviar:
         for m in net.modules():
             if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
