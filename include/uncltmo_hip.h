@@ -347,6 +347,33 @@ int uncl_tile_count(int H, int W);
 int uncl_tile_gather(const float* frames, float* tiles, int F, int H, int W, void* stream);
 int uncl_tile_blend(const float* tiles, float* frames, int F, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Inference pre- / post-processing either side of the tiler, fp32 planes.
+ * ---------------------------------------------------------------------------------------------------- */
+/* one scratch area for the calls below */
+size_t uncl_frame_workspace_bytes(void);
+/* load_inference / load_inference2 arithmetic (utils/model_save_util.py:209-217): rgb (3,H,W) linear radiance ->
+ * rgb_out (3,H,W; NULL to skip) = rgb - min(rgb.min(), 0) and gray_log (H,W) = log10(((Y - Y.min()) / max) * f + 1),
+ * normalised by its maximum, Y = 0.299 R + 0.587 G + 0.114 B (hdr_image_util.py:68-74).  stats (device, 4 floats):
+ * rgb min / max, luminance min / max. */
+int uncl_hdr_log_gray(const float* rgb, int H, int W, float f_factor, float* rgb_out, float* gray_log, float* stats, void* workspace,
+                      void* stream);
+/* F.pad(x, (left, W1-W-left, top, H1-H-top), mode='replicate') on `planes` planes of H x W
+ * (data_loader_util.add_frame_to_im / add_frame_to_im_batch / resize_im, utils/data_loader_util.py:135-185) */
+int uncl_replicate_pad(const float* x, float* y, int planes, int H, int W, int top, int left, int H1, int W1, void* stream);
+/* out[r] = the ranks[r]-th smallest of the n values of x (0-based, exact; radix select, no sort).  ranks: HOST array,
+ * nr <= 8.  The two neighbours of a fractional rank are what np.percentile interpolates (model_save_util.py:389-390,
+ * hdr_image_util.py:93-97). */
+int uncl_order_stats(const float* x, long long n, const unsigned long long* ranks, int nr, float* out, void* workspace, void* stream);
+/* clamp to [lo,hi], stretch to [0,1], multiply by sqrt(rgb / (Y + 1e-8)) and cut the H x W window at (top,left) out of the
+ * padded H1 x W1 planes (model_save_util.py:391-400, hdr_image_util.back_to_color_tensor :120-131).  out: (3,H,W). */
+int uncl_color_finish(const float* rgb, const float* fake, float* out, int H1, int W1, int top, int left, int H, int W, float lo,
+                      float hi, void* stream);
+int uncl_clamp01(const float* x, float* y, long long n, void* stream);
+/* (C,H,W) fp32 -> (H,W,C) uint8: clamp(x,0,1), (v - lo) / (hi - lo), clip to [0,1], truncate(v * 255)
+ * (hdr_image_util.save_gray_tensor_as_numpy_stretch :237-241 with to_0_1_range_outlier :93-103) */
+int uncl_to_uint8(const float* x, unsigned char* out, int C, int H, int W, float lo, float hi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

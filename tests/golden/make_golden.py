@@ -303,12 +303,63 @@ def capture_tiler(out):
     del torch.Tensor.cuda
 
 
+def inference_inputs():
+    """Synthetic linear-radiance frame (heavy-tailed, slightly negative like shifted EXR data) and a stand-in generator
+    output on the padded grid; shared with tests/test_gpu_inference.py and tests/test_oracle_golden.py."""
+    rgb = torch.from_numpy(synth.hash_uniform("inf_rgb", 3 * 300 * 280).reshape(3, 300, 280).copy()).float() ** 4 * 1000 - 0.01
+    fake = torch.from_numpy(synth.hash_uniform("inf_fake", 304 * 288).reshape(1, 1, 304, 288).copy()).float() ** 2
+    return rgb, 1275.0, fake
+
+
+def capture_inference(out):
+    """Pre / post-processing around the tiler, from the reference's own functions where they are callable
+    (hdr_image_util.to_gray_tensor / back_to_color_tensor / to_0_1_range_outlier, data_loader_util.resize_im) and from the
+    statements of load_inference / run_model_on_single_image2 that sit between file I/O calls (model_save_util.py:209-217,
+    :389-401), executed here verbatim on tensors."""
+    from utils import hdr_image_util, data_loader_util
+    rgb_img, f_factor, fake = inference_inputs()
+    device = DEV
+    # ---- model_save_util.py:209-217
+    if rgb_img.min() < 0:
+        rgb_img = rgb_img - rgb_img.min()
+    gray_im = hdr_image_util.to_gray_tensor(rgb_img).to(device)
+    gray_im = gray_im - gray_im.min()
+    gray_im = torch.log10((gray_im / gray_im.max()) * f_factor + 1)
+    gray_im = gray_im / gray_im.max()
+    out.update(summarize(gray_im, "inf.gray_log", 4096))
+    # ---- :299-300
+    rgb_p, diffY, diffX = data_loader_util.resize_im(rgb_img, 1, 0)
+    gray_p, diffY, diffX = data_loader_util.resize_im(gray_im, 1, 0)
+    out["inf.diff"] = np.array([diffY, diffX], dtype=np.int64)
+    out.update(summarize(rgb_p, "inf.rgb_padded", 4096))
+    out.update(summarize(gray_p, "inf.gray_padded", 4096))
+    # ---- :389-401 on a stand-in generator output
+    max_p = np.percentile(fake.cpu().numpy(), 99.5)
+    min_p = np.percentile(fake.cpu().numpy(), 0.5)
+    out["inf.percentiles"] = np.array([min_p, max_p], dtype=np.float64)
+    fake2 = fake.clamp(min_p, max_p)
+    fake_im_gray_stretch = (fake2 - fake2.min()) / (fake2.max() - fake2.min())
+    fake_im_color2 = hdr_image_util.back_to_color_tensor(rgb_p, fake_im_gray_stretch[0], device)
+    im_max = fake_im_color2.max()
+    fake_im_color2 = fake_im_color2[:, diffY // 2:-(diffY - diffY // 2), diffX // 2:-(diffX - diffX // 2)]
+    fake_im_color2 = fake_im_color2.clamp(min=0, max=im_max)
+    out.update(summarize(fake_im_color2, "inf.color", 8192))
+    # ---- hdr_image_util.py:237-241 (save_gray_tensor_as_numpy_stretch up to the file write)
+    tensor = fake_im_color2.clamp(0, 1).clone().permute(1, 2, 0).detach().cpu().numpy()
+    tensor_0_1 = hdr_image_util.to_0_1_range_outlier(np.squeeze(tensor))
+    im = (tensor_0_1 * 255).astype("uint8")
+    out["inf.uint8.sum"] = np.int64(im.astype(np.int64).sum())
+    pos = np.minimum((synth.hash_uniform("samp:inf.uint8", 8192).astype(np.float64) * im.size).astype(np.int64), im.size - 1)
+    out["inf.uint8.pos"], out["inf.uint8.val"] = pos, im.reshape(-1)[pos]
+
+
 def main():
-    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "tiler"]
+    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "tiler", "inference"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
-            "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "tiler": lambda o: capture_tiler(o)}
+            "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "tiler": lambda o: capture_tiler(o),
+            "inference": lambda o: capture_inference(o)}
     for name in which:
         out = {}
         jobs[name](out)

@@ -1,0 +1,97 @@
+"""GPU parity of the inference pre- / post-processing against goldens captured from the
+reference's own functions, numpy, and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_summary
+from hip_util import rel_l2
+from uncltmo_amd import frame_util, inference, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def inference_inputs():
+    rgb = torch.from_numpy(synth.hash_uniform("inf_rgb", 3 * 300 * 280).reshape(3, 300, 280).copy()).float() ** 4 * 1000 - 0.01
+    fake = torch.from_numpy(synth.hash_uniform("inf_fake", 304 * 288).reshape(1, 1, 304, 288).copy()).float() ** 2
+    return rgb, 1275.0, fake
+
+
+def test_pre_processing_matches_reference_golden(golden):
+    g = golden("inference")
+    rgb, f, _ = inference_inputs()
+    rgb_s, gray = frame_util.hdr_log_gray(rgb.cuda(), f)
+    assert float(rgb_s.min()) == 0.0 and gray.shape == (1, 300, 280)
+    check_summary(gray, g, "inf.gray_log", rtol=2e-6, atol=2e-7)      # device log10f vs torch's CPU log10: last-bit differences
+    rgb_p, dY, dX = frame_util.resize_im(rgb_s, 1, 0)
+    gray_p, _, _ = frame_util.resize_im(gray, 1, 0)
+    assert [dY, dX] == list(g["inf.diff"])
+    check_summary(rgb_p, g, "inf.rgb_padded", rtol=0, atol=0)         # shift + replicate padding: bit-exact
+    check_summary(gray_p, g, "inf.gray_padded", rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 304 * 288, 3 * 1024 * 1024 + 5])
+def test_percentile_is_exactly_numpy(n):
+    x = torch.from_numpy(synth.hash_uniform("pct%d" % n, n).copy()).float()
+    x = (x - 0.3) * 7.0                                      # negative and positive values
+    if n > 100:
+        x[::3] = x[1]                                        # many ties
+        x[5] = float("inf")
+        x[6] = -0.0
+    qs = [0.0, 0.1, 0.5, 37.3, 50.0, 99.0, 99.5, 100.0]
+    got = frame_util.percentile(x.cuda(), qs)
+    ref = [np.percentile(x.numpy(), q) for q in qs]
+    for q, a, b in zip(qs, got, ref):
+        assert a == b or (np.isnan(a) and np.isnan(b)), (n, q, a, b)
+
+
+def test_post_processing_matches_reference_golden(golden):
+    g = golden("inference")
+    rgb, f, fake = inference_inputs()
+    rgb_s, gray = frame_util.hdr_log_gray(rgb.cuda(), f)
+    rgb_p, dY, dX = frame_util.resize_im(rgb_s, 1, 0)
+    min_p, max_p = frame_util.percentile(fake.cuda(), [0.5, 99.5])
+    assert [float(min_p), float(max_p)] == [float(v) for v in g["inf.percentiles"]]
+    col = frame_util.back_to_color_and_crop(rgb_p, fake.cuda(), min_p, max_p, dY, dX)
+    check_summary(col, g, "inf.color", rtol=1e-6, atol=1e-7)
+    im = frame_util.to_uint8_outlier(col).cpu().numpy()
+    assert im.shape == (300, 280, 3) and im.dtype == np.uint8
+    d = im.reshape(-1)[g["inf.uint8.pos"]].astype(np.int64) - g["inf.uint8.val"].astype(np.int64)
+    # truncation to 8 bits: a last-bit difference of the fp32 stretch can move a value across an integer boundary
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 2e-3, (np.abs(d).max(), (d != 0).mean())
+    assert abs(int(im.astype(np.int64).sum()) - int(g["inf.uint8.sum"])) <= 2e-3 * im.size
+
+
+def test_whole_frame_vs_oracle_pipeline():
+    """rgb -> log luminance -> pad -> tiled generator (fp32 parity mode) -> percentile clamp -> colour -> 8 bit, against the
+    CPU oracle running the same stages (4 tiles)."""
+    from oracle import inference as OI
+    from oracle import tiler as OT
+    from oracle.generator import unet_image_forward
+    from uncltmo_amd.generator import UNet
+    net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+               "replicate", 2, 0, compute_dtype="fp32")
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().eval()
+    rgb = synth.smooth_hdr_frames(3, 300, 280, salt="inf_e2e").reshape(3, 300, 280) * 50.0 + 0.01
+    col, im = inference.run_model_on_frame(net, rgb.cuda(), 1275.0)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    rgb_s, gray = OI.hdr_log_gray(rgb, 1275.0)
+    rgb_p, dY, dX = OI.resize_im(rgb_s)
+    gray_p, _, _ = OI.resize_im(gray)
+    with torch.no_grad():
+        fake = OT.tiled_forward(gray_p.unsqueeze(0), lambda t: unet_image_forward(sd, t))
+    ref = OI.finish(rgb_p, fake, dY, dX)
+    assert col.shape == ref.shape == (3, 300, 280)
+    assert rel_l2(col.cpu(), ref) < 1e-4
+    ref_im = OI.to_uint8(ref)
+    d = im.cpu().numpy().astype(np.int64) - ref_im.astype(np.int64)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 2e-2
+
+
+def test_arguments_are_checked():
+    from uncltmo_amd import _hip
+    with pytest.raises(_hip.HipError):
+        frame_util.hdr_log_gray(torch.zeros(3, 8, 8), 10.0)          # host tensor: no CPU path
+    with pytest.raises(_hip.HipError):
+        frame_util.hdr_log_gray(torch.zeros(3, 8, 8).cuda(), -1.0)   # UNCL_ERR_ARG

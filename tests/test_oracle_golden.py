@@ -162,3 +162,28 @@ def test_tiler(golden, sdG):
     with pytest.raises(ValueError):
         OT.axis_plan(256)
     assert OT.tile_count(1024, 1024) == 25 and OT.tile_count(2160, 3840) == 220
+
+
+def inference_inputs():
+    """Same synthetic frame / stand-in generator output as tests/golden/make_golden.py:inference_inputs."""
+    rgb = torch.from_numpy(synth.hash_uniform("inf_rgb", 3 * 300 * 280).reshape(3, 300, 280).copy()).float() ** 4 * 1000 - 0.01
+    fake = torch.from_numpy(synth.hash_uniform("inf_fake", 304 * 288).reshape(1, 1, 304, 288).copy()).float() ** 2
+    return rgb, 1275.0, fake
+
+
+def test_inference_pre_and_post_processing(golden):
+    from oracle import inference as OI
+    g = golden("inference")
+    rgb, f, fake = inference_inputs()
+    rgb_s, gray = OI.hdr_log_gray(rgb, f)
+    check_summary(gray, g, "inf.gray_log", rtol=1e-6, atol=1e-7)
+    rgb_p, dY, dX = OI.resize_im(rgb_s)
+    gray_p, _, _ = OI.resize_im(gray)
+    assert [dY, dX] == list(g["inf.diff"])
+    check_summary(rgb_p, g, "inf.rgb_padded", rtol=1e-6, atol=1e-7)
+    check_summary(gray_p, g, "inf.gray_padded", rtol=1e-6, atol=1e-7)
+    col = OI.finish(rgb_p, fake, dY, dX)
+    check_summary(col, g, "inf.color", rtol=1e-6, atol=1e-7)
+    im = OI.to_uint8(col)
+    assert int(im.astype(np.int64).sum()) == int(g["inf.uint8.sum"])
+    assert np.array_equal(im.reshape(-1)[g["inf.uint8.pos"]], g["inf.uint8.val"])

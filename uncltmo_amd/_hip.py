@@ -153,6 +153,17 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p]),
     "uncl_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "uncl_frame_workspace_bytes": (C.c_size_t, []),
+    "uncl_hdr_log_gray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "uncl_replicate_pad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p]),
+    "uncl_order_stats": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "uncl_color_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_float, C.c_void_p]),
+    "uncl_clamp01": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "uncl_to_uint8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "uncl_tile_count": (C.c_int, [C.c_int, C.c_int]),
     "uncl_tile_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_tile_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

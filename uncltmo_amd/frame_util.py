@@ -1,0 +1,154 @@
+"""Frame helpers either side of the tiler, MI355X-native: same names and argument meaning as the reference's
+utils/data_loader_util.py (resize_im, add_frame_to_im, add_frame_to_im_batch, crop_input_hdr_batch :135-185) and
+utils/hdr_image_util.py (to_gray_tensor is folded into hdr_log_gray; back_to_color_tensor :120-131; to_0_1_range_outlier
+:93-103), all on device tensors through csrc/frame_ops.hip.  There is no CPU path."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+
+
+def _ws(dev):
+    return torch.empty(_hip.lib().uncl_frame_workspace_bytes(), dtype=torch.uint8, device=dev)
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise _hip.HipError("%s is on %s; the HIP path needs it on the MI355X" % (what, t.device))
+
+
+def add_frame_to_im_batch(images_batch, diffX, diffY):
+    """(B,C,H,W) -> replicate-padded (B,C,H+diffY,W+diffX); data_loader_util.py:182-185."""
+    _need_gpu(images_batch, "images_batch")
+    b, c, h, w = images_batch.shape
+    x = images_batch.float().contiguous()
+    y = torch.empty(b, c, h + diffY, w + diffX, dtype=torch.float32, device=x.device)
+    _hip.check(_hip.lib().uncl_replicate_pad(x.data_ptr(), y.data_ptr(), b * c, h, w, diffY // 2, diffX // 2, h + diffY, w + diffX,
+                                             _hip.stream_ptr()), "uncl_replicate_pad")
+    return y
+
+
+def add_frame_to_im(input_im, diffX, diffY):
+    """(C,H,W) -> replicate-padded; data_loader_util.py:175-179."""
+    return add_frame_to_im_batch(input_im.unsqueeze(0), diffX, diffY).squeeze(0)
+
+
+def resize_im(im, add_frame, final_shape_addition):
+    """data_loader_util.py:135-158: pad (C,H,W) with replicated borders to 16*floor(H/16)+16 so that the generator's tiles
+    need no further padding (upstream overrides `add_frame` to True).  Returns (im, diffY, diffX)."""
+    h, w = im.shape[1], im.shape[2]
+    h1, w1 = int(16 * int(h / 16.)) + 16, int(16 * int(w / 16.)) + 16
+    diffY, diffX = abs(h - h1), abs(w - w1)
+    return add_frame_to_im(im, diffX=diffX, diffY=diffY), diffY, diffX
+
+
+def crop_input_hdr_batch(input_hdr_batch, diffY, diffX):
+    """data_loader_util.py:165-172 (a view)."""
+    b, c, h, w = input_hdr_batch.shape
+    th, tw = h - diffY, w - diffX
+    i, j = int(round((h - th) / 2.)), int(round((w - tw) / 2.))
+    return input_hdr_batch[:, :, i:i + th, j:j + tw]
+
+
+def hdr_log_gray(rgb_img, f_factor):
+    """The tensor arithmetic of load_inference / load_inference2 (model_save_util.py:209-217): (3,H,W) linear radiance ->
+    (rgb shifted to be non-negative (3,H,W), log-compressed luminance in [0,1] (1,H,W))."""
+    _need_gpu(rgb_img, "rgb_img")
+    lib = _hip.lib()
+    x = rgb_img.float().contiguous()
+    _, h, w = x.shape
+    rgb = torch.empty_like(x)
+    gray = torch.empty(1, h, w, dtype=torch.float32, device=x.device)
+    stats = torch.empty(4, dtype=torch.float32, device=x.device)
+    ws = _ws(x.device)
+    _hip.check(lib.uncl_hdr_log_gray(x.data_ptr(), h, w, float(f_factor), rgb.data_ptr(), gray.data_ptr(), stats.data_ptr(),
+                                     ws.data_ptr(), _hip.stream_ptr()), "uncl_hdr_log_gray")
+    return rgb, gray
+
+
+def _numpy_percentile_plan(n, q):
+    """(previous index, next index, finish(prev_value, next_value)) exactly as the installed numpy's np.percentile (method
+    'linear') treats a float32 array of n values.  numpy 2 derives the fractional rank in the array's dtype (float32), older
+    releases in float64: the plan is built from numpy's own helpers when they are importable so that the result matches
+    `np.percentile(x.cpu().numpy(), q)` (model_save_util.py:389-390) on this host bit for bit; otherwise float64 rules."""
+    try:
+        from numpy.lib import _function_base_impl as npf
+        q_ = np.asanyarray(np.true_divide(q, np.float32(100)))
+        props = npf._QuantileMethods["linear"]
+        virt = np.asanyarray(props["get_virtual_index"](n, q_))
+        if np.issubdtype(virt.dtype, np.integer):
+            i = int(virt)
+            return i, i, (lambda a, b: np.float32(a))
+        prev, nxt = npf._get_indexes(np.empty(1, dtype=np.float32), virt, n)
+        gamma = npf._get_gamma(virt, prev, props)
+        fin = lambda a, b: npf._lerp(np.float32(a), np.float32(b), gamma)
+        return int(prev) % n, int(nxt) % n, fin
+    except (ImportError, AttributeError, KeyError, TypeError):
+        pos = q / 100.0 * (n - 1)
+        lo = int(np.floor(pos))
+        t = pos - lo
+
+        def fin(a, b):
+            a, b = np.float32(a), np.float32(b)
+            d = b - a
+            return np.float32(a + d * t if t < 0.5 else b - d * (1 - t))
+        return lo, min(lo + 1, n - 1), fin
+
+
+def percentile(x, qs):
+    """np.percentile(x.cpu().numpy(), q) for each q (linear interpolation), from exact order statistics selected on the
+    device: a few floats cross to the host instead of the image (model_save_util.py:389-390, hdr_image_util.py:93-97).
+    NaNs are not supported (the reference would return NaN)."""
+    _need_gpu(x, "x")
+    lib = _hip.lib()
+    xf = x.float().contiguous()
+    n = xf.numel()
+    plans = [_numpy_percentile_plan(n, q) for q in qs]
+    ranks = []
+    for lo, hi, _ in plans:
+        ranks += [lo, hi]
+    out = torch.empty(len(ranks), dtype=torch.float32, device=xf.device)
+    ws = _ws(xf.device)
+    for i0 in range(0, len(ranks), 8):           # the select resolves up to eight ranks per sweep over the data
+        part = ranks[i0:i0 + 8]
+        arr = (C.c_ulonglong * len(part))(*part)
+        _hip.check(lib.uncl_order_stats(xf.data_ptr(), n, arr, len(part), out.data_ptr() + 4 * i0, ws.data_ptr(),
+                                        _hip.stream_ptr()), "uncl_order_stats")
+    v = out.cpu().numpy()
+    return [fin(v[2 * i], v[2 * i + 1]) for i, (_, _, fin) in enumerate(plans)]
+
+
+def back_to_color_and_crop(rgb_padded, fake, min_p, max_p, diffY, diffX):
+    """model_save_util.py:391-400: clamp to the percentiles, min-max stretch, back_to_color_tensor (hdr_image_util.py:120-131)
+    and removal of the resize_im padding, fused.  rgb_padded (3,H1,W1) non-negative, fake (..,H1,W1) -> (3,H,W).  The final
+    `clamp(0, im_max)` of the reference cannot change a value (the maximum is taken before the crop) and is dropped."""
+    _need_gpu(fake, "fake")
+    h1, w1 = rgb_padded.shape[1], rgb_padded.shape[2]
+    h, w = h1 - diffY, w1 - diffX
+    rgb = rgb_padded.float().contiguous()
+    f = fake.reshape(h1, w1).float().contiguous()
+    out = torch.empty(3, h, w, dtype=torch.float32, device=f.device)
+    _hip.check(_hip.lib().uncl_color_finish(rgb.data_ptr(), f.data_ptr(), out.data_ptr(), h1, w1, diffY // 2, diffX // 2, h, w,
+                                            float(np.float32(min_p)), float(np.float32(max_p)), _hip.stream_ptr()),
+               "uncl_color_finish")
+    return out
+
+
+def to_uint8_outlier(color):
+    """hdr_image_util.save_gray_tensor_as_numpy_stretch up to the file write (:237-241): clamp(0,1), to_0_1_range_outlier
+    (percentiles 0.1 / 99.0 over all channels, :93-103), *255, truncate.  (C,H,W) fp32 -> (H,W,C) uint8 on the device."""
+    _need_gpu(color, "color")
+    lib = _hip.lib()
+    x = color.float().contiguous()
+    c, h, w = x.shape
+    cl = torch.empty_like(x)
+    _hip.check(lib.uncl_clamp01(x.data_ptr(), cl.data_ptr(), x.numel(), _hip.stream_ptr()), "uncl_clamp01")
+    im_min, im_max = percentile(cl, [0.1, 99.0])
+    if float(im_max) - float(im_min) == 0:
+        im_max = np.float32(im_max) + np.float32(1e-08)
+    out = torch.empty(h, w, c, dtype=torch.uint8, device=x.device)
+    _hip.check(lib.uncl_to_uint8(cl.data_ptr(), out.data_ptr(), c, h, w, float(im_min), float(im_max), _hip.stream_ptr()),
+               "uncl_to_uint8")
+    return out
