@@ -111,21 +111,31 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
     // ---- coalesced stores.  A run = the channels of one (pixel, tap-row) that are contiguous in the output:
     // RUN virtual channels = min(128, 2*Cout) -> RUN/8 slots; runs of consecutive pixels are adjacent in memory.
     const int run = min(CT, 2 * a.Cout);          // virtual channels per contiguous run
-    const int rs = run >> 3;                      // slots per run
+    const int rs = run >> 3;                      // slots per run (a power of two)
+    const int rs_sh = __builtin_ctz(rs);
     const int runs_per_px = CT / run;             // 2 (Cout=32), 1 otherwise
+    // pixel coordinates without per-element integer division: one division per tile for the sample index, then an exact
+    // float reciprocal (rem < H*W <= 2^16) with a one-step correction for the row
+    const int hw = a.H * a.W;
+    const int n0 = m0 / hw, rem0 = m0 - n0 * hw;
+    const float rcpW = 1.0f / (float)a.W;
     for (int v = tid; v < 128 * 16; v += 256) {
       // order: [run index within pixel][pixel][slot in run]
-      const int sl = v % rs;
-      const int p = (v / rs) % 128;
-      const int ri = v / (rs * 128);
+      const int sl = v & (rs - 1);
+      const int p = (v >> rs_sh) & 127;
+      const int ri = v >> (rs_sh + 7);
       if (ri >= runs_per_px) continue;
       const int m = m0 + p;
       if (m >= a.M) continue;
       const int slot = ri * rs + sl;              // slot inside the 128-channel tile
       const int cv = ct * CT + slot * 8;          // virtual channel
-      const int tap = cv / a.Cout, co = cv - tap * a.Cout;
-      const int n = m / (a.H * a.W), rem = m - n * (a.H * a.W);
-      const int y = rem / a.W, x = rem - y * a.W;
+      const int tap = cv >= 2 * a.Cout ? (cv >= 3 * a.Cout ? 3 : 2) : (cv >= a.Cout ? 1 : 0);
+      const int co = cv - tap * a.Cout;
+      int rem = rem0 + p, n = n0;
+      while (rem >= hw) { rem -= hw; ++n; }       // a 128-pixel tile crosses at most one sample boundary when H*W >= 128
+      int y = (int)((float)rem * rcpW);
+      int x = rem - y * a.W;
+      if (x < 0) { --y; x += a.W; } else if (x >= a.W) { ++y; x -= a.W; }
       const size_t opix = ((size_t)n * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1);
       const vec val = *reinterpret_cast<const vec*>(sO + p * 256 + ((slot ^ (p & 15)) << 4));
       *reinterpret_cast<vec*>(a.out + opix * a.Cout + co) = val;
