@@ -174,7 +174,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = world > 1
+    dist = world > 1 or os.environ.get("UNCL_FORCE_DIST") == "1"   # the override lets a 1-GPU box exercise the RCCL path
     torch.cuda.set_device(local_rank)
     if dist:
         import torch.distributed as td
