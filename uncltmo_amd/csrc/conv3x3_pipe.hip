@@ -84,7 +84,7 @@ __device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off)
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1]
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
-__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_pipe_kernel(const PipeArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void conv3x3_pipe_kernel(const PipeArgs a) {
   using E = Elem<bf16_t>;
   using vec = bf16x8;
   static_assert(WAVES == 4, "staging pattern below is written for 256 threads");
@@ -566,7 +566,7 @@ int launch_pipe(PipeArgs& a, hipStream_t s) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WAVES * 64, lds) !=
             hipSuccess || per_cu <= 0)
       per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > ((NT == 1 && MPW == 2) ? 3 : 2)) per_cu = (NT == 1 && MPW == 2) ? 3 : 2;
     hipDeviceProp_t p;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -634,6 +634,15 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   const bool prev = d->prev0 != nullptr && d->prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->Cout == 32) {
+    // 8-row tiles at three workgroups per CU (50 KB LDS, 168 VGPRs) overlap the serial load / stage / store phases of the
+    // single-chunk 32 -> 32 transposed layers better than 16-row tiles at two (measured: up_path.{2,3}.conv.conv1 -9 %);
+    // the valid 32 -> 32 layer and the multi-chunk concat layers are faster (or read less) with the larger tile
+    if (d->pad == 2 && d->src_mode == UNCL_SRC_PLAIN && d->Cin == 32 && !prev) {
+      a.n_ct = 1;
+      a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + 7) / 8;
+      a.total_tiles = d->N * a.tiles_x * a.tiles_y;
+      return dispatch_mode<1, 2>(a, d->src_mode, prev, s);
+    }
     constexpr int TH = 16;
     a.n_ct = 1;
     a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
