@@ -361,7 +361,11 @@ extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
   a.oH = d->out_H; a.oW = d->out_W; a.oC = d->out_C;
   a.z_mode = d->z_mode; a.out1_act = d->out1_act; a.skip_main = d->skip_main_store;
 
-  const int nt = d->Cout >= 128 ? 4 : (d->Cout == 64 ? 2 : (d->Cout % 128 == 0 ? 4 : (d->Cout % 64 == 0 ? 2 : 1)));
+  int nt = d->Cout >= 128 ? 4 : (d->Cout == 64 ? 2 : (d->Cout % 128 == 0 ? 4 : (d->Cout % 64 == 0 ? 2 : 1)));
+  // bf16 1x1 layers (the graph block: a few GFLOP on 144 nodes per sample) are launch-parallelism bound, not tile-efficiency
+  // bound: 128 pixels x 64 channels per workgroup gives 4x the workgroups of the 256 x 128 tile
+  const bool small_1x1 = d->ksize == 1 && d->dtype == UNCL_BF16 && d->z_mode != UNCL_Z_UP2X2 && nt >= 2;
+  if (small_1x1) nt = 2;
   const int CT = nt * 32;
   if (d->Cout % CT != 0) return UNCL_ERR_ARG;
   a.n_ct = d->Cout / CT;
@@ -387,10 +391,12 @@ extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
     a.N = 1; a.H = 1; a.W = (int)M;
     a.s0H = 1; a.s0W = (int)M;
     a.Hout = 1; a.Wout = (int)M;
-    a.tiles_x = (int)((M + 255) / 256);
+    const int tw = small_1x1 ? 128 : 256;
+    a.tiles_x = (int)((M + tw - 1) / tw);
     grid = dim3(a.tiles_x, 1, a.n_ct * zcount);
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (small_1x1) return launch<bf16_t, 1, 1, 4, 2>(a, grid, s);
   if (d->dtype == UNCL_BF16) return dispatch<bf16_t>(a, d->ksize, nt, grid, s);
   return dispatch<float>(a, d->ksize, nt, grid, s);
 }
