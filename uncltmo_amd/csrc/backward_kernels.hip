@@ -51,12 +51,22 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ partial, int rows, int cols, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// out[c] (+)= sum over `rows` partial rows: 32 columns x 8 row lanes per workgroup, fp64, fixed order
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int rows, int cols, float* __restrict__ out,
+                                                          int accumulate) {
+  __shared__ double red[8][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * cols + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (c < cols)
+    for (int r = rg; r < rows; r += 8) s += (double)partial[(size_t)r * cols + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    double t = 0.0;
+    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    out[c] = accumulate ? out[c] + (float)t : (float)t;
+  }
 }
 
 // ---- skip-concat backward (unet_parts.py:319-322, 292-298)
@@ -371,11 +381,11 @@ extern "C" int uncl_outc_backward(const float* g_out, const float* x_out, const 
   const int blocks = nblocks((size_t)P * 4, 1024);
   hipLaunchKernelGGL(outc_bwd_kernel, dim3(blocks), dim3(256), 0, s, g_out, x_out, (const bf16_t*)g_upx, (const bf16_t*)up_x, w,
                      (bf16_t*)G_up, (float*)workspace, (size_t)P, last_act, slope);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, blocks, 33, (float*)workspace + 1024 * 33,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(2), dim3(256), 0, s, (const float*)workspace, blocks, 33, (float*)workspace + 1024 * 33,
                      0);
   // split the 33 sums into gw[32], gb[1]
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace + 1024 * 33, 1, 32, gw, accumulate);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace + 1024 * 33 + 32, 1, 1, gb, accumulate);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace + 1024 * 33, 1, 32, gw, accumulate);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace + 1024 * 33 + 32, 1, 1, gb, accumulate);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
@@ -477,7 +487,7 @@ extern "C" int uncl_conv_in_c1_wgrad(const void* G, const float* x, float* gw, f
   float* part = (float*)workspace;
   hipLaunchKernelGGL(conv_in_wgrad_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)G, x, part, N, H, W);
   float* tot = part + (size_t)512 * 320;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(5), dim3(64), 0, s, (const float*)part, blocks, 320, tot, 0);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(10), dim3(256), 0, s, (const float*)part, blocks, 320, tot, 0);
   hipLaunchKernelGGL(conv_in_final_kernel, dim3(5), dim3(64), 0, s, (const float*)tot, gw, gb, accumulate);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;

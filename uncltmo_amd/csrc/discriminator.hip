@@ -298,15 +298,27 @@ __global__ __launch_bounds__(256) void d_conv1_wgrad_kernel(const float* __restr
   if (tap == 0) out[256 + co] = bsum;
 }
 
-// out[j] (+)= sum over `count` partial rows of width `width` (fixed order)
-__global__ void d_partial_sum_kernel(const float* __restrict__ partial, int count, int width, int off0, int n0, float* __restrict__ dst0,
-                                     int n1, float* __restrict__ dst1, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n0 + n1) return;
+// out[j] (+)= sum over `count` partial rows of width `width`: 32 columns x 8 row lanes per workgroup, fp64, fixed order
+__global__ __launch_bounds__(256) void d_partial_sum_kernel(const float* __restrict__ partial, int count, int width, int off0,
+                                                            int n0, float* __restrict__ dst0, int n1, float* __restrict__ dst1,
+                                                            int accumulate) {
+  __shared__ double red[8][33];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   double s = 0.0;
-  for (int r = 0; r < count; ++r) s += (double)partial[(size_t)r * width + off0 + j];
-  float* d = j < n0 ? dst0 + j : dst1 + (j - n0);
-  *d = accumulate ? *d + (float)s : (float)s;
+  if (j < n0 + n1) {
+    const float* p = partial + off0 + j;
+#pragma unroll 8
+    for (int r = rg; r < count; r += 8) s += (double)p[(size_t)r * width];
+  }
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && j < n0 + n1) {
+    double t = 0.0;
+    for (int i = 0; i < 8; ++i) t += red[i][c];
+    float* d = j < n0 ? dst0 + j : dst1 + (j - n0);
+    *d = accumulate ? *d + (float)t : (float)t;
+  }
 }
 
 // g_x[n][y][x] = sum_{ky,kx,co} g_h1pre[(y-ky)/2][(x-kx)/2][co] w0[co][ky][kx]
@@ -428,14 +440,14 @@ extern "C" int uncl_simple_d_backward(const float* x, const float* w0, const flo
     else if (!accumulate)
       (void)hipMemsetAsync(gwl, 0, H2 * H2 * sizeof(float), st);
     hipLaunchKernelGGL(d_conv2_wgrad_kernel, dim3(64, N), dim3(256), 0, st, b.g_h2pre, b.h1, b.w2part);
-    hipLaunchKernelGGL(d_partial_sum_kernel, dim3((8192 + 32 + 255) / 256), dim3(256), 0, st, b.w2part, N * 64, 8192 + 32, 0, 8192, gw2,
+    hipLaunchKernelGGL(d_partial_sum_kernel, dim3((8192 + 32 + 31) / 32), dim3(256), 0, st, b.w2part, N * 64, 8192 + 32, 0, 8192, gw2,
                        32, gb2, accumulate);
   }
   hipLaunchKernelGGL(d_conv2_dgrad_kernel, dim3((unsigned)((t1 + 255) / 256 < 4096 ? (t1 + 255) / 256 : 4096)), dim3(256), 0,
                      st, b.g_h2pre, w2, b.h1, b.g_h1pre, N);
   if (params) {
     hipLaunchKernelGGL(d_conv1_wgrad_kernel, dim3(32, N), dim3(256), 0, st, b.g_h1pre, x, b.w0part);
-    hipLaunchKernelGGL(d_partial_sum_kernel, dim3(2), dim3(256), 0, st, b.w0part, N * 32, 256 + 16, 0, 256, gw0, 16, gb0, accumulate);
+    hipLaunchKernelGGL(d_partial_sum_kernel, dim3((256 + 16 + 31) / 32), dim3(256), 0, st, b.w0part, N * 32, 256 + 16, 0, 256, gw0, 16, gb0, accumulate);
   }
   if (g_x != nullptr)
     hipLaunchKernelGGL(d_conv1_dgrad_kernel, dim3((unsigned)((t0 + 255) / 256 < 4096 ? (t0 + 255) / 256 : 4096)), dim3(256), 0,

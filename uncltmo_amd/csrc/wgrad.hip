@@ -254,12 +254,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     partial[(size_t)blockIdx.x * C + threadIdx.x] = t;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 32 columns x 8 partial-row lanes per workgroup, fp64, fixed order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ double red[8][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[(size_t)b * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (c < C)
+    for (int b = rg; b < blocks; b += 8) s += (double)partial[(size_t)b * C + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    double t = 0.0;
+    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    out[c] = accumulate ? out[c] + (float)t : (float)t;
+  }
 }
 
 // packed fp32 [tap][Cout][Cin] gradient -> reference-layout fp32 gradient (inverse of uncl_pack_conv_weight)
@@ -347,9 +357,9 @@ extern "C" int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, fl
     const int cw = C - c0 < 256 ? C - c0 : 256;
     if (256 % (cw / 8) != 0) return UNCL_ERR_ARG;
     const int rpb = 256 / (cw / 8);
-    const int blocks = (int)((rows + rpb - 1) / rpb < 96 ? (rows + rpb - 1) / rpb : 96);
+    const int blocks = (int)((rows + rpb - 1) / rpb < 512 ? (rows + rpb - 1) / rpb : 512);
     hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x + c0, (float*)workspace, (size_t)rows, cw, ld);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cw + 63) / 64), dim3(64), 0, s, (const float*)workspace, blocks, cw, out + c0,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cw + 31) / 32), dim3(256), 0, s, (const float*)workspace, blocks, cw, out + c0,
                        accumulate);
   }
   UNCL_CHECK_LAUNCH();

@@ -142,7 +142,7 @@ class _GeneratorBase(nn.Module):
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
         code = self._dtype_code()
-        key = (code, _hip.PARAM_EPOCH[0]) + tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        key = (code,) + tuple((k, v.data_ptr(), v._version, getattr(v, "_uncl_epoch", 0)) for k, v in sd.items())
         if key == self._pack_key:
             return self._packed
         lib = _hip.lib()

@@ -38,5 +38,9 @@ class Adam(torch.optim.Optimizer):
                                           arr([self.state[p]["exp_avg_sq"] for p in ps]), n, len(ps), float(group["lr"]),
                                           float(b1), float(b2), float(group["eps"]), int(step), _hip.stream_ptr()),
                        "uncl_adam_step")
-            _hip.PARAM_EPOCH[0] += 1    # parameters changed behind autograd's back: invalidate cached weight packs
+            # parameters changed behind autograd's back (no ._version bump): mark THESE tensors so that the module that owns
+            # them re-packs its weights -- and only that module (the discriminator's step leaves the generator's packs valid)
+            for p in ps:
+                p._uncl_epoch = getattr(p, "_uncl_epoch", 0) + 1
+            _hip.PARAM_EPOCH[0] += 1
         return loss
