@@ -179,9 +179,13 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     g_pending = g;
     b_pending = kc == 0;
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    // the upsampled map has the skip's extent on three of the four decoder levels (2*126 = 252, 2*61 = 122, 2*12 = 24):
+    // then it needs no replicate padding and takes the same scalar-base / masked paths as the skip itself
+    const bool same_ext = a.s1H == a.s0H && a.s1W == a.s0W;
+    const bf16_t* xsrc = (MODE != 0 && g == 1) ? a.src1 : a.src0;
     if (reuse) {
       // xr / xvalid still hold this tile's x2 slice
-    } else if (MODE != 0 && g == 1) {
+    } else if (MODE != 0 && g == 1 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
       const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
       const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
@@ -209,14 +213,14 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
       if (interior && !PREV) {
         // the whole halo tile is inside the image: one scalar base, a constant stride between slots
-        const bf16_t* base = a.src0 + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
+        const bf16_t* base = xsrc + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
         // the stride between slots goes into the scalar base, so one offset VGPR serves all regular slots
 #pragma unroll
         for (int j = 0; j < RS; ++j) xr[j] = ld16o(base + j * 2 * row_el, (unsigned)xoff_r * 2u);
         xr[RS] = ld16o(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
         xvalid = 0xffffffffu;
       } else {
-        const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+        const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
         const int toff = (iy0 * a.s0W + ix0) * a.s0C;  // may be negative on the border; masked below
         unsigned valid = 0;
         const bool xok = (unsigned)(ix0 + hx) < (unsigned)a.W;
