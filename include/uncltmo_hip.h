@@ -324,6 +324,12 @@ int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b_stride, in
  * best_worst (optional int32[2]): first arg-max / arg-min (GanTrainerImg.py:357-359, 398-402) */
 int uncl_tmqi_naturalness(const float* x, int F, int frame_h, int frame_w, int h, int w, float scale, double* scores,
                           int32_t* best_worst, void* stream);
+/* Full TMQI in fp64 (TMQI.py:107-207, `original` branch): structural fidelity over the 5-level pyramid, naturalness, and
+ * Q = 0.8012 S^0.3046 + 0.1988 N^0.7088.  hdr: fp32 (H,W) luminance in any range; ldr: fp32 (H,W), multiplied by ldr_scale
+ * (255 for images in [0,1]).  out: 8 doubles on the device: Q, S, N, s_local[0..4].  H, W >= 176.
+ * Used by the reference's evaluators (Tester.py:339, TesterImg.py:335), not by the training step. */
+size_t uncl_tmqi_workspace_bytes(int H, int W);
+int uncl_tmqi(const float* hdr, const float* ldr, int H, int W, float ldr_scale, double* out, void* workspace, void* stream);
 /* gx[n] (+)= gscale[n] * d mean(Gaussian local variance of x[n]) / dx */
 int uncl_gauss_var_backward(const float* x, const float* gscale, float* gx, int N, int H, int W, int accumulate, void* stream);
 /* Backward of uncl_gauss_stats for NHWC tensors (the video generator's per-frame features, Unet.py:274-278):

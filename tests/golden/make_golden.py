@@ -353,13 +353,32 @@ def capture_inference(out):
     out["inf.uint8.pos"], out["inf.uint8.val"] = pos, im.reshape(-1)[pos]
 
 
+def tmqi_inputs(h, w, salt):
+    """HDR luminance (heavy-tailed, any range) and a tone-mapped LDR image in [0,255] derived from it."""
+    hdr = synth.smooth_hdr_frames(1, h, w, salt="tmqi_h" + salt)[0, 0].double().numpy() ** 3 * 4000.0 + 0.05
+    noise = synth.hash_uniform("tmqi_n" + salt, h * w).reshape(h, w).astype(np.float64)
+    ldr = 255.0 * np.clip((np.log10(hdr) - np.log10(hdr.min())) / (np.log10(hdr.max()) - np.log10(hdr.min())) * 0.9 + 0.04 * noise, 0, 1)
+    return hdr, ldr
+
+
+def capture_tmqi(out):
+    """Full TMQI (Q, S, N, per-level structural fidelity) from the reference's TMQI class (TMQI.py:92-146)."""
+    import TMQI as ref_tmqi
+    for (h, w), salt in (((256, 256), "a"), ((200, 176), "b")):
+        hdr, ldr = tmqi_inputs(h, w, salt)
+        Q, S, N, s_local, _ = ref_tmqi.TMQI()(hdr, ldr)
+        out["tmqi.%s.QSN" % salt] = np.array([Q, S, N], dtype=np.float64)
+        out["tmqi.%s.s_local" % salt] = np.array(s_local, dtype=np.float64)
+        print("captured tmqi", salt, Q, S, N, s_local, flush=True)
+
+
 def main():
-    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "tiler", "inference"]
+    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "tiler", "inference", "tmqi"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
             "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "tiler": lambda o: capture_tiler(o),
-            "inference": lambda o: capture_inference(o)}
+            "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o)}
     for name in which:
         out = {}
         jobs[name](out)

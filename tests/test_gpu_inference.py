@@ -95,3 +95,35 @@ def test_arguments_are_checked():
         frame_util.hdr_log_gray(torch.zeros(3, 8, 8), 10.0)          # host tensor: no CPU path
     with pytest.raises(_hip.HipError):
         frame_util.hdr_log_gray(torch.zeros(3, 8, 8).cuda(), -1.0)   # UNCL_ERR_ARG
+
+
+# ---- full TMQI on device ----------------------------------------------------------
+def tmqi_inputs(h, w, salt):
+    hdr = synth.smooth_hdr_frames(1, h, w, salt="tmqi_h" + salt)[0, 0].double().numpy() ** 3 * 4000.0 + 0.05
+    noise = synth.hash_uniform("tmqi_n" + salt, h * w).reshape(h, w).astype(np.float64)
+    ldr = 255.0 * np.clip((np.log10(hdr) - np.log10(hdr.min())) / (np.log10(hdr.max()) - np.log10(hdr.min())) * 0.9 + 0.04 * noise, 0, 1)
+    return hdr, ldr
+
+
+@pytest.mark.parametrize("shape,salt", [((256, 256), "a"), ((200, 176), "b")])
+def test_full_tmqi_matches_reference_golden(golden, shape, salt):
+    from uncltmo_amd.tmqi import TMQI
+    g = golden("tmqi")
+    hdr, ldr = tmqi_inputs(shape[0], shape[1], salt)
+    Q, S, N, sl = TMQI()(torch.from_numpy(hdr).float().cuda(), torch.from_numpy(ldr).float().cuda())
+    # the device takes fp32 images (the goldens were computed from the float64 arrays): 1e-5 covers the input rounding
+    np.testing.assert_allclose([Q, S, N], g["tmqi.%s.QSN" % salt], rtol=2e-5)
+    np.testing.assert_allclose(sl, g["tmqi.%s.s_local" % salt], rtol=2e-5)
+
+
+def test_full_tmqi_large_frame_vs_oracle():
+    from oracle import tmqi as OT
+    from uncltmo_amd.tmqi import TMQI
+    hdr, ldr = tmqi_inputs(400, 528, "c")
+    h32, l32 = torch.from_numpy(hdr).float(), torch.from_numpy(ldr / 255.0).float()
+    Q, S, N, sl = TMQI()(h32.cuda(), l32.cuda(), ldr_scale=255.0)
+    rQ, rS, rN, rsl = OT.tmqi(h32.double().numpy(), (l32 * 255.0).double().numpy())
+    np.testing.assert_allclose([Q, S, N], [rQ, rS, rN], rtol=1e-6)
+    np.testing.assert_allclose(sl, rsl, rtol=1e-6)
+    with pytest.raises(Exception):
+        TMQI()(h32[:100, :100].cuda(), l32[:100, :100].cuda())           # pyramid would not hold an 11x11 window

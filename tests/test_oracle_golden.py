@@ -187,3 +187,21 @@ def test_inference_pre_and_post_processing(golden):
     im = OI.to_uint8(col)
     assert int(im.astype(np.int64).sum()) == int(g["inf.uint8.sum"])
     assert np.array_equal(im.reshape(-1)[g["inf.uint8.pos"]], g["inf.uint8.val"])
+
+
+def tmqi_inputs(h, w, salt):
+    """Same synthetic HDR / LDR pair as tests/golden/make_golden.py:tmqi_inputs."""
+    hdr = synth.smooth_hdr_frames(1, h, w, salt="tmqi_h" + salt)[0, 0].double().numpy() ** 3 * 4000.0 + 0.05
+    noise = synth.hash_uniform("tmqi_n" + salt, h * w).reshape(h, w).astype(np.float64)
+    ldr = 255.0 * np.clip((np.log10(hdr) - np.log10(hdr.min())) / (np.log10(hdr.max()) - np.log10(hdr.min())) * 0.9 + 0.04 * noise, 0, 1)
+    return hdr, ldr
+
+
+def test_full_tmqi_matches_reference_class(golden):
+    from oracle import tmqi as OT
+    g = golden("tmqi")
+    for (h, w), salt in (((256, 256), "a"), ((200, 176), "b")):
+        hdr, ldr = tmqi_inputs(h, w, salt)
+        Q, S, N, sl = OT.tmqi(hdr, ldr)
+        np.testing.assert_allclose([Q, S, N], g["tmqi.%s.QSN" % salt], rtol=1e-9)
+        np.testing.assert_allclose(sl, g["tmqi.%s.s_local" % salt], rtol=1e-9)

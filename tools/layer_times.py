@@ -24,6 +24,8 @@ SHAPES = {"inc.conv.conv1": (32, 32, 252, 9), "down_path.0.mpconv.1.conv": (32, 
 
 
 def main():
+    if len(sys.argv) > 1:          # A/B on the same box: python tools/layer_times.py tools/_ab/libX.so
+        _hip.LIB_PATH = os.path.abspath(sys.argv[1])
     lib = _hip.lib()
     net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
                "replicate", 2, 0, compute_dtype="bf16")

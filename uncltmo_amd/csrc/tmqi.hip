@@ -1,0 +1,215 @@
+// Full TMQI (tone-mapped image quality index) on device, fp64: structural fidelity S over a 5-level pyramid, statistical
+// naturalness N and Q = a S^alpha + (1-a) N^beta  (TMQI.py:107-207; SURVEY.md section 8 row (f) rank 2 -- the metric the
+// reference's in-training evaluator and the paper report).  Everything is HBM-bound element / window work in double
+// precision (the reference rescales the HDR luminance to [0, 2^32-1] and subtracts squared means: fp32 would cancel):
+//   * 11x11 sigma-1.5 Gaussian 'valid' filters of {a, b, a^2, b^2, ab} as two separable passes (row pass writes five
+//     planes, column pass fuses the s_map formula and a deterministic block reduction of its mean),
+//   * norm.cdf through erfc, the 2x2 mean + stride-2 decimation between levels,
+//   * N from uncl_tmqi_naturalness (csrc/loss_heads.hip), the final product / powers in one thread.
+#include "common.h"
+
+extern "C" int uncl_tmqi_naturalness(const float* x, int F, int frame_h, int frame_w, int h, int w, float scale, double* scores,
+                                     int32_t* best_worst, void* stream);
+
+namespace {
+
+constexpr int GW = 11;
+constexpr int LEVELS = 5;
+constexpr int PB = 1024;   // partial-sum workgroups
+
+struct GaussD { double g[GW]; };
+
+__global__ __launch_bounds__(256) void mm_kernel(const float* __restrict__ x, size_t n, double* __restrict__ partial) {
+  double mn = INFINITY, mx = -INFINITY;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double v = (double)x[i];
+    mn = fmin(mn, v); mx = fmax(mx, v);
+  }
+  __shared__ double smn[256], smx[256];
+  smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      smn[threadIdx.x] = fmin(smn[threadIdx.x], smn[threadIdx.x + o]);
+      smx[threadIdx.x] = fmax(smx[threadIdx.x], smx[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = smn[0]; partial[2 * blockIdx.x + 1] = smx[0]; }
+}
+
+__global__ void mm_final_kernel(const double* __restrict__ partial, int count, double* __restrict__ mm) {
+  if (threadIdx.x == 0) {
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < count; ++i) { mn = fmin(mn, partial[2 * i]); mx = fmax(mx, partial[2 * i + 1]); }
+    mm[0] = mn; mm[1] = mx;
+  }
+}
+
+// a = (2^32 - 1) * (hdr - min) / (max - min)  (TMQI.py:137), b = ldr * scale
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ hdr, const float* __restrict__ ldr, double scale,
+                                                   const double* __restrict__ mm, double* __restrict__ a, double* __restrict__ b,
+                                                   size_t n) {
+  const double mn = mm[0], span = mm[1] - mm[0];
+  const double factor = 4294967295.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    a[i] = factor * ((double)hdr[i] - mn) / span;
+    b[i] = (double)ldr[i] * scale;
+  }
+}
+
+// row pass: five planes of (h, w - 10): G_x * {a, b, a^2, b^2, ab}
+__global__ __launch_bounds__(256) void rowpass_kernel(const double* __restrict__ a, const double* __restrict__ b, int h, int w,
+                                                      double* __restrict__ out, GaussD gw) {
+  const int wo = w - (GW - 1);
+  const size_t total = (size_t)h * wo, plane = total;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int y = (int)(i / wo), x = (int)(i - (size_t)y * wo);
+    const double* pa = a + (size_t)y * w + x;
+    const double* pb = b + (size_t)y * w + x;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const double va = pa[t], vb = pb[t], g = gw.g[t];
+      s0 += g * va; s1 += g * vb; s2 += g * (va * va); s3 += g * (vb * vb); s4 += g * (va * vb);
+    }
+    out[i] = s0; out[plane + i] = s1; out[2 * plane + i] = s2; out[3 * plane + i] = s3; out[4 * plane + i] = s4;
+  }
+}
+
+__device__ __forceinline__ double norm_cdf(double x, double u, double sig) {
+  return 0.5 * erfc(-(x - u) / (sig * 1.4142135623730951));
+}
+
+// column pass + s_map (TMQI.py:183-205) + per-workgroup partial sum of the map
+__global__ __launch_bounds__(256) void colpass_smap_kernel(const double* __restrict__ rp, int h, int wo, double u, double sig,
+                                                           double* __restrict__ partial, GaussD gw) {
+  const int ho = h - (GW - 1);
+  const size_t total = (size_t)ho * wo, plane = (size_t)h * wo;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int y = (int)(i / wo), x = (int)(i - (size_t)y * wo);
+    double m[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const size_t o = (size_t)(y + t) * wo + x;
+      const double g = gw.g[t];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) m[k] += g * rp[k * plane + o];
+    }
+    const double mu1 = m[0], mu2 = m[1];
+    const double s1 = sqrt(fmax(m[2] - mu1 * mu1, 0.0)), s2 = sqrt(fmax(m[3] - mu2 * mu2, 0.0));
+    const double s12 = m[4] - mu1 * mu2;
+    const double p1 = norm_cdf(s1, u, sig), p2 = norm_cdf(s2, u, sig);
+    acc += ((2.0 * p1 * p2 + 0.01) / (p1 * p1 + p2 * p2 + 0.01)) * ((s12 + 10.0) / (s1 * s2 + 10.0));
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void level_final_kernel(const double* __restrict__ partial, int count, double npix, double* __restrict__ dst) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < count; ++i) s += partial[i];
+    *dst = s / npix;
+  }
+}
+
+// 'valid' 2x2 mean then every second sample (TMQI.py:164-170): out (ceil((h-1)/2), ceil((w-1)/2))
+__global__ __launch_bounds__(256) void down_kernel(const double* __restrict__ in, int h, int w, double* __restrict__ out, int h2,
+                                                   int w2) {
+  const size_t total = (size_t)h2 * w2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int y = (int)(i / w2), x = (int)(i - (size_t)y * w2);
+    const double* p = in + (size_t)(2 * y) * w + 2 * x;
+    out[i] = 0.25 * p[0] + 0.25 * p[1] + 0.25 * p[w] + 0.25 * p[w + 1];
+  }
+}
+
+// out: [0] Q, [1] S, [2] N (already there), [3..7] s_local
+__global__ void combine_kernel(double* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const double wgt[LEVELS] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+    double S = 1.0;
+    for (int l = 0; l < LEVELS; ++l) S *= pow(out[3 + l], wgt[l]);
+    out[1] = S;
+    out[0] = 0.8012 * pow(S, 0.3046) + (1.0 - 0.8012) * pow(out[2], 0.7088);
+  }
+}
+
+inline int nb(size_t n, int cap) {
+  const size_t b = (n + 255) / 256;
+  return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" size_t uncl_tmqi_workspace_bytes(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  const size_t px = (size_t)H * W;
+  // a, b (level 0), a', b' (next level, at most a quarter), five row-pass planes, partial sums, min/max
+  return (2 * px + 2 * ((px + 3) / 4 + (size_t)H + W) + 5 * px + 2 * PB + 16) * sizeof(double);
+}
+
+// hdr: fp32 (H,W) luminance in any range; ldr: fp32 (H,W) tone-mapped luminance, multiplied by ldr_scale (255 for [0,1]
+// images) before use.  out (device, 8 doubles): Q, S, N, s_local[0..4].  The smallest pyramid level must still hold an
+// 11x11 window: H, W >= 176.
+extern "C" int uncl_tmqi(const float* hdr, const float* ldr, int H, int W, float ldr_scale, double* out, void* workspace,
+                         void* stream) {
+  if (!hdr || !ldr || !out || !workspace || H < 176 || W < 176) return UNCL_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t px = (size_t)H * W;
+  double* a0 = reinterpret_cast<double*>(workspace);
+  double* b0 = a0 + px;
+  const size_t q = (px + 3) / 4 + (size_t)H + W;
+  double* a1 = b0 + px;
+  double* b1 = a1 + q;
+  double* rp = b1 + q;
+  double* partial = rp + 5 * px;
+  double* mm = partial + 2 * PB;
+  GaussD gw;
+  {
+    double s = 0.0;
+    for (int k = 0; k < GW; ++k) { gw.g[k] = exp(-0.5 * ((k - 5) / 1.5) * ((k - 5) / 1.5)); s += gw.g[k]; }
+    for (int k = 0; k < GW; ++k) gw.g[k] /= s;   // outer(g, g) / sum(outer) == (g / sum g) x (g / sum g)
+  }
+  // naturalness of the (unscaled) LDR image first (TMQI.py:128)
+  int rc = uncl_tmqi_naturalness(ldr, 1, H, W, H, W, ldr_scale, out + 2, nullptr, stream);
+  if (rc != UNCL_OK) return rc;
+  const int bm = nb(px, PB);
+  hipLaunchKernelGGL(mm_kernel, dim3(bm), dim3(256), 0, st, hdr, px, partial);
+  hipLaunchKernelGGL(mm_final_kernel, dim3(1), dim3(64), 0, st, partial, bm, mm);
+  hipLaunchKernelGGL(prep_kernel, dim3(nb(px, 4096)), dim3(256), 0, st, hdr, ldr, (double)ldr_scale, mm, a0, b0, px);
+  double *ca = a0, *cb = b0, *na = a1, *nb_ = b1;
+  int h = H, w = W;
+  double f = 32.0;
+  for (int l = 0; l < LEVELS; ++l) {
+    f *= 0.5;
+    const int wo = w - (GW - 1), ho = h - (GW - 1);
+    if (wo <= 0 || ho <= 0) return UNCL_ERR_ARG;
+    const double csf = 100.0 * 2.6 * (0.0192 + 0.114 * f) * exp(-pow(0.114 * f, 1.1));
+    const double u = 128.0 / (1.4 * csf), sig = u / 3.0;
+    hipLaunchKernelGGL(rowpass_kernel, dim3(nb((size_t)h * wo, 4096)), dim3(256), 0, st, ca, cb, h, w, rp, gw);
+    const int bp = nb((size_t)ho * wo, PB);
+    hipLaunchKernelGGL(colpass_smap_kernel, dim3(bp), dim3(256), 0, st, rp, h, wo, u, sig, partial, gw);
+    hipLaunchKernelGGL(level_final_kernel, dim3(1), dim3(64), 0, st, partial, bp, (double)ho * (double)wo, out + 3 + l);
+    if (l + 1 < LEVELS) {
+      const int h2 = h / 2, w2 = w / 2;   // ceil((h-1)/2)
+      hipLaunchKernelGGL(down_kernel, dim3(nb((size_t)h2 * w2, 4096)), dim3(256), 0, st, ca, h, w, na, h2, w2);
+      hipLaunchKernelGGL(down_kernel, dim3(nb((size_t)h2 * w2, 4096)), dim3(256), 0, st, cb, h, w, nb_, h2, w2);
+      double* t;
+      t = ca; ca = na; na = t;
+      t = cb; cb = nb_; nb_ = t;
+      h = h2; w = w2;
+    }
+  }
+  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, out);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
