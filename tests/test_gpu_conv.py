@@ -204,3 +204,24 @@ def test_bad_arguments_are_refused():
     assert _hip.lib().uncl_conv_igemm(C.byref(d), None) == -1
     d.dtype, d.ksize, d.Cin, d.Cout = _hip.BF16, 3, 24, 32     # Cin not a multiple of the 32-channel K-chunk
     assert _hip.lib().uncl_conv_igemm(C.byref(d), None) == -1
+
+
+@pytest.mark.parametrize("code,h,w", [(_hip.F32, 37, 45), (BF, 37, 45), (BF, 256, 256), (BF, 10, 70)])
+def test_first_layer_one_channel_conv(code, h, w):
+    """inc.conv.conv (Cin = 1): fp32 VALU kernel is the parity path; the bf16 path runs on the matrix cores with the fp32
+    input split into a bf16 head + tail, so only the weights and the stored result are bf16-rounded."""
+    n = 3
+    x = rnd(n, 1, h, w, seed=71).abs()
+    wt, b = rnd(32, 1, 3, 3, seed=72, scale=0.3), rnd(32, seed=73)
+    out = torch.zeros(n, h - 2, w - 2, 32, dtype=_hip.torch_dtype(code), device="cuda")
+    xd, wd, bd = x.reshape(n, h, w).cuda().contiguous(), wt.cuda().contiguous(), b.cuda()
+    _hip.check(_hip.lib().uncl_conv_in_c1(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), code, n, h, w, 32,
+                                          _hip.ACT_RELU, _hip.stream_ptr()), "uncl_conv_in_c1")
+    torch.cuda.synchronize()
+    if code == _hip.F32:
+        assert rel_l2(from_nhwc(out), F.relu(F.conv2d(x, wt, b))) < 1e-6
+    else:
+        ref = F.relu(F.conv2d(x, q(wt, BF), b))                     # bf16 weights, fp32-class input
+        assert rel_l2(from_nhwc(out), ref) < 3e-3                   # one bf16 rounding of the stored activations
+        # the input is NOT rounded to bf16: against a reference that does round it the error is visibly larger
+        assert rel_l2(from_nhwc(out), ref) < 0.7 * rel_l2(F.relu(F.conv2d(q(x, BF), q(wt, BF), b)), ref) + 3e-3

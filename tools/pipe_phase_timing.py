@@ -18,14 +18,14 @@ PHASES = ["cursor+prefetch issue", "MFMA phase", "barrier(before epilogue)", "ep
           "global stores issue", "end-of-step barrier", "vmcnt(0) wait", "LDS staging writes", "barrier(after staging)"]
 
 
-def build():
+def build(extra=()):
     out = os.path.join(ROOT, "tools", "_timing")
     os.makedirs(out, exist_ok=True)
-    lib = os.path.join(out, "libuncltmo_hip_timing.so")
+    lib = os.path.join(out, "libuncltmo_hip_timing%s.so" % ("_fi" if extra else ""))
     srcs = sorted(glob.glob(os.path.join(ROOT, "uncltmo_amd", "csrc", "*.hip")))
     if os.path.exists(lib) and all(os.path.getmtime(lib) > os.path.getmtime(s) for s in srcs):
         return lib
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DUNCL_PIPE_TIMING",
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-DUNCL_PIPE_TIMING", *extra,
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "uncltmo_amd", "csrc"), "-o", lib] + srcs
     subprocess.check_call(cmd)
     return lib
@@ -37,9 +37,13 @@ def main():
     ap.add_argument("--layer", default="up3")
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--force-interior", action="store_true",
+                    help="timing experiment: treat every tile as interior (border values are wrong, time is what an all-"
+                         "interior layout would cost); inputs are placed in the middle of a larger allocation")
     args = ap.parse_args()
-    lib_path = build()
+    lib_path = build(("-DUNCL_FORCE_INTERIOR",) if args.force_interior else ())
     if args.build_only:
+        build(("-DUNCL_FORCE_INTERIOR",))
         return
     import torch
     from uncltmo_amd import _hip
@@ -50,12 +54,17 @@ def main():
     bf = torch.bfloat16
     n = args.n
     g = torch.Generator(device="cuda").manual_seed(1)
+    keep = []
 
     def rnd(*shape, scale=1.0):
-        return (torch.rand(*shape, device="cuda", generator=g) * scale).to(bf)
+        n_el = 1
+        for d_ in shape:
+            n_el *= d_
+        big = (torch.rand(n_el + (1 << 22), device="cuda", generator=g) * scale).to(bf)   # 4 MiB of slack on either side
+        keep.append(big)
+        return big[1 << 21:(1 << 21) + n_el].reshape(*shape)
 
     d = _hip.ConvDesc()
-    keep = []
     if args.layer == "up3":      # concat-ssr transposed 3x3, 128 -> 32 at 252^2 -> 254^2
         h, c, cin, cout, pad, mode = 252, 32, 128, 32, 2, _hip.SRC_CONCAT_SSR
         x1 = rnd(n, h, h, c); keep.append(x1)

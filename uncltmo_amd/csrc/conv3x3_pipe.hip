@@ -210,7 +210,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       }
       xvalid = valid;
     } else {
+#ifdef UNCL_FORCE_INTERIOR  // timing experiment only (tools/pipe_phase_timing.py --force-interior): wrong borders
+      const bool interior = true;
+#else
       const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
+#endif
       if (interior && !PREV) {
         // the whole halo tile is inside the image: one scalar base, a constant stride between slots
         const bf16_t* base = xsrc + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;

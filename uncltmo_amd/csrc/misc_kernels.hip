@@ -101,6 +101,93 @@ __global__ __launch_bounds__(256) void conv_in_c1_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16 path of the first layer on the matrix cores.  K = 9 taps is far too short for an MFMA GEMM to matter as arithmetic,
+// but the VALU form needs 288 multiply-adds per pixel (the kernel above is instruction-bound at ~2.6 TB/s of stores).  Here
+// a 32-pixel x 32-channel block is two v_mfma_f32_32x32x16_bf16: the fp32 input taps are split into a bf16 head and a bf16
+// tail (x = hi + lo to 2^-17), so the input keeps fp32-class precision while the weights are bf16 like every other layer's.
+//   A (weights)  lane (cout = lane & 31, half = lane >> 5): k = 8*half + j  ->  tap k (zero for k >= 9)
+//   B (patch)    lane (pixel = lane & 31, half):            k = 8*half + j  ->  input tap k of that pixel
+// The result tile is transposed through a wave-private LDS scratch so that stores are 16 bytes per lane, 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------------------
+constexpr int CM_TY = 8, CM_TX = 64;
+
+__global__ __launch_bounds__(256) void conv_in_c1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, bf16_t* __restrict__ out, int H,
+                                                              int W, float slope, int tiles_x) {
+  constexpr int PW = CM_TX + 2;
+  __shared__ float sP[(CM_TY + 2) * PW];
+  __shared__ __attribute__((aligned(16))) char sT[4][2048];   // per wave: [32 px][64 B], 16-byte slots XOR (px >> 1) & 3
+  const int n = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * CM_TY, x0 = tx * CM_TX;
+  const int Ho = H - 2, Wo = W - 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const float* xn = x + (size_t)n * H * W;
+  for (int i = tid; i < (CM_TY + 2) * PW; i += 256) {
+    const int r = i / PW, c = i - r * PW;
+    sP[i] = xn[(size_t)min(y0 + r, H - 1) * W + min(x0 + c, W - 1)];
+  }
+  // weight fragment and this lane's biases (channels 8q + 4*lh + r)
+  bf16x8 A;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * lh + j;
+    A[j] = (bf16_t)(k < 9 ? w[lr * 9 + k] : 0.f);
+  }
+  float bv[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[4 * q + r] = b ? b[8 * q + 4 * lh + r] : 0.f;
+  f32x16 zero16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+  __syncthreads();
+  char* st = sT[wave];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int r = wave * 2 + rr, px = cc * 32 + lr;
+      bf16x8 Bh, Bl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 8 * lh + j;                       // tap of this k slot (compile-time per half after unrolling)
+        float v = 0.f;
+        if (lh == 0) v = sP[(r + j / 3) * PW + px + j % 3];
+        else if (j == 0) v = sP[(r + 2) * PW + px + 2];
+        (void)t;
+        const bf16_t hi = (bf16_t)v;
+        Bh[j] = hi;
+        Bl[j] = (bf16_t)(v - (float)hi);
+      }
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bh, zero16, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bl, acc, 0, 0, 0);
+      // bias + activation, [pixel][channel] image in the wave's scratch
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[4 * q + e] + bv[4 * q + e];
+          o[e] = (bf16_t)(fmaxf(t, 0.f) + slope * fminf(t, 0.f));
+        }
+        *reinterpret_cast<bf16x4*>(st + lr * 64 + ((q ^ ((lr >> 1) & 3)) << 4) + (lh << 3)) = o;
+      }
+      // read back 16 bytes per lane in memory order and store (two passes of 16 pixels x 4 slots)
+      const int oy = y0 + r;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int p = ps * 16 + (lane >> 2), sl = lane & 3;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(st + p * 64 + ((sl ^ ((p >> 1) & 3)) << 4));
+        const int ox = x0 + cc * 32 + p;
+        if (oy < Ho && ox < Wo) *reinterpret_cast<bf16x8*>(out + (((size_t)n * Ho + oy) * Wo + ox) * 32 + sl * 8) = v;
+      }
+    }
+  }
+}
+
 extern "C" int uncl_conv_in_c1(const float* x, const float* w, const float* b, void* out, int dtype, int N, int H,
                                int W, int Cout, int act, void* stream) {
   if (!x || !w || !out || N <= 0 || H < 3 || W < 3 || Cout % 8 != 0) return UNCL_ERR_ARG;
@@ -108,6 +195,13 @@ extern "C" int uncl_conv_in_c1(const float* x, const float* w, const float* b, v
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   const size_t lds = (size_t)Cout * 10 * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == UNCL_BF16 && Cout == 32 && (act == UNCL_ACT_RELU || act == UNCL_ACT_LRELU || act == UNCL_ACT_NONE)) {
+    const int tx = (W - 2 + CM_TX - 1) / CM_TX, ty = (H - 2 + CM_TY - 1) / CM_TY;
+    const float slope = act == UNCL_ACT_RELU ? 0.f : (act == UNCL_ACT_LRELU ? 0.2f : 1.f);
+    hipLaunchKernelGGL(conv_in_c1_mfma_kernel, dim3(tx * ty, N), dim3(256), 0, s, x, w, b, (bf16_t*)out, H, W, slope, tx);
+    UNCL_CHECK_LAUNCH();
+    return UNCL_OK;
+  }
   if (dtype == UNCL_BF16)
     hipLaunchKernelGGL(conv_in_c1_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, x, w, b, (bf16_t*)out, N, H, W, Cout,
                        act);
