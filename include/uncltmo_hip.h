@@ -44,6 +44,9 @@ extern "C" {
 #define UNCL_SRC_CONCAT_SSR 2 /* x = cat[src0, up(src1), src0^2, sqrt(src0+1e-8)] (unet_parts.py:319-322)
                                  src1 is replicate-padded to src0's size   (unet_parts.py:292-298)        */
 #define UNCL_SRC_CONCAT2 3    /* x = cat[src0, src1]  ("original_unet" operator, unet_parts.py:311-312)    */
+#define UNCL_SRC_IMAGE1 4     /* uncl_conv3x3_pipe only: x = act(conv3x3_valid(src0; pre_w, pre_b)), the 32-channel first
+                                 layer (unet_parts.py:19) recomputed from the fp32 one-channel image src0 (N, H+2, W+2)
+                                 inside the loader, so inc.conv.conv's output never goes to HBM (inference)         */
 
 /* what blockIdx.z enumerates besides Cout tiles */
 #define UNCL_Z_NONE 0
@@ -91,6 +94,8 @@ typedef struct uncl_conv_desc {
   int out1_act;
   float* out1;          /* [N, Hout, Wout] fp32                                              */
   int skip_main_store;  /* 1: do not write `out` (inference does not need up_x)              */
+  const float* pre_w;   /* UNCL_SRC_IMAGE1: first-layer weights (32,1,3,3) fp32, reference layout */
+  const float* pre_b;   /* UNCL_SRC_IMAGE1: first-layer bias (32) fp32 or NULL                    */
 } uncl_conv_desc;
 
 int uncl_conv_igemm(const uncl_conv_desc* d, void* stream);

@@ -1,5 +1,7 @@
 """GPU parity of the implicit-GEMM convolution kernel (every loader / epilogue mode) against plain torch CPU
 fp32 convolutions of the same op, through the C ABI."""
+import ctypes as C
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -225,3 +227,30 @@ def test_first_layer_one_channel_conv(code, h, w):
         assert rel_l2(from_nhwc(out), ref) < 3e-3                   # one bf16 rounding of the stored activations
         # the input is NOT rounded to bf16: against a reference that does round it the error is visibly larger
         assert rel_l2(from_nhwc(out), ref) < 0.7 * rel_l2(F.relu(F.conv2d(q(x, BF), q(wt, BF), b)), ref) + 3e-3
+
+
+@pytest.mark.parametrize("h,w", [(40, 70), (256, 256)])
+def test_pipe_first_layer_recomputed_in_the_loader(h, w):
+    """UNCL_SRC_IMAGE1: inc.conv.conv (1 -> 32) is rebuilt from the fp32 image inside inc.conv.conv1's loader; the result
+    must equal running the two layers one after the other (with the first layer's output rounded to bf16 in between)."""
+    n = 2
+    x = rnd(n, 1, h, w, seed=81).abs()
+    w0, b0 = rnd(32, 1, 3, 3, seed=82, scale=0.3), rnd(32, seed=83)
+    w1, b1 = q(rnd(32, 32, 3, 3, seed=84, scale=0.06), BF), rnd(32, seed=85)
+    mid = q(F.relu(F.conv2d(x, q(w0, BF), b0)), BF)
+    ref = F.relu(F.conv2d(mid, w1, b1))
+    ho, wo = h - 4, w - 4
+    out = torch.zeros(n, ho, wo, 32, dtype=torch.bfloat16, device="cuda")
+    pooled = torch.zeros(n, ho // 2, wo // 2, 32, dtype=torch.bfloat16, device="cuda")
+    run_pipe(pool_out=pooled, dtype=BF, ksize=3, pad=0, src_mode=_hip.SRC_IMAGE1, N=n, H=h - 2, W=w - 2, Cin=32, Cout=32,
+             src0=x.reshape(n, h, w).cuda().contiguous(), src0_H=h, src0_W=w, src0_C=1, pre_w=w0.cuda().contiguous(),
+             pre_b=b0.cuda(), weight=pack_weight(w1, BF), bias=b1.cuda(), act=_hip.ACT_RELU, out=out, out_H=ho, out_W=wo,
+             out_C=32)
+    assert rel_l2(from_nhwc(out), ref) < TOL[BF]
+    assert rel_l2(from_nhwc(pooled), F.max_pool2d(q(ref, BF), 2)) < TOL[BF]
+    # wrong shapes for this mode are refused
+    d = _hip.ConvDesc()
+    for k_, v in dict(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_IMAGE1, N=n, H=h - 2, W=w - 2, Cin=32, Cout=32,
+                      src0=out.data_ptr(), src0_H=h, src0_W=w, src0_C=1, weight=out.data_ptr(), out=out.data_ptr()).items():
+        setattr(d, k_, v)
+    assert _hip.lib().uncl_conv3x3_pipe(C.byref(d), None, _hip.stream_ptr()) != 0

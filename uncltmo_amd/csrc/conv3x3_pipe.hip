@@ -43,6 +43,10 @@ struct PipeArgs {
   int pH, pW;
   int tiles_x, tiles_y, n_ct, total_tiles, tiles_per_wg, nk;
   int out1_act, skip_main;
+  const float* img;     // MODE 3: fp32 one-channel image (N, imgH, imgW); x = act(conv3x3_valid(img; pre_w, pre_b))
+  const float* pre_w;   // (32,1,3,3)
+  const float* pre_b;   // (32) or NULL
+  int imgH, imgW;
 };
 
 __device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -82,7 +86,7 @@ __device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off)
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1]
+// MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1], 3 first layer recomputed from the image
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
 __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void conv3x3_pipe_kernel(const PipeArgs a) {
   using E = Elem<bf16_t>;
@@ -115,6 +119,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   char* sX = smem;
   char* sW = smem + NPIX * RP;
   char* sB = sW + WROWS * RP;  // CT fp32 biases of the current cout tile (outside the epilogue image)
+  // MODE 3: the fp32 image patch under the halo tile ((HH+2) x (HW+2)) and the first layer's 32 biases
+  constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;
+  float* sP = reinterpret_cast<float*>(sB + CT * 4);
+  float* sPB = sP + PN3;
   char* sO = smem;
 
   const int tid = threadIdx.x;
@@ -154,6 +162,19 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 
   vec xr[XV];
   vec wr[WVN];
+  constexpr int IRN = (PN3 + NTHR - 1) / NTHR;   // MODE 3: image-patch values prefetched per thread
+  float ir[IRN];
+  vec preA;                                       // MODE 3: first-layer weight fragment (cout = lr, k = 8*lh + j -> tap)
+  if (MODE == 3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lh + j;
+      preA[j] = (bf16_t)(k < 9 ? a.pre_w[lr * 9 + k] : 0.f);
+    }
+    if (tid < 32) sPB[tid] = a.pre_b ? a.pre_b[tid] : 0.f;
+#pragma unroll
+    for (int k = 0; k < IRN; ++k) ir[k] = 0.f;
+  }
   f32x4 br = {0.f, 0.f, 0.f, 0.f};
   unsigned xvalid = 0;
   int g_pending = 0;
@@ -183,7 +204,18 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     // then it needs no replicate padding and takes the same scalar-base / masked paths as the skip itself
     const bool same_ext = a.s1H == a.s0H && a.s1W == a.s0W;
     const bf16_t* xsrc = (MODE != 0 && g == 1) ? a.src1 : a.src0;
-    if (reuse) {
+    if (MODE == 3) {
+      // the image patch under the halo tile: first-layer pixel (y, x) reads image rows y..y+2, columns x..x+2.  Rows and
+      // columns past the image only feed outputs that are never stored (valid convolution), so they are clamped.
+      const float* ib = a.img + (size_t)n * a.imgH * a.imgW;
+#pragma unroll
+      for (int k = 0; k < IRN; ++k) {
+        const int idx = min(tid + k * NTHR, PN3 - 1);
+        const int pr = idx / PW3, pc = idx - pr * PW3;
+        ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pc, a.imgW - 1)];
+      }
+      xvalid = 0xffffffffu;
+    } else if (reuse) {
       // xr / xvalid still hold this tile's x2 slice
     } else if (MODE != 0 && g == 1 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
@@ -272,6 +304,47 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 
   auto write_lds = [&](bool with_w) {
     const bool all_ok = xvalid == 0xffffffffu;  // wave-uniform in practice (interior tiles)
+    if (MODE == 3) {
+      // stage the image patch, then build the 32-channel halo tile with the matrix cores: per 32 halo pixels two
+      // v_mfma_f32_32x32x16_bf16 over the nine taps of the bf16 head and of the bf16 tail of the fp32 input (x = hi + lo
+      // to 2^-17); the D layout (lane = pixel, 4 consecutive channels per register quad) is already the staging layout.
+#pragma unroll
+      for (int k = 0; k < IRN; ++k)
+        if (tid + k * NTHR < PN3) sP[tid + k * NTHR] = ir[k];
+      __syncthreads();
+      f32x16 z16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z16[i] = 0.f;
+      constexpr int MT3 = (NPIX + 31) / 32;
+      for (int mt = wave; mt < MT3; mt += WAVES) {
+        const int p = mt * 32 + lr;
+        const int pcl = min(p, NPIX - 1);
+        const int py = pcl / HW, px = pcl - py * HW;
+        vec Bh, Bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = 0.f;
+          if (lh == 0) v = sP[(py + j / 3) * PW3 + px + j % 3];
+          else if (j == 0) v = sP[(py + 2) * PW3 + px + 2];
+          const bf16_t hi = (bf16_t)v;
+          Bh[j] = hi;
+          Bl[j] = (bf16_t)(v - (float)hi);
+        }
+        f32x16 c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bh, z16, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bl, c3, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 pb = *reinterpret_cast<const f32x4*>(sPB + 8 * q + 4 * lh);
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = c3[4 * q + e] + pb[e];
+            o[e] = (bf16_t)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+          }
+          if (p < NPIX) *reinterpret_cast<bf16x4*>(sX + p * RP + (q << 4) + (lh << 3)) = o;
+        }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j <= RS; ++j) {
       if (j == RS && !e_on) continue;
@@ -308,6 +381,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 #pragma unroll
     for (int j = 0; j < WVN; ++j) asm volatile("" ::"v"(wr[j]));
     asm volatile("" ::"v"(br));
+    if (MODE == 3) {
+#pragma unroll
+      for (int k = 0; k < IRN; ++k) asm volatile("" ::"v"(ir[k]));
+    }
   };
 
   // advance the (tile, kc) cursor by one step; returns false past the end of this workgroup's range
@@ -562,7 +639,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
 int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
-  constexpr size_t lds = (size_t)(TH + 2) * 34 * 80 + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4;
+  constexpr size_t lds = (size_t)(TH + 2) * 34 * 80 + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
+                         (MODE == 3 ? (size_t)((TH + 4) * 36 + 32) * 4 : 0);
   auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV>;
   static bool attr_done = false;
   static int max_blocks = 0;
@@ -592,6 +670,10 @@ int launch_pipe(PipeArgs& a, hipStream_t s) {
 
 template <int NT, int MPW>
 int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
+  if (mode == UNCL_SRC_IMAGE1) {
+    if constexpr (NT == 1 && MPW == 4) return launch_pipe<1, 4, 4, 3, false>(a, s);
+    return UNCL_ERR_ARG;
+  }
   if (mode == UNCL_SRC_PLAIN) return prev ? launch_pipe<NT, MPW, 4, 0, true>(a, s) : launch_pipe<NT, MPW, 4, 0, false>(a, s);
   if (mode == UNCL_SRC_CONCAT_SSR) return launch_pipe<NT, MPW, 4, 1, false>(a, s);
   return launch_pipe<NT, MPW, 4, 2, false>(a, s);
@@ -605,13 +687,19 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
                              void* stream) {
   if (d == nullptr || d->dtype != UNCL_BF16 || d->ksize != 3) return UNCL_ERR_ARG;
   if (d->pad != 0 && d->pad != 2) return UNCL_ERR_ARG;
-  if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_CONCAT2) return UNCL_ERR_ARG;
+  if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_IMAGE1) return UNCL_ERR_ARG;
+  if (d->src_mode == UNCL_SRC_IMAGE1) {
+    // x = act(conv3x3_valid(image)): 32 channels over (H, W) = image extent - 2; this layer itself must be 32 -> 32, valid
+    if (d->Cin != 32 || d->Cout != 32 || d->pad != 0 || d->pre_w == nullptr || d->src0_C != 1 || d->src0_H != d->H + 2 ||
+        d->src0_W != d->W + 2 || d->prev0 != nullptr || d->res != nullptr || mask != nullptr)
+      return UNCL_ERR_ARG;
+  }
   if (d->Cin <= 0 || d->Cin % 32 != 0 || d->Cout <= 0 || d->Cout % 32 != 0) return UNCL_ERR_ARG;
   if (d->z_mode != UNCL_Z_NONE || d->scale_n != nullptr) return UNCL_ERR_ARG;
   if (d->act != UNCL_ACT_NONE && d->act != UNCL_ACT_RELU && d->act != UNCL_ACT_LRELU) return UNCL_ERR_ARG;
   if (d->src0 == nullptr || d->weight == nullptr) return UNCL_ERR_ARG;
   if (d->out == nullptr && !(d->skip_main_store && d->out1 != nullptr)) return UNCL_ERR_ARG;
-  if (d->src_mode != UNCL_SRC_PLAIN) {
+  if (d->src_mode == UNCL_SRC_CONCAT_SSR || d->src_mode == UNCL_SRC_CONCAT2) {
     if (d->src1 == nullptr || d->src0_C != d->src1_C || d->src0_C % 32 != 0 || d->prev0 != nullptr) return UNCL_ERR_ARG;
     const int groups = d->src_mode == UNCL_SRC_CONCAT_SSR ? 4 : 2;
     if (d->Cin != groups * d->src0_C) return UNCL_ERR_ARG;
@@ -638,6 +726,11 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   if (d->out != nullptr && (d->out_H != a.Hout || d->out_W != a.Wout)) return UNCL_ERR_ARG;
   a.pH = a.Hout / 2; a.pW = a.Wout / 2;
   a.out1_act = d->out1_act; a.skip_main = d->skip_main_store;
+  a.img = nullptr; a.pre_w = nullptr; a.pre_b = nullptr; a.imgH = a.imgW = 0;
+  if (d->src_mode == UNCL_SRC_IMAGE1) {
+    a.img = (const float*)d->src0; a.pre_w = d->pre_w; a.pre_b = d->pre_b; a.imgH = d->src0_H; a.imgW = d->src0_W;
+    a.s0H = d->H; a.s0W = d->W; a.s0C = 32;
+  }
   a.nk = d->Cin / 32;
   const bool prev = d->prev0 != nullptr && d->prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

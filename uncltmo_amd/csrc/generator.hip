@@ -101,6 +101,7 @@ struct Ctx {
   Layout L;
   int n;             // tiles in this chunk
   int save_preact;   // keep pre-GELU values (training)
+  int fuse_in;       // inference: inc.conv.conv is recomputed inside inc.conv.conv1's loader (its output never goes to HBM)
   hipStream_t s;
   void* ptr(int b) const { return ws + L.off[b]; }
   const void* pptr(int b) const { return prev ? prev + L.off[b] : nullptr; }
@@ -222,8 +223,18 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   int rc;
 #define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
   // encoder
-  RUN(uncl_conv_in_c1(x, w->inc0_w, w->inc0_b, c.ptr(B_INC0), w->dtype, c.n, S_IN, S_IN, 32, w->act, c.s));
-  RUN(conv3(c, W_INC1, B_INC0, B_X0, 32, 32, 0, false, 0, -1, B_X0P));
+  if (c.fuse_in) {
+    uncl_conv_desc d = base_desc(c, W_INC1, 3, 0, 32, 32, w->act);
+    d.src_mode = UNCL_SRC_IMAGE1;
+    d.src0 = x; d.src0_H = S_IN; d.src0_W = S_IN; d.src0_C = 1;
+    d.pre_w = w->inc0_w; d.pre_b = w->inc0_b;
+    d.H = S_INC0; d.W = S_INC0;
+    set_out(d, c.ptr(B_X0), B_X0);
+    RUN(run3(c, W_INC1, d, c.ptr(B_X0P)));
+  } else {
+    RUN(uncl_conv_in_c1(x, w->inc0_w, w->inc0_b, c.ptr(B_INC0), w->dtype, c.n, S_IN, S_IN, 32, w->act, c.s));
+    RUN(conv3(c, W_INC1, B_INC0, B_X0, 32, 32, 0, false, 0, -1, B_X0P));
+  }
   RUN(conv3(c, W_D0A, B_X0, B_D0A, 32, 64, 0, true, 1, B_X0P));
   RUN(conv3(c, W_D0B, B_D0A, B_X1, 64, 64, 0, false, 0, -1, B_X1P));
   RUN(conv3(c, W_D1A, B_X1, B_D1A, 64, 128, 0, true, 2, B_X1P));
@@ -550,6 +561,8 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.L = L;
     c.n = (r->N - n0 < chunk) ? r->N - n0 : chunk;
     c.save_preact = r->save_preact;
+    // the backward pass reads inc.conv.conv's output (ReLU mask, weight gradient), the video path hands its channels on
+    c.fuse_in = w->dtype == UNCL_BF16 && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr;
     c.s = reinterpret_cast<hipStream_t>(stream);
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
