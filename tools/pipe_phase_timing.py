@@ -71,6 +71,8 @@ def main():
         d.src1, d.src1_H, d.src1_W, d.src1_C = x1.data_ptr(), h, h, c
     elif args.layer == "inc1":   # plain valid 3x3, 32 -> 32 at 254^2 -> 252^2 (static weights)
         h, c, cin, cout, pad, mode = 254, 32, 32, 32, 0, _hip.SRC_PLAIN
+    elif args.layer == "inc1f":  # the same layer with inc.conv.conv recomputed from the fp32 image in the loader
+        h, c, cin, cout, pad, mode = 254, 32, 32, 32, 0, _hip.SRC_IMAGE1
     elif args.layer == "up2":    # concat-ssr transposed 3x3, 256 -> 64 at 122^2 -> 124^2 (NT=2)
         h, c, cin, cout, pad, mode = 122, 64, 256, 64, 2, _hip.SRC_CONCAT_SSR
         x1 = rnd(n, h, h, c); keep.append(x1)
@@ -79,12 +81,19 @@ def main():
         h, c, cin, cout, pad, mode = 126, 32, 32, 64, 0, _hip.SRC_PLAIN
     else:                        # plain valid 3x3, 128 -> 128 at 28^2
         h, c, cin, cout, pad, mode = 28, 128, 128, 128, 0, _hip.SRC_PLAIN
-    x = rnd(n, h, h, c); keep.append(x)
+    if mode == _hip.SRC_IMAGE1:
+        x = torch.rand(n, h + 2, h + 2, device="cuda", generator=g); keep.append(x)
+        pw = (torch.rand(32, 9, device="cuda", generator=g) - 0.5); pb = torch.zeros(32, device="cuda"); keep += [pw, pb]
+        d.pre_w, d.pre_b = pw.data_ptr(), pb.data_ptr()
+    else:
+        x = rnd(n, h, h, c); keep.append(x)
     w = rnd(9, cout, cin, scale=0.05); b = torch.zeros(cout, device="cuda")
     ho = h + 2 * pad - 2
     out = torch.empty(n, ho, ho, cout, dtype=bf, device="cuda")
     d.dtype, d.ksize, d.pad, d.src_mode, d.N, d.H, d.W, d.Cin, d.Cout = _hip.BF16, 3, pad, mode, n, h, h, cin, cout
     d.src0, d.src0_H, d.src0_W, d.src0_C = x.data_ptr(), h, h, c
+    if mode == _hip.SRC_IMAGE1:
+        d.src0_H, d.src0_W, d.src0_C = h + 2, h + 2, 1
     d.weight, d.bias, d.act = w.data_ptr(), b.data_ptr(), _hip.ACT_RELU
     d.out, d.out_H, d.out_W, d.out_C = out.data_ptr(), ho, ho, cout
     buf = (C.c_ulonglong * 16)()

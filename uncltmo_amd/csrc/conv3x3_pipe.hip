@@ -119,10 +119,9 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   char* sX = smem;
   char* sW = smem + NPIX * RP;
   char* sB = sW + WROWS * RP;  // CT fp32 biases of the current cout tile (outside the epilogue image)
-  // MODE 3: the fp32 image patch under the halo tile ((HH+2) x (HW+2)) and the first layer's 32 biases
+  // MODE 3: the fp32 image patch under the halo tile ((HH+2) x (HW+2))
   constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;
   float* sP = reinterpret_cast<float*>(sB + CT * 4);
-  float* sPB = sP + PN3;
   char* sO = smem;
 
   const int tid = threadIdx.x;
@@ -165,13 +164,15 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   constexpr int IRN = (PN3 + NTHR - 1) / NTHR;   // MODE 3: image-patch values prefetched per thread
   float ir[IRN];
   vec preA;                                       // MODE 3: first-layer weight fragment (cout = lr, k = 8*lh + j -> tap)
+  float preB[16];                                 // MODE 3: first-layer biases of this lane's channels 8q + 4*lh + r
   if (MODE == 3) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * lh + j;
       preA[j] = (bf16_t)(k < 9 ? a.pre_w[lr * 9 + k] : 0.f);
     }
-    if (tid < 32) sPB[tid] = a.pre_b ? a.pre_b[tid] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) preB[i] = a.pre_b ? a.pre_b[8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f;
 #pragma unroll
     for (int k = 0; k < IRN; ++k) ir[k] = 0.f;
   }
@@ -315,33 +316,41 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       f32x16 z16;
 #pragma unroll
       for (int i = 0; i < 16; ++i) z16[i] = 0.f;
-      constexpr int MT3 = (NPIX + 31) / 32;
-      for (int mt = wave; mt < MT3; mt += WAVES) {
-        const int p = mt * 32 + lr;
-        const int pcl = min(p, NPIX - 1);
-        const int py = pcl / HW, px = pcl - py * HW;
-        vec Bh, Bl;
+      constexpr int MT3 = (NPIX + 31) / 32, IT3 = (MT3 + WAVES - 1) / WAVES;
+      static_assert(HW == 34 && NPIX < 2048, "the reciprocal multiply below divides by 34");
+      // every lane issues its eight tap reads unconditionally (the upper half-wave only owns tap 8: its other slots read
+      // a valid address and are zeroed), the M-tile loop is unrolled so that the reads of one tile overlap the MFMAs and
+      // LDS writes of the previous one
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = 0.f;
-          if (lh == 0) v = sP[(py + j / 3) * PW3 + px + j % 3];
-          else if (j == 0) v = sP[(py + 2) * PW3 + px + 2];
-          const bf16_t hi = (bf16_t)v;
-          Bh[j] = hi;
-          Bl[j] = (bf16_t)(v - (float)hi);
-        }
-        f32x16 c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bh, z16, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bl, c3, 0, 0, 0);
+      for (int i = 0; i < IT3; ++i) {
+        const int mt = wave + WAVES * i;           // wave-uniform
+        if (mt < MT3) {
+          const int p = mt * 32 + lr;
+          const int pcl = min(p, NPIX - 1);
+          const int py = (pcl * 241) >> 13, px = pcl - py * HW;   // / 34 for pcl < 2048 (HW == 34)
+          const float* pp = sP + py * PW3 + px;
+          vec Bh, Bl;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 pb = *reinterpret_cast<const f32x4*>(sPB + 8 * q + 4 * lh);
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = c3[4 * q + e] + pb[e];
-            o[e] = (bf16_t)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+          for (int j = 0; j < 8; ++j) {
+            const int o0 = (j / 3) * PW3 + j % 3;  // tap j (lower half-wave)
+            float v = pp[lh ? 2 * PW3 + 2 : o0];   // upper half-wave: tap 8 in slot 0
+            if (j > 0) v = lh ? 0.f : v;
+            const bf16_t hi = (bf16_t)v;
+            Bh[j] = hi;
+            Bl[j] = (bf16_t)(v - (float)hi);
           }
-          if (p < NPIX) *reinterpret_cast<bf16x4*>(sX + p * RP + (q << 4) + (lh << 3)) = o;
+          f32x16 c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bh, z16, 0, 0, 0);
+          c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bl, c3, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = c3[4 * q + e] + preB[4 * q + e];
+              o[e] = (bf16_t)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+            }
+            if (p < NPIX) *reinterpret_cast<bf16x4*>(sX + p * RP + (q << 4) + (lh << 3)) = o;
+          }
         }
       }
     } else
