@@ -254,3 +254,19 @@ def test_pipe_first_layer_recomputed_in_the_loader(h, w):
                       src0=out.data_ptr(), src0_H=h, src0_W=w, src0_C=1, weight=out.data_ptr(), out=out.data_ptr()).items():
         setattr(d, k_, v)
     assert _hip.lib().uncl_conv3x3_pipe(C.byref(d), None, _hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n,act", [(64, 64, 26, 30, 2, "relu"), (128, 128, 28, 28, 3, "lrelu"), (16 * 5, 64, 9, 41, 1, "none"),
+                                                (256, 256, 10, 10, 4, "relu")])
+def test_dma_kernel_transposed_layers_zero_borders(cin, cout, h, w, n, act):
+    """Plain-source layers with Cout % 64 == 0 run on the LDS-DMA kernel (csrc/conv3x3_dma.hip): pad-2 (transposed) layers
+    read their zero border from the zero page, K walks in 16-channel steps (Cin = 80 is five of them)."""
+    x, wt, b = q(rnd(n, cin, h, w, seed=91), BF), q(rnd(cin, cout, 3, 3, seed=92, scale=0.05), BF), rnd(cout, seed=93)
+    y = F.conv_transpose2d(x, wt, b)
+    code = {"relu": _hip.ACT_RELU, "lrelu": _hip.ACT_LRELU, "none": _hip.ACT_NONE}[act]
+    ref = {"relu": F.relu(y), "lrelu": F.leaky_relu(y, 0.2), "none": y}[act]
+    out = torch.zeros(n, h + 2, w + 2, cout, dtype=torch.bfloat16, device="cuda")
+    run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout,
+             src0=to_nhwc(x, BF), src0_H=h, src0_W=w, src0_C=cin, weight=pack_weight(wt, BF, transposed=True, flip=True),
+             bias=b.cuda(), act=code, out=out, out_H=h + 2, out_W=w + 2, out_C=cout)
+    assert rel_l2(from_nhwc(out), ref) < TOL[BF]
