@@ -91,6 +91,4 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-// csrc/conv3x3_dma.hip: LDS-DMA variant of the 3x3 kernel for the layers in its scope; UNCL_ERR_ARG = not handled
-int conv3x3_dma_try(const uncl_conv_desc* d, void* pool_out, hipStream_t s);
 

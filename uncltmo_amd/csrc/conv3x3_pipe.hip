@@ -16,8 +16,6 @@
 //    and read back row-wise, so every global store instruction writes 1 KiB of contiguous NHWC bytes; the same
 //    image feeds the fused 2x2 max-pool output (unet_parts.py:212,233) and the fused 1-channel 1x1 + sigmoid
 //    (outconv, Unet_singleFrame.py:207-209).
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -692,29 +690,12 @@ int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
 
 }  // namespace
 
-// UNCL_DMA=1 sends the layers in its scope to the LDS-DMA kernel (same-box A/B of the two staging schemes; measured 4-10 %
-// slower than register staging on every such layer, so it is off by default)
-static bool dma_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("UNCL_DMA");
-    on = (e != nullptr && e[0] == '1') ? 1 : 0;
-  }
-  return on == 1;
-}
-
 // Same descriptor as uncl_conv_igemm; handles bf16 3x3 with src_mode PLAIN / CONCAT_SSR / CONCAT2.
 // `pool_out` (optional) receives maxpool2x2(out) as NHWC (N, Hout/2, Wout/2, Cout).
 static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void* mask, float mask_slope, int accumulate,
                              void* stream) {
   if (d == nullptr || d->dtype != UNCL_BF16 || d->ksize != 3) return UNCL_ERR_ARG;
   if (d->pad != 0 && d->pad != 2) return UNCL_ERR_ARG;
-  if (mask == nullptr && !accumulate && d->z_mode == UNCL_Z_NONE && d->scale_n == nullptr && d->weight != nullptr &&
-      d->src0 != nullptr && dma_enabled()) {
-    // forward layers inside the LDS-DMA kernel's scope (plain source, Cout % 64 == 0, no residual / tail) go there
-    const int rc = conv3x3_dma_try(d, pool_out, reinterpret_cast<hipStream_t>(stream));
-    if (rc != UNCL_ERR_ARG) return rc;
-  }
   if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_IMAGE1) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_IMAGE1) {
     // x = act(conv3x3_valid(image)): 32 channels over (H, W) = image extent - 2; this layer itself must be 32 -> 32, valid
