@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuncltmo_hip.so")
+# UNCL_HIP_LIB points measurement tools at another build of the same ABI (same-box A/B runs); the product uses the in-tree one
+LIB_PATH = os.environ.get("UNCL_HIP_LIB") or os.path.join(_HERE, "libuncltmo_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
