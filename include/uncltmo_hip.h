@@ -37,6 +37,8 @@ extern "C" {
 #define UNCL_ACT_LRELU 2 /* slope 0.2 */
 #define UNCL_ACT_GELU 3  /* exact erf */
 #define UNCL_ACT_SIGMOID 4
+#define UNCL_ACT_TANH 5
+#define UNCL_ACT_MSIG 6  /* 1 / (1 + exp(-3 x)): the reference's "msig" last layer (models/Blocks.py:85-91)  */
 
 /* input-side fusions of the implicit-GEMM convolution (what the loader synthesises while staging LDS) */
 #define UNCL_SRC_PLAIN 0      /* x = src0                                                                  */
@@ -204,7 +206,7 @@ typedef struct uncl_gen_weights {
   const float* outc_w;            /* (32) fp32                                              */
   const float* outc_b;            /* (1) fp32                                               */
   int act;                        /* UNCL_ACT_RELU or UNCL_ACT_LRELU (generator activation) */
-  int last_act;                   /* UNCL_ACT_SIGMOID / NONE                                */
+  int last_act;                   /* UNCL_ACT_SIGMOID / TANH / MSIG / NONE (Unet_singleFrame.py:207-212) */
 } uncl_gen_weights;
 
 typedef struct uncl_gen_run {

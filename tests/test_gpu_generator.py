@@ -171,3 +171,34 @@ def test_tiler_full_size_properties():
     aff = lambda p, **kw: (0.25 * p + 0.5, None)
     y2 = tiler.test_big_size_image2(x, aff, 0, 0, 0)
     assert (y2 - (0.25 * x + 0.5)).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("last_layer,activation", [("tanh", "relu"), ("msig", "relu"), ("none", "relu")])
+def test_generator_other_last_layers(last_layer, activation):
+    """The other heads the reference's constructor accepts with the published topology (Unet_singleFrame.py:207-212,
+    models/Blocks.py:85-91): fp32 parity forward, bf16 backward.  (activation='leakyrelu' is accepted too and covered at
+    the layer level; with the published skip operator it feeds negative values to sqrt(x + 1e-8) and both the reference
+    and this path produce NaN.)"""
+    from uncltmo_amd.generator import UNet
+    args = (1, 1, last_layer, 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", activation, 1, "replicate", 2, 0)
+    net = UNet(*args, compute_dtype="fp32")
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().eval()
+    x = synth.smooth_hdr_frames(2, salt="ll")
+    with torch.no_grad():
+        y, up = net(x.cuda())
+        y_ref, up_ref = OG.unet_image_forward(cpu_sd(net), x, last_layer=last_layer, activation=activation)
+    assert rel_l2(y.cpu(), y_ref) < 1e-4 and rel_l2(up.float().cpu(), up_ref) < 1e-4
+    # backward through the head (bf16 path): gradient of the 1x1 head's parameters against the oracle's autograd
+    netb = UNet(*args, compute_dtype="bf16")
+    synth.fill_state_dict(netb, "g0")
+    netb = netb.cuda().eval()
+    wy = 0.5 + synth.smooth_hdr_frames(2, salt="llw")
+    yb, _ = netb(x.cuda())
+    (yb * wy.cuda()).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(not k.endswith("relative_pos")) for k, v in netb.state_dict().items()}
+    yo, _ = OG.unet_image_forward(sd, x, last_layer=last_layer, activation=activation)
+    (yo * wy).sum().backward()
+    named = dict(netb.named_parameters())
+    for k in ("outc.conv.weight", "outc.conv.bias", "up_path.3.conv.conv1.weight", "inc.conv.conv.weight"):
+        assert rel_l2(named[k].grad.cpu(), sd[k].grad) < 6e-2, k

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNCL_HIP_LIB") or os.path.join(_HERE, "libuncltmo_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_TANH, ACT_MSIG = 0, 1, 2, 3, 4, 5, 6
 SRC_PLAIN, SRC_MAXPOOL2, SRC_CONCAT_SSR, SRC_CONCAT2, SRC_IMAGE1 = 0, 1, 2, 3, 4
 Z_NONE, Z_GROUPS, Z_UP2X2 = 0, 1, 2
 G_NUM_WEIGHTS = 26

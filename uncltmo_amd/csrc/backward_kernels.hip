@@ -25,7 +25,11 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
     const size_t p = i >> 2;
     const int v = (int)(i & 3);
     const float s = x_out[p];
-    const float gp = last_act == UNCL_ACT_SIGMOID ? g_out[p] * s * (1.f - s) : g_out[p];
+    // derivative of the last activation expressed through its output s (Unet_singleFrame.py:207-212, Blocks.py:85-91)
+    float gp = g_out[p];
+    if (last_act == UNCL_ACT_SIGMOID) gp *= s * (1.f - s);
+    else if (last_act == UNCL_ACT_TANH) gp *= 1.f - s * s;
+    else if (last_act == UNCL_ACT_MSIG) gp *= 3.f * s * (1.f - s);
     float u[8], gu[8], o[8];
     E8::unpack(ldv8(up_x + p * 32 + v * 8), u);
     if (g_upx) E8::unpack(ldv8(g_upx + p * 32 + v * 8), gu);

@@ -72,6 +72,8 @@ __device__ __forceinline__ float uncl_act(float v, int act) {
     case UNCL_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
     case UNCL_ACT_GELU: return uncl_gelu(v);
     case UNCL_ACT_SIGMOID: return uncl_sigmoid(v);
+    case UNCL_ACT_TANH: return tanhf(v);
+    case UNCL_ACT_MSIG: return 1.f / (1.f + __expf(-3.f * v));
     default: return v;
   }
 }

@@ -49,7 +49,7 @@ def _attach(root, dotted, tensor, as_param):
 
 
 _ACT = {"relu": _hip.ACT_RELU, "leakyrelu": _hip.ACT_LRELU}
-_LAST = {"sigmoid": _hip.ACT_SIGMOID, "none": _hip.ACT_NONE}
+_LAST = {"sigmoid": _hip.ACT_SIGMOID, "tanh": _hip.ACT_TANH, "msig": _hip.ACT_MSIG, "none": _hip.ACT_NONE}
 
 
 class _GeneratorBase(nn.Module):
