@@ -8,8 +8,8 @@ One step = one pass of the hot path over one batch of synthetic frames that are 
 tiles are independent so there is no data-path collective) and the slowest rank's time is used.
 
 Extra objects on the JSON line:
-  roofline     dense-bf16 MFMA roofline of the dominant kernel (the implicit-GEMM conv of up_path.3.conv.conv,
-               25.6 % of the generator's FLOPs): algorithmic FLOPs per launch / mean launch duration measured
+  roofline     dense-bf16 MFMA roofline of the dominant kernel (the implicit-GEMM conv of up_path.3.conv.conv with
+               up_path.3.up recomputed in its loader, 26.3 % of the generator's FLOPs): algorithmic FLOPs per launch / mean launch duration measured
                with HIP events inside the timed steps.
   cpu_baseline the CPU oracle (a port, not the reference's own code) timed on this box's host cores on a bounded
                sample of the same workload (generator forward over 256^2 tiles), reported in the same unit.
@@ -29,7 +29,10 @@ import torch  # noqa: E402
 
 GFLOP_PER_TILE = 18.2858            # 2*MAC of the 27 conv layers, one 256^2 tile
 DOM_LAYER = 24                      # packed-weight index of up_path.3.conv.conv
-DOM_GFLOP_PER_TILE = 4.6820         # 64516 x 32 x 1152 x 2
+# 64516 px x 32 x 1152 x 2 (the 3x3 over the 128-channel concat) + 15876 px x 32 x 128 x 2 (up_path.3.up, computed inside
+# the same launch since r1g; the halo pixels it recomputes are not counted)
+DOM_GFLOP_PER_TILE = 4.6820 + 0.1300
+DOM_GFLOP_PER_TILE_F32 = 4.6820     # fp32 parity mode: separate up-conv launch
 PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_TFLOPS = 157.3
 FRAMES, H, W, TILES_PER_FRAME = 8, 1024, 1024, 25
@@ -65,7 +68,7 @@ def pmc_traffic(dtype):
         doc = json.load(open(files[-1]))
         dom = doc["dominant"]
         for k in doc["kernels"]:
-            if k["grid_x"] == dom["grid_x"] and "pipe_kernel<1, 4, 4, 1" in k["kernel"]:
+            if k["grid_x"] == dom["grid_x"] and "pipe_kernel<1, 4, 4, 4" in k["kernel"]:
                 return int(k["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except (OSError, KeyError, ValueError):
         pass
@@ -228,7 +231,8 @@ def main():
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         ms = dt / a.steps * 1e3
         fps = world * FRAMES * a.steps / dt
-        dom_tflops = DOM_GFLOP_PER_TILE * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
+        dom_gflop = DOM_GFLOP_PER_TILE if a.dtype == "bf16" else DOM_GFLOP_PER_TILE_F32
+        dom_tflops = dom_gflop * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
         fwd_tflops = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / ms          # per GPU
         traffic, traffic_src = pmc_traffic(a.dtype)
         line = {
@@ -242,12 +246,13 @@ def main():
             "roofline": {"bound": "mfma", "achieved": dom_tflops, "peak": peak, "unit": "TFLOP/s",
                          "frac": dom_tflops / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
-                         "algorithmic_bytes": int(FRAMES * TILES_PER_FRAME * (2 * 252 * 252 + 254 * 254) * 64),
+                         # skip 252^2 + coarse map 126^2 in, 254^2 out, 32 bf16 channels each
+                         "algorithmic_bytes": int(FRAMES * TILES_PER_FRAME * (252 * 252 + 126 * 126 + 254 * 254) * 64),
                          "hbm_gbps": (traffic / dom_ms / 1e6 if traffic and dom_ms > 0 else None),
-                         "kernel": ("conv3x3_pipe_kernel<1,4,4,1,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
+                         "kernel": ("conv3x3_pipe_kernel<1,4,4,4,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
                                    + " @ up_path.3.conv.conv",
                          "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
-                         "gflop_per_tile": DOM_GFLOP_PER_TILE},
+                         "gflop_per_tile": dom_gflop},
             "forward_mfma": {"achieved": fwd_tflops, "peak": peak, "unit": "TFLOP/s", "frac": fwd_tflops / peak,
                              "gflop_per_tile": GFLOP_PER_TILE, "note": "whole step incl. tiler, per GPU"},
         }

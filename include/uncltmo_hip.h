@@ -50,6 +50,10 @@ extern "C" {
                                  layer (unet_parts.py:19) recomputed from the fp32 one-channel image src0 (N, H+2, W+2)
                                  inside the loader, so inc.conv.conv's output never goes to HBM (inference)         */
 
+#define UNCL_SRC_CONCAT_SSR_UP 5 /* uncl_conv3x3_pipe only: UNCL_SRC_CONCAT_SSR with up() fused: src1 (N, H/2, W/2, 32) is the
+                                 INPUT of the 2x2 stride-2 ConvTranspose2d (unet_parts.py:269,288; weights up_w, up_b), whose
+                                 32-channel output is recomputed per halo tile and never goes to HBM (inference)     */
+
 /* what blockIdx.z enumerates besides Cout tiles */
 #define UNCL_Z_NONE 0
 #define UNCL_Z_GROUPS 1   /* grouped 1x1 conv: z = group (gcn_lib/torch_nn.py:58, groups=4)                */
@@ -98,6 +102,8 @@ typedef struct uncl_conv_desc {
   int skip_main_store;  /* 1: do not write `out` (inference does not need up_x)              */
   const float* pre_w;   /* UNCL_SRC_IMAGE1: first-layer weights (32,1,3,3) fp32, reference layout */
   const float* pre_b;   /* UNCL_SRC_IMAGE1: first-layer bias (32) fp32 or NULL                    */
+  const void* up_w;     /* UNCL_SRC_CONCAT_SSR_UP: packed k2 s2 transposed-conv weights [4 taps][32][32] bf16 */
+  const float* up_b;    /* UNCL_SRC_CONCAT_SSR_UP: its bias (32) fp32 or NULL                      */
 } uncl_conv_desc;
 
 int uncl_conv_igemm(const uncl_conv_desc* d, void* stream);

@@ -175,6 +175,42 @@ def test_pipe_transposed_concat_ssr_and_tail():
     assert rel_l2(out1.cpu().unsqueeze(1), ref1) < 1e-4
 
 
+@pytest.mark.parametrize("h,w,n", [(9, 13, 3), (23, 40, 2), (126, 126, 2)])
+def test_pipe_concat_ssr_with_upconv_recomputed_in_the_loader(h, w, n):
+    """UNCL_SRC_CONCAT_SSR_UP: up() (ConvTranspose2d k2 s2, unet_parts.py:269,288) of the coarse map is rebuilt per halo tile
+    inside the concat layer's loader.  Same result as running uncl_upconv2x2 and then the UNCL_SRC_CONCAT_SSR layer, up to the
+    bf16 rounding of the up-sampled map (the fused path starts its fp32 accumulation from the bias instead of adding it last)."""
+    c = 32
+    H, W = 2 * h, 2 * w
+    x2 = q(rnd(n, c, H, W, seed=101).abs(), BF)
+    xs = q(rnd(n, c, h, w, seed=102), BF)
+    wu, bu = q(rnd(c, c, 2, 2, seed=103, scale=0.1), BF), rnd(c, seed=104)
+    wt, b = q(rnd(4 * c, 32, 3, 3, seed=105, scale=0.05), BF), rnd(32, seed=106)
+    x1 = q(F.conv_transpose2d(xs, wu, bu, stride=2), BF)
+    cat = torch.cat([x2, x1, x2 ** 2, (x2 + 1e-8) ** 0.5], 1)
+    ref = F.relu(F.conv_transpose2d(cat, wt, b))
+    x2d, xsd, wud, bud = to_nhwc(x2, BF), to_nhwc(xs, BF), pack_weight(wu, BF, transposed=True), bu.cuda()
+    wd, bd = pack_weight(wt, BF, transposed=True, flip=True), b.cuda()
+    common = dict(dtype=BF, ksize=3, pad=2, N=n, H=H, W=W, Cin=4 * c, Cout=32, src0=x2d, src0_H=H, src0_W=W, src0_C=c,
+                  weight=wd, bias=bd, act=_hip.ACT_RELU, out_H=H + 2, out_W=W + 2, out_C=32)
+    fused = torch.zeros(n, H + 2, W + 2, 32, dtype=torch.bfloat16, device="cuda")
+    run_pipe(src_mode=_hip.SRC_CONCAT_SSR_UP, src1=xsd, src1_H=h, src1_W=w, src1_C=c, up_w=wud, up_b=bud, out=fused, **common)
+    assert rel_l2(from_nhwc(fused), ref) < 2e-2
+    up = torch.zeros(n, H, W, c, dtype=torch.bfloat16, device="cuda")
+    _hip.check(_hip.lib().uncl_upconv2x2(xsd.data_ptr(), None, 0, wud.data_ptr(), bud.data_ptr(), up.data_ptr(), n, h, w, c, c,
+                                         _hip.stream_ptr()), "upconv")
+    two = torch.zeros_like(fused)
+    run_pipe(src_mode=_hip.SRC_CONCAT_SSR, src1=up, src1_H=H, src1_W=W, src1_C=c, out=two, **common)
+    assert rel_l2(fused.float().cpu(), two.float().cpu()) < 1e-3
+    assert (fused != two).float().mean().item() < 0.05
+    # the fused mode is the 32-channel last decoder level only, and the up-sampled map must have the skip's extent
+    d = _hip.ConvDesc()
+    for k_, v in dict(common, src_mode=_hip.SRC_CONCAT_SSR_UP, src0=x2d.data_ptr(), weight=wd.data_ptr(), bias=bd.data_ptr(),
+                      src1=xsd.data_ptr(), src1_H=h - 1, src1_W=w, src1_C=c, up_w=wud.data_ptr(), out=fused.data_ptr()).items():
+        setattr(d, k_, v)
+    assert _hip.lib().uncl_conv3x3_pipe(C.byref(d), None, _hip.stream_ptr()) != 0
+
+
 def test_pipe_broadcast_residual_and_skip_store():
     cin, cout, h = 256, 256, 10
     x, wt, b = q(rnd(3, cin, h, h, seed=40), BF), q(rnd(cin, cout, 3, 3, seed=41, scale=0.05), BF), rnd(cout, seed=42)

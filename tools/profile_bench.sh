@@ -1,6 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r1c
+TAG=${1:-r1g}
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu > $O/bench_stats.log 2>&1
@@ -8,3 +9,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python3 be
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 bench.py --steps 4 --warmup 1 --no-cpu > $O/bench_write.log 2>&1
 ls -R $O | head -40
 tail -2 $O/bench_stats.log | cut -c1-300
+python3 tools/pmc_summary.py $O $TAG 5 && cp profiles/${TAG}_pmc_traffic.json $O/

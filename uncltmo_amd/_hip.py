@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNCL_HIP_LIB") or os.path.join(_HERE, "libuncltmo_hip
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_TANH, ACT_MSIG = 0, 1, 2, 3, 4, 5, 6
-SRC_PLAIN, SRC_MAXPOOL2, SRC_CONCAT_SSR, SRC_CONCAT2, SRC_IMAGE1 = 0, 1, 2, 3, 4
+SRC_PLAIN, SRC_MAXPOOL2, SRC_CONCAT_SSR, SRC_CONCAT2, SRC_IMAGE1, SRC_CONCAT_SSR_UP = 0, 1, 2, 3, 4, 5
 Z_NONE, Z_GROUPS, Z_UP2X2 = 0, 1, 2
 G_NUM_WEIGHTS = 26
 
@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("z_mode", C.c_int), ("groups", C.c_int),
         ("out1_w", C.c_void_p), ("out1_b", C.c_void_p), ("out1_act", C.c_int), ("out1", C.c_void_p),
         ("skip_main_store", C.c_int),
-        ("pre_w", C.c_void_p), ("pre_b", C.c_void_p),
+        ("pre_w", C.c_void_p), ("pre_b", C.c_void_p), ("up_w", C.c_void_p), ("up_b", C.c_void_p),
     ]
 
 

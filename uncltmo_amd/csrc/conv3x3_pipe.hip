@@ -47,6 +47,8 @@ struct PipeArgs {
   const float* pre_w;   // (32,1,3,3)
   const float* pre_b;   // (32) or NULL
   int imgH, imgW;
+  const bf16_t* up_w;   // MODE 4: packed [4 taps][32 cout][32 cin] weights of the 2x2 stride-2 transposed conv
+  const float* up_b;    // MODE 4: its bias (32) or NULL
 };
 
 __device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -86,7 +88,8 @@ __device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off)
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1], 3 first layer recomputed from the image
+// MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1], 3 first layer recomputed from the image,
+//       4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) recomputed inside the loader (32 channels, same extent as the skip)
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
 __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void conv3x3_pipe_kernel(const PipeArgs a) {
   using E = Elem<bf16_t>;
@@ -123,6 +126,14 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;
   float* sP = reinterpret_cast<float*>(sB + CT * 4);
   char* sO = smem;
+  // MODE 4: source patch of the fused 2x2 transposed conv [9 x 17 px][64 B], its weights [128 rows][64 B] and bias; they
+  // live in the weight image's space between the barrier that retires the previous step and the staging of the new weights
+  constexpr int UPH = HH / 2, UPW = HW / 2, UPN = UPH * UPW;
+  char* sU = sW;
+  char* sUW = sU + ((UPN * 64 + 255) & ~255);
+  float* sUB = reinterpret_cast<float*>(sUW + 128 * 64);
+  static_assert(MODE != 4 || ((UPN * 64 + 255) & ~255) + 128 * 64 + 128 <= WROWS * 80, "fused up-conv scratch fits in the weight image");
+  static_assert(MODE != 4 || (NT == 1 && MPW == 4 && UPN * 4 <= 3 * 256), "fused up-conv staging is written for the 16 x 32 tile");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -180,6 +191,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   unsigned xvalid = 0;
   int g_pending = 0;
   bool b_pending = false;
+  int u_iy0 = 0, u_ix0 = 0;   // MODE 4: image coordinates of the halo tile whose up-conv patch is in flight
 
   // K-chunk order.  MODE 1 walks each 32-channel slice of the skip as [x1, x2, x2^2, sqrt(x2)]: the x2 registers loaded
   // for the second step are kept and re-staged (squared, then square-rooted) for the third and fourth, so the skip is
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   auto load_regs = [&](int n, int y0, int x0, int cout0, int kc, bool with_w) {
     int g = 0, cbase = kc * 32, wk = kc;
     bool reuse = false;
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 4) {
       const int ph = kc & 3;
       cbase = (kc >> 2) * 32;
       g = ph == 0 ? 1 : (ph == 1 ? 0 : ph);
@@ -218,7 +230,28 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       xvalid = 0xffffffffu;
     } else if (reuse) {
       // xr / xvalid still hold this tile's x2 slice
-    } else if (MODE != 0 && g == 1 && !same_ext) {
+    } else if (MODE == 4 && g == 1) {
+      // the 9 x 17 source pixels of the 2x2 stride-2 transposed conv under the 18 x 34 halo tile (tile origins are even),
+      // 4 vectors of 8 channels each, and its 8 KB of weights; out-of-image source pixels are clamped (their outputs are
+      // outside the image too and are staged as zeros)
+      const int sy0 = iy0 >> 1, sx0 = ix0 >> 1;
+      u_iy0 = iy0; u_ix0 = ix0;
+      const bf16_t* ub = a.src1 + (size_t)n * a.s1H * a.s1W * 32;
+      // once per tile: the thread's addressing is recomputed here rather than carried in registers across the whole loop
+      int t4 = tid;
+      asm volatile("" : "+v"(t4));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int v = min(t4 + k * NTHR, UPN * 4 - 1);
+        const int sp = v >> 2, sl = v & 3;
+        const int spy = sp / UPW, spx = sp - spy * UPW;
+        const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
+        xr[k] = ld16o(ub, (unsigned)(((yy * a.s1W + xx) * 32 + sl * 8) * 2));
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) xr[3 + k] = ld16o(a.up_w, (unsigned)((t4 + k * NTHR) * 16));
+      xvalid = 0xffffffffu;
+    } else if (MODE != 0 && MODE != 4 && g == 1 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
       const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
       const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
@@ -303,6 +336,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     if (b_pending && tid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)tid * 16u);
   };
 
+  f32x16 acc[MPW][NT];
+  f32x16 zero16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+
   auto write_lds = [&](bool with_w) {
     const bool all_ok = xvalid == 0xffffffffu;  // wave-uniform in practice (interior tiles)
     if (MODE == 3) {
@@ -353,12 +391,80 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
           }
         }
       }
+    } else if (MODE == 4 && g_pending == 1) {
+      // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: a skinny GEMM per 32 source pixels (K = 32 input
+      // channels, 4 taps x 32 output channels), every result scattered to output pixel (2 sy + dy, 2 sx + dx) of the
+      // staging image in the D layout it already has; pixels outside the image are the conv's zero padding
+      int t4 = tid;
+      asm volatile("" : "+v"(t4));   // as in load_regs: no loop-carried addressing registers for this once-per-tile block
+      const int lr = t4 & 31, lh = (t4 >> 5) & 1;
+      static_assert(WAVES == 4, "one wave per tap of the 2x2 kernel");
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int v = t4 + k * NTHR;
+        if (v < UPN * 4) *reinterpret_cast<vec*>(sU + (v >> 2) * 64 + (((v & 3) ^ (((v >> 2) >> 2) & 3)) << 4)) = xr[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = t4 + k * NTHR, row = v >> 2;
+        *reinterpret_cast<vec*>(sUW + row * 64 + (((v & 3) ^ ((row >> 2) & 3)) << 4)) = xr[3 + k];
+      }
+      if (t4 < 32) sUB[t4] = a.up_b ? a.up_b[t4] : 0.f;
+      __syncthreads();
+      // Work split: wave = tap (dy, dx), five M-tiles of 32 source pixels each.  The A rows are read in the order
+      // cout(r) = 16*bit2(r) + 4*(r >> 3) + (r & 3), which makes the D registers of a lane 16 CONSECUTIVE output channels
+      // (16 lh .. 16 lh + 15) of its pixel: two 16-byte LDS writes per pixel instead of four 8-byte ones.  The bias is the
+      // initial accumulator.
+      constexpr int MTU = (UPN + 31) / 32;
+      const int tap = __builtin_amdgcn_readfirstlane(t4 >> 6);
+      const int arow = tap * 32 + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
+      vec Au[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        Au[ks] = *reinterpret_cast<const vec*>(sUW + arow * 64 + (((2 * ks + lh) ^ ((arow >> 2) & 3)) << 4));
+      f32x16 cb;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 ubv = *reinterpret_cast<const f32x4*>(sUB + 16 * lh + 4 * qd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cb[4 * qd + e] = ubv[e];
+      }
+      const int iy0h = u_iy0 + (tap >> 1), ix0h = u_ix0 + (tap & 1);
+#pragma unroll
+      for (int mt = 0; mt < MTU; ++mt) {
+        const int sp = mt * 32 + lr, spc = min(sp, UPN - 1);
+        const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;     // / 17 for spc < 1024
+        f32x16 cu = cb;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const vec Bu = *reinterpret_cast<const vec*>(sU + spc * 64 + (((2 * ks + lh) ^ ((spc >> 2) & 3)) << 4));
+          cu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Au[ks], Bu, cu, 0, 0, 0);
+        }
+        const bool in_img = (unsigned)(iy0h + 2 * spy) < (unsigned)a.H && (unsigned)(ix0h + 2 * spx) < (unsigned)a.W;
+        char* dst = sX + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * RP + (lh << 5);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = cu[8 * h + e];
+          vec o = E::pack(f);
+          if (!in_img) o = E::zero();
+          if (MTU * 32 == UPN || mt < MTU - 1 || sp < UPN) *reinterpret_cast<vec*>(dst + (h << 4)) = o;
+        }
+      }
+      __syncthreads();   // the scratch is in the weight image: everybody is done with it before the new weights land
+      // the up-conv chunk is the first of its tile (32-channel skip): the accumulators are dead here, and saying so gives
+      // their registers to the block above
+#pragma unroll
+      for (int m = 0; m < MPW; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
     } else
 #pragma unroll
     for (int j = 0; j <= RS; ++j) {
       if (j == RS && !e_on) continue;
       vec v = xr[j];
-      if (MODE == 1 && g_pending >= 2) {
+      if ((MODE == 1 || MODE == 4) && g_pending >= 2) {
         float f[8];
         E::unpack(v, f);
         if (g_pending == 2) {
@@ -413,10 +519,6 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     return true;
   };
 
-  f32x16 acc[MPW][NT];
-  f32x16 zero16;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
 
   // epilogue addressing that does not change between tiles
   const int sw_e = (lr >> 1) & (SLOTS - 1);                            // swizzle of this lane's pixel column
@@ -447,7 +549,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         }
         if (ks == 0 && tx == 0) {
           // first tap of the chunk: on the first chunk of a tile the accumulation starts from zero (inline C = 0)
-          if (c_kc == 0) {
+          if (MODE != 4 && c_kc == 0) {
 #pragma unroll
             for (int m = 0; m < MPW; ++m)
 #pragma unroll
@@ -685,6 +787,10 @@ int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
   }
   if (mode == UNCL_SRC_PLAIN) return prev ? launch_pipe<NT, MPW, 4, 0, true>(a, s) : launch_pipe<NT, MPW, 4, 0, false>(a, s);
   if (mode == UNCL_SRC_CONCAT_SSR) return launch_pipe<NT, MPW, 4, 1, false>(a, s);
+  if (mode == UNCL_SRC_CONCAT_SSR_UP) {
+    if constexpr (NT == 1 && MPW == 4) return launch_pipe<1, 4, 4, 4, false>(a, s);
+    return UNCL_ERR_ARG;
+  }
   return launch_pipe<NT, MPW, 4, 2, false>(a, s);
 }
 
@@ -696,7 +802,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
                              void* stream) {
   if (d == nullptr || d->dtype != UNCL_BF16 || d->ksize != 3) return UNCL_ERR_ARG;
   if (d->pad != 0 && d->pad != 2) return UNCL_ERR_ARG;
-  if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_IMAGE1) return UNCL_ERR_ARG;
+  if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_CONCAT_SSR_UP) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_IMAGE1) {
     // x = act(conv3x3_valid(image)): 32 channels over (H, W) = image extent - 2; this layer itself must be 32 -> 32, valid
     if (d->Cin != 32 || d->Cout != 32 || d->pad != 0 || d->pre_w == nullptr || d->src0_C != 1 || d->src0_H != d->H + 2 ||
@@ -713,6 +819,12 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     const int groups = d->src_mode == UNCL_SRC_CONCAT_SSR ? 4 : 2;
     if (d->Cin != groups * d->src0_C) return UNCL_ERR_ARG;
     if (d->src1_H > d->src0_H || d->src1_W > d->src0_W) return UNCL_ERR_ARG;
+  }
+  if (d->src_mode == UNCL_SRC_CONCAT_SSR_UP) {
+    // src1 is the INPUT of the 2x2 stride-2 transposed conv: 32 channels, its output must have exactly the skip's extent
+    if (d->src1 == nullptr || d->up_w == nullptr || d->src0_C != 32 || d->src1_C != 32 || d->Cin != 128 || d->Cout != 32 ||
+        2 * d->src1_H != d->src0_H || 2 * d->src1_W != d->src0_W || d->prev0 != nullptr || mask != nullptr)
+      return UNCL_ERR_ARG;
   }
   if (d->out1_w != nullptr && (d->Cout != 32 || d->out1 == nullptr)) return UNCL_ERR_ARG;
   // 32-bit element offsets inside one sample
@@ -740,6 +852,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     a.img = (const float*)d->src0; a.pre_w = d->pre_w; a.pre_b = d->pre_b; a.imgH = d->src0_H; a.imgW = d->src0_W;
     a.s0H = d->H; a.s0W = d->W; a.s0C = 32;
   }
+  a.up_w = (const bf16_t*)d->up_w; a.up_b = d->up_b;
   a.nk = d->Cin / 32;
   const bool prev = d->prev0 != nullptr && d->prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

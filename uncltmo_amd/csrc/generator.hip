@@ -101,6 +101,7 @@ struct Ctx {
   Layout L;
   int n;             // tiles in this chunk
   int save_preact;   // keep pre-GELU values (training)
+  int fuse_up;       // inference: up_path.3.up is recomputed inside up_path.3.conv.conv's loader (same idea, last decoder level)
   int fuse_in;       // inference: inc.conv.conv is recomputed inside inc.conv.conv1's loader (its output never goes to HBM)
   hipStream_t s;
   void* ptr(int b) const { return ws + L.off[b]; }
@@ -159,7 +160,19 @@ int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, boo
 int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int outbuf, int ch, int cout, int prev_ch,
              void* final_out, const uncl_conv_desc* tail) {
   int rc;
-  if (use_pipe(c)) {
+  // inference, last decoder level: the 32-channel up-conv is recomputed per halo tile inside the concat layer's loader
+  const bool fuse_up = c.fuse_up && use_pipe(c) && ch == 32 && cout == 32 && 2 * kDims[x1].h == kDims[skip].h;
+  if (fuse_up) {
+    uncl_conv_desc d = base_desc(c, wi_up + 1, 3, 2, 4 * ch, cout, c.w->act);
+    set_src0(d, c, skip);
+    d.src1 = c.ptr(x1);
+    d.src1_H = kDims[x1].h; d.src1_W = kDims[x1].w; d.src1_C = kDims[x1].c;
+    d.src_mode = UNCL_SRC_CONCAT_SSR_UP;
+    d.up_w = c.w->w[wi_up]; d.up_b = c.w->b[wi_up];
+    d.H = kDims[skip].h; d.W = kDims[skip].w;
+    set_out(d, c.ptr(abuf), abuf);
+    if ((rc = run3(c, wi_up + 1, d, nullptr)) != UNCL_OK) return rc;
+  } else if (use_pipe(c)) {
     ProfScope ps(wi_up, c.s);
     const int h = kDims[x1].h == 1 ? 12 : kDims[x1].h, w = kDims[x1].h == 1 ? 12 : kDims[x1].w;
     const bool pv = prev_ch > 0 && c.prev;
@@ -178,7 +191,7 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
     ProfScope ps(wi_up, c.s);
     if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
   }
-  {
+  if (!fuse_up) {
     uncl_conv_desc d = base_desc(c, wi_up + 1, 3, 2, 4 * ch, cout, c.w->act);
     set_src0(d, c, skip);
     d.src1 = c.ptr(upbuf);
@@ -563,6 +576,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.save_preact = r->save_preact;
     // the backward pass reads inc.conv.conv's output (ReLU mask, weight gradient), the video path hands its channels on
     c.fuse_in = w->dtype == UNCL_BF16 && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr;
+    c.fuse_up = c.fuse_in;
     c.s = reinterpret_cast<hipStream_t>(stream);
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
