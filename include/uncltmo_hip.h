@@ -132,6 +132,18 @@ int uncl_unpack_conv_wgrad(const float* packed, float* dst, int Cout, int Cin, i
 /* bias gradient: out[c] (+)= sum_rows x[row][c], x bf16 [rows][ld]; workspace uncl_colsum_workspace_bytes(C) */
 size_t uncl_colsum_workspace_bytes(int C);
 int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, float* out, int accumulate, void* workspace, void* stream);
+/* The same sum in two calls, for a backward pass with many bias gradients: uncl_colsum_bf16_stage writes the per-workgroup
+ * partial sums of one matrix (C <= 256) into its own `partial` buffer (512*C floats) and fills `item`; one
+ * uncl_colsum_finish reduces up to UNCL_COLSUM_MAX_ITEMS staged items in a single launch (same summation order). */
+#define UNCL_COLSUM_MAX_ITEMS 48
+typedef struct uncl_colsum_item {
+  const float* partial;
+  float* out;
+  int blocks, C, accumulate, reserved;
+} uncl_colsum_item;
+int uncl_colsum_bf16_stage(const void* x, long long rows, int C, int ld, float* partial, float* out, int accumulate,
+                           uncl_colsum_item* item, void* stream);
+int uncl_colsum_finish(const uncl_colsum_item* items, int n_items, void* stream);
 
 /* Data gradient of a 3x3 layer: uncl_conv3x3_pipe over re-packed weights with an identity activation; the stored
  * gradient is multiplied by the activation derivative of the layer that produced the tensor it flows into
@@ -175,6 +187,15 @@ int uncl_conv_in_c1_wgrad(const void* G, const float* x, float* gw, float* gb, i
  * the kernel runs it as a pad-2 correlation; for the stride-2 2x2 the four taps index (dy, dx) unflipped. */
 int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int Cout, int Cin, int k, int transposed,
                           int flip, void* stream);
+/* The same re-layout for many weights in one launch per UNCL_PACK_MAX_ITEMS items (a training step re-packs every weight
+ * of the generator, forward and data-gradient forms, after each optimiser step). */
+#define UNCL_PACK_MAX_ITEMS 64
+typedef struct uncl_pack_item {
+  const float* src;
+  void* dst;
+  int Cout, Cin, k, transposed, flip, reserved;
+} uncl_pack_item;
+int uncl_pack_conv_weights(const uncl_pack_item* items, int n_items, int dtype, void* stream);
 
 /* First generator layer: Conv2d(1 -> Cout, 3x3, valid) + bias + act, input fp32 (N,H,W), output NHWC.
  * Replaces inc.conv.conv (unet_parts.py:19,26).  weight: fp32 (Cout,1,3,3). */
@@ -330,6 +351,13 @@ size_t uncl_nce_workspace_bytes(int N);
 int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
                   int neg_shared, float k, float c, float w, float* loss, float* g_anchor, float* g_pos, float* g_neg,
                   int accumulate_loss, int accumulate_grad, void* workspace, void* stream);
+/* Gradients of uncl_nce_loss computed at backward time (autograd of GanTrainerImg.py:410-439): `workspace` is the one the
+ * forward call filled, `upstream` an optional device scalar multiplied in, gradients are written in grad_dtype (= dtype, or
+ * UNCL_F32).  pos_row / neg_row >= 0: the shared positive / negative is that row of `anchor` (infoNCE2, :398-402) and its
+ * gradient is folded into g_anchor's row (g_pos / g_neg NULL); -1 otherwise.  E must be a multiple of 16 bytes of elements. */
+int uncl_nce_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
+                      int neg_shared, float k, float c, const void* workspace, const float* upstream, void* g_anchor, void* g_pos,
+                      void* g_neg, int grad_dtype, int pos_row, int neg_row, void* stream);
 /* w * mean_n |a_n - b_n| over strided per-sample scalars (nn.L1Loss on per-frame means, GanTrainerImg.py:308-313) */
 int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss, float* g_a,
                   float* g_b, int accumulate_loss, void* stream);

@@ -103,6 +103,45 @@ def test_colsum_bias_grad():
     assert rel_l2(out.cpu(), x.float().cpu().sum(0)) < 1e-5
 
 
+def test_colsum_staged_batch_equals_single_calls():
+    """uncl_colsum_bf16_stage + one uncl_colsum_finish (the backward pass's form) == uncl_colsum_bf16 per matrix, bit for bit."""
+    lib = _hip.lib()
+    shapes = [(70000, 32), (5000, 256), (144 * 7, 128), (9, 64)]
+    xs = [q(rnd(r, c, seed=140 + i)).to(torch.bfloat16).cuda() for i, (r, c) in enumerate(shapes)]
+    items = (_hip.ColsumItem * len(xs))()
+    parts = [torch.empty(512 * c, device="cuda") for _, c in shapes]
+    outs = [torch.full((c,), 0.5, device="cuda") for _, c in shapes]
+    for i, (x, (r, c)) in enumerate(zip(xs, shapes)):
+        _hip.check(lib.uncl_colsum_bf16_stage(x.data_ptr(), r, c, c, parts[i].data_ptr(), outs[i].data_ptr(), i % 2, C.byref(items[i]),
+                                              _hip.stream_ptr()), "stage")
+    _hip.check(lib.uncl_colsum_finish(items, len(xs), _hip.stream_ptr()), "finish")
+    ws = torch.empty(lib.uncl_colsum_workspace_bytes(256), dtype=torch.uint8, device="cuda")
+    for i, (x, (r, c)) in enumerate(zip(xs, shapes)):
+        ref = torch.full((c,), 0.5, device="cuda")
+        _hip.check(lib.uncl_colsum_bf16(x.data_ptr(), r, c, c, ref.data_ptr(), i % 2, ws.data_ptr(), _hip.stream_ptr()), "colsum")
+        assert torch.equal(outs[i], ref)
+        assert rel_l2(outs[i].cpu(), x.float().cpu().sum(0) + (0.5 if i % 2 else 0.0)) < 1e-5
+    assert lib.uncl_colsum_finish(items, 49, _hip.stream_ptr()) != 0     # more than UNCL_COLSUM_MAX_ITEMS
+
+
+def test_batched_weight_packing_equals_single_calls():
+    lib = _hip.lib()
+    cases = [((64, 32, 3, 3), False, False), ((32, 64, 3, 3), True, True), ((128, 128, 2, 2), True, False), ((256, 512, 1, 1), False, False)]
+    for code in (_hip.BF16, _hip.F32):
+        ws = [rnd(*shape, seed=150 + i).cuda() for i, (shape, _, _) in enumerate(cases)]
+        items = (_hip.PackItem * len(cases))()
+        dsts = []
+        for it, w, (shape, tr, fl) in zip(items, ws, cases):
+            k = shape[2]
+            co, ci = (shape[1], shape[0]) if tr else (shape[0], shape[1])
+            d = torch.zeros(w.numel(), dtype=_hip.torch_dtype(code), device="cuda")
+            dsts.append(d)
+            it.src, it.dst, it.Cout, it.Cin, it.k, it.transposed, it.flip = w.data_ptr(), d.data_ptr(), co, ci, k, int(tr), int(fl)
+        _hip.check(lib.uncl_pack_conv_weights(items, len(cases), code, _hip.stream_ptr()), "pack batch")
+        for d, w, (shape, tr, fl) in zip(dsts, ws, cases):
+            assert torch.equal(d, pack_weight(w.cpu(), code, transposed=tr, flip=fl))
+
+
 # ---- whole generator backward ---------------------------------------------------------------------------------
 from oracle import generator as OG                       # noqa: E402
 from uncltmo_amd import synth                            # noqa: E402

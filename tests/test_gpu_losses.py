@@ -150,6 +150,29 @@ def test_nce_golden_and_shared_rows(golden):
     fr = fb.detach().float().cpu().requires_grad_(True)
     lr_ = OL.nce(fr, fr[2].unsqueeze(0).repeat(4, 1, 1, 1), fr[1].unsqueeze(0).repeat(4, 1, 1, 1), 1, 1e-2)
     np.testing.assert_allclose(lb.item(), lr_.item(), rtol=1e-4)
+    # ... and its gradient: one bf16 channel-last tensor holding the anchor's and the two shared rows' contributions,
+    # scaled by the upstream factor on the device
+    (0.37 * lb).backward()
+    (0.37 * lr_).backward()
+    assert fb.grad.dtype == torch.bfloat16 and fb.grad.permute(0, 2, 3, 1).is_contiguous()
+    assert rel_l2(fb.grad.float().cpu(), fr.grad) < 6e-3
+    # positive and negative the SAME row; separate shared rows that are not part of the anchor; per-sample rows
+    for pr, qr in [(3, 3), (0, 3)]:
+        f1 = fea.clone().requires_grad_(True)
+        OL.nce(f1, f1[pr].unsqueeze(0).repeat(4, 1, 1, 1), f1[qr].unsqueeze(0).repeat(4, 1, 1, 1), 1, 1e-2).backward()
+        f2 = fea.cuda().requires_grad_(True)
+        HL.nce(f2, f2[pr:pr + 1], f2[qr:qr + 1], 1, 1e-2).backward()
+        if pr == qr:       # the two logits are equal: loss = log 2 and every gradient cancels to rounding noise
+            assert f2.grad.abs().max().item() < 1e-5 and f1.grad.abs().max().item() < 1e-5
+        else:
+            assert rel_l2(f2.grad.cpu(), f1.grad) < 1e-4
+    a1, p1, q1 = [torch.rand(s_, 8, 12, 12, generator=torch.Generator().manual_seed(60 + i)).requires_grad_(True)
+                  for i, s_ in enumerate((4, 1, 4))]
+    OL.nce(a1, p1.repeat(4, 1, 1, 1), q1, 2.0, 0.5).backward()
+    a2, p2, q2 = [t.detach().cuda().requires_grad_(True) for t in (a1, p1, q1)]
+    HL.nce(a2, p2, q2, 2.0, 0.5).backward()
+    for t2, t1 in ((a2, a1), (p2, p1), (q2, q1)):
+        assert rel_l2(t2.grad.cpu(), t1.grad) < 1e-4
 
 
 def test_tmqi_naturalness_golden_and_selection(golden):

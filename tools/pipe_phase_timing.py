@@ -2,7 +2,7 @@
 
 Measurement tool, not part of the product path: builds a second copy of the library with -DUNCL_PIPE_TIMING into
 tools/_timing/ (wave 0 of every workgroup accumulates s_memtime deltas per loop phase) and prints the share of each
-phase.  Run on the GPU box:  python tools/pipe_phase_timing.py [--layer up3|down1|mid]
+phase.  Run on the GPU box:  python tools/pipe_phase_timing.py [--layer up3|up3f|inc1|inc1f|up2|down1|mid]
 """
 import argparse
 import ctypes as C
@@ -69,6 +69,12 @@ def main():
         h, c, cin, cout, pad, mode = 252, 32, 128, 32, 2, _hip.SRC_CONCAT_SSR
         x1 = rnd(n, h, h, c); keep.append(x1)
         d.src1, d.src1_H, d.src1_W, d.src1_C = x1.data_ptr(), h, h, c
+    elif args.layer == "up3f":   # the same layer with up_path.3.up (k2 s2, 32 -> 32) recomputed in the loader
+        h, c, cin, cout, pad, mode = 252, 32, 128, 32, 2, _hip.SRC_CONCAT_SSR_UP
+        x1 = rnd(n, h // 2, h // 2, c); keep.append(x1)
+        uw = rnd(4, 32, 32, scale=0.1); ub = torch.zeros(32, device="cuda"); keep += [uw, ub]
+        d.src1, d.src1_H, d.src1_W, d.src1_C = x1.data_ptr(), h // 2, h // 2, c
+        d.up_w, d.up_b = uw.data_ptr(), ub.data_ptr()
     elif args.layer == "inc1":   # plain valid 3x3, 32 -> 32 at 254^2 -> 252^2 (static weights)
         h, c, cin, cout, pad, mode = 254, 32, 32, 32, 0, _hip.SRC_PLAIN
     elif args.layer == "inc1f":  # the same layer with inc.conv.conv recomputed from the fp32 image in the loader

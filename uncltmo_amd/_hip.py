@@ -76,6 +76,16 @@ _lib = None
 PARAM_EPOCH = [0]   # bumped by uncltmo_amd.optim.Adam after its in-place kernel update
 
 # name -> (restype, argtypes); every symbol include/uncltmo_hip.h declares
+class ColsumItem(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("blocks", C.c_int), ("C", C.c_int), ("accumulate", C.c_int),
+                ("reserved", C.c_int)]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("k", C.c_int),
+                ("transposed", C.c_int), ("flip", C.c_int), ("reserved", C.c_int)]
+
+
 SIGNATURES = {
     "uncl_version": (C.c_int, []),
     "uncl_device_ok": (C.c_int, []),
@@ -86,6 +96,10 @@ SIGNATURES = {
     "uncl_conv_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "uncl_unpack_conv_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p]),
+    "uncl_colsum_bf16_stage": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.POINTER(ColsumItem), C.c_void_p]),
+    "uncl_colsum_finish": (C.c_int, [C.POINTER(ColsumItem), C.c_int, C.c_void_p]),
+    "uncl_pack_conv_weights": (C.c_int, [C.POINTER(PackItem), C.c_int, C.c_int, C.c_void_p]),
     "uncl_colsum_workspace_bytes": (C.c_size_t, [C.c_int]),
     "uncl_colsum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "uncl_conv3x3_dgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
@@ -145,6 +159,9 @@ SIGNATURES = {
     "uncl_nce_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                 C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_nce_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p]),
     "uncl_l1_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "uncl_tmqi_naturalness": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,

@@ -311,7 +311,16 @@ struct BwdScratch {
   char* tD;
   float* f32;    // (N,144,256) fp32 max-relative scatter target
   char* mix;     // (N,126,126,32) bf16: a stage input with the previous frame's head channels (video)
-  float* misc;   // colsum / outc / conv_in partial sums
+  float* misc;   // outc / conv_in partial sums
+  float* cs;     // staged column sums of the bias gradients (512 floats per channel, CS_CHANNELS channels)
+};
+constexpr int CS_CHANNELS = 8192;
+
+// bias gradients of one backward pass: stage 1 per layer, one finishing launch at the end
+struct ColsumQueue {
+  uncl_colsum_item it[UNCL_COLSUM_MAX_ITEMS];
+  int n = 0;
+  int channels = 0;
 };
 
 // carry arena of the recurrent hand-off: head-channel gradients of the eight mixed stage inputs, bf16 (N, pixels, C/32)
@@ -332,6 +341,7 @@ size_t bwd_scratch_bytes(int N) {
   b += (size_t)N * 144 * 256 * 4;
   b += (size_t)N * 126 * 126 * 32 * 2;
   b += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
+  b += (size_t)CS_CHANNELS * 512 * 4;
   return b + 4096;
 }
 
@@ -346,8 +356,26 @@ struct BCtx {
   int n;
   float slope;
   hipStream_t s;
+  ColsumQueue* q;
   void* F(int buf) const { return fws + L.off[buf]; }
   void* G(int buf) const { return gws + L.off[buf]; }
+  // out[c] (+)= sum_rows x[row][c], finished by flush_colsums()
+  int colsum(const void* x, long long rows, int C, float* out) const {
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int cw = C - c0 < 256 ? C - c0 : 256;
+      if (q->n >= UNCL_COLSUM_MAX_ITEMS || q->channels + cw > CS_CHANNELS) return UNCL_ERR_ARG;
+      const int rc = uncl_colsum_bf16_stage((const bf16_t*)x + c0, rows, cw, C, sc.cs + (size_t)q->channels * 512, out + c0,
+                                            b->accumulate, &q->it[q->n], s);
+      if (rc != UNCL_OK) return rc;
+      q->n += 1; q->channels += cw;
+    }
+    return UNCL_OK;
+  }
+  int flush_colsums() const {
+    const int rc = uncl_colsum_finish(q->it, q->n, s);
+    q->n = 0; q->channels = 0;
+    return rc;
+  }
   bool video() const { return b->carry_in != nullptr || b->carry_out != nullptr; }
   const void* cin(int slot) const { return b->carry_in ? (const char*)b->carry_in + carry_off(slot, n) : nullptr; }
   void* cout(int slot) const { return b->carry_out ? (char*)b->carry_out + carry_off(slot, n) : nullptr; }
@@ -379,7 +407,7 @@ int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const voi
   d.src0 = src ? src : c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
   int rc = uncl_conv_wgrad(&d, gy, c.b->gw[wi], c.s);
   if (rc != UNCL_OK) return rc;
-  return uncl_colsum_bf16(gy, (long long)c.n * oh * ow, cout, cout, c.b->gb[wi], c.b->accumulate, c.sc.misc, c.s);
+  return c.colsum(gy, (long long)c.n * oh * ow, cout, c.b->gb[wi]);
 }
 
 // data gradient of a 3x3 layer: gy (N,gh,gw,gc) -> out buffer (cout_d channels), pad_d = 2 - pad_fwd
@@ -400,7 +428,7 @@ int wgrad1(const BCtx& c, int wi, const void* x, int xc_total, int cin, const vo
   d.out_C = gy_total;  // leading dimension of gy
   int rc = uncl_conv_wgrad(&d, gy, gw, c.s);
   if (rc != UNCL_OK || !bias) return rc;
-  return uncl_colsum_bf16(gy, (long long)c.n * NODES, gy_total, gy_total, c.b->gb[wi], c.b->accumulate, c.sc.misc, c.s);
+  return c.colsum(gy, (long long)c.n * NODES, gy_total, c.b->gb[wi]);
 }
 int dgrad1(const BCtx& c, int wi, const void* gy, int cin_d, int cout_d, void* out, const void* res, int groups = 0) {
   uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, groups ? cin_d / groups : cin_d, groups ? cout_d / groups : cout_d);
@@ -439,7 +467,7 @@ int backward_all(const BCtx& c) {
       d.src0 = c.F(q.skip); d.src0_H = sh; d.src0_W = sw; d.src0_C = q.ch;
       d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
       RUN(uncl_conv_wgrad(&d, c.G(q.a), b->gw[q.wi + 1], c.s));
-      RUN(uncl_colsum_bf16(c.G(q.a), (long long)c.n * ah * aw, q.cout, q.cout, b->gb[q.wi + 1], b->accumulate, c.sc.misc, c.s));
+      RUN(c.colsum(c.G(q.a), (long long)c.n * ah * aw, q.cout, b->gb[q.wi + 1]));
     }
     RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
     RUN(uncl_ssr_backward(c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
@@ -449,7 +477,7 @@ int backward_all(const BCtx& c) {
     const void* x1m = c.mixed(slot);
     if (!x1m) return UNCL_ERR_LAUNCH;
     RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
-    RUN(uncl_colsum_bf16(c.G(q.up), (long long)c.n * uh * uw, q.ch, q.ch, b->gb[q.wi], b->accumulate, c.sc.misc, c.s));
+    RUN(c.colsum(c.G(q.up), (long long)c.n * uh * uw, q.ch, b->gb[q.wi]));
     // the ReLU derivative of the layer that produced x1 is applied by the dgrad kernel (single frames) or, for clips,
     // by the hand-off kernel after the head channels have been exchanged between frames
     const void* x1mask = i == 0 ? nullptr : c.F(q.x1);
@@ -476,7 +504,7 @@ int backward_all(const BCtx& c) {
   for (int g = 0; g < 4; ++g)  // grouped 1x1: four independent 128 -> 128 blocks
     RUN(wgrad1(c, W_GGC, (const bf16_t*)c.F(B_GMR) + g * 128, 512, 128, (const bf16_t*)c.sc.tC + g * 128, 512, 128,
                b->gw[W_GGC] + (size_t)g * 128 * 128, false));
-  RUN(uncl_colsum_bf16(c.sc.tC, (long long)c.n * NODES, 512, 512, b->gb[W_GGC], b->accumulate, c.sc.misc, c.s));
+  RUN(c.colsum(c.sc.tC, (long long)c.n * NODES, 512, b->gb[W_GGC]));
   RUN(dgrad1(c, W_GGC, c.sc.tC, 512, 512, c.sc.tD, nullptr, 4));
   if (hipMemsetAsync(c.sc.f32, 0, (size_t)c.n * per256 * 4, c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
   RUN(uncl_gcn_maxrel_backward(c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, c.sc.tB, c.n, NODES,
@@ -633,6 +661,11 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   c.sc.tD = p; p += (size_t)N * 144 * 512 * 2;
   c.sc.f32 = reinterpret_cast<float*>(p); p += (size_t)N * 144 * 256 * 4;
   c.sc.mix = p; p += (size_t)N * 126 * 126 * 32 * 2;
-  c.sc.misc = reinterpret_cast<float*>(p);
-  return backward_all(c);
+  c.sc.misc = reinterpret_cast<float*>(p); p += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
+  c.sc.cs = reinterpret_cast<float*>(p);
+  ColsumQueue q;
+  c.q = &q;
+  const int rc = backward_all(c);
+  const int rc2 = c.flush_colsums();
+  return rc != UNCL_OK ? rc : rc2;
 }

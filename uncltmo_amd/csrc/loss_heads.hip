@@ -128,6 +128,85 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const T* __restrict__ a, 
   }
 }
 
+// Backward-time form of pass 3 (uncl_nce_backward): 16-byte vectors, gradients in the feature dtype, the upstream scalar
+// read on the device.  p_row / q_row >= 0: the shared positive / negative IS that row of the anchor tensor (infoNCE2,
+// GanTrainerImg.py:398-402); its summed gradient is then folded into g_a's row in registers, so the feature tensor gets one
+// complete gradient in one pass (no slice-backward zero fill, no adds, no fp32 copy of a 134 MB tensor).
+template <typename T, typename GT>
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const T* __restrict__ a, const T* __restrict__ p, const T* __restrict__ q,
+                                                      size_t E, size_t p_stride, size_t q_stride, int N, float k, float c,
+                                                      float inv_hw, const float* __restrict__ gs, const float* __restrict__ upstream,
+                                                      GT* __restrict__ g_a, GT* __restrict__ g_p, GT* __restrict__ g_q, int p_row,
+                                                      int q_row) {
+  constexpr int V = Elem<T>::EPV;
+  using vec = typename Elem<T>::vec;
+  const float up = (upstream ? upstream[0] : 1.f) * inv_hw;
+  auto store = [&](GT* dst, const float* f) {
+    if constexpr (sizeof(GT) == sizeof(T)) {
+      *reinterpret_cast<vec*>(dst) = Elem<T>::pack(f);
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) dst[i] = (GT)f[i];
+    }
+  };
+  for (size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; e < E; e += (size_t)gridDim.x * 256 * V) {
+    float accp[V], accq[V], hold_p[V], hold_q[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) accp[i] = accq[i] = hold_p[i] = hold_q[i] = 0.f;
+    float pv[V], qv[V];
+    if (p_stride == 0) Elem<T>::unpack(*reinterpret_cast<const vec*>(p + e), pv);
+    if (q_stride == 0) Elem<T>::unpack(*reinterpret_cast<const vec*>(q + e), qv);
+    for (int n = 0; n < N; ++n) {
+      float av[V], ga[V], gpp[V], gqq[V];
+      Elem<T>::unpack(*reinterpret_cast<const vec*>(a + (size_t)n * E + e), av);
+      if (p_stride != 0) Elem<T>::unpack(*reinterpret_cast<const vec*>(p + (size_t)n * p_stride + e), pv);
+      if (q_stride != 0) Elem<T>::unpack(*reinterpret_cast<const vec*>(q + (size_t)n * q_stride + e), qv);
+      const float gp = gs[2 * n] * up, gq = gs[2 * n + 1] * up;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float dp = av[i] - pv[i], dq = av[i] - qv[i];
+        const float ip = 1.f / (c + k * fabsf(dp)), iq = 1.f / (c + k * fabsf(dq));
+        const float sgp = dp > 0.f ? 1.f : (dp < 0.f ? -1.f : 0.f), sgq = dq > 0.f ? 1.f : (dq < 0.f ? -1.f : 0.f);
+        const float tp = av[i] * pv[i] * k * sgp * ip * ip, tq = av[i] * qv[i] * k * sgq * iq * iq;
+        ga[i] = gp * (pv[i] * ip - tp) + gq * (qv[i] * iq - tq);
+        gpp[i] = gp * (av[i] * ip + tp);
+        gqq[i] = gq * (av[i] * iq + tq);
+        accp[i] += gpp[i];
+        accq[i] += gqq[i];
+      }
+      if (n == p_row || n == q_row) {       // finished after the loop, when the shared rows' sums are known
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          if (n == p_row) hold_p[i] = ga[i];
+          if (n == q_row) hold_q[i] = ga[i];
+        }
+      } else if (g_a) {
+        store(g_a + (size_t)n * E + e, ga);
+      }
+      if (p_stride != 0 && g_p) store(g_p + (size_t)n * E + e, gpp);
+      if (q_stride != 0 && g_q) store(g_q + (size_t)n * E + e, gqq);
+    }
+    if (p_row >= 0 && p_row == q_row) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) hold_p[i] += accp[i] + accq[i];
+      if (g_a) store(g_a + (size_t)p_row * E + e, hold_p);
+    } else {
+      if (p_row >= 0 && g_a) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) hold_p[i] += accp[i];
+        store(g_a + (size_t)p_row * E + e, hold_p);
+      }
+      if (q_row >= 0 && g_a) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) hold_q[i] += accq[i];
+        store(g_a + (size_t)q_row * E + e, hold_q);
+      }
+    }
+    if (p_stride == 0 && p_row < 0 && g_p) store(g_p + e, accp);
+    if (q_stride == 0 && q_row < 0 && g_q) store(g_q + e, accq);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // L1 between two per-sample scalars: L = w * mean_n |a_n - b_n| ; g_a = w sign / N
 // ------------------------------------------------------------------------------------------------------
@@ -468,6 +547,40 @@ extern "C" int uncl_nce_loss(const void* anchor, const void* pos, const void* ne
   } else {
     return UNCL_ERR_ARG;
   }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// Gradients of uncl_nce_loss at backward time: `workspace` is the one the forward call filled (it holds d loss / d s per
+// sample for w = the forward's w), `upstream` an optional device scalar multiplied in.  grad_dtype = dtype (gradients in the
+// feature type) or UNCL_F32.  pos_row / neg_row >= 0 (with pos_shared / neg_shared): the shared row is that row of `anchor`
+// and its gradient is folded into g_anchor (g_pos / g_neg must then be NULL); -1 otherwise.
+extern "C" int uncl_nce_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw,
+                                 int pos_shared, int neg_shared, float k, float c, const void* workspace, const float* upstream,
+                                 void* g_anchor, void* g_pos, void* g_neg, int grad_dtype, int pos_row, int neg_row, void* stream) {
+  if (!anchor || !pos || !neg || !workspace || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+  if (dtype != UNCL_F32 && dtype != UNCL_BF16) return UNCL_ERR_ARG;
+  if (grad_dtype != dtype && grad_dtype != UNCL_F32) return UNCL_ERR_ARG;
+  const int V = dtype == UNCL_BF16 ? 8 : 4;
+  if (E % V != 0) return UNCL_ERR_ARG;
+  for (const void* ptr : {anchor, pos, neg, (const void*)g_anchor, (const void*)g_pos, (const void*)g_neg})
+    if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15)) return UNCL_ERR_ARG;
+  if (pos_row >= 0 && (!pos_shared || g_pos || pos_row >= N)) return UNCL_ERR_ARG;
+  if (neg_row >= 0 && (!neg_shared || g_neg || neg_row >= N)) return UNCL_ERR_ARG;
+  if (pos_row < -1 || neg_row < -1) return UNCL_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float* gs = reinterpret_cast<const float*>(workspace) + (size_t)N * 256 * 2;
+  const size_t ps = pos_shared ? 0 : (size_t)E, qs = neg_shared ? 0 : (size_t)E;
+  const size_t nv = (size_t)E / V;
+  const int blocks = (int)((nv + 255) / 256 < 8192 ? (nv + 255) / 256 : 8192);
+  const float inv_hw = 1.f / (float)hw;
+#define UNCL_NCE_BWD(T, GT)                                                                                                   \
+  hipLaunchKernelGGL((nce_bwd_kernel<T, GT>), dim3(blocks), dim3(256), 0, st, (const T*)anchor, (const T*)pos, (const T*)neg, \
+                     (size_t)E, ps, qs, N, k, c, inv_hw, gs, upstream, (GT*)g_anchor, (GT*)g_pos, (GT*)g_neg, pos_row, neg_row)
+  if (dtype == UNCL_F32) UNCL_NCE_BWD(float, float);
+  else if (grad_dtype == UNCL_BF16) UNCL_NCE_BWD(bf16_t, bf16_t);
+  else UNCL_NCE_BWD(bf16_t, float);
+#undef UNCL_NCE_BWD
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

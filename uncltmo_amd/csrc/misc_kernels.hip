@@ -37,6 +37,45 @@ extern "C" int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int
   return UNCL_OK;
 }
 
+// every weight of a network in one launch (grid.y = item): a training step re-packs 50+ tensors after each optimiser step
+struct PackBatch {
+  uncl_pack_item it[UNCL_PACK_MAX_ITEMS];
+};
+template <typename T>
+__global__ void pack_weight_batch_kernel(const PackBatch t) {
+  const uncl_pack_item& e = t.it[blockIdx.y];
+  const int kk = e.k * e.k, Cin = e.Cin, Cout = e.Cout;
+  const size_t total = (size_t)kk * Cout * Cin;
+  T* dst = reinterpret_cast<T*>(e.dst);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int tap = (int)(i / ((size_t)Cin * Cout));
+    const int ts = e.flip ? (kk - 1 - tap) : tap;
+    const size_t s = e.transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
+    dst[i] = (T)e.src[s];
+  }
+}
+
+extern "C" int uncl_pack_conv_weights(const uncl_pack_item* items, int n_items, int dtype, void* stream) {
+  if (n_items == 0) return UNCL_OK;
+  if (!items || n_items < 0 || (dtype != UNCL_BF16 && dtype != UNCL_F32)) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int i0 = 0; i0 < n_items; i0 += UNCL_PACK_MAX_ITEMS) {
+    const int n = n_items - i0 < UNCL_PACK_MAX_ITEMS ? n_items - i0 : UNCL_PACK_MAX_ITEMS;
+    PackBatch t = {};
+    for (int i = 0; i < n; ++i) {
+      const uncl_pack_item& e = items[i0 + i];
+      if (!e.src || !e.dst || e.Cout <= 0 || e.Cin <= 0 || e.k <= 0) return UNCL_ERR_ARG;
+      t.it[i] = e;
+    }
+    if (dtype == UNCL_BF16) hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, s, t);
+    else hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(96, n), dim3(256), 0, s, t);
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // first layer: Conv2d(1 -> Cout, 3x3 valid) + bias + act.  One thread = two vertically adjacent output pixels x 8 output
 // channels: the 8 weights of a tap are two 16-byte LDS reads shared by both pixels (8 FMAs per LDS read instead of 1),

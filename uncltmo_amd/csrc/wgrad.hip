@@ -275,6 +275,36 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+// the same reduction for up to UNCL_COLSUM_MAX_ITEMS staged column sums in ONE launch (grid.y = item): a backward pass ends
+// with one of these instead of a dependent 16 us launch after every layer
+struct ColsumBatch {
+  uncl_colsum_item it[UNCL_COLSUM_MAX_ITEMS];
+};
+__global__ __launch_bounds__(256) void colsum_final_batch_kernel(const ColsumBatch t) {
+  const uncl_colsum_item& e = t.it[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= e.C) return;
+  __shared__ double red[8][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0;
+  if (c < e.C) {
+    int b = rg;
+    for (; b + 24 < e.blocks; b += 32) {      // four loads in flight, summed in the order of the one-at-a-time loop
+      const float v0 = e.partial[(size_t)b * e.C + c], v1 = e.partial[(size_t)(b + 8) * e.C + c];
+      const float v2 = e.partial[(size_t)(b + 16) * e.C + c], v3 = e.partial[(size_t)(b + 24) * e.C + c];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; b < e.blocks; b += 8) s += (double)e.partial[(size_t)b * e.C + c];
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < e.C) {
+    double tt = 0.0;
+    for (int i = 0; i < 8; ++i) tt += red[i][cl];
+    e.out[c] = e.accumulate ? e.out[c] + (float)tt : (float)tt;
+  }
+}
+
 // packed fp32 [tap][Cout][Cin] gradient -> reference-layout fp32 gradient (inverse of uncl_pack_conv_weight)
 __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int kk,
                                     int transposed, int flip, int accumulate) {
@@ -365,6 +395,34 @@ extern "C" int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, fl
     hipLaunchKernelGGL(colsum_final_kernel, dim3((cw + 31) / 32), dim3(256), 0, s, (const float*)workspace, blocks, cw, out + c0,
                        accumulate);
   }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// Two-call form for a whole backward pass: stage 1 per layer into its own partial buffer (512*C floats, C <= 256), then one
+// uncl_colsum_finish over all staged items.  Same arithmetic and summation order as uncl_colsum_bf16.
+extern "C" int uncl_colsum_bf16_stage(const void* x, long long rows, int C, int ld, float* partial, float* out, int accumulate,
+                                      uncl_colsum_item* item, void* stream) {
+  if (!x || !out || !partial || !item || rows <= 0 || C < 8 || C > 256 || C % 8 != 0 || ld < C || 256 % (C / 8) != 0)
+    return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = 256 / (C / 8);
+  const int blocks = (int)((rows + rpb - 1) / rpb < 512 ? (rows + rpb - 1) / rpb : 512);
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, partial, (size_t)rows, C, ld);
+  UNCL_CHECK_LAUNCH();
+  item->partial = partial; item->blocks = blocks; item->C = C; item->out = out; item->accumulate = accumulate;
+  return UNCL_OK;
+}
+
+extern "C" int uncl_colsum_finish(const uncl_colsum_item* items, int n_items, void* stream) {
+  if (n_items == 0) return UNCL_OK;
+  if (!items || n_items < 0 || n_items > UNCL_COLSUM_MAX_ITEMS) return UNCL_ERR_ARG;
+  ColsumBatch t = {};
+  for (int i = 0; i < n_items; ++i) {
+    if (!items[i].partial || !items[i].out || items[i].C <= 0 || items[i].C > 256 || items[i].blocks <= 0) return UNCL_ERR_ARG;
+    t.it[i] = items[i];
+  }
+  hipLaunchKernelGGL(colsum_final_batch_kernel, dim3(8, n_items), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

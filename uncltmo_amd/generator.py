@@ -162,46 +162,58 @@ class _GeneratorBase(nn.Module):
             return t.data_ptr()
 
         gw.inc0_w, gw.inc0_b = f32("inc.conv.conv.weight"), f32("inc.conv.conv.bias")
+        # every re-layout of the step goes into one flat buffer through one batched launch (uncl_pack_conv_weights):
+        # jobs = (source fp32 tensor, offset in elements, Cout, Cin, k, transposed, flip)
+        jobs, fwd_off, wd_off = [], [], []
+        total = 0
+
+        def job(src, numel, co, ci, kk, tr, fl):
+            nonlocal total
+            src = src.contiguous()
+            keep.append(src)
+            jobs.append((src, total, co, ci, kk, tr, fl))
+            off = total
+            total += (numel + 127) & ~127          # 256-byte aligned slices
+            return off
+
         for i in range(_hip.G_NUM_WEIGHTS):
             name = lib.uncl_gen_layer_name(i).decode()
             shape, kind = spec[name + ".weight"]
             transposed = kind == "convT"
             k = shape[2]
             cout, cin = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
-            src = sd[name + ".weight"].detach().float().contiguous()
-            dst = torch.empty(k * k * cout * cin, dtype=tdt, device=dev)
-            flip = 1 if (transposed and k == 3) else 0
-            _hip.check(lib.uncl_pack_conv_weight(src.data_ptr(), dst.data_ptr(), code, cout, cin, k, int(transposed),
-                                                 flip, st), "uncl_pack_conv_weight(%s)" % name)
-            keep += [src, dst]
-            gw.w[i] = dst.data_ptr()
+            src = sd[name + ".weight"].detach().float()
+            fwd_off.append(job(src, src.numel(), cout, cin, k, int(transposed), 1 if (transposed and k == 3) else 0))
             gw.b[i] = f32(name + ".bias")
         # weights re-packed for the data-gradient convolutions (bf16 training path only)
-        wd = []
         if code == _hip.BF16:
             for i in range(_hip.G_NUM_WEIGHTS):
                 name = lib.uncl_gen_layer_name(i).decode()
                 shape, kind = spec[name + ".weight"]
                 src = sd[name + ".weight"].detach().float().contiguous()
                 k = shape[2]
-                dst = torch.empty(src.numel(), dtype=tdt, device=dev)
                 if kind == "convT" and k == 3:      # dgrad = valid conv with the weight read as a Conv2d weight
-                    args = [(src, dst, shape[0], shape[1], 3, 0, 0)]
+                    wd_off.append(job(src, src.numel(), shape[0], shape[1], 3, 0, 0))
                 elif kind == "convT":                # 2x2 stride 2: [4][Cin][Cout]
-                    args = [(src, dst, shape[0], shape[1], 2, 0, 0)]
+                    wd_off.append(job(src, src.numel(), shape[0], shape[1], 2, 0, 0))
                 elif name.endswith("graph_conv.gconv.nn.0"):   # grouped 1x1: transpose every 128x128 block
                     g, blk = 4, shape[1]
-                    args = [(src[j * blk:(j + 1) * blk], dst[j * blk * blk:(j + 1) * blk * blk], blk, blk, 1, 1, 0)
-                            for j in range(g)]
+                    offs = [job(src[j * blk:(j + 1) * blk], blk * blk, blk, blk, 1, 1, 0) for j in range(g)]
+                    assert all(offs[j] == offs[0] + j * blk * blk for j in range(g))    # blk*blk is a multiple of 128
+                    wd_off.append(offs[0])
                 else:                                # Conv2d (Cout,Cin,k,k): read as a ConvTranspose2d weight, flipped for 3x3
-                    args = [(src, dst, shape[1], shape[0], k, 1, 1 if k == 3 else 0)]
-                for (a_src, a_dst, co, ci, kk, tr, fl) in args:
-                    a_src = a_src.contiguous()
-                    keep.append(a_src)
-                    _hip.check(lib.uncl_pack_conv_weight(a_src.data_ptr(), a_dst.data_ptr(), code, co, ci, kk, tr, fl, st),
-                               "uncl_pack_conv_weight(dgrad %s)" % name)
-                keep += [src, dst]
-                wd.append(dst)
+                    wd_off.append(job(src, src.numel(), shape[1], shape[0], k, 1, 1 if k == 3 else 0))
+        flat = torch.empty(total, dtype=tdt, device=dev)
+        keep.append(flat)
+        esz = flat.element_size()
+        items = (_hip.PackItem * len(jobs))()
+        for it, (src, off, co, ci, kk, tr, fl) in zip(items, jobs):
+            it.src, it.dst = src.data_ptr(), flat.data_ptr() + off * esz
+            it.Cout, it.Cin, it.k, it.transposed, it.flip = co, ci, kk, tr, fl
+        _hip.check(lib.uncl_pack_conv_weights(items, len(jobs), code, st), "uncl_pack_conv_weights")
+        for i in range(_hip.G_NUM_WEIGHTS):
+            gw.w[i] = flat.data_ptr() + fwd_off[i] * esz
+        wd = [flat[o:] for o in wd_off]            # views: .data_ptr() is the packed data-gradient weight
         self._wd = wd
         pe = sd["gcn.pos_embed"].detach().reshape(256, 144).t().contiguous().to(tdt)    # (144,256) NHWC
         keep.append(pe)

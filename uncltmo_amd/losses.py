@@ -34,44 +34,115 @@ def contrastive_D_loss(real_logits, fake_logits):
     return _CganFn.apply(real_logits, fake_logits)
 
 
+def _dense(t):
+    """A view of `t` whose memory is one dense block (the NCE sums run over all elements of a sample, so any common layout
+    of anchor / positive / negative will do) and the permutation that maps a gradient in that layout back to t's axes."""
+    if t.is_contiguous():
+        return t, None
+    if t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous():          # channel-last features (the generator's up_x)
+        return t.permute(0, 2, 3, 1), (0, 3, 1, 2)
+    return t.contiguous(), None
+
+
+def _row_of(row, whole):
+    """index i if `row` (leading dim 1) is whole[i:i+1] viewing the same memory, else -1"""
+    if row.shape[0] != 1 or row.shape[1:] != whole.shape[1:] or row.stride()[1:] != whole.stride()[1:]:
+        return -1
+    if row.untyped_storage().data_ptr() != whole.untyped_storage().data_ptr() or whole.stride(0) == 0:
+        return -1
+    off = row.storage_offset() - whole.storage_offset()
+    if off < 0 or off % whole.stride(0) != 0 or off // whole.stride(0) >= whole.shape[0]:
+        return -1
+    return off // whole.stride(0)
+
+
 class _NceFn(torch.autograd.Function):
-    """anchor / pos / neg: same shape (N, ...) contiguous in ANY common layout; `hw` = spatial positions averaged."""
+    """anchor / pos / neg: same shape (N, ...) in ANY common layout; `hw` = spatial positions averaged.  The loss is computed
+    in forward, the gradients in backward (uncl_nce_backward) in the feature dtype and layout, scaled by the upstream
+    gradient on the device.  pos_row / neg_row >= 0: positive / negative are that row of the anchor tensor itself
+    (infoNCE2): they are then not separate autograd inputs and the anchor receives the complete gradient."""
 
     @staticmethod
-    def forward(ctx, anchor, pos, neg, hw, k, c, pos_shared, neg_shared):
+    def forward(ctx, anchor, pos, neg, hw, k, c, pos_shared, neg_shared, pos_row, neg_row):
         lib = _hip.lib()
         n = anchor.shape[0]
         E = anchor.numel() // n
         code = _hip.BF16 if anchor.dtype == torch.bfloat16 else _hip.F32
-        a, p, q = anchor.detach().contiguous(), pos.detach().contiguous(), neg.detach().contiguous()
+        a, perm = _dense(anchor.detach())
+        if perm is None:
+            p, q = pos.detach().contiguous(), neg.detach().contiguous()
+        else:
+            back = [perm.index(i) for i in range(4)]
+            p, q = pos.detach().permute(*back).contiguous(), neg.detach().permute(*back).contiguous()
         dev = a.device
         ws = torch.empty(lib.uncl_nce_workspace_bytes(n), dtype=torch.uint8, device=dev)
         loss = _scalar(dev)
         need = ctx.needs_input_grad
-        ga = torch.empty(a.shape, dtype=torch.float32, device=dev) if need[0] else None
-        gp = torch.empty(p.shape, dtype=torch.float32, device=dev) if need[1] else None
-        gq = torch.empty(q.shape, dtype=torch.float32, device=dev) if need[2] else None
+        vec = 8 if code == _hip.BF16 else 4
+        aligned = all(t.data_ptr() % 16 == 0 for t in (a, p, q))
+        ctx.deferred = E % vec == 0 and aligned
+        if pos_row >= 0 or neg_row >= 0:
+            if not ctx.deferred:
+                raise ValueError("uncltmo_amd: row-shared NCE needs 16-byte aligned rows")
+            if pos_row >= 0:
+                p = a[pos_row:pos_row + 1]
+            if neg_row >= 0:
+                q = a[neg_row:neg_row + 1]
+        ga = gp = gq = None
+        if not ctx.deferred:      # odd sizes (the discriminator's two-element features): fp32 gradients from the fused call
+            ga = torch.empty(a.shape, dtype=torch.float32, device=dev) if need[0] else None
+            gp = torch.empty(p.shape, dtype=torch.float32, device=dev) if need[1] else None
+            gq = torch.empty(q.shape, dtype=torch.float32, device=dev) if need[2] else None
         P = lambda t: t.data_ptr() if t is not None else None
         _hip.check(lib.uncl_nce_loss(a.data_ptr(), p.data_ptr(), q.data_ptr(), code, n, E, hw, int(pos_shared), int(neg_shared),
                                      float(k), float(c), 1.0, loss.data_ptr(), P(ga), P(gp), P(gq), 0, 0, ws.data_ptr(),
                                      _hip.stream_ptr()), "uncl_nce_loss")
         ctx.g = (ga, gp, gq)
         ctx.dt = (anchor.dtype, pos.dtype, neg.dtype)
+        ctx.saved = (a, p, q, ws, perm)
+        ctx.args = (code, n, E, hw, int(pos_shared), int(neg_shared), float(k), float(c), int(pos_row), int(neg_row))
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        out = [None if t is None else (t * g).to(dt) for t, dt in zip(ctx.g, ctx.dt)]
-        return out[0], out[1], out[2], None, None, None, None, None
+        if not ctx.deferred:
+            out = [None if t is None else (t * g).to(dt) for t, dt in zip(ctx.g, ctx.dt)]
+            return (out[0], out[1], out[2]) + (None,) * 7
+        lib = _hip.lib()
+        a, p, q, ws, perm = ctx.saved
+        code, n, E, hw, ps, qs, k, c, pos_row, neg_row = ctx.args
+        need = ctx.needs_input_grad
+        gs = g.detach().float().reshape(1).contiguous()
+        ga = torch.empty_like(a) if need[0] else None
+        gp = torch.empty_like(p) if need[1] and pos_row < 0 else None
+        gq = torch.empty_like(q) if need[2] and neg_row < 0 else None
+        P = lambda t: t.data_ptr() if t is not None else None
+        _hip.check(lib.uncl_nce_backward(a.data_ptr(), p.data_ptr(), q.data_ptr(), code, n, E, hw, ps, qs, k, c, ws.data_ptr(),
+                                         gs.data_ptr(), P(ga), P(gp), P(gq), code, pos_row, neg_row, _hip.stream_ptr()),
+                   "uncl_nce_backward")
+        if perm is not None:
+            ga, gp, gq = [None if t is None else t.permute(*perm) for t in (ga, gp, gq)]
+        return (ga, gp, gq) + (None,) * 7
 
 
 def nce(anchor, positive, negative, k, c, hw=None):
     """2-way InfoNCE with s(a,b) = mean_hw sum_c a b / (c + k|a-b|).  Tensors are (N,C,H,W)-shaped (any memory layout
-    shared by the three); `positive` / `negative` may have a leading dim of 1 (one row shared by all samples)."""
+    shared by the three); `positive` / `negative` may have a leading dim of 1 (one row shared by all samples), and may be
+    rows of `anchor` itself (infoNCE2, GanTrainerImg.py:398-402): the anchor then gets their gradient as well."""
     if hw is None:
         hw = anchor.shape[-1] * anchor.shape[-2]
-    return _NceFn.apply(anchor, positive, negative, hw, k, c, positive.shape[0] == 1 and anchor.shape[0] != 1,
-                        negative.shape[0] == 1 and anchor.shape[0] != 1)
+    n = anchor.shape[0]
+    pos_shared = positive.shape[0] == 1 and n != 1
+    neg_shared = negative.shape[0] == 1 and n != 1
+    E = anchor.numel() // n
+    vec_ok = E % (8 if anchor.dtype == torch.bfloat16 else 4) == 0 and _dense(anchor.detach())[0].data_ptr() % 16 == 0 and \
+        (E * anchor.element_size()) % 16 == 0
+    pos_row = _row_of(positive, anchor) if (pos_shared and vec_ok and positive.requires_grad == anchor.requires_grad) else -1
+    neg_row = _row_of(negative, anchor) if (neg_shared and vec_ok and negative.requires_grad == anchor.requires_grad) else -1
+    # a row of the anchor is passed as a detached tensor: its gradient is folded into the anchor's inside the kernel
+    pos_in = positive.detach() if pos_row >= 0 else positive
+    neg_in = negative.detach() if neg_row >= 0 else negative
+    return _NceFn.apply(anchor, pos_in, neg_in, hw, k, c, pos_shared, neg_shared, pos_row, neg_row)
 
 
 class _FrameStatsFn(torch.autograd.Function):
