@@ -40,6 +40,8 @@ extern "C" {
 #define UNCL_ACT_TANH 5
 #define UNCL_ACT_MSIG 6  /* 1 / (1 + exp(-3 x)): the reference's "msig" last layer (models/Blocks.py:85-91)  */
 
+#define UNCL_PACK_MAX_ITEMS 64 /* items per launch of the batched weight re-layouts (uncl_pack_conv_weights, uncl_unpack_conv_wgrads) */
+
 /* input-side fusions of the implicit-GEMM convolution (what the loader synthesises while staging LDS) */
 #define UNCL_SRC_PLAIN 0      /* x = src0                                                                  */
 #define UNCL_SRC_MAXPOOL2 1   /* x = maxpool2x2(src0), floor            (unet_parts.py:212,233)           */
@@ -129,6 +131,13 @@ int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* dw_packed, v
 /* packed fp32 gradient -> reference layout (inverse of uncl_pack_conv_weight), written or accumulated */
 int uncl_unpack_conv_wgrad(const float* packed, float* dst, int Cout, int Cin, int k, int transposed, int flip,
                            int accumulate, void* stream);
+/* the same for many tensors in one launch per UNCL_PACK_MAX_ITEMS items (end of a generator backward pass) */
+typedef struct uncl_unpack_item {
+  const float* packed;
+  float* dst;
+  int Cout, Cin, k, transposed, flip, accumulate;
+} uncl_unpack_item;
+int uncl_unpack_conv_wgrads(const uncl_unpack_item* items, int n_items, void* stream);
 /* bias gradient: out[c] (+)= sum_rows x[row][c], x bf16 [rows][ld]; workspace uncl_colsum_workspace_bytes(C) */
 size_t uncl_colsum_workspace_bytes(int C);
 int uncl_colsum_bf16(const void* x, long long rows, int C, int ld, float* out, int accumulate, void* workspace, void* stream);
@@ -189,7 +198,6 @@ int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int Cout, int 
                           int flip, void* stream);
 /* The same re-layout for many weights in one launch per UNCL_PACK_MAX_ITEMS items (a training step re-packs every weight
  * of the generator, forward and data-gradient forms, after each optimiser step). */
-#define UNCL_PACK_MAX_ITEMS 64
 typedef struct uncl_pack_item {
   const float* src;
   void* dst;

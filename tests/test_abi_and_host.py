@@ -41,9 +41,9 @@ def test_ctypes_mirror_covers_the_header():
 def test_struct_layouts_match_the_c_side():
     """sizeof() of the ctypes mirrors must equal the C structs (compiled here with the host compiler)."""
     from uncltmo_amd import _hip
-    code = '#include <stdio.h>\n#include "uncltmo_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(uncl_conv_desc), ' \
+    code = '#include <stdio.h>\n#include "uncltmo_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(uncl_conv_desc), ' \
            'sizeof(uncl_gen_weights), sizeof(uncl_gen_run), sizeof(uncl_gen_bwd), sizeof(uncl_colsum_item), ' \
-           'sizeof(uncl_pack_item));return 0;}\n'
+           'sizeof(uncl_pack_item), sizeof(uncl_unpack_item));return 0;}\n'
     src = os.path.join(ROOT, "build", "abi_sizes.c")
     os.makedirs(os.path.dirname(src), exist_ok=True)
     open(src, "w").write(code)
@@ -51,7 +51,8 @@ def test_struct_layouts_match_the_c_side():
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
     sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(_hip.ConvDesc), ctypes.sizeof(_hip.GenWeights), ctypes.sizeof(_hip.GenRun),
-                     ctypes.sizeof(_hip.GenBwd), ctypes.sizeof(_hip.ColsumItem), ctypes.sizeof(_hip.PackItem)]
+                     ctypes.sizeof(_hip.GenBwd), ctypes.sizeof(_hip.ColsumItem), ctypes.sizeof(_hip.PackItem),
+                     ctypes.sizeof(_hip.UnpackItem)]
 
 
 def test_state_dict_contract_and_no_cpu_fallback():

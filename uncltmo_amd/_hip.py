@@ -81,6 +81,11 @@ class ColsumItem(C.Structure):
                 ("reserved", C.c_int)]
 
 
+class UnpackItem(C.Structure):
+    _fields_ = [("packed", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("k", C.c_int),
+                ("transposed", C.c_int), ("flip", C.c_int), ("accumulate", C.c_int)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("k", C.c_int),
                 ("transposed", C.c_int), ("flip", C.c_int), ("reserved", C.c_int)]
@@ -99,6 +104,7 @@ SIGNATURES = {
     "uncl_colsum_bf16_stage": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.POINTER(ColsumItem), C.c_void_p]),
     "uncl_colsum_finish": (C.c_int, [C.POINTER(ColsumItem), C.c_int, C.c_void_p]),
+    "uncl_unpack_conv_wgrads": (C.c_int, [C.POINTER(UnpackItem), C.c_int, C.c_void_p]),
     "uncl_pack_conv_weights": (C.c_int, [C.POINTER(PackItem), C.c_int, C.c_int, C.c_void_p]),
     "uncl_colsum_workspace_bytes": (C.c_size_t, [C.c_int]),
     "uncl_colsum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

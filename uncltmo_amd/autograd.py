@@ -64,17 +64,22 @@ class _GradSet:
                  "outc.conv.weight": self.g_oc_w.reshape(1, 32, 1, 1), "outc.conv.bias": self.g_oc_b,
                  "gcn.pos_embed": self.g_pe.t().reshape(1, 256, 12, 12).contiguous()}
         off = 0
+        items = (_hip.UnpackItem * len(self.names))()
+        flat = torch.empty(sum(self.sizes), dtype=torch.float32, device=self.dev)      # one allocation, one launch
         for i, nm in enumerate(self.names):
             shape, kind = self.spec[nm + ".weight"]
             transposed = kind == "convT"
             k = shape[2]
             cout, cin = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
-            dst = torch.empty(shape, dtype=torch.float32, device=self.dev)
-            _hip.check(lib.uncl_unpack_conv_wgrad(self.gw_flat.data_ptr() + off * 4, dst.data_ptr(), cout, cin, k, int(transposed),
-                                                  1 if (transposed and k == 3) else 0, 0, st), "uncl_unpack_conv_wgrad")
+            dst = flat[off:off + self.sizes[i]].view(shape)
+            it = items[i]
+            it.packed, it.dst = self.gw_flat.data_ptr() + off * 4, dst.data_ptr()
+            it.Cout, it.Cin, it.k, it.transposed, it.flip, it.accumulate = cout, cin, k, int(transposed), \
+                (1 if (transposed and k == 3) else 0), 0
             grads[nm + ".weight"] = dst
             grads[nm + ".bias"] = self.gb[i]
             off += self.sizes[i]
+        _hip.check(lib.uncl_unpack_conv_wgrads(items, len(self.names), st), "uncl_unpack_conv_wgrads")
         return grads
 
 

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
   float* sR = reinterpret_cast<float*>(smem);  // [KS][32][32] cross-wave reduction (after the loop)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ty = blockIdx.y;                              // vertical tap handled by this workgroup
+  // KS == 3: blockIdx.y = vertical tap; KS == 1 on the 2x2 stride-2 transposed conv: blockIdx.y = its tap (dy, dx)
+  const int ty = KS == 3 ? (int)blockIdx.y : 0;
+  const int up_tap = (KS == 1 && a.up_tap >= 0) ? (int)blockIdx.y : -1;
   const int kc = blockIdx.z % a.nci, cc = blockIdx.z / a.nci;  // input / output channel chunk
   int tile = (int)blockIdx.x * a.tiles_per_wg;
   const int tile_end = min(tile + a.tiles_per_wg, a.total_tiles);
@@ -113,12 +115,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
       bool ok = gy_ < a.Hout && gx_ < a.Wout;
       if (KS == 1) ok = ok && ((long long)gy_ * 32 + gx_ < a.M);
       size_t off = ok ? ((size_t)n * a.Hout * a.Wout + (size_t)gy_ * a.Wout + gx_) * a.gy_ld : 0;
-      if (KS == 1 && a.up_tap >= 0 && ok) {
+      if (KS == 1 && up_tap >= 0 && ok) {
         const long long m = (long long)gy_ * 32 + gx_;
         const int hw = a.upH * a.upW;
         const int nn = (int)(m / hw), rem = (int)(m - (long long)nn * hw);
         const int yy = rem / a.upW, xx = rem - yy * a.upW;
-        off = (((size_t)nn * 2 * a.upH + 2 * yy + (a.up_tap >> 1)) * (2 * a.upW) + 2 * xx + (a.up_tap & 1)) * a.gy_ld;
+        off = (((size_t)nn * 2 * a.upH + 2 * yy + (up_tap >> 1)) * (2 * a.upW) + 2 * xx + (up_tap & 1)) * a.gy_ld;
       }
       vec v = ld16g(a.gy + off + cc * 32 + ch * 8);
       if (!ok) v = E::zero();
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
   __syncthreads();
   for (int i = tid; i < KS * 1024; i += 256) {
     const int tx = i >> 10, co = (i >> 5) & 31, ci = i & 31;
-    const int tap = KS == 3 ? ty * 3 + tx : 0;
+    const int tap = KS == 3 ? ty * 3 + tx : (up_tap >= 0 ? up_tap : 0);
     atomicAdd(a.dw + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
   }
 }
@@ -222,12 +224,13 @@ int launch_wg(WgArgs& a, hipStream_t s) {
   // one persistent workgroup per resident slot (2 per CU x 256 CUs): every workgroup ends with a cross-wave reduction and
   // 1024 * KS float atomics, so oversubscribing the CUs only multiplies that tail (measured on the training step: 2048
   // workgroups 4.7 ms of weight gradients, 512 workgroups 3.4 ms, 128 workgroups 6.8 ms)
-  int groups = 512 / (KS * pairs);
+  const int gy_ = (KS == 1 && a.up_tap >= 0) ? 4 : KS;       // grid.y: vertical taps, or the four taps of the 2x2 kernel
+  int groups = 512 / (gy_ * pairs);
   if (groups < 1) groups = 1;
   if (groups > a.total_tiles) groups = a.total_tiles;
   a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
   groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-  hipLaunchKernelGGL(kern, dim3(groups, KS, pairs), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(groups, gy_, pairs), dim3(256), lds, s, a);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
@@ -317,6 +320,21 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+struct UnpackBatch {
+  uncl_unpack_item it[UNCL_PACK_MAX_ITEMS];
+};
+__global__ void unpack_wgrad_batch_kernel(const UnpackBatch t) {
+  const uncl_unpack_item& e = t.it[blockIdx.y];
+  const int kk = e.k * e.k, Cin = e.Cin, Cout = e.Cout;
+  const size_t total = (size_t)kk * Cout * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((size_t)Cin * Cout));
+    const int ts = e.flip ? (kk - 1 - tap) : tap;
+    const size_t d = e.transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
+    e.dst[d] = e.accumulate ? e.dst[d] + e.packed[i] : e.packed[i];
+  }
+}
+
 }  // namespace
 
 // dw_packed must be zeroed by the caller (it is accumulated with atomics).  Descriptor fields used: ksize (3 or 1),
@@ -363,19 +381,34 @@ extern "C" int uncl_upconv2x2_wgrad(const void* x, const void* gy, float* dw_pac
   const long long M = (long long)N * H * W;
   if (M > 0x7fffffffLL) return UNCL_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  for (int tap = 0; tap < 4; ++tap) {
-    WgArgs a;
-    a.src0 = (const bf16_t*)x; a.src1 = nullptr; a.gy = (const bf16_t*)gy; a.dw = dw_packed + (size_t)tap * Cout * C;
-    a.Cin = C; a.Cout = Cout; a.pad = 0; a.ks = 1;
-    a.s0C = C; a.s1H = a.s1W = a.s1C = 0;
-    const int rows = (int)((M + 31) / 32);
-    a.H = rows; a.W = 32; a.s0H = rows; a.s0W = 32; a.Hout = rows; a.Wout = 32; a.M = M;
-    a.tiles_x = 1; a.tiles_y = (rows + 15) / 16; a.total_tiles = a.tiles_y;
-    a.nci = C / 32;
-    a.up_tap = tap; a.upH = H; a.upW = W; a.gy_ld = Cout;
-    const int rc = launch_wg<0, 1>(a, s);
-    if (rc != UNCL_OK) return rc;
+  WgArgs a;     // one launch: grid.y enumerates the four taps, each adding into its own [Cout][C] slice of dw_packed
+  a.src0 = (const bf16_t*)x; a.src1 = nullptr; a.gy = (const bf16_t*)gy; a.dw = dw_packed;
+  a.Cin = C; a.Cout = Cout; a.pad = 0; a.ks = 1;
+  a.s0C = C; a.s1H = a.s1W = a.s1C = 0;
+  const int rows = (int)((M + 31) / 32);
+  a.H = rows; a.W = 32; a.s0H = rows; a.s0W = 32; a.Hout = rows; a.Wout = 32; a.M = M;
+  a.tiles_x = 1; a.tiles_y = (rows + 15) / 16; a.total_tiles = a.tiles_y;
+  a.nci = C / 32;
+  a.up_tap = 0; a.upH = H; a.upW = W; a.gy_ld = Cout;
+  return launch_wg<0, 1>(a, s);
+}
+
+// every packed gradient of a network -> reference layout, one launch per UNCL_PACK_MAX_ITEMS tensors
+extern "C" int uncl_unpack_conv_wgrads(const uncl_unpack_item* items, int n_items, void* stream) {
+  if (n_items == 0) return UNCL_OK;
+  if (!items || n_items < 0) return UNCL_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int i0 = 0; i0 < n_items; i0 += UNCL_PACK_MAX_ITEMS) {
+    const int n = n_items - i0 < UNCL_PACK_MAX_ITEMS ? n_items - i0 : UNCL_PACK_MAX_ITEMS;
+    UnpackBatch t = {};
+    for (int i = 0; i < n; ++i) {
+      const uncl_unpack_item& e = items[i0 + i];
+      if (!e.packed || !e.dst || e.Cout <= 0 || e.Cin <= 0 || e.k <= 0) return UNCL_ERR_ARG;
+      t.it[i] = e;
+    }
+    hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(96, n), dim3(256), 0, s, t);
   }
+  UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
 
