@@ -209,6 +209,192 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
   }
 }
 
+// 3x3 form: ONE workgroup covers all nine taps of its (ci chunk, co chunk) pair.  Six waves = (vertical tap ty) x (upper /
+// lower eight rows of the 16 x 32 pixel tile), three accumulators (tx) each; the input tile carries its two halo rows, so a
+// tile pass moves 39 KB of X and 32 KB of gY for 288 MFMAs where three single-ty workgroups moved 3 x 67 KB.  The kernel is
+// bound by what it pulls through L2 -> L1 (every pair re-streams both tensors), so the bytes per MFMA are its speed.
+template <int MODE>
+__global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int TH = 16, TW = 32, XH = TH + 2, XW = TW + 2;
+  constexpr int NX = XH * XW, NG = TH * TW, NT = 384, PP = NT / 4;   // PP pixels staged per pass
+  constexpr int XV = (NX + PP - 1) / PP, GV = (NG + PP - 1) / PP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;
+  char* sG = smem + NX * 64;
+  float* sR = reinterpret_cast<float*>(smem);  // [9][32][32] cross-wave reduction (after the loop)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ty = wave >> 1, rh = wave & 1;
+  const int kc = blockIdx.z % a.nci, cc = blockIdx.z / a.nci;
+  int tile = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile + a.tiles_per_wg, a.total_tiles);
+  if (tile >= tile_end) return;
+
+  int g = 0, cbase = kc * 32;
+  if (MODE != 0) { g = cbase / a.s0C; cbase -= g * a.s0C; }
+  vec xr[XV], gr[GV];
+  unsigned xvalid = 0;
+
+  auto load_tile = [&](int t) {
+    int r = t;
+    const int tx_ = r % a.tiles_x; r /= a.tiles_x;
+    const int ty_ = r % a.tiles_y; r /= a.tiles_y;
+    const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    // the per-thread staging pattern is recomputed per tile (a handful of VALU ops) instead of living in ~30 registers
+    int t4 = tid;
+    asm volatile("" : "+v"(t4));
+    const int p0 = t4 >> 2, ch = t4 & 3;
+    unsigned valid = 0;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = min(p0 + j * PP, NX - 1);
+      const int hy = pix / XW, hx = pix - hy * XW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      valid |= (ok ? 1u : 0u) << j;
+      // wave-uniform sample base + 32-bit per-lane offset: one address register per load
+      if (MODE != 0 && g == 1) {
+        const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
+        const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
+        const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
+        xr[j] = *reinterpret_cast<const vec*>(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
+      } else {
+        const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+        const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
+        xr[j] = *reinterpret_cast<const vec*>(base + off);
+      }
+    }
+    xvalid = valid;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = min(p0 + j * PP, NG - 1);
+      const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
+      const bool ok = gy_ < a.Hout && gx_ < a.Wout;
+      const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
+      const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
+      vec v = *reinterpret_cast<const vec*>(base + off);
+      if (!ok) v = E::zero();
+      gr[j] = v;
+    }
+  };
+  auto write_lds = [&]() {
+    int t4 = tid;
+    asm volatile("" : "+v"(t4));
+    const int p0 = t4 >> 2, ch = t4 & 3;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = p0 + j * PP;
+      if (pix >= NX) continue;
+      vec v = xr[j];
+      if (MODE == 1 && g >= 2) {
+        float f[8];
+        E::unpack(v, f);
+        if (g == 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f);
+        }
+        v = E::pack(f);
+      }
+      if (!((xvalid >> j) & 1u)) v = E::zero();
+      *reinterpret_cast<vec*>(sX + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = p0 + j * PP;
+      if (pix >= NG) continue;
+      *reinterpret_cast<vec*>(sG + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = gr[j];
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const int grp = lane >> 4;
+  const int c0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
+
+  load_tile(tile);
+  write_lds();
+  __syncthreads();
+  while (true) {
+    const bool more = tile + 1 < tile_end;
+    if (more) load_tile(tile + 1);
+#pragma unroll 2
+    for (int r = 0; r < 8; ++r) {
+      const int row = rh * 8 + r;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const vec A = tr_frag(sG, row * TW + half * 16 + kb, c0, lane);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const vec B = tr_frag(sX, (row + ty) * XW + half * 16 + tx + kb, c0, lane);
+          acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[tx], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (!more) break;
+    write_lds();
+    __syncthreads();
+    ++tile;
+  }
+  // ---- the two row halves of every tap are summed through LDS (fixed order), then one atomic per element
+  const int lr = lane & 31, lh = lane >> 5;
+  if (rh == 0) {
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * lh;
+        sR[((ty * 3 + tx) * 32 + co) * 32 + lr] = acc[tx][i];
+      }
+  }
+  __syncthreads();
+  if (rh == 1) {
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * lh;
+        sR[((ty * 3 + tx) * 32 + co) * 32 + lr] += acc[tx][i];
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * 1024; i += NT) {
+    const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+    atomicAdd(a.dw + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
+  }
+}
+
+template <int MODE>
+int launch_wg3(WgArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)18 * 34 * 64 + 512 * 64;
+  auto kern = wgrad3_kernel<MODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int pairs = a.nci * (a.Cout / 32);
+  int groups = 512 / pairs;      // one persistent workgroup per resident slot, see launch_wg
+  if (groups < 1) groups = 1;
+  if (groups > a.total_tiles) groups = a.total_tiles;
+  a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
+  groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  hipLaunchKernelGGL(kern, dim3(groups, 1, pairs), dim3(384), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
 template <int MODE, int KS>
 int launch_wg(WgArgs& a, hipStream_t s) {
   constexpr int XW = 32 + KS - 1;
@@ -369,7 +555,7 @@ extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* d
   a.up_tap = -1; a.upH = a.upW = 0;
   a.gy_ld = d->out_C > 0 ? d->out_C : d->Cout;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->ksize == 3) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg<0, 3>(a, s) : launch_wg<1, 3>(a, s);
+  if (d->ksize == 3) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3<0>(a, s) : launch_wg3<1>(a, s);
   return launch_wg<0, 1>(a, s);
 }
 
