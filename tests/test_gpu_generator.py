@@ -95,6 +95,37 @@ def make_gv(dtype):
     return g.cuda().eval()
 
 
+def test_knn_graph_many_samples_unsplit_rows():
+    """DenseDilatedKnnGraph (gcn_lib/torch_edge.py:54-86,150-158) on more samples than a third of the CUs: the kernel then keeps
+    a whole sample per workgroup.  Same indices as the split form on the same samples (each dot product is one sequential fma
+    chain either way), and the neighbours are the nine smallest entries of the fp64 distance matrix."""
+    import ctypes as C
+    from uncltmo_amd import _hip
+    lib = _hip.lib()
+    n_s, nodes, ch, k = 100, 144, 256, 9
+    x = torch.randn(n_s, nodes, ch, generator=torch.Generator().manual_seed(7)).cuda()
+    rel = (torch.rand(nodes, nodes, generator=torch.Generator().manual_seed(8)) * 0.1).cuda()
+
+    def run(xs, want_dist=False):
+        idx = torch.empty(xs.shape[0], nodes, k, dtype=torch.int32, device="cuda")
+        dist = torch.empty(xs.shape[0], nodes, nodes, device="cuda") if want_dist else None
+        _hip.check(lib.uncl_gcn_knn(xs.data_ptr(), _hip.F32, rel.data_ptr(), idx.data_ptr(), dist.data_ptr() if want_dist else None,
+                                    xs.shape[0], nodes, ch, k, None, _hip.stream_ptr()), "uncl_gcn_knn")
+        torch.cuda.synchronize()
+        return idx, dist
+
+    whole, dist = run(x, True)
+    parts = torch.cat([run(x[i:i + 25].contiguous())[0] for i in range(0, n_s, 25)], 0)
+    assert torch.equal(whole, parts)
+    xn = torch.nn.functional.normalize(x.double().cpu(), dim=-1)
+    sq = (xn * xn).sum(-1, keepdim=True)
+    ref = sq - 2 * xn @ xn.transpose(1, 2) + sq.transpose(1, 2) + rel.double().cpu()
+    assert (dist.double().cpu() - ref).abs().max().item() < 1e-5
+    got = torch.gather(ref, 2, whole.long().cpu())
+    want = torch.topk(ref, k, dim=2, largest=False).values
+    assert (got - want).abs().max().item() < 1e-5          # the same nine distances (ties / last-ulp swaps aside)
+
+
 def test_gauss_stats_vs_torch():
     import torch.nn.functional as F
     x = synth.ldr_frames(3, 62, 70, salt="gs")                      # (3,1,62,70)

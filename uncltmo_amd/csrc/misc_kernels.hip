@@ -258,7 +258,7 @@ extern "C" int uncl_conv_in_c1(const float* x, const float* w, const float* b, v
 // ------------------------------------------------------------------------------------------------------
 #define KNN_MAX_NODES 144
 #define KNN_C 256
-#define KNN_SPLIT 3        // workgroups per sample (144 rows -> 48 each, 3 per wave)
+#define KNN_SPLIT 3        // workgroups per sample when there are fewer samples than CUs/3 (144 rows -> 48 each, 3 per wave)
 #define KNN_LD (KNN_C + 4)  // padded row: consecutive rows shift one 16-byte slot -> conflict-free b128 reads
 
 template <typename T>
@@ -284,52 +284,80 @@ __global__ __launch_bounds__(1024) void gcn_knn_kernel(const T* __restrict__ x, 
     if (lane == 0) ssq[i] = s2;
   }
   __syncthreads();
-  // rows are dealt round-robin to the gridDim.y workgroups of this sample (each re-normalises the sample: cheap)
-  for (int i = wave * gridDim.y + blockIdx.y; i < n; i += nw * gridDim.y) {
-    const float* xi = sx + (size_t)i * KNN_LD;
-    float d[3];
-    int jj[3];
+  // Rows are dealt round-robin to the gridDim.y workgroups of this sample (each re-normalises the sample: cheap) and, inside
+  // a workgroup, to its waves; a wave walks its rows THREE at a time: every 16-byte read of a key row x_j then feeds twelve
+  // FMAs (three query rows, read as same-address broadcasts) instead of four, which moves the loop from the LDS pipe to the
+  // VALU.  Each (i, j) dot product is still one sequential fmaf chain over the channels: bit-identical to the one-row form.
+  constexpr int RB = 3;
+  const int split = gridDim.y, stride = split * nw;
+  for (int ib = blockIdx.y + split * wave; ib < n; ib += RB * stride) {
+    const float* xi[RB];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int j = lane + 64 * t;
-      jj[t] = j;
-      d[t] = INFINITY;
-      if (j < n) {
-        const float* xj = sx + (size_t)j * KNN_LD;
-        float dot = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < KNN_C; c += 4) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(xi + c);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(xj + c);
-          dot = fmaf(a[0], b[0], dot);
-          dot = fmaf(a[1], b[1], dot);
-          dot = fmaf(a[2], b[2], dot);
-          dot = fmaf(a[3], b[3], dot);
+    for (int rb = 0; rb < RB; ++rb) xi[rb] = sx + (size_t)min(ib + rb * stride, n - 1) * KNN_LD;
+    const float* xj[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) xj[t] = sx + (size_t)min(lane + 64 * t, n - 1) * KNN_LD;
+    float dot[RB][3];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) dot[rb][t] = 0.f;
+#pragma unroll 2
+    for (int c = 0; c < KNN_C; c += 4) {
+      f32x4 a[RB], b[3];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xi[rb] + c);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const f32x4*>(xj[t] + c);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          float dd = dot[rb][t];
+          dd = fmaf(a[rb][0], b[t][0], dd);
+          dd = fmaf(a[rb][1], b[t][1], dd);
+          dd = fmaf(a[rb][2], b[t][2], dd);
+          dd = fmaf(a[rb][3], b[t][3], dd);
+          dot[rb][t] = dd;
         }
-        // same association as the reference: (|xi|^2 + (-2 xi.xj)) + |xj|^2, then + relative_pos
-        float dd = (ssq[i] + (-2.f * dot)) + ssq[j];
-        if (rel != nullptr) dd += rel[(size_t)i * n + j];
-        d[t] = dd;
-        if (dist_out != nullptr) dist_out[((size_t)blockIdx.x * n + i) * n + j] = dd;
-      }
     }
-    // k rounds of wave-wide arg-min; ties go to the lower node index
-    for (int r = 0; r < k; ++r) {
-      float bv = d[0];
-      int bj = jj[0];
 #pragma unroll
-      for (int t = 1; t < 3; ++t)
-        if (d[t] < bv) { bv = d[t]; bj = jj[t]; }
+    for (int rb = 0; rb < RB; ++rb) {
+      const int i = ib + rb * stride;
+      if (i >= n) break;     // wave-uniform
+      float d[3];
+      int jj[3];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oj = __shfl_xor(bj, o, 64);
-        if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+      for (int t = 0; t < 3; ++t) {
+        const int j = lane + 64 * t;
+        jj[t] = j;
+        d[t] = INFINITY;
+        if (j < n) {
+          // same association as the reference: (|xi|^2 + (-2 xi.xj)) + |xj|^2, then + relative_pos
+          float dd = (ssq[i] + (-2.f * dot[rb][t])) + ssq[j];
+          if (rel != nullptr) dd += rel[(size_t)i * n + j];
+          d[t] = dd;
+          if (dist_out != nullptr) dist_out[((size_t)blockIdx.x * n + i) * n + j] = dd;
+        }
       }
+      // k rounds of wave-wide arg-min; ties go to the lower node index
+      for (int r = 0; r < k; ++r) {
+        float bv = d[0];
+        int bj = jj[0];
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-        if (jj[t] == bj) d[t] = INFINITY;
-      if (lane == 0) idx[((size_t)blockIdx.x * n + i) * k + r] = bj;
+        for (int t = 1; t < 3; ++t)
+          if (d[t] < bv) { bv = d[t]; bj = jj[t]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const int oj = __shfl_xor(bj, o, 64);
+          if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (jj[t] == bj) d[t] = INFINITY;
+        if (lane == 0) idx[((size_t)blockIdx.x * n + i) * k + r] = bj;
+      }
     }
   }
 }
@@ -345,6 +373,8 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
   if (!x || !idx || N <= 0 || n <= 0 || n > KNN_MAX_NODES || C != KNN_C || k <= 0 || k > n) return UNCL_ERR_ARG;
   const size_t lds = ((size_t)n * KNN_LD + n) * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // one workgroup per CU (the sample fills the LDS): with a CU per sample to spare the rows are not split
+  const int split = N * KNN_SPLIT <= 256 ? KNN_SPLIT : 1;
   static bool attr[2] = {false, false};
   if (dtype == UNCL_BF16) {
     if (!attr[1]) {
@@ -352,7 +382,7 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
       attr[1] = true;
     }
-    hipLaunchKernelGGL(gcn_knn_kernel<bf16_t>, dim3(N, KNN_SPLIT), dim3(1024), lds, s, (const bf16_t*)x, relative_pos, idx, dist_out,
+    hipLaunchKernelGGL(gcn_knn_kernel<bf16_t>, dim3(N, split), dim3(1024), lds, s, (const bf16_t*)x, relative_pos, idx, dist_out,
                        n, k);
   } else if (dtype == UNCL_F32) {
     if (!attr[0]) {
@@ -360,7 +390,7 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
       attr[0] = true;
     }
-    hipLaunchKernelGGL(gcn_knn_kernel<float>, dim3(N, KNN_SPLIT), dim3(1024), lds, s, (const float*)x, relative_pos, idx, dist_out, n,
+    hipLaunchKernelGGL(gcn_knn_kernel<float>, dim3(N, split), dim3(1024), lds, s, (const float*)x, relative_pos, idx, dist_out, n,
                        k);
   } else {
     return UNCL_ERR_ARG;
