@@ -270,18 +270,28 @@ __global__ __launch_bounds__(1024) void gcn_knn_kernel(const T* __restrict__ x, 
   float* ssq = sx + (size_t)n * KNN_LD;        // [n]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const T* xs = x + (size_t)blockIdx.x * n * KNN_C;
-  // L2-normalise each node over channels (F.normalize: x / max(|x|, 1e-12)), keep |xn|^2
-  for (int i = wave; i < n; i += nw) {
-    float v[4];
+  // L2-normalise each node over channels (F.normalize: x / max(|x|, 1e-12)), keep |xn|^2; a wave's rows are all requested
+  // before the first one is reduced (one memory latency per wave instead of one per row)
+  constexpr int NR = (KNN_MAX_NODES + 15) / 16;
+  float v[NR][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = (float)xs[(size_t)i * KNN_C + lane * 4 + t];
-    float ss = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  for (int r = 0; r < NR; ++r) {
+    const int i = min(wave + r * nw, n - 1);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] *= inv;
-    *reinterpret_cast<f32x4*>(sx + (size_t)i * KNN_LD + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
-    float s2 = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-    if (lane == 0) ssq[i] = s2;
+    for (int t = 0; t < 4; ++t) v[r][t] = (float)xs[(size_t)i * KNN_C + lane * 4 + t];
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = wave + r * nw;
+    if (i < n) {
+      float ss = wave_sum(v[r][0] * v[r][0] + v[r][1] * v[r][1] + v[r][2] * v[r][2] + v[r][3] * v[r][3]);
+      const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[r][t] *= inv;
+      *reinterpret_cast<f32x4*>(sx + (size_t)i * KNN_LD + lane * 4) = f32x4{v[r][0], v[r][1], v[r][2], v[r][3]};
+      float s2 = wave_sum(v[r][0] * v[r][0] + v[r][1] * v[r][1] + v[r][2] * v[r][2] + v[r][3] * v[r][3]);
+      if (lane == 0) ssq[i] = s2;
+    }
   }
   __syncthreads();
   // Rows are dealt round-robin to the gridDim.y workgroups of this sample (each re-normalises the sample: cheap) and, inside
