@@ -10,7 +10,8 @@ tiles are independent so there is no data-path collective) and the slowest rank'
 Extra objects on the JSON line:
   roofline     dense-bf16 MFMA roofline of the dominant kernel (the implicit-GEMM conv of up_path.3.conv.conv with
                up_path.3.up recomputed in its loader, 26.3 % of the generator's FLOPs): algorithmic FLOPs per launch / mean launch duration measured
-               with HIP events inside the timed steps.
+               with HIP events inside the timed steps (two-stream execution: the interval is shared with kernels of
+               the other half of the batch; `exclusive` = the same kernel measured alone on one stream).
   cpu_baseline the CPU oracle (a port, not the reference's own code) timed on this box's host cores on a bounded
                sample of the same workload (generator forward over 256^2 tiles), reported in the same unit.
 """
@@ -218,9 +219,23 @@ def main():
     # per-launch durations of the dominant kernel, recorded by HIP events on the launch stream during the steps
     buf = (ctypes.c_float * 4096)()
     nrec = lib.uncl_prof_read(buf, 4096)
-    lib.uncl_prof_enable(-1, 0)
     dom_ms = sum(buf[i] for i in range(nrec)) / max(nrec, 1)
     tiles_per_launch = FRAMES * TILES_PER_FRAME * a.steps / max(nrec, 1)
+    # The timed steps run the product configuration: the 200 tiles go through the generator as two halves on two streams, so
+    # the dominant kernel's launch intervals above OVERLAP kernels of the other half.  Its duration with the GPU to itself is
+    # measured separately (untimed, single stream) and reported beside the live figure.
+    lib.uncl_gen_set_streams(1)
+    step()
+    torch.cuda.synchronize()
+    lib.uncl_prof_read(buf, 4096)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    nx = lib.uncl_prof_read(buf, 4096)
+    excl_ms = sum(buf[i] for i in range(nx)) / max(nx, 1)
+    excl_tiles = FRAMES * TILES_PER_FRAME * 3 / max(nx, 1)
+    lib.uncl_gen_set_streams(2)
+    lib.uncl_prof_enable(-1, 0)
     if dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -233,6 +248,7 @@ def main():
         fps = world * FRAMES * a.steps / dt
         dom_gflop = DOM_GFLOP_PER_TILE if a.dtype == "bf16" else DOM_GFLOP_PER_TILE_F32
         dom_tflops = dom_gflop * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
+        excl_tflops = dom_gflop * excl_tiles / excl_ms if excl_ms > 0 else 0.0
         fwd_tflops = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / ms          # per GPU
         traffic, traffic_src = pmc_traffic(a.dtype)
         line = {
@@ -247,12 +263,17 @@ def main():
                          "frac": dom_tflops / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          # skip 252^2 + coarse map 126^2 in, 254^2 out, 32 bf16 channels each
-                         "algorithmic_bytes": int(FRAMES * TILES_PER_FRAME * (252 * 252 + 126 * 126 + 254 * 254) * 64),
+                         "algorithmic_bytes": int(tiles_per_launch * (252 * 252 + 126 * 126 + 254 * 254) * 64),
                          "hbm_gbps": (traffic / dom_ms / 1e6 if traffic and dom_ms > 0 else None),
                          "kernel": ("conv3x3_pipe_kernel<1,4,4,4,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
                                    + " @ up_path.3.conv.conv",
                          "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
-                         "gflop_per_tile": dom_gflop},
+                         "gflop_per_tile": dom_gflop,
+                         "concurrency": "two streams: each launch covers half of the tiles and its interval overlaps "
+                                        "kernels of the other half (live figure = time-shared GPU)",
+                         "exclusive": {"achieved": excl_tflops, "frac": excl_tflops / peak, "avg_launch_ms": excl_ms,
+                                       "tiles_per_launch": excl_tiles,
+                                       "note": "same kernel, single stream, 3 untimed steps after the timed region"}},
             "forward_mfma": {"achieved": fwd_tflops, "peak": peak, "unit": "TFLOP/s", "frac": fwd_tflops / peak,
                              "gflop_per_tile": GFLOP_PER_TILE, "note": "whole step incl. tiler, per GPU"},
         }

@@ -69,6 +69,35 @@ def test_generator_bf16_vs_oracle():
     assert rel_l2(up.float().cpu(), up_ref) < 5e-2
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_large_batch_on_two_streams_equals_one_stream(dtype):
+    """uncl_gen_forward spreads an un-chunked batch of >= 64 tiles over two streams (halves of the batch, forked and joined
+    with events).  Per-tile results do not depend on the split, and the call keeps the caller's stream semantics."""
+    from uncltmo_amd import _hip
+    net = make_g(dtype)
+    n = 71 if dtype == "bf16" else 65
+    x = synth.hdr_frames(n, 256, 256, salt="two-streams").cuda()
+    lib = _hip.lib()
+    try:
+        with torch.no_grad():
+            _hip.check(lib.uncl_gen_set_streams(1), "set_streams")
+            y1, k1 = net.infer(x, want_knn=True)
+            y1 = y1.clone()
+            _hip.check(lib.uncl_gen_set_streams(2), "set_streams")
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # a non-default caller stream
+                y2, k2 = net.infer(x, want_knn=True)
+                y2 = y2.clone()
+            torch.cuda.current_stream().wait_stream(side)
+            _hip.check(lib.uncl_gen_set_streams(3), "set_streams")
+            y3, _ = net.infer(x, want_knn=True)
+    finally:
+        lib.uncl_gen_set_streams(2)
+    assert torch.equal(y1, y2) and torch.equal(k1, k2) and torch.equal(y1, y3)
+    assert lib.uncl_gen_set_streams(0) != 0 and lib.uncl_gen_set_streams(5) != 0
+
+
 def test_generator_train_mode_with_injected_droppath(golden):
     g = golden("generator")
     net = make_g("fp32")

@@ -145,6 +145,7 @@ SIGNATURES = {
     "uncl_gcn_maxrel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
     "uncl_gen_layer_name": (C.c_char_p, [C.c_int]),
+    "uncl_gen_set_streams": (C.c_int, [C.c_int]),
     "uncl_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "uncl_prof_read": (C.c_int, [C.c_void_p, C.c_int]),
     "uncl_gen_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

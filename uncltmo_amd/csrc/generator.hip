@@ -553,6 +553,14 @@ int backward_all(const BCtx& c) {
 
 }  // namespace
 
+// streams an un-chunked inference batch of >= 64 tiles is spread over (1 = the caller's stream only), see uncl_gen_forward
+static int g_streams = 2;
+extern "C" int uncl_gen_set_streams(int n) {
+  if (n < 1 || n > 4) return UNCL_ERR_ARG;
+  g_streams = n;
+  return UNCL_OK;
+}
+
 extern "C" int uncl_prof_enable(int layer, int max_records) {
   for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
   delete[] g_prof.ev;
@@ -596,6 +604,30 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   Layout L = make_layout(n_alloc, w->dtype);
   if (r->workspace_bytes < L.total) return UNCL_ERR_ARG;
   const size_t es = w->dtype == UNCL_BF16 ? 2 : 4;
+  // A large un-chunked inference batch runs as two halves on two streams (the caller's and an internal one, joined by
+  // events before returning): the launches of one half fill the ramp-down of the other's persistent grids and the gaps
+  // between dependent launches.  Every buffer is (N, ...), so the halves own disjoint slices of the same workspace.
+  const int split_cfg = g_streams;
+  const bool split2 = split_cfg >= 2 && chunk == r->N && r->N >= 64 && !r->keep_activations && !r->save_preact &&
+                      r->prev_workspace == nullptr;
+  constexpr int MAX_SIDE = 3;
+  static hipStream_t side[MAX_SIDE] = {nullptr, nullptr, nullptr};
+  static hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {nullptr, nullptr, nullptr};
+  hipStream_t main_s = reinterpret_cast<hipStream_t>(stream);
+  const int parts = split2 ? (split_cfg > MAX_SIDE + 1 ? MAX_SIDE + 1 : split_cfg) : 1;
+  if (split2) {
+    if (!ev_fork) {
+      if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return UNCL_ERR_LAUNCH;
+      for (int i = 0; i < MAX_SIDE; ++i)
+        if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess)
+          return UNCL_ERR_LAUNCH;
+    }
+    if (hipEventRecord(ev_fork, main_s) != hipSuccess) return UNCL_ERR_LAUNCH;
+    for (int i = 0; i < parts - 1; ++i)
+      if (hipStreamWaitEvent(side[i], ev_fork, 0) != hipSuccess) return UNCL_ERR_LAUNCH;
+    chunk = (r->N + parts - 1) / parts;
+  }
   for (int n0 = 0; n0 < r->N; n0 += chunk) {
     Ctx c;
     c.w = w;
@@ -605,11 +637,11 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     // the backward pass reads inc.conv.conv's output (ReLU mask, weight gradient), the video path hands its channels on
     c.fuse_in = w->dtype == UNCL_BF16 && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr;
     c.fuse_up = c.fuse_in;
-    c.s = reinterpret_cast<hipStream_t>(stream);
+    c.s = (split2 && n0 > 0) ? side[n0 / chunk - 1] : main_s;
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
     Layout Lc = L;
-    if (r->keep_activations)
+    if (r->keep_activations || split2)
       for (int b = 0; b < B_COUNT; ++b) Lc.off[b] = L.off[b] + L.per_n[b] * (size_t)n0;
     c.L = Lc;
     c.ws = reinterpret_cast<char*>(r->workspace);
@@ -622,6 +654,9 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
                        r->drop_scale ? r->drop_scale + r->N + n0 : nullptr);
     if (rc != UNCL_OK) return rc;
   }
+  for (int i = 0; split2 && i < parts - 1; ++i)
+    if (hipEventRecord(ev_join[i], side[i]) != hipSuccess || hipStreamWaitEvent(main_s, ev_join[i], 0) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
   return UNCL_OK;
 }
 
