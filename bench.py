@@ -52,6 +52,9 @@ def parse():
                          "of T=5 (4 crops of 256x256 per 512x512 clip) -- both reported for DESIGN.md, not the headline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-exclusive", action="store_true",
+                    help="skip the untimed single-stream pass that measures the dominant kernel alone (profiling runs: "
+                         "keeps every launch of the trace in the product configuration)")
     return ap.parse_args()
 
 
@@ -224,17 +227,19 @@ def main():
     # The timed steps run the product configuration: the 200 tiles go through the generator as two halves on two streams, so
     # the dominant kernel's launch intervals above OVERLAP kernels of the other half.  Its duration with the GPU to itself is
     # measured separately (untimed, single stream) and reported beside the live figure.
-    lib.uncl_gen_set_streams(1)
-    step()
-    torch.cuda.synchronize()
-    lib.uncl_prof_read(buf, 4096)
-    for _ in range(3):
+    excl_ms, excl_tiles = 0.0, 0.0
+    if not a.no_exclusive:
+        lib.uncl_gen_set_streams(1)
         step()
-    torch.cuda.synchronize()
-    nx = lib.uncl_prof_read(buf, 4096)
-    excl_ms = sum(buf[i] for i in range(nx)) / max(nx, 1)
-    excl_tiles = FRAMES * TILES_PER_FRAME * 3 / max(nx, 1)
-    lib.uncl_gen_set_streams(2)
+        torch.cuda.synchronize()
+        lib.uncl_prof_read(buf, 4096)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        nx = lib.uncl_prof_read(buf, 4096)
+        excl_ms = sum(buf[i] for i in range(nx)) / max(nx, 1)
+        excl_tiles = FRAMES * TILES_PER_FRAME * 3 / max(nx, 1)
+        lib.uncl_gen_set_streams(2)
     lib.uncl_prof_enable(-1, 0)
     if dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
