@@ -411,6 +411,14 @@ int uncl_tile_blend(const float* tiles, float* frames, int F, int H, int W, void
  * ---------------------------------------------------------------------------------------------------- */
 /* one scratch area for the calls below */
 size_t uncl_frame_workspace_bytes(void);
+/* Radiance .hdr (RGBE) input (replaces imageio's FreeImage reader behind hdr_image_util.read_hdr_image,
+ * utils/hdr_image_util.py:35-39).  uncl_rgbe_decode: HOST function, run-length / flat scanline decode of the bytes after
+ * the resolution line into H*W*4 RGBE bytes.  uncl_rgbe_to_planes: device kernel, RGBE bytes -> (3, H/scale, W/scale) fp32
+ * (value = mantissa * 2^(E-136)); scale 1, or an even factor reproducing cv2.resize(img, (W//s, H//s)) of
+ * load_inference2 (utils/model_save_util.py:225-226). */
+int uncl_rgbe_decode(const uint8_t* data, size_t n, int H, int W, uint8_t* out);
+int uncl_rgbe_to_planes(const uint8_t* rgbe, float* out, int H, int W, int scale, void* stream);
+
 /* load_inference / load_inference2 arithmetic (utils/model_save_util.py:209-217): rgb (3,H,W) linear radiance ->
  * rgb_out (3,H,W; NULL to skip) = rgb - min(rgb.min(), 0) and gray_log (H,W) = log10(((Y - Y.min()) / max) * f + 1),
  * normalised by its maximum, Y = 0.299 R + 0.587 G + 0.114 B (hdr_image_util.py:68-74).  stats (device, 4 floats):
