@@ -188,6 +188,8 @@ def main():
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from uncltmo_amd import _hip, synth, tiler
     from uncltmo_amd.generator import UNet
+    if os.environ.get("UNCL_STREAMS"):        # experiments: 1 = everything on the caller's stream
+        _hip.check(_hip.lib().uncl_gen_set_streams(int(os.environ["UNCL_STREAMS"])), "uncl_gen_set_streams")
     if a.mode in ("train", "train_video"):
         train_bench(a, rank, world, dist)
         if dist:
