@@ -58,6 +58,14 @@ def parse():
     return ap.parse_args()
 
 
+def _flush_c_stdio():
+    """RCCL prints its version banner through C stdio, which (piped) would otherwise be flushed at exit, after the JSON line."""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def pmc_traffic(dtype):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected separately over this same command, gfx950 correction applied; profiles/*_pmc_traffic.json).  bench.py
@@ -161,6 +169,7 @@ def train_bench(a, rank, world, dist):
         # per frame: 2 generator forwards + 1 (summed) backward = 2*18.286 + 36.572 GFLOP (the reference runs 2 backwards)
         tfl = n * (2 * GFLOP_PER_TILE + 2 * GFLOP_PER_TILE) / ms
         name = "GanTrainer (video, T=5)" if video else "GanTrainerImg"
+        _flush_c_stdio()
         print(json.dumps({"metric": "HDR frames/sec (256x256 full %s step)" % name, "value": world * n * a.steps / dt,
                           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -286,6 +295,7 @@ def main():
         }
         if world == 1 and not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+        _flush_c_stdio()
         print(json.dumps(line), flush=True)
     if dist:
         td.destroy_process_group()
