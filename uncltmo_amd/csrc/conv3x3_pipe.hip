@@ -107,8 +107,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   constexpr int WVN = (WROWS + 63) / 64;
   constexpr bool W_RAGGED = WROWS % 64 != 0;
   constexpr int SLOTS = CT / 8;
-  static_assert(TH * TW * CT * 2 <= NPIX * 80 + WROWS * 80, "epilogue image must fit in the staging LDS");
-  constexpr bool W_CLOBBERED = TH * TW * CT * 2 > NPIX * 80;  // epilogue image reaches into sW
+  // The epilogue image [TH*TW pixels][CT channels] re-uses the activation staging area; where it is the larger of the two
+  // (64-channel tiles: 32 KB vs 27 KB) the weight image starts behind it, so that the weights of a single-chunk layer
+  // (down_path.0.mpconv.1.conv, 32 -> 64) stay resident across tiles instead of being re-staged (37 KB) for every tile.
+  constexpr int XIMG = NPIX * 80 > TH * TW * CT * 2 ? NPIX * 80 : TH * TW * CT * 2;
+  constexpr bool W_CLOBBERED = false;
   constexpr int ST_IT = (TH * TW * SLOTS) / NTHR;             // main-store passes
   constexpr int ROWS_PER_IT = NTHR / (TW * SLOTS);            // output rows covered per pass
   static_assert(ROWS_PER_IT * TW * SLOTS == NTHR, "store pass must cover whole rows");
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   constexpr int RP = 80;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
-  char* sW = smem + NPIX * RP;
+  char* sW = smem + XIMG;
   char* sB = sW + WROWS * RP;  // CT fp32 biases of the current cout tile (outside the epilogue image)
   // MODE 3: the fp32 image patch under the halo tile ((HH+2) x (HW+2))
   constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;
@@ -750,7 +753,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 template <int NT, int MPW, int WAVES, int MODE, bool PREV>
 int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
-  constexpr size_t lds = (size_t)(TH + 2) * 34 * 80 + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
+  constexpr size_t ximg = (size_t)(TH + 2) * 34 * 80 > (size_t)TH * 32 * NT * 32 * 2 ? (size_t)(TH + 2) * 34 * 80 : (size_t)TH * 32 * NT * 32 * 2;
+  constexpr size_t lds = ximg + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
                          (MODE == 3 ? (size_t)((TH + 4) * 36 + 32) * 4 : 0);
   auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV>;
   static bool attr_done = false;
