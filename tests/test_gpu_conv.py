@@ -211,6 +211,39 @@ def test_pipe_concat_ssr_with_upconv_recomputed_in_the_loader(h, w, n):
     assert _hip.lib().uncl_conv3x3_pipe(C.byref(d), None, _hip.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("cin,cout,h,w,n,pad,res", [(256, 256, 12, 12, 5, 0, None), (64, 128, 11, 15, 7, 0, "per_sample"),
+                                                    (128, 64, 6, 9, 9, 2, None), (256, 256, 10, 10, 3, 2, "broadcast"),
+                                                    (64, 64, 3, 3, 11, 0, None)])
+def test_pipe_small_maps_whole_samples_per_tile(cin, cout, h, w, n, pad, res):
+    """Maps of <= 256 output pixels run with whole samples per tile (the kernel's FLAT form: several samples share the 256
+    accumulator rows, each lane reads its own 3x3 window); odd batch sizes leave the last tile partly empty."""
+    x = q(rnd(n, cin, h, w, seed=111), BF)
+    b = rnd(cout, seed=113)
+    if pad == 0:
+        wt = q(rnd(cout, cin, 3, 3, seed=112, scale=0.04), BF)
+        y, packed = F.conv2d(x, wt, b), pack_weight(wt, BF)
+    else:
+        wt = q(rnd(cin, cout, 3, 3, seed=112, scale=0.04), BF)
+        y, packed = F.conv_transpose2d(x, wt, b), pack_weight(wt, BF, transposed=True, flip=True)
+    ref = F.relu(y)
+    ho, wo = ref.shape[2], ref.shape[3]
+    kw = {}
+    if res == "broadcast":
+        r = q(rnd(1, cout, ho, wo, seed=114), BF)
+        ref = ref + r
+        kw = dict(res=to_nhwc(r, BF), res_batch_stride0=1)
+    elif res == "per_sample":
+        r = q(rnd(n, cout, ho, wo, seed=114), BF)
+        ref = ref + r
+        kw = dict(res=to_nhwc(r, BF), res_batch_stride0=0)
+    out = torch.full((n + 1, ho, wo, cout), 7.0, dtype=torch.bfloat16, device="cuda")      # one guard sample behind the batch
+    run_pipe(dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=to_nhwc(x, BF),
+             src0_H=h, src0_W=w, src0_C=cin, weight=packed, bias=b.cuda(), act=_hip.ACT_RELU, out=out, out_H=ho, out_W=wo,
+             out_C=cout, **kw)
+    assert rel_l2(from_nhwc(out[:n]), ref) < TOL[BF]
+    assert (out[n] == 7.0).all()                                                        # nothing written past the batch
+
+
 def test_pipe_broadcast_residual_and_skip_store():
     cin, cout, h = 256, 256, 10
     x, wt, b = q(rnd(3, cin, h, h, seed=40), BF), q(rnd(cin, cout, 3, 3, seed=41, scale=0.05), BF), rnd(cout, seed=42)

@@ -47,6 +47,7 @@ struct PipeArgs {
   const float* pre_w;   // (32,1,3,3)
   const float* pre_b;   // (32) or NULL
   int imgH, imgW;
+  int flat_S, flat_hw, flat_N;  // FLAT: whole samples per tile, output pixels per sample, samples in the batch
   const bf16_t* up_w;   // MODE 4: packed [4 taps][32 cout][32 cin] weights of the 2x2 stride-2 transposed conv
   const float* up_b;    // MODE 4: its bias (32) or NULL
 };
@@ -90,8 +91,15 @@ __device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off)
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1], 3 first layer recomputed from the image,
 //       4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) recomputed inside the loader (32 channels, same extent as the skip)
-template <int NT, int MPW, int WAVES, int MODE, bool PREV>
+//
+// FLAT (small maps: a whole sample's output is <= 128 pixels): the tile is not a rectangle of one sample but flat_S WHOLE
+// samples -- the 256 accumulator rows are the output pixels of those samples one after the other (consecutive in memory, so
+// the store loop sees a 32-pixel-wide image), the staging area holds their zero-padded input maps back to back, and every
+// lane reads its own window: fragment address = lane base (its pixel's top-left input slot) + tap offset.  A 10 x 10 map
+// fills 78 % of the tile instead of 20 % of a 16 x 32 rectangle.
+template <int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
 __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void conv3x3_pipe_kernel(const PipeArgs a) {
+  static_assert(!FLAT || (MODE == 0 && !PREV), "flat tiles: plain source only");
   using E = Elem<bf16_t>;
   using vec = bf16x8;
   static_assert(WAVES == 4, "staging pattern below is written for 256 threads");
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   static_assert(HH % 2 == 0, "two halo rows per staging pass");
   constexpr int RS = HH / 2;   // regular slots: 32 columns x 2 rows x 4 vectors per pass
   constexpr int XV = RS + 1;   // + one slot for the two extra halo columns
+  constexpr int XV_ = XV;
   constexpr int WROWS = 9 * CT;
   constexpr int WVN = (WROWS + 63) / 64;
   constexpr bool W_RAGGED = WROWS % 64 != 0;
@@ -160,6 +169,32 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   const int pix_e = ey * HW + 32 + ec;
   const int lds_w0 = p0 * 80 + (ch << 4);  // + j * 64 * 80
   const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;  // + j * (64 / CT) * Cout * Cin
+
+  // FLAT: source sample (or -1: zero padding / unused slot) and element offset inside the group for each staging slot
+  int flat_s[FLAT ? XV_ : 1];
+  unsigned flat_off[FLAT ? XV_ : 1];
+  int flat_lane[FLAT ? MPW : 1];     // byte address of the top-left input slot of this lane's output pixel, per M-tile
+  if (FLAT) {
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad, hpwp = Hp * Wp;
+#pragma unroll
+    for (int j = 0; j < XV_; ++j) {
+      const int sl = j < XV_ - 1 ? pix_r0 + j * 2 * HW : pix_e;
+      const int sj = sl / hpwp, r = sl - sj * hpwp;
+      const int py = r / Wp, px = r - py * Wp;
+      const int iy = py - a.pad, ix = px - a.pad;
+      const bool in = sj < a.flat_S && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      flat_s[j] = in ? sj : -1;
+      flat_off[j] = in ? (unsigned)(((sj * a.H + iy) * a.W + ix) * a.s0C + ch * 8) : 0u;
+    }
+    const int Wo = a.W + 2 * a.pad - 2;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      const int q = min((wave * MPW + m) * 32 + lr, a.flat_S * a.flat_hw - 1);
+      const int sj = q / a.flat_hw, r = q - sj * a.flat_hw;
+      const int oy = r / Wo, ox = r - oy * Wo;
+      flat_lane[m] = (sj * hpwp + oy * Wp + ox) * RP;
+    }
+  }
 
   // ---- tile cursor (contiguous range per workgroup, carried without divisions)
   int t_ct, t_tx, t_ty, t_n;
@@ -276,6 +311,20 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
         valid |= (ok ? 1u : 0u) << RS;
         xr[RS] = ld16o(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
+      }
+      xvalid = valid;
+    } else if (FLAT) {
+      // slot sl of the staging area = sample sl / (Hp Wp) of this tile's group, padded-map pixel (py, px): the thread's slots
+      // and their source offsets do not depend on the tile, only the group's base does
+      const bf16_t* base = a.src0 + (size_t)n * a.flat_S * a.s0H * a.s0W * a.s0C + cbase;
+      const int left = a.flat_N - n * a.flat_S;          // samples of the batch still covered by this group
+      unsigned valid = 0;
+#pragma unroll
+      for (int j = 0; j <= RS; ++j) {
+        const int sj = flat_s[j];
+        const bool ok = sj >= 0 && sj < left && (j < RS || e_on);
+        valid |= (ok ? 1u : 0u) << j;
+        xr[j] = ld16o(base, ok ? flat_off[j] * 2u : 0u);
       }
       xvalid = valid;
     } else {
@@ -545,6 +594,23 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             const int row = (ty * 3 + tx) * CT + nt * 32 + lr;
             A[ty][nt] = *reinterpret_cast<const vec*>(sW + row * RP + (chunk << 4));
           }
+        if (FLAT) {
+          // every lane reads its own 3x3 window: no sharing of rows between the M-tiles
+          const int Wp = a.W + 2 * a.pad;
+#pragma unroll
+          for (int m = 0; m < MPW; ++m) {
+            vec Bf[3];
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+              Bf[ty] = *reinterpret_cast<const vec*>(sX + flat_lane[m] + (ty * Wp + tx) * RP + (chunk << 4));
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ty][nt], Bf[ty], (ks == 0 && tx == 0 && ty == 0 && c_kc == 0) ? zero16 : acc[m][nt], 0, 0, 0);
+          }
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < MPW + 2; ++r) {
           const int pix = (wave * MPW + r) * HW + lr + tx;
@@ -635,10 +701,16 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       PT(3)  // bias/activation, transposing LDS writes, barrier
       if (!a.skip_main) {
         const int ox = c_x0 + st_col;
+        // FLAT: the tile's pixels are flat_S whole samples, consecutive in memory: a 32-wide image of Hout = 8 rows whose
+        // last valid pixel is given by the samples this group really covers (a.Hout / a.Wout are that virtual image)
+        const size_t n_px = FLAT ? (size_t)c_n * a.flat_S * a.flat_hw : (size_t)c_n * a.Hout * a.Wout;
+        const int flat_valid = FLAT ? min(a.flat_S, a.flat_N - c_n * a.flat_S) * a.flat_hw : 0;
         if (ox < a.Wout && c_y0 + st_row < a.Hout) {
           const size_t pix0 = (size_t)(c_y0 + st_row) * a.Wout + ox;
-          bf16_t* ob = a.out + ((size_t)c_n * a.Hout * a.Wout + pix0) * a.oC + c_co + st_sl * 8;
-          const int rows_left = a.Hout - (c_y0 + st_row);  // passes with it*ROWS_PER_IT < rows_left are in range
+          bf16_t* ob = a.out + (n_px + pix0) * a.oC + c_co + st_sl * 8;
+          // passes with it*ROWS_PER_IT < rows_left are in range
+          const int rows_left = FLAT ? ((flat_valid - (int)pix0 + TW * ROWS_PER_IT - 1) / (TW * ROWS_PER_IT)) * ROWS_PER_IT
+                                     : a.Hout - (c_y0 + st_row);
           const unsigned row_stride = (unsigned)(ROWS_PER_IT * a.Wout * a.oC);
           // LDS reads of the image in groups of four ahead of their (conditional) stores: one LDS latency per group
           auto VAL = [&](int it) { return *reinterpret_cast<const vec*>(sO + st_lds + it * (NTHR / SLOTS) * (CT * 2)); };
@@ -677,7 +749,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             }
           } else {
             // residual (pos_embed, Unet_singleFrame.py:94) is added to the stored bf16 features in fp32
-            const bf16_t* rb = a.res + ((a.res_b0 ? 0 : (size_t)c_n * a.Hout * a.Wout) + pix0) * a.oC + c_co + st_sl * 8;
+            const bf16_t* rb = a.res + ((a.res_b0 ? 0 : n_px) + pix0) * a.oC + c_co + st_sl * 8;
 #pragma unroll
             for (int it = 0; it < ST_IT; ++it) {
               if (it * ROWS_PER_IT < rows_left) {
@@ -692,7 +764,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
           }
         }
       }
-      if (a.pool_out != nullptr) {
+      if (!FLAT && a.pool_out != nullptr) {
         bf16_t* pb = a.pool_out + (size_t)c_n * a.pH * a.pW * a.oC + c_co;
         for (int v = tid; v < (TH / 2) * (TW / 2) * SLOTS; v += NTHR) {
           const int pp = v / SLOTS, sl = v - pp * SLOTS;
@@ -713,7 +785,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
           }
         }
       }
-      if (a.out1_w != nullptr) {
+      if (!FLAT && a.out1_w != nullptr) {
         for (int pl = tid; pl < TH * TW; pl += NTHR) {
           const int prow = pl / TW, pcol = pl - prow * TW;
           const int oy = c_y0 + prow, ox = c_x0 + pcol;
@@ -750,13 +822,13 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   PT_FLUSH()
 }
 
-template <int NT, int MPW, int WAVES, int MODE, bool PREV>
+template <int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
 int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
   constexpr size_t ximg = (size_t)(TH + 2) * 34 * 80 > (size_t)TH * 32 * NT * 32 * 2 ? (size_t)(TH + 2) * 34 * 80 : (size_t)TH * 32 * NT * 32 * 2;
   constexpr size_t lds = ximg + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
                          (MODE == 3 ? (size_t)((TH + 4) * 36 + 32) * 4 : 0);
-  auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV>;
+  auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV, FLAT>;
   static bool attr_done = false;
   static int max_blocks = 0;
   if (!attr_done) {
@@ -857,6 +929,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     a.s0H = d->H; a.s0W = d->W; a.s0C = 32;
   }
   a.up_w = (const bf16_t*)d->up_w; a.up_b = d->up_b;
+  a.flat_S = 0; a.flat_hw = 0; a.flat_N = d->N;
   a.nk = d->Cin / 32;
   const bool prev = d->prev0 != nullptr && d->prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -879,6 +952,22 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   if (d->Cout % 64 != 0) return UNCL_ERR_ARG;
   constexpr int TH = 8;
   a.n_ct = d->Cout / 64;
+  a.flat_S = 0; a.flat_hw = 0; a.flat_N = d->N;
+  {
+    // small maps (the 10 x 10 / 12 x 12 bottleneck levels): whole samples per tile instead of a mostly empty rectangle
+    const int howo = a.Hout * a.Wout, hpwp = (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
+    int S = howo > 0 ? 256 / howo : 0;
+    while (S > 1 && S * hpwp > 10 * 34) --S;
+    const bool plain_store = mask == nullptr && !accumulate && pool_out == nullptr && d->out1_w == nullptr && !d->skip_main_store;
+    if (S >= 1 && S * hpwp <= 10 * 34 && d->src_mode == UNCL_SRC_PLAIN && !prev && plain_store &&
+        (d->res == nullptr || !d->res_batch_stride0 || S == 1)) {
+      a.flat_S = S; a.flat_hw = howo;
+      a.Hout = 8; a.Wout = 32;      // the store loop's view of the tile: 256 consecutive pixels
+      a.tiles_x = a.tiles_y = 1;
+      a.total_tiles = ((d->N + S - 1) / S) * a.n_ct;
+      return launch_pipe<2, 2, 4, 0, false, true>(a, s);
+    }
+  }
   a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
   a.total_tiles = d->N * a.tiles_x * a.tiles_y * a.n_ct;
   return dispatch_mode<2, 2>(a, d->src_mode, prev, s);
