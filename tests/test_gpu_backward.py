@@ -95,6 +95,33 @@ def test_dgrad_via_pipe_kernel_is_conv_with_transposed_weights():
     assert rel_l2(from_nhwc(gx), x.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("n,accumulate", [(5, 0), (4, 1)])
+def test_dgrad_small_map_with_relu_mask_and_accumulation(n, accumulate):
+    """Data gradient of the 12x12 -> 10x10 bottleneck conv (256 channels): whole samples per tile, stored through the
+    activation mask of the producing layer and optionally added to the gradient already there."""
+    cin, cout, h = 256, 256, 12
+    x = q(rnd(n, cin, h, h, seed=21))
+    wt = q(rnd(cout, cin, 3, 3, seed=22, scale=0.05))
+    gy = q(rnd(n, cout, h - 2, h - 2, seed=23))
+    act_in = q(rnd(n, cin, h, h, seed=24))                      # the tensor whose ReLU produced x (mask = act_in > 0)
+    xin = x.clone().requires_grad_(True)
+    F.conv2d(xin, wt).backward(gy)
+    want = xin.grad * (act_in > 0).float()
+    prior = q(rnd(n, cin, h, h, seed=25))
+    gx = to_nhwc(prior, BF).clone() if accumulate else torch.zeros(n, h, h, cin, dtype=torch.bfloat16, device="cuda")
+    d = _hip.ConvDesc()
+    keep = [to_nhwc(gy, BF), pack_weight(wt, BF, transposed=True, flip=True), to_nhwc(act_in, BF)]
+    for k_, v in dict(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_PLAIN, N=n, H=h - 2, W=h - 2, Cin=cout, Cout=cin,
+                      src0=keep[0].data_ptr(), src0_H=h - 2, src0_W=h - 2, src0_C=cout, weight=keep[1].data_ptr(),
+                      act=_hip.ACT_NONE, out=gx.data_ptr(), out_H=h, out_W=h, out_C=cin).items():
+        setattr(d, k_, v)
+    _hip.check(_hip.lib().uncl_conv3x3_dgrad(C.byref(d), keep[2].data_ptr(), 0.0, accumulate, _hip.stream_ptr()), "dgrad")
+    torch.cuda.synchronize()
+    if accumulate:
+        want = want + prior
+    assert rel_l2(from_nhwc(gx), want) < 1.5e-2
+
+
 def test_colsum_bias_grad():
     x = q(rnd(5000, 512, seed=14)).to(torch.bfloat16).cuda()
     out = torch.zeros(512, device="cuda")

@@ -725,7 +725,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             }
           } else if (a.res == nullptr) {
             // gradient store: ReLU mask of the producing layer and / or accumulation into an existing gradient
-            const bf16_t* mb = a.mask ? a.mask + ((size_t)c_n * a.Hout * a.Wout + pix0) * a.oC + c_co + st_sl * 8 : nullptr;
+            const bf16_t* mb = a.mask ? a.mask + (n_px + pix0) * a.oC + c_co + st_sl * 8 : nullptr;
             // rows past the end are clamped to the last valid one for the loads, so they issue back to back
 #pragma unroll
             for (int it = 0; it < ST_IT; ++it) {
@@ -958,7 +958,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     const int howo = a.Hout * a.Wout, hpwp = (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
     int S = howo > 0 ? 256 / howo : 0;
     while (S > 1 && S * hpwp > 10 * 34) --S;
-    const bool plain_store = mask == nullptr && !accumulate && pool_out == nullptr && d->out1_w == nullptr && !d->skip_main_store;
+    const bool plain_store = pool_out == nullptr && d->out1_w == nullptr && !d->skip_main_store;   // gradient stores are fine
     if (S >= 1 && S * hpwp <= 10 * 34 && d->src_mode == UNCL_SRC_PLAIN && !prev && plain_store &&
         (d->res == nullptr || !d->res_batch_stride0 || S == 1)) {
       a.flat_S = S; a.flat_hw = howo;
