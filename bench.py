@@ -281,7 +281,7 @@ def main():
                          # skip 252^2 + coarse map 126^2 in, 254^2 out, 32 bf16 channels each
                          "algorithmic_bytes": int(tiles_per_launch * (252 * 252 + 126 * 126 + 254 * 254) * 64),
                          "hbm_gbps": (traffic / dom_ms / 1e6 if traffic and dom_ms > 0 else None),
-                         "kernel": ("conv3x3_pipe_kernel<1,4,4,4,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
+                         "kernel": ("conv3x3_pipe_kernel<1,4,4,4,false,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
                                    + " @ up_path.3.conv.conv",
                          "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
                          "gflop_per_tile": dom_gflop,

@@ -12,7 +12,7 @@ import os
 import sqlite3
 import sys
 
-DOMINANT = "conv3x3_pipe_kernel<1, 4, 4, 4, false>"     # up_path.3.conv.conv (loader-fused up-conv)
+DOMINANT = "conv3x3_pipe_kernel<1, 4, 4, 4, false, false>"    # up_path.3.conv.conv (loader-fused up-conv)
 
 
 def read(dirname, counter):
