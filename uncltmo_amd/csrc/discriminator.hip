@@ -6,8 +6,10 @@
 //   out = <fea, wl>                        (N)       tail Linear(3844 -> 1, no bias)
 //   fea_final = [mean(fea), mean(gauss local variance of fea)]   (uncl_gauss_stats on fea)
 //
-// The network is 71.5 MFLOP per frame and is evaluated 7 times per training step on <= a few dozen frames: it is
-// latency / LDS bound, not MFMA work; direct fp32 VALU convolutions keep it bit-comparable with the CPU reference.
+// The network is 71.5 MFLOP per frame and is evaluated 7 times per training step on <= a few dozen frames.  Everything stays
+// fp32 (parity with the CPU reference to 1e-4): the one-channel first layer and the data gradients are direct VALU
+// convolutions; the 16 -> 32 second layer (88 % of the FLOPs) and its weight gradient run on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) from register-resident weights / accumulators.
 #include "common.h"
 
 namespace {
@@ -50,77 +52,89 @@ __global__ __launch_bounds__(256) void d_conv1_kernel(const float* __restrict__ 
   }
 }
 
-// ---- conv2 + 1x1 head: workgroup = 8x8 output pixels x 32 channels; wave g owns channels 8g..8g+7
-__global__ __launch_bounds__(256) void d_conv2_head_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
-                                                           const float* __restrict__ b2, const float* __restrict__ w4,
-                                                           const float* __restrict__ b4, const float* __restrict__ wl,
-                                                           float* __restrict__ h2, float* __restrict__ fea,
-                                                           float* __restrict__ partial) {
-  extern __shared__ float sm[];
-  float* sw = sm;                     // [k = tap*16 + ci][co]   8192 floats
-  float* sa = sm + 256 * C2;          // [ci][18*18]             5184 floats
-  float* sp = sa + C1 * 324;          // [4][64] head partials
-  const int n = blockIdx.y;
-  const int ty = blockIdx.x / 8, tx = blockIdx.x % 8;
-  const int y0 = ty * 8, x0 = tx * 8;
-  for (int i = threadIdx.x; i < 256 * C2; i += 256) {
-    const int co = i % C2, k = i / C2, ci = k % C1, tap = k / C1;
-    sw[i] = w2[(co * C1 + ci) * 16 + tap];  // reference layout (co, ci, 4, 4)
-  }
-  for (int i = threadIdx.x; i < C1 * 324; i += 256) {
-    const int ci = i / 324, r = i % 324, ly = r / 18, lx = r % 18;
-    const int gy = min(2 * y0 + ly, H1 - 1), gx = min(2 * x0 + lx, H1 - 1);
-    sa[i] = h1[(((size_t)n * H1 + gy) * H1 + gx) * C1 + ci];
-  }
-  __syncthreads();
-  const int p = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int py = p >> 3, px = p & 7;
-  float acc[8];
+// ---- conv2 + 1x1 head on the matrix cores (exact fp32 products: v_mfma_f32_32x32x2_f32).  The layer is a
+// (N*3844 pixels) x (32 channels) x (K = 16 taps * 16 channels) GEMM; a VALU form (one thread = one pixel x 8 channels, 102 us
+// for 32 frames) spent its time re-staging the 32 KB weight matrix for every 64-pixel tile and reading LDS once per 2.7
+// FMAs; this one takes 40 us.  A workgroup is two waves that keep the
+// WHOLE weight matrix in registers (lane (co, half) holds w[co][tap][8*half + j]: 128 values) and walk (frame, 8x8 tile) work
+// items persistently; each item stages its 18 x 18 x 16 input patch (rows padded to 20 floats: conflict-free b128 reads) and
+// every wave runs 128 MFMAs for its 32 pixels.  The 8x8 tiles define the partial-sum layout the tail reduction expects.
+__global__ __launch_bounds__(128) void d_conv2_head_mfma_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2, const float* __restrict__ w4,
+                                                                const float* __restrict__ b4, const float* __restrict__ wl,
+                                                                float* __restrict__ h2, float* __restrict__ fea,
+                                                                float* __restrict__ partial, int n_items) {
+  constexpr int PP = 20;                       // floats per staged pixel (16 channels + 4 of padding)
+  __shared__ __attribute__((aligned(16))) float sa[18 * 18 * PP];
+  __shared__ float sred[2][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  // A operand of MFMA (tap, j): row co = lr, k-slot = channel 8*lh + j of that tap
+  float wreg[16][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = b2[g * 8 + j];
-  for (int tap = 0; tap < 16; ++tap) {
-    const int ky = tap >> 2, kx = tap & 3;
-    const float* ap = sa + (2 * py + ky) * 18 + 2 * px + kx;
+  for (int t = 0; t < 16; ++t)
 #pragma unroll
-    for (int ci = 0; ci < C1; ++ci) {
-      const float a = ap[ci * 324];
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(sw + (tap * C1 + ci) * C2 + g * 8);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(sw + (tap * C1 + ci) * C2 + g * 8 + 4);
-      acc[0] = fmaf(a, wa[0], acc[0]); acc[1] = fmaf(a, wa[1], acc[1]);
-      acc[2] = fmaf(a, wa[2], acc[2]); acc[3] = fmaf(a, wa[3], acc[3]);
-      acc[4] = fmaf(a, wb[0], acc[4]); acc[5] = fmaf(a, wb[1], acc[5]);
-      acc[6] = fmaf(a, wb[2], acc[6]); acc[7] = fmaf(a, wb[3], acc[7]);
+    for (int j = 0; j < 8; ++j) wreg[t][j] = w2[(lr * C1 + 8 * lh + j) * 16 + t];
+  float binit[16], w4r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int co = 8 * (i >> 2) + 4 * lh + (i & 3);        // accumulator register i of this lane = output channel co
+    binit[i] = b2[co];
+    w4r[i] = w4[co];
+  }
+  const float b4v = b4[0];
+  const int py = 4 * wave + (lr >> 3), px = lr & 7;        // this lane's pixel inside the 8x8 tile
+  const float* bbase = sa + ((2 * py) * 18 + 2 * px) * PP + 8 * lh;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int n = item >> 6, tile = item & 63;
+    const int y0 = (tile >> 3) * 8, x0 = (tile & 7) * 8;
+    __syncthreads();                                       // the previous item's readers are done with the patch
+    for (int v = tid; v < 18 * 18 * 4; v += 128) {
+      const int pix = v >> 2, c4 = v & 3, ly = pix / 18, lx = pix - ly * 18;
+      const int gy = min(2 * y0 + ly, H1 - 1), gx = min(2 * x0 + lx, H1 - 1);
+      *reinterpret_cast<f32x4*>(sa + pix * PP + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(h1 + (((size_t)n * H1 + gy) * H1 + gx) * C1 + c4 * 4);
     }
-  }
-  const int oy = y0 + py, ox = x0 + px;
-  const bool valid = oy < H2 && ox < H2;
-  float head = 0.f;
+    __syncthreads();
+    f32x16 acc;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    acc[j] = lrelu(acc[j]);
-    head = fmaf(acc[j], w4[g * 8 + j], head);
-  }
-  if (valid) {
-    float* o = h2 + (((size_t)n * H2 + oy) * H2 + ox) * C2 + g * 8;
-    *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-    *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-  }
-  sp[g * 64 + p] = head;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    float f = ((sp[p] + sp[64 + p]) + (sp[128 + p] + sp[192 + p])) + b4[0];
-    float lo = 0.f, sf = 0.f;
+    for (int i = 0; i < 16; ++i) acc[i] = binit[i];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float* bp = bbase + ((t >> 2) * 18 + (t & 3)) * PP;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(bp), v1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[t][j], v0[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[t][4 + j], v1[j], acc, 0, 0, 0);
+    }
+    const int oy = y0 + py, ox = x0 + px;
+    const bool valid = oy < H2 && ox < H2;
+    float head = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[i] = lrelu(acc[i]);
+      head = fmaf(acc[i], w4r[i], head);
+    }
     if (valid) {
+      float* o = h2 + (((size_t)n * H2 + oy) * H2 + ox) * C2 + 4 * lh;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        *reinterpret_cast<f32x4*>(o + 8 * q4) = f32x4{acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+    }
+    head += __shfl_xor(head, 32, 64);                      // the two channel halves of the pixel
+    const float f = head + b4v;
+    float lo = 0.f, sf = 0.f;
+    if (valid && lh == 0) {
       fea[((size_t)n * H2 + oy) * H2 + ox] = f;
       lo = f * wl[oy * H2 + ox];
       sf = f;
     }
     lo = wave_sum(lo);
     sf = wave_sum(sf);
-    if (threadIdx.x == 0) {
-      partial[((size_t)n * 64 + blockIdx.x) * 2] = lo;
-      partial[((size_t)n * 64 + blockIdx.x) * 2 + 1] = sf;
-    }
+    if (lane == 0) { sred[wave][0] = lo; sred[wave][1] = sf; }
+    __syncthreads();
+    if (tid < 2) partial[((size_t)n * 64 + tile) * 2 + tid] = sred[0][tid] + sred[1][tid];
   }
 }
 
@@ -222,48 +236,74 @@ __global__ __launch_bounds__(256) void d_conv2_dgrad_kernel(const float* __restr
   }
 }
 
-// conv2 weight / bias gradient.  Workgroup = one 8x8 block of output pixels of one frame; thread = one (tap, ci) column
-// (256 of them) accumulating all 32 output channels; partial sums per workgroup, reduced in a fixed order afterwards.
-__global__ __launch_bounds__(256) void d_conv2_wgrad_kernel(const float* __restrict__ g_h2pre, const float* __restrict__ h1,
-                                                            float* __restrict__ partial /* [wg][8192 + 32] */) {
-  __shared__ float sg[64 * C2];          // [pixel][co]
-  __shared__ float sa[C1 * 324];         // [ci][18*18]
-  const int n = blockIdx.y;
-  const int ty = blockIdx.x / 8, tx = blockIdx.x % 8;
-  const int y0 = ty * 8, x0 = tx * 8;
-  for (int i = threadIdx.x; i < 64 * C2; i += 256) {
-    const int p = i / C2, co = i % C2;
-    const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
-    sg[i] = (oy < H2 && ox < H2) ? g_h2pre[(((size_t)n * H2 + oy) * H2 + ox) * C2 + co] : 0.f;
-  }
-  for (int i = threadIdx.x; i < C1 * 324; i += 256) {
-    const int ci = i / 324, r = i % 324, ly = r / 18, lx = r % 18;
-    const int gy = min(2 * y0 + ly, H1 - 1), gx = min(2 * x0 + lx, H1 - 1);
-    sa[i] = h1[(((size_t)n * H1 + gy) * H1 + gx) * C1 + ci];
-  }
-  __syncthreads();
-  const int tap = threadIdx.x >> 4, ci = threadIdx.x & 15;
-  const int ky = tap >> 2, kx = tap & 3;
-  float acc[C2];
+// conv2 weight / bias gradient on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 products): dW[co][tap*16+ci] is a 32 x 256 matrix
+// reduced over ALL pixels, so persistent workgroups keep their share of it in accumulators (wave w owns taps 4w .. 4w+3 =
+// two 32-column blocks) while they walk (frame, 8x8 tile) items -- per item 8 KB of gradient and a 26 KB input patch are
+// staged, then every k-step (two pixels) is one A read (g^T), two B reads and two MFMAs per wave.  One partial per workgroup
+// instead of one per tile: the fixed-order reduction that follows reads grid_x rows, not N*64.
+__global__ __launch_bounds__(256) void d_conv2_wgrad_mfma_kernel(const float* __restrict__ g_h2pre, const float* __restrict__ h1,
+                                                                 float* __restrict__ partial /* [grid][8192 + 32] */, int n_items) {
+  constexpr int PP = 20;
+  __shared__ __attribute__((aligned(16))) float sg[64 * C2];            // [pixel][co]
+  __shared__ __attribute__((aligned(16))) float sa[18 * 18 * PP];       // [py][px][ci (+4 pad)]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[2];
 #pragma unroll
-  for (int c = 0; c < C2; ++c) acc[c] = 0.f;
-  for (int p = 0; p < 64; ++p) {
-    const float a = sa[ci * 324 + (2 * (p >> 3) + ky) * 18 + 2 * (p & 7) + kx];
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int c = 0; c < C2; c += 4) {
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(sg + p * C2 + c);
-      acc[c] = fmaf(a, gv[0], acc[c]); acc[c + 1] = fmaf(a, gv[1], acc[c + 1]);
-      acc[c + 2] = fmaf(a, gv[2], acc[c + 2]); acc[c + 3] = fmaf(a, gv[3], acc[c + 3]);
+    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+  float bsum = 0.f;
+  // B operand of column block b: column lr -> tap 4*wave + 2*b + (lr >> 4), channel lr & 15
+  int boff[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int tap = 4 * wave + 2 * b + (lr >> 4);
+    boff[b] = ((tap >> 2) * 18 + (tap & 3)) * PP + (lr & 15);
+  }
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int n = item >> 6, tile = item & 63;
+    const int y0 = (tile >> 3) * 8, x0 = (tile & 7) * 8;
+    __syncthreads();
+    for (int v = tid; v < 64 * C2 / 4; v += 256) {
+      const int p = v >> 3, c4 = v & 7;
+      const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (oy < H2 && ox < H2) g = *reinterpret_cast<const f32x4*>(g_h2pre + (((size_t)n * H2 + oy) * H2 + ox) * C2 + c4 * 4);
+      *reinterpret_cast<f32x4*>(sg + p * C2 + c4 * 4) = g;
+    }
+    for (int v = tid; v < 18 * 18 * 4; v += 256) {
+      const int pix = v >> 2, c4 = v & 3, ly = pix / 18, lx = pix - ly * 18;
+      const int gy = min(2 * y0 + ly, H1 - 1), gx = min(2 * x0 + lx, H1 - 1);
+      *reinterpret_cast<f32x4*>(sa + pix * PP + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(h1 + (((size_t)n * H1 + gy) * H1 + gx) * C1 + c4 * 4);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      const int p = 2 * i + lh;                                        // this lane's pixel of the k-step
+      const float a = sg[p * C2 + lr];
+      const float* ap = sa + ((2 * (p >> 3)) * 18 + 2 * (p & 7)) * PP;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ap[boff[0]], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ap[boff[1]], acc[1], 0, 0, 0);
+    }
+    if (tid < C2) {
+      float b = 0.f;
+      for (int p = 0; p < 64; ++p) b += sg[p * C2 + tid];
+      bsum += b;
     }
   }
-  float* out = partial + ((size_t)n * 64 + blockIdx.x) * (8192 + 32);
+  float* out = partial + (size_t)blockIdx.x * (8192 + 32);
 #pragma unroll
-  for (int c = 0; c < C2; ++c) out[(c * C1 + ci) * 16 + tap] = acc[c];   // reference layout (co, ci, 4, 4)
-  if (threadIdx.x < C2) {
-    float b = 0.f;
-    for (int p = 0; p < 64; ++p) b += sg[p * C2 + threadIdx.x];
-    out[8192 + threadIdx.x] = b;
+  for (int b = 0; b < 2; ++b) {
+    const int tap = 4 * wave + 2 * b + (lr >> 4), ci = lr & 15;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = 8 * (i >> 2) + 4 * lh + (i & 3);
+      out[(co * C1 + ci) * 16 + tap] = acc[b][i];                      // reference layout (co, ci, 4, 4)
+    }
   }
+  if (tid < C2) out[8192 + tid] = bsum;
 }
 
 // conv1 weight / bias gradient.  Workgroup = 16x32 output pixels of one frame; thread = (tap, co).
@@ -347,15 +387,6 @@ __global__ __launch_bounds__(256) void d_conv1_dgrad_kernel(const float* __restr
   }
 }
 
-__global__ void d_w4_final_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ gw4, float* __restrict__ gb4,
-                                  int accumulate) {
-  const int c = threadIdx.x;
-  if (c > C2) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[(size_t)b * (C2 + 1) + c];
-  float* dst = c < C2 ? gw4 + c : gb4;
-  *dst = accumulate ? *dst + (float)s : (float)s;
-}
 
 }  // namespace
 
@@ -399,15 +430,12 @@ extern "C" int uncl_simple_d_forward(const float* x, const float* w0, const floa
   const size_t t1 = (size_t)N * H1 * H1;
   hipLaunchKernelGGL(d_conv1_kernel, dim3((unsigned)((t1 + 255) / 256 < 4096 ? (t1 + 255) / 256 : 4096)), dim3(256), 0, st, x,
                      w0, b0, b.h1, N);
-  const size_t lds = (256 * C2 + C1 * 324 + 256) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(d_conv2_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return UNCL_ERR_LAUNCH;
-    attr = true;
+  {
+    // persistent two-wave workgroups (four per CU at 232 VGPRs), each walking its share of the (frame, tile) items
+    const int items = 64 * N;
+    hipLaunchKernelGGL(d_conv2_head_mfma_kernel, dim3(items < 1024 ? items : 1024), dim3(128), 0, st, b.h1, w2, b2, w4, b4, wl,
+                       b.h2, b.fea, b.partial, items);
   }
-  hipLaunchKernelGGL(d_conv2_head_kernel, dim3(64, N), dim3(256), lds, st, b.h1, w2, b2, w4, b4, wl, b.h2, b.fea, b.partial);
   hipLaunchKernelGGL(d_final_kernel, dim3((N + 63) / 64), dim3(64), 0, st, b.partial, out, N);
   UNCL_CHECK_LAUNCH();
   if (fea_final != nullptr) {
@@ -434,13 +462,14 @@ extern "C" int uncl_simple_d_backward(const float* x, const float* w0, const flo
   const bool params = gw0 != nullptr;
   if (params) {
     if (!gb0 || !gw2 || !gb2 || !gw4 || !gb4 || !gwl) return UNCL_ERR_ARG;
-    hipLaunchKernelGGL(d_w4_final_kernel, dim3(1), dim3(64), 0, st, b.w4part, hb, gw4, gb4, accumulate);
+    hipLaunchKernelGGL(d_partial_sum_kernel, dim3(2), dim3(256), 0, st, b.w4part, hb, C2 + 1, 0, C2, gw4, 1, gb4, accumulate);
     if (g_out != nullptr)
       hipLaunchKernelGGL(d_wl_bwd_kernel, dim3((H2 * H2 + 255) / 256), dim3(256), 0, st, g_out, b.fea, gwl, N, accumulate);
     else if (!accumulate)
       (void)hipMemsetAsync(gwl, 0, H2 * H2 * sizeof(float), st);
-    hipLaunchKernelGGL(d_conv2_wgrad_kernel, dim3(64, N), dim3(256), 0, st, b.g_h2pre, b.h1, b.w2part);
-    hipLaunchKernelGGL(d_partial_sum_kernel, dim3((8192 + 32 + 31) / 32), dim3(256), 0, st, b.w2part, N * 64, 8192 + 32, 0, 8192, gw2,
+    const int w2rows = N * 64 < 512 ? N * 64 : 512;      // one partial per persistent workgroup
+    hipLaunchKernelGGL(d_conv2_wgrad_mfma_kernel, dim3(w2rows), dim3(256), 0, st, b.g_h2pre, b.h1, b.w2part, N * 64);
+    hipLaunchKernelGGL(d_partial_sum_kernel, dim3((8192 + 32 + 31) / 32), dim3(256), 0, st, b.w2part, w2rows, 8192 + 32, 0, 8192, gw2,
                        32, gb2, accumulate);
   }
   hipLaunchKernelGGL(d_conv2_dgrad_kernel, dim3((unsigned)((t1 + 255) / 256 < 4096 ? (t1 + 255) / 256 : 4096)), dim3(256), 0,
