@@ -199,40 +199,81 @@ __global__ void d_wl_bwd_kernel(const float* __restrict__ g_out, const float* __
 }
 
 // conv2 data gradient: g_h1pre[n][y][x][ci] = lrelu'(h1) * sum_{ky,kx,co: (y-ky),(x-kx) even, in range} g_h2pre[(y-ky)/2][(x-kx)/2][co] w2[co][ci][ky][kx]
-__global__ __launch_bounds__(256) void d_conv2_dgrad_kernel(const float* __restrict__ g_h2pre, const float* __restrict__ w2,
-                                                            const float* __restrict__ h1, float* __restrict__ g_h1pre,
-                                                            int N) {
-  __shared__ float sw[16 * C2 * C1];  // [tap][co][ci]
-  for (int i = threadIdx.x; i < 16 * C2 * C1; i += 256) {
-    const int ci = i % C1, co = (i / C1) % C2, tap = i / (C1 * C2);
-    sw[i] = w2[(co * C1 + ci) * 16 + tap];
-  }
-  __syncthreads();
-  const size_t total = (size_t)N * H1 * H1;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int x = (int)(i % H1), y = (int)((i / H1) % H1), n = (int)(i / ((size_t)H1 * H1));
-    float acc[C1];
+//
+// With y = 2a + py, x = 2b + px the four parity classes of (y, x) all read the SAME 2x2 neighbourhood {a-1, a} x {b-1, b} of
+// the gradient map and differ only in the weights (ky = py + 2u, kx = px + 2v).  That makes it a GEMM per position (a, b):
+// rows = (px, ci) = 32, K = (u, v, co) = 128, one weight matrix per py -- on the fp32 matrix cores (v_mfma_f32_32x32x2_f32)
+// with both weight matrices resident in registers (128 values per lane) and every B fragment (gradient values) shared by the
+// two py.  Persistent workgroups of four waves walk (frame, 4 rows of a, 32 columns of b) items: wave = row a, lane = b.
+__global__ __launch_bounds__(256) void d_conv2_dgrad_mfma_kernel(const float* __restrict__ g_h2pre, const float* __restrict__ w2,
+                                                                 const float* __restrict__ h1, float* __restrict__ g_h1pre,
+                                                                 int n_items) {
+  constexpr int GP = 36;                        // floats per staged gradient pixel (32 channels + 4 of padding)
+  __shared__ __attribute__((aligned(16))) float sg[5 * 33 * GP];   // rows a0-1 .. a0+3, columns b0-1 .. b0+31
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  // A operand: row lr = (px = lr >> 4, ci = lr & 15); MFMA (uv, j) of parity py: k-slot = (u, v, co = 16 lh + j)
+  float wreg[2][4][16];
 #pragma unroll
-    for (int c = 0; c < C1; ++c) acc[c] = 0.f;
-    for (int ky = (y & 1); ky < 4; ky += 2) {
-      const int oy = (y - ky) >> 1;
-      if (y - ky < 0 || oy >= H2) continue;
-      for (int kx = (x & 1); kx < 4; kx += 2) {
-        const int ox = (x - kx) >> 1;
-        if (x - kx < 0 || ox >= H2) continue;
-        const float* gp = g_h2pre + (((size_t)n * H2 + oy) * H2 + ox) * C2;
-        const float* wp = sw + (ky * 4 + kx) * C2 * C1;
-        for (int co = 0; co < C2; ++co) {
-          const float gv = gp[co];
+  for (int py = 0; py < 2; ++py)
 #pragma unroll
-          for (int c = 0; c < C1; ++c) acc[c] = fmaf(gv, wp[co * C1 + c], acc[c]);
+    for (int uv = 0; uv < 4; ++uv)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int ky = py + 2 * (uv >> 1), kx = (lr >> 4) + 2 * (uv & 1);
+        wreg[py][uv][j] = w2[((16 * lh + j) * C1 + (lr & 15)) * 16 + ky * 4 + kx];
+      }
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // 64 x 64 positions per frame = 16 row blocks x 2 column halves
+    const int n = item >> 5, rb = (item >> 1) & 15, half = item & 1;
+    const int a0 = rb * 4, b0 = half * 32;
+    __syncthreads();
+    for (int v = tid; v < 5 * 33 * 8; v += 256) {
+      const int pix = v >> 3, c4 = v & 7, ly = pix / 33, lx = pix - ly * 33;
+      const int oy = a0 - 1 + ly, ox = b0 - 1 + lx;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)oy < (unsigned)H2 && (unsigned)ox < (unsigned)H2)
+        g = *reinterpret_cast<const f32x4*>(g_h2pre + (((size_t)n * H2 + oy) * H2 + ox) * C2 + c4 * 4);
+      *reinterpret_cast<f32x4*>(sg + pix * GP + c4 * 4) = g;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[py][i] = 0.f;
+    // this lane's position: row a = a0 + wave (staged row wave + 1), column b = b0 + lr (staged column lr + 1)
+#pragma unroll
+    for (int uv = 0; uv < 4; ++uv) {
+      const float* gp = sg + ((wave + 1 - (uv >> 1)) * 33 + (lr + 1 - (uv & 1))) * GP + 16 * lh;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + 4 * j4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[0][uv][4 * j4 + e], gv[e], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[1][uv][4 * j4 + e], gv[e], acc[1], 0, 0, 0);
         }
       }
     }
-    const float* hp = h1 + i * C1;
-    float* o = g_h1pre + i * C1;
+    // D register 4q+e of this lane = row 8q + 4lh + e = (px = q >> 1, ci = 8 (q & 1) + 4 lh + e) of position (a, b)
+    const int a = a0 + wave, bcol = b0 + lr;
 #pragma unroll
-    for (int c = 0; c < C1; ++c) o[c] = acc[c] * (hp[c] > 0.f ? 1.f : SLOPE);
+    for (int py = 0; py < 2; ++py) {
+      const int y = 2 * a + py;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = 2 * bcol + (q >> 1);
+        if (y < H1 && x < H1) {
+          const size_t off = (((size_t)n * H1 + y) * H1 + x) * C1 + 8 * (q & 1) + 4 * lh;
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[py][4 * q + e] * (hv[e] > 0.f ? 1.f : SLOPE);
+          *reinterpret_cast<f32x4*>(g_h1pre + off) = o;
+        }
+      }
+    }
   }
 }
 
@@ -472,8 +513,11 @@ extern "C" int uncl_simple_d_backward(const float* x, const float* w0, const flo
     hipLaunchKernelGGL(d_partial_sum_kernel, dim3((8192 + 32 + 31) / 32), dim3(256), 0, st, b.w2part, w2rows, 8192 + 32, 0, 8192, gw2,
                        32, gb2, accumulate);
   }
-  hipLaunchKernelGGL(d_conv2_dgrad_kernel, dim3((unsigned)((t1 + 255) / 256 < 4096 ? (t1 + 255) / 256 : 4096)), dim3(256), 0,
-                     st, b.g_h2pre, w2, b.h1, b.g_h1pre, N);
+  {
+    const int items = N * 32;     // (frame, 16 row blocks, 2 column halves)
+    hipLaunchKernelGGL(d_conv2_dgrad_mfma_kernel, dim3(items < 512 ? items : 512), dim3(256), 0, st, b.g_h2pre, w2, b.h1, b.g_h1pre,
+                       items);
+  }
   if (params) {
     hipLaunchKernelGGL(d_conv1_wgrad_kernel, dim3(32, N), dim3(256), 0, st, b.g_h1pre, x, b.w0part);
     hipLaunchKernelGGL(d_partial_sum_kernel, dim3((256 + 16 + 31) / 32), dim3(256), 0, st, b.w0part, N * 32, 256 + 16, 0, 256, gw0, 16, gb0, accumulate);
