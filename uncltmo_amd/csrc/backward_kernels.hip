@@ -17,13 +17,17 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ w, bf16_t* __restrict__ G_up,
                                                        float* __restrict__ partial, size_t P, int last_act, float slope) {
   __shared__ float red[4][33];
-  float aw[32], ab = 0.f;
+  // thread = (pixel, 8-channel vector): 4 threads per pixel; the vector index is the same for every element a thread visits
+  // (the grid stride is a multiple of 4), so its eight weight-gradient sums live in registers
+  float aw[8], ab = 0.f;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) aw[c] = 0.f;
-  // thread = (pixel, 8-channel vector): 4 threads per pixel
+  for (int c = 0; c < 8; ++c) aw[c] = 0.f;
+  const int v = (int)(threadIdx.x & 3);
+  float wv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) wv[c] = w[v * 8 + c];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P * 4; i += (size_t)gridDim.x * 256) {
     const size_t p = i >> 2;
-    const int v = (int)(i & 3);
     const float s = x_out[p];
     // derivative of the last activation expressed through its output s (Unet_singleFrame.py:207-212, Blocks.py:85-91)
     float gp = g_out[p];
@@ -35,17 +39,20 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
     if (g_upx) E8::unpack(ldv8(g_upx + p * 32 + v * 8), gu);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const float t = (g_upx ? gu[c] : 0.f) + gp * w[v * 8 + c];
+      const float t = (g_upx ? gu[c] : 0.f) + gp * wv[c];
       o[c] = u[c] > 0.f ? t : slope * t;
-      aw[v * 8 + c] = fmaf(gp, u[c], aw[v * 8 + c]);
+      aw[c] = fmaf(gp, u[c], aw[c]);
     }
     if (v == 0) ab += gp;
     stv8(G_up + p * 32 + v * 8, o);
   }
+  // sum over the 16 lanes of a wave that share the vector index (xor 4, 8, 16, 32), lanes 0..3 hold the results
 #pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const float t = wave_sum(aw[c]);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = t;
+  for (int c = 0; c < 8; ++c) {
+    float t = aw[c];
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63) < 4) red[threadIdx.x >> 6][v * 8 + c] = t;
   }
   const float tb = wave_sum(ab);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][32] = tb;

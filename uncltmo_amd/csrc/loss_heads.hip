@@ -64,10 +64,28 @@ __global__ __launch_bounds__(256) void nce_sim_kernel(const T* __restrict__ a, c
   const T* pn = p + (size_t)n * p_stride;
   const T* qn = q + (size_t)n * q_stride;
   float sp = 0.f, sq = 0.f;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (size_t)gridDim.x * 256) {
-    const float av = ldf(an, e), pv = ldf(pn, e), qv = ldf(qn, e);
-    sp += av * pv * (1.f / (c + k * fabsf(av - pv)));
-    sq += av * qv * (1.f / (c + k * fabsf(av - qv)));
+  constexpr int V = Elem<T>::EPV;
+  using vec = typename Elem<T>::vec;
+  const bool vec_ok = E % V == 0 && ((reinterpret_cast<uintptr_t>(an) | reinterpret_cast<uintptr_t>(pn) | reinterpret_cast<uintptr_t>(qn)) & 15) == 0;
+  if (vec_ok) {
+    // 16-byte loads: the feature maps of the generator are 2 M elements per sample
+    for (size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; e < E; e += (size_t)gridDim.x * 256 * V) {
+      float av[V], pv[V], qv[V];
+      Elem<T>::unpack(*reinterpret_cast<const vec*>(an + e), av);
+      Elem<T>::unpack(*reinterpret_cast<const vec*>(pn + e), pv);
+      Elem<T>::unpack(*reinterpret_cast<const vec*>(qn + e), qv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {      // hardware reciprocal (1 ulp) as in the gradient pass
+        sp += av[i] * pv[i] * __builtin_amdgcn_rcpf(c + k * fabsf(av[i] - pv[i]));
+        sq += av[i] * qv[i] * __builtin_amdgcn_rcpf(c + k * fabsf(av[i] - qv[i]));
+      }
+    }
+  } else {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (size_t)gridDim.x * 256) {
+      const float av = ldf(an, e), pv = ldf(pn, e), qv = ldf(qn, e);
+      sp += av * pv * (1.f / (c + k * fabsf(av - pv)));
+      sq += av * qv * (1.f / (c + k * fabsf(av - qv)));
+    }
   }
   sp = wave_sum(sp); sq = wave_sum(sq);
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sp; red[threadIdx.x >> 6][1] = sq; }
@@ -156,6 +174,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const T* __restrict__ a, c
     float pv[V], qv[V];
     if (p_stride == 0) Elem<T>::unpack(*reinterpret_cast<const vec*>(p + e), pv);
     if (q_stride == 0) Elem<T>::unpack(*reinterpret_cast<const vec*>(q + e), qv);
+#pragma unroll 2
     for (int n = 0; n < N; ++n) {
       float av[V], ga[V], gpp[V], gqq[V];
       Elem<T>::unpack(*reinterpret_cast<const vec*>(a + (size_t)n * E + e), av);
@@ -165,7 +184,8 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const T* __restrict__ a, c
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         const float dp = av[i] - pv[i], dq = av[i] - qv[i];
-        const float ip = 1.f / (c + k * fabsf(dp)), iq = 1.f / (c + k * fabsf(dq));
+        // hardware reciprocal (1 ulp): the IEEE division sequence made this HBM-sized pass VALU-bound
+        const float ip = __builtin_amdgcn_rcpf(c + k * fabsf(dp)), iq = __builtin_amdgcn_rcpf(c + k * fabsf(dq));
         const float sgp = dp > 0.f ? 1.f : (dp < 0.f ? -1.f : 0.f), sgq = dq > 0.f ? 1.f : (dq < 0.f ? -1.f : 0.f);
         const float tp = av[i] * pv[i] * k * sgp * ip * ip, tq = av[i] * qv[i] * k * sgq * iq * iq;
         ga[i] = gp * (pv[i] * ip - tp) + gq * (qv[i] * iq - tq);
