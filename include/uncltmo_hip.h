@@ -362,14 +362,16 @@ int uncl_cgan_loss(const float* real, const float* fake, int N, float w, float* 
 size_t uncl_nce_workspace_bytes(int N);
 int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
                   int neg_shared, float k, float c, float w, float* loss, float* g_anchor, float* g_pos, float* g_neg,
-                  int accumulate_loss, int accumulate_grad, void* workspace, void* stream);
+                  int accumulate_loss, int accumulate_grad, void* workspace, const int* shared_rows, void* stream);
 /* Gradients of uncl_nce_loss computed at backward time (autograd of GanTrainerImg.py:410-439): `workspace` is the one the
  * forward call filled, `upstream` an optional device scalar multiplied in, gradients are written in grad_dtype (= dtype, or
  * UNCL_F32).  pos_row / neg_row >= 0: the shared positive / negative is that row of `anchor` (infoNCE2, :398-402) and its
- * gradient is folded into g_anchor's row (g_pos / g_neg NULL); -1 otherwise.  E must be a multiple of 16 bytes of elements. */
+ * gradient is folded into g_anchor's row (g_pos / g_neg NULL); -1 otherwise.  E must be a multiple of 16 bytes of elements.
+ * shared_rows (both calls, optional): DEVICE int[2] = {positive row, negative row} of `anchor`, e.g. the arg-max / arg-min
+ * uncl_tmqi_naturalness wrote -- the selection of infoNCE2 (GanTrainerImg.py:398-402) then never visits the host. */
 int uncl_nce_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
                       int neg_shared, float k, float c, const void* workspace, const float* upstream, void* g_anchor, void* g_pos,
-                      void* g_neg, int grad_dtype, int pos_row, int neg_row, void* stream);
+                      void* g_neg, int grad_dtype, int pos_row, int neg_row, const int* shared_rows, void* stream);
 /* w * mean_n |a_n - b_n| over strided per-sample scalars (nn.L1Loss on per-frame means, GanTrainerImg.py:308-313) */
 int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss, float* g_a,
                   float* g_b, int accumulate_loss, void* stream);

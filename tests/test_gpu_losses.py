@@ -156,6 +156,11 @@ def test_nce_golden_and_shared_rows(golden):
     (0.37 * lr_).backward()
     assert fb.grad.dtype == torch.bfloat16 and fb.grad.permute(0, 2, 3, 1).is_contiguous()
     assert rel_l2(fb.grad.float().cpu(), fr.grad) < 6e-3
+    # the same with the two row indices left on the device (what the trainer does with the naturalness arg-max / arg-min)
+    fd = fb.detach().clone().requires_grad_(True)
+    ld = HL.nce_rows(fd, torch.tensor([2, 1], dtype=torch.int32, device="cuda"), 1, 1e-2)
+    (0.37 * ld).backward()
+    assert ld.item() == lb.item() and torch.equal(fd.grad, fb.grad)
     # positive and negative the SAME row; separate shared rows that are not part of the anchor; per-sample rows
     for pr, qr in [(3, 3), (0, 3)]:
         f1 = fea.clone().requires_grad_(True)

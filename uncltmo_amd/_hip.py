@@ -167,10 +167,10 @@ SIGNATURES = {
     "uncl_nce_workspace_bytes": (C.c_size_t, [C.c_int]),
     "uncl_nce_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                 C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                C.c_int, C.c_void_p, C.c_void_p]),
+                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uncl_nce_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                    C.c_int, C.c_int, C.c_void_p]),
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uncl_l1_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "uncl_tmqi_naturalness": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,

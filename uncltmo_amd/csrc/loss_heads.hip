@@ -57,12 +57,13 @@ __device__ __forceinline__ float ldf(const T* p, size_t i) { return (float)p[i];
 template <typename T>
 __global__ __launch_bounds__(256) void nce_sim_kernel(const T* __restrict__ a, const T* __restrict__ p, const T* __restrict__ q,
                                                       size_t E, size_t p_stride, size_t q_stride, float k, float c,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, const int* __restrict__ rows) {
   __shared__ float red[4][2];
   const int n = blockIdx.y;
   const T* an = a + (size_t)n * E;
-  const T* pn = p + (size_t)n * p_stride;
-  const T* qn = q + (size_t)n * q_stride;
+  // rows (device): the shared positive / negative are rows rows[0] / rows[1] of the anchor tensor (selected on the device)
+  const T* pn = rows ? a + (size_t)rows[0] * E : p + (size_t)n * p_stride;
+  const T* qn = rows ? a + (size_t)rows[1] * E : q + (size_t)n * q_stride;
   float sp = 0.f, sq = 0.f;
   constexpr int V = Elem<T>::EPV;
   using vec = typename Elem<T>::vec;
@@ -155,9 +156,13 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const T* __restrict__ a, c
                                                       size_t E, size_t p_stride, size_t q_stride, int N, float k, float c,
                                                       float inv_hw, const float* __restrict__ gs, const float* __restrict__ upstream,
                                                       GT* __restrict__ g_a, GT* __restrict__ g_p, GT* __restrict__ g_q, int p_row,
-                                                      int q_row) {
+                                                      int q_row, const int* __restrict__ rows) {
   constexpr int V = Elem<T>::EPV;
   using vec = typename Elem<T>::vec;
+  if (rows) {           // row indices chosen on the device (arg-max / arg-min of the naturalness scores)
+    p_row = rows[0]; q_row = rows[1];
+    p = a + (size_t)p_row * E; q = a + (size_t)q_row * E;
+  }
   const float up = (upstream ? upstream[0] : 1.f) * inv_hw;
   auto store = [&](GT* dst, const float* f) {
     if constexpr (sizeof(GT) == sizeof(T)) {
@@ -541,8 +546,13 @@ extern "C" size_t uncl_nce_workspace_bytes(int N) { return ((size_t)N * 256 * 2 
 extern "C" int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw,
                              int pos_shared, int neg_shared, float k, float c, float w, float* loss, float* g_anchor,
                              float* g_pos, float* g_neg, int accumulate_loss, int accumulate_grad, void* workspace,
-                             void* stream) {
-  if (!anchor || !pos || !neg || !loss || !workspace || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+                             const int* shared_rows, void* stream) {
+  if (!anchor || !loss || !workspace || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+  if (shared_rows) {        // positive / negative = rows of the anchor picked on the device: loss only (see uncl_nce_backward)
+    if (g_anchor || g_pos || g_neg) return UNCL_ERR_ARG;
+    pos = neg = anchor; pos_shared = neg_shared = 1;
+  }
+  if (!pos || !neg) return UNCL_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
   const int blocks = (int)((E + 255) / 256 < 256 ? (E + 255) / 256 : 256);
@@ -552,14 +562,14 @@ extern "C" int uncl_nce_loss(const void* anchor, const void* pos, const void* ne
   const int gblocks = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
   if (dtype == UNCL_F32) {
     hipLaunchKernelGGL(nce_sim_kernel<float>, dim3(blocks, N), dim3(256), 0, st, (const float*)anchor, (const float*)pos,
-                       (const float*)neg, (size_t)E, ps, qs, k, c, partial);
+                       (const float*)neg, (size_t)E, ps, qs, k, c, partial, shared_rows);
     hipLaunchKernelGGL(nce_ce_kernel, dim3(1), dim3(256), 0, st, partial, blocks, N, 1.0 / (double)hw, w, loss, gs, accumulate_loss);
     if (need_grad)
       hipLaunchKernelGGL(nce_grad_kernel<float>, dim3(gblocks), dim3(256), 0, st, (const float*)anchor, (const float*)pos,
                          (const float*)neg, (size_t)E, ps, qs, N, k, c, 1.f / (float)hw, gs, g_anchor, g_pos, g_neg, accumulate_grad);
   } else if (dtype == UNCL_BF16) {
     hipLaunchKernelGGL(nce_sim_kernel<bf16_t>, dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)anchor, (const bf16_t*)pos,
-                       (const bf16_t*)neg, (size_t)E, ps, qs, k, c, partial);
+                       (const bf16_t*)neg, (size_t)E, ps, qs, k, c, partial, shared_rows);
     hipLaunchKernelGGL(nce_ce_kernel, dim3(1), dim3(256), 0, st, partial, blocks, N, 1.0 / (double)hw, w, loss, gs, accumulate_loss);
     if (need_grad)
       hipLaunchKernelGGL(nce_grad_kernel<bf16_t>, dim3(gblocks), dim3(256), 0, st, (const bf16_t*)anchor, (const bf16_t*)pos,
@@ -577,8 +587,14 @@ extern "C" int uncl_nce_loss(const void* anchor, const void* pos, const void* ne
 // and its gradient is folded into g_anchor (g_pos / g_neg must then be NULL); -1 otherwise.
 extern "C" int uncl_nce_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw,
                                  int pos_shared, int neg_shared, float k, float c, const void* workspace, const float* upstream,
-                                 void* g_anchor, void* g_pos, void* g_neg, int grad_dtype, int pos_row, int neg_row, void* stream) {
-  if (!anchor || !pos || !neg || !workspace || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+                                 void* g_anchor, void* g_pos, void* g_neg, int grad_dtype, int pos_row, int neg_row,
+                                 const int* shared_rows, void* stream) {
+  if (!anchor || !workspace || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+  if (shared_rows) {        // device-chosen rows of the anchor: equivalent to pos_row / neg_row read from device memory
+    if (g_pos || g_neg) return UNCL_ERR_ARG;
+    pos = neg = anchor; pos_shared = neg_shared = 1; pos_row = neg_row = 0;
+  }
+  if (!pos || !neg) return UNCL_ERR_ARG;
   if (dtype != UNCL_F32 && dtype != UNCL_BF16) return UNCL_ERR_ARG;
   if (grad_dtype != dtype && grad_dtype != UNCL_F32) return UNCL_ERR_ARG;
   const int V = dtype == UNCL_BF16 ? 8 : 4;
@@ -596,7 +612,7 @@ extern "C" int uncl_nce_backward(const void* anchor, const void* pos, const void
   const float inv_hw = 1.f / (float)hw;
 #define UNCL_NCE_BWD(T, GT)                                                                                                   \
   hipLaunchKernelGGL((nce_bwd_kernel<T, GT>), dim3(blocks), dim3(256), 0, st, (const T*)anchor, (const T*)pos, (const T*)neg, \
-                     (size_t)E, ps, qs, N, k, c, inv_hw, gs, upstream, (GT*)g_anchor, (GT*)g_pos, (GT*)g_neg, pos_row, neg_row)
+                     (size_t)E, ps, qs, N, k, c, inv_hw, gs, upstream, (GT*)g_anchor, (GT*)g_pos, (GT*)g_neg, pos_row, neg_row, shared_rows)
   if (dtype == UNCL_F32) UNCL_NCE_BWD(float, float);
   else if (grad_dtype == UNCL_BF16) UNCL_NCE_BWD(bf16_t, bf16_t);
   else UNCL_NCE_BWD(bf16_t, float);

@@ -63,7 +63,7 @@ class _NceFn(torch.autograd.Function):
     (infoNCE2): they are then not separate autograd inputs and the anchor receives the complete gradient."""
 
     @staticmethod
-    def forward(ctx, anchor, pos, neg, hw, k, c, pos_shared, neg_shared, pos_row, neg_row):
+    def forward(ctx, anchor, pos, neg, hw, k, c, pos_shared, neg_shared, pos_row, neg_row, rows_dev=None):
         lib = _hip.lib()
         n = anchor.shape[0]
         E = anchor.numel() // n
@@ -81,6 +81,11 @@ class _NceFn(torch.autograd.Function):
         vec = 8 if code == _hip.BF16 else 4
         aligned = all(t.data_ptr() % 16 == 0 for t in (a, p, q))
         ctx.deferred = E % vec == 0 and aligned
+        if rows_dev is not None:
+            if not ctx.deferred:
+                raise ValueError("uncltmo_amd: row-shared NCE needs 16-byte aligned rows")
+            rows_dev = rows_dev.detach().to(torch.int32).contiguous()
+            p = q = a[0:1]          # placeholders: the kernels take the rows from `rows_dev`
         if pos_row >= 0 or neg_row >= 0:
             if not ctx.deferred:
                 raise ValueError("uncltmo_amd: row-shared NCE needs 16-byte aligned rows")
@@ -96,7 +101,8 @@ class _NceFn(torch.autograd.Function):
         P = lambda t: t.data_ptr() if t is not None else None
         _hip.check(lib.uncl_nce_loss(a.data_ptr(), p.data_ptr(), q.data_ptr(), code, n, E, hw, int(pos_shared), int(neg_shared),
                                      float(k), float(c), 1.0, loss.data_ptr(), P(ga), P(gp), P(gq), 0, 0, ws.data_ptr(),
-                                     _hip.stream_ptr()), "uncl_nce_loss")
+                                     P(rows_dev), _hip.stream_ptr()), "uncl_nce_loss")
+        ctx.rows_dev = rows_dev
         ctx.g = (ga, gp, gq)
         ctx.dt = (anchor.dtype, pos.dtype, neg.dtype)
         ctx.saved = (a, p, q, ws, perm)
@@ -107,22 +113,34 @@ class _NceFn(torch.autograd.Function):
     def backward(ctx, g):
         if not ctx.deferred:
             out = [None if t is None else (t * g).to(dt) for t, dt in zip(ctx.g, ctx.dt)]
-            return (out[0], out[1], out[2]) + (None,) * 7
+            return (out[0], out[1], out[2]) + (None,) * 8
         lib = _hip.lib()
         a, p, q, ws, perm = ctx.saved
         code, n, E, hw, ps, qs, k, c, pos_row, neg_row = ctx.args
         need = ctx.needs_input_grad
         gs = g.detach().float().reshape(1).contiguous()
         ga = torch.empty_like(a) if need[0] else None
-        gp = torch.empty_like(p) if need[1] and pos_row < 0 else None
-        gq = torch.empty_like(q) if need[2] and neg_row < 0 else None
+        rows_dev = ctx.rows_dev
+        gp = torch.empty_like(p) if need[1] and pos_row < 0 and rows_dev is None else None
+        gq = torch.empty_like(q) if need[2] and neg_row < 0 and rows_dev is None else None
         P = lambda t: t.data_ptr() if t is not None else None
         _hip.check(lib.uncl_nce_backward(a.data_ptr(), p.data_ptr(), q.data_ptr(), code, n, E, hw, ps, qs, k, c, ws.data_ptr(),
-                                         gs.data_ptr(), P(ga), P(gp), P(gq), code, pos_row, neg_row, _hip.stream_ptr()),
+                                         gs.data_ptr(), P(ga), P(gp), P(gq), code, pos_row, neg_row, P(rows_dev),
+                                         _hip.stream_ptr()),
                    "uncl_nce_backward")
         if perm is not None:
             ga, gp, gq = [None if t is None else t.permute(*perm) for t in (ga, gp, gq)]
-        return (ga, gp, gq) + (None,) * 7
+        return (ga, gp, gq) + (None,) * 8
+
+
+def nce_rows(anchor, rows, k, c, hw=None):
+    """infoNCE2 (GanTrainerImg.py:398-402): positive / negative are rows rows[0] / rows[1] of `anchor`, where `rows` is a
+    DEVICE int tensor (the arg-max / arg-min tmqi_naturalness returns): the selection never goes through the host, and the
+    anchor receives the complete gradient (its own plus the two shared rows')."""
+    if hw is None:
+        hw = anchor.shape[-1] * anchor.shape[-2]
+    dummy = anchor.detach()[0:1]
+    return _NceFn.apply(anchor, dummy, dummy, hw, k, c, True, True, -1, -1, rows)
 
 
 def nce(anchor, positive, negative, k, c, hw=None):

@@ -178,9 +178,10 @@ class GanTrainer:
         return self.nce(fea_fake, [fea_real], [fea_neg], cl_loss_type, k, constant)
 
     def infoNCE2(self, fea_fake, fake, hdr_input, cl_loss_type, k, constant):
-        _, bw = L.tmqi_naturalness(fake)
-        best, worst = int(bw[0]), int(bw[1])      # one small host read, as the reference's list.index() implies
-        return self.nce(fea_fake, [fea_fake[best:best + 1]], [fea_fake[worst:worst + 1]], cl_loss_type, k, constant)
+        if cl_loss_type != "InfoNCE":
+            raise NotImplementedError("HIP nce covers the published InfoNCE form with one positive and one negative")
+        _, bw = L.tmqi_naturalness(fake)          # (best, worst) frame indices stay on the device
+        return L.nce_rows(fea_fake, bw, k, constant)
 
     def nce(self, fea_anchor, feas_positive, feas_negative, cl_loss_type, k, constant):
         if cl_loss_type != "InfoNCE" or len(feas_positive) != 1 or len(feas_negative) != 1:
