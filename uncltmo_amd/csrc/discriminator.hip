@@ -7,9 +7,9 @@
 //   fea_final = [mean(fea), mean(gauss local variance of fea)]   (uncl_gauss_stats on fea)
 //
 // The network is 71.5 MFLOP per frame and is evaluated 7 times per training step on <= a few dozen frames.  Everything stays
-// fp32 (parity with the CPU reference to 1e-4): the one-channel first layer and the data gradients are direct VALU
-// convolutions; the 16 -> 32 second layer (88 % of the FLOPs) and its weight gradient run on the fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) from register-resident weights / accumulators.
+// fp32 (parity with the CPU reference to 1e-4): the one-channel first layer (forward, weight and data gradient) is direct
+// VALU convolution; the 16 -> 32 second layer (88 % of the FLOPs), its weight gradient and its data gradient run on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) from register-resident weights / accumulators.
 #include "common.h"
 
 namespace {
