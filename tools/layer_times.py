@@ -27,6 +27,7 @@ def main():
     if len(sys.argv) > 1:          # A/B on the same box: python tools/layer_times.py tools/_ab/libX.so
         _hip.LIB_PATH = os.path.abspath(sys.argv[1])
     lib = _hip.lib()
+    lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "1")))   # per-layer times are meaningful on one stream
     net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
                "replicate", 2, 0, compute_dtype="bf16")
     synth.fill_state_dict(net, "g0")
