@@ -501,9 +501,13 @@ int backward_all(const BCtx& c) {
   RUN(wgrad1(c, W_GFC2, c.F(B_GGC), 512, 512, c.sc.tA, 256, 256, b->gw[W_GFC2], true));
   RUN(dgrad1(c, W_GFC2, c.sc.tA, 256, 512, c.sc.tC, nullptr));
   RUN(uncl_gelu_backward(c.sc.tC, c.F(B_GGCZ), c.sc.tC, (long long)c.n * per512, c.s));
-  for (int g = 0; g < 4; ++g)  // grouped 1x1: four independent 128 -> 128 blocks
-    RUN(wgrad1(c, W_GGC, (const bf16_t*)c.F(B_GMR) + g * 128, 512, 128, (const bf16_t*)c.sc.tC + g * 128, 512, 128,
-               b->gw[W_GGC] + (size_t)g * 128 * 128, false));
+  {  // grouped 1x1: four independent 128 -> 128 blocks, one launch (grid.y = group)
+    uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, 128, 128);
+    d.src0 = c.F(B_GMR); d.src0_H = 12; d.src0_W = 12; d.src0_C = 512;
+    d.out_C = 512;
+    d.z_mode = UNCL_Z_GROUPS; d.groups = 4;
+    RUN(uncl_conv_wgrad(&d, c.sc.tC, b->gw[W_GGC], c.s));
+  }
   RUN(c.colsum(c.sc.tC, (long long)c.n * NODES, 512, b->gb[W_GGC]));
   RUN(dgrad1(c, W_GGC, c.sc.tC, 512, 512, c.sc.tD, nullptr, 4));
   if (hipMemsetAsync(c.sc.f32, 0, (size_t)c.n * per256 * 4, c.s) != hipSuccess) return UNCL_ERR_LAUNCH;

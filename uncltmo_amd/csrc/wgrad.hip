@@ -30,6 +30,7 @@ struct WgArgs {
   int tiles_x, tiles_y, total_tiles, tiles_per_wg, nci;
   long long M;          // ks == 1: number of valid flattened pixels (rows of 32)
   int gy_ld;            // elements between consecutive pixels of gy (>= Cout; grouped convs pass the full width)
+  int groups;           // ks == 1, up_tap < 0: grouped 1x1 conv, blockIdx.y = group (channels g*Cin.. of X, g*Cout.. of gy)
   int up_tap, upH, upW; // ks == 1, up_tap >= 0: gy is the (N,2*upH,2*upW,Cout) output gradient of a 2x2 stride-2
                         // transposed conv and pixel m=(n,y,x) pairs with gy pixel (n, 2y+dy, 2x+dx)
 };
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
   // KS == 3: blockIdx.y = vertical tap; KS == 1 on the 2x2 stride-2 transposed conv: blockIdx.y = its tap (dy, dx)
   const int ty = KS == 3 ? (int)blockIdx.y : 0;
   const int up_tap = (KS == 1 && a.up_tap >= 0) ? (int)blockIdx.y : -1;
+  const int cgrp = (KS == 1 && a.up_tap < 0) ? (int)blockIdx.y : 0;     // grouped 1x1: this workgroup's group
   const int kc = blockIdx.z % a.nci, cc = blockIdx.z / a.nci;  // input / output channel chunk
   int tile = (int)blockIdx.x * a.tiles_per_wg;
   const int tile_end = min(tile + a.tiles_per_wg, a.total_tiles);
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
         xr[j] = ld16g(a.src1 + ((size_t)n * a.s1H * a.s1W + (size_t)sy * a.s1W + sx) * a.s1C + cbase + ch * 8);
       } else {
         const size_t off = ok ? ((size_t)n * a.s0H * a.s0W + (size_t)iy * a.s0W + ix) * a.s0C : 0;
-        xr[j] = ld16g(a.src0 + off + cbase + ch * 8);
+        xr[j] = ld16g(a.src0 + off + cgrp * a.Cin + cbase + ch * 8);
       }
     }
     xvalid = valid;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
         const int yy = rem / a.upW, xx = rem - yy * a.upW;
         off = (((size_t)nn * 2 * a.upH + 2 * yy + (up_tap >> 1)) * (2 * a.upW) + 2 * xx + (up_tap & 1)) * a.gy_ld;
       }
-      vec v = ld16g(a.gy + off + cc * 32 + ch * 8);
+      vec v = ld16g(a.gy + off + cgrp * a.Cout + cc * 32 + ch * 8);
       if (!ok) v = E::zero();
       gr[j] = v;
     }
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
   for (int i = tid; i < KS * 1024; i += 256) {
     const int tx = i >> 10, co = (i >> 5) & 31, ci = i & 31;
     const int tap = KS == 3 ? ty * 3 + tx : (up_tap >= 0 ? up_tap : 0);
-    atomicAdd(a.dw + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
+    atomicAdd(a.dw + (size_t)cgrp * a.Cout * a.Cin + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
   }
 }
 
@@ -410,7 +412,8 @@ int launch_wg(WgArgs& a, hipStream_t s) {
   // one persistent workgroup per resident slot (2 per CU x 256 CUs): every workgroup ends with a cross-wave reduction and
   // 1024 * KS float atomics, so oversubscribing the CUs only multiplies that tail (measured on the training step: 2048
   // workgroups 4.7 ms of weight gradients, 512 workgroups 3.4 ms, 128 workgroups 6.8 ms)
-  const int gy_ = (KS == 1 && a.up_tap >= 0) ? 4 : KS;       // grid.y: vertical taps, or the four taps of the 2x2 kernel
+  // grid.y: vertical taps, the four taps of the 2x2 kernel, or the groups of a grouped 1x1
+  const int gy_ = (KS == 1 && a.up_tap >= 0) ? 4 : (KS == 1 ? a.groups : KS);
   int groups = 512 / (gy_ * pairs);
   if (groups < 1) groups = 1;
   if (groups > a.total_tiles) groups = a.total_tiles;
@@ -553,6 +556,7 @@ extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* d
   a.nci = d->Cin / 32;
   if (d->ksize == 3) a.M = 0;
   a.up_tap = -1; a.upH = a.upW = 0;
+  a.groups = (d->ksize == 1 && d->z_mode == UNCL_Z_GROUPS && d->groups > 1) ? d->groups : 1;
   a.gy_ld = d->out_C > 0 ? d->out_C : d->Cout;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->ksize == 3) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3<0>(a, s) : launch_wg3<1>(a, s);
@@ -575,7 +579,7 @@ extern "C" int uncl_upconv2x2_wgrad(const void* x, const void* gy, float* dw_pac
   a.H = rows; a.W = 32; a.s0H = rows; a.s0W = 32; a.Hout = rows; a.Wout = 32; a.M = M;
   a.tiles_x = 1; a.tiles_y = (rows + 15) / 16; a.total_tiles = a.tiles_y;
   a.nci = C / 32;
-  a.up_tap = 0; a.upH = H; a.upW = W; a.gy_ld = Cout;
+  a.up_tap = 0; a.upH = H; a.upW = W; a.gy_ld = Cout; a.groups = 1;
   return launch_wg<0, 1>(a, s);
 }
 
