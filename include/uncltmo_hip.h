@@ -372,6 +372,12 @@ int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtyp
 int uncl_nce_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
                       int neg_shared, float k, float c, const void* workspace, const float* upstream, void* g_anchor, void* g_pos,
                       void* g_neg, int grad_dtype, int pos_row, int neg_row, const int* shared_rows, void* stream);
+/* err = sum_i weights[i] * terms[i][0] over device scalars, and its backward out[i] = g[0] * weights[i]: the weighting of
+ * the loss terms in update_g_d_loss / train_G (GanTrainerImg.py:285-313,330-339) as one launch per direction.
+ * `terms` is a HOST array of n device pointers, `weights` a host array, n <= UNCL_WSUM_MAX. */
+#define UNCL_WSUM_MAX 16
+int uncl_weighted_sum(const float* const* terms, const float* weights, int n, float* out, void* stream);
+int uncl_weighted_sum_backward(const float* g, const float* weights, int n, float* out, void* stream);
 /* w * mean_n |a_n - b_n| over strided per-sample scalars (nn.L1Loss on per-frame means, GanTrainerImg.py:308-313) */
 int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss, float* g_a,
                   float* g_b, int accumulate_loss, void* stream);

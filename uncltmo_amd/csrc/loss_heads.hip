@@ -233,6 +233,26 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const T* __restrict__ a, c
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Weighted sum of device scalars (the trainers' `err = w1*l1 + w2*l2 + ...`, GanTrainerImg.py:285-313) and its backward:
+// one launch each instead of two tiny element-wise launches (and two autograd nodes) per term.
+// ------------------------------------------------------------------------------------------------------
+struct WSumArgs {
+  const float* term[UNCL_WSUM_MAX];
+  float w[UNCL_WSUM_MAX];
+  int n;
+};
+__global__ void weighted_sum_kernel(const WSumArgs t, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < t.n; ++i) s = fmaf(t.w[i], t.term[i][0], s);
+    out[0] = s;
+  }
+}
+__global__ void weighted_sum_bwd_kernel(const WSumArgs t, const float* __restrict__ g, float* __restrict__ out) {
+  if ((int)threadIdx.x < t.n) out[threadIdx.x] = g[0] * t.w[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------
 // L1 between two per-sample scalars: L = w * mean_n |a_n - b_n| ; g_a = w sign / N
 // ------------------------------------------------------------------------------------------------------
 __global__ void l1_pairs_kernel(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss,
@@ -617,6 +637,31 @@ extern "C" int uncl_nce_backward(const void* anchor, const void* pos, const void
   else if (grad_dtype == UNCL_BF16) UNCL_NCE_BWD(bf16_t, bf16_t);
   else UNCL_NCE_BWD(bf16_t, float);
 #undef UNCL_NCE_BWD
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// out[0] = sum_i weights[i] * terms[i][0]   (terms: host array of n device pointers, n <= UNCL_WSUM_MAX)
+extern "C" int uncl_weighted_sum(const float* const* terms, const float* weights, int n, float* out, void* stream) {
+  if (!terms || !weights || !out || n <= 0 || n > UNCL_WSUM_MAX) return UNCL_ERR_ARG;
+  WSumArgs t = {};
+  t.n = n;
+  for (int i = 0; i < n; ++i) {
+    if (!terms[i]) return UNCL_ERR_ARG;
+    t.term[i] = terms[i]; t.w[i] = weights[i];
+  }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), t, out);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// out[i] = g[0] * weights[i]: the n input gradients of uncl_weighted_sum for the upstream gradient g (a device scalar)
+extern "C" int uncl_weighted_sum_backward(const float* g, const float* weights, int n, float* out, void* stream) {
+  if (!g || !weights || !out || n <= 0 || n > UNCL_WSUM_MAX) return UNCL_ERR_ARG;
+  WSumArgs t = {};
+  t.n = n;
+  for (int i = 0; i < n; ++i) t.w[i] = weights[i];
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), t, g, out);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

@@ -2,6 +2,8 @@
 (csrc/loss_heads.hip, csrc/stats_kernels.hip).  Names follow the trainer methods they replace
 (GanTrainerImg.py:219-229 contrastive_D_loss, :410-439 nce, :341-408 pseudo_label_loss / infoNCE2,
 GanTrainer.py:669-682 L_TV)."""
+import ctypes as C
+
 import torch
 
 from . import _hip
@@ -226,6 +228,42 @@ def tmqi_naturalness(frames, patch=None):
     _hip.check(_hip.lib().uncl_tmqi_naturalness(xf.data_ptr(), n, h, w, ph, pw, 255.0, scores.data_ptr(), bw.data_ptr(),
                                                 _hip.stream_ptr()), "uncl_tmqi_naturalness")
     return scores, bw
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        lib = _hip.lib()
+        n = len(terms)
+        ts = [t.detach().reshape(1).float().contiguous() for t in terms]
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        w = (C.c_float * n)(*weights)
+        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        _hip.check(lib.uncl_weighted_sum(ptrs, w, n, out.data_ptr(), _hip.stream_ptr()), "uncl_weighted_sum")
+        ctx.weights = tuple(weights)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.weights)
+        w = (C.c_float * n)(*ctx.weights)
+        gs = g.detach().reshape(1).float().contiguous()
+        out = torch.empty(n, dtype=torch.float32, device=gs.device)
+        _hip.check(_hip.lib().uncl_weighted_sum_backward(gs.data_ptr(), w, n, out.data_ptr(), _hip.stream_ptr()),
+                   "uncl_weighted_sum_backward")
+        return (None,) + tuple(out[i] for i in range(n))
+
+
+def weighted_sum(pairs):
+    """sum_i w_i * t_i for (python float w_i, 0-dim device tensor t_i) pairs: the loss weighting of the trainers
+    (GanTrainerImg.py:285-313) as one launch forward and one backward instead of a chain of scalar tensor ops."""
+    pairs = [(float(w), t) for w, t in pairs]
+    out = None
+    for i in range(0, len(pairs), 16):
+        chunk = pairs[i:i + 16]
+        s = _WeightedSumFn.apply([w for w, _ in chunk], *[t for _, t in chunk])
+        out = s if out is None else out + s
+    return out
 
 
 class _TvFn(torch.autograd.Function):

@@ -148,31 +148,37 @@ class GanTrainer:
         cgan = self.contrastive_D_loss(d_fake_bp, d_real_pos_bp)
         if epoch <= self.epoch_step2:
             first = epoch <= self.epoch_step1
-            err = f * (1.0 if first else 1e-6) * cgan
-            err = err + f * 0.5 * self.infoNCE(d_fea_fake, d_fea_real_pos, d_fea_input, fake, hdr_input, "InfoNCE", 1, 1e-2)
-            err = err + f * 0.5 * (0.2 * self.infoNCE(d_fea_fake, d_fea_real_pos, d_fea_real_neg, fake, hdr_input, "InfoNCE",
-                                                       1e3, 2))
+            # the weights of GanTrainerImg.py:285-313, kept as python floats and applied in one launch (L.weighted_sum)
+            f = float(f)
+            terms = [(f * (1.0 if first else 1e-6), cgan),
+                     (f * 0.5, self.infoNCE(d_fea_fake, d_fea_real_pos, d_fea_input, fake, hdr_input, "InfoNCE", 1, 1e-2)),
+                     (f * 0.5 * 0.2, self.infoNCE(d_fea_fake, d_fea_real_pos, d_fea_real_neg, fake, hdr_input, "InfoNCE", 1e3, 2))]
             n2 = self.infoNCE2(fea_fake, fake, hdr_input, "InfoNCE", 1, 1e-2)
-            err = err + (f * 1e-6 * n2 if first else f * 0.1 * (5 * n2))
+            terms.append((f * 1e-6 if first else f * 0.1 * 5, n2))
             m_f, v_f = L.frame_stats(fake)
             with torch.no_grad():
                 m_p, v_p = L.frame_stats(ldr_pos)
             lm, lc = L.l1_mean(m_f, m_p), L.l1_mean(v_f, v_p)
-            err = err + (f * 1e-6 * lm if first else f * 0.5 * (1e2 * lm))
-            err = err + (f * 1e-6 * lc if first else f * 0.5 * (2 * lc))
-            err = err + f * 1e-6 * self.pseudo_label_loss(fake, hdr_input)
+            terms.append((f * 1e-6 if first else f * 0.5 * 1e2, lm))
+            terms.append((f * 1e-6 if first else f * 0.5 * 2, lc))
+            terms += [(f * 1e-6 * w, t) for w, t in self.pseudo_label_terms(fake, hdr_input)]
+            err = L.weighted_sum(terms)
         else:
             err = self._last_regime_loss(cgan, fake, ldr_pos, hdr_input)
         self.errG_d = err
         self.G_loss_d.append(err.detach())
 
-    def pseudo_label_loss(self, fake, hdr_input):
+    def pseudo_label_terms(self, fake, hdr_input):
+        """The two L1 terms of pseudo_label_loss (GanTrainerImg.py:341-368) as (weight, tensor) pairs."""
         n = fake.shape[0]
         scores, bw = L.tmqi_naturalness(fake, patch=128)
         patches = fake.reshape(n, 1, 2, 128, 2, 128).permute(0, 2, 4, 1, 3, 5).reshape(4 * n, 1, 128, 128)
         m, v = L.frame_stats(patches)
         best = bw[0].long()
-        return L.l1_mean(m, m[best].expand_as(m)) + L.l1_mean(v, v[best].expand_as(v))
+        return [(1.0, L.l1_mean(m, m[best].expand_as(m))), (1.0, L.l1_mean(v, v[best].expand_as(v)))]
+
+    def pseudo_label_loss(self, fake, hdr_input):
+        return L.weighted_sum(self.pseudo_label_terms(fake, hdr_input))
 
     def infoNCE(self, fea_fake, fea_real, fea_neg, fake, hdr_input, cl_loss_type, k, constant):
         return self.nce(fea_fake, [fea_real], [fea_neg], cl_loss_type, k, constant)

@@ -22,8 +22,8 @@ class GanTrainer(_ImageTrainer):
         f = self.loss_g_d_factor
         m_f, _ = L.frame_stats(fake)
         m_p, _ = L.frame_stats(ldr_pos)
-        err = f * 1e-6 * cgan
-        err = err + f * 0.5 * (1e2 * L.l1_mean(m_f, m_p.detach()))
-        err = err + f * 0.5 * (1e2 * self.pseudo_label_loss(fake, hdr_input))
-        err = err + f * 0.2 * (1e5 * L.tv_loss(fake))
-        return err
+        f = float(f)
+        terms = [(f * 1e-6, cgan), (f * 0.5 * 1e2, L.l1_mean(m_f, m_p.detach()))]
+        terms += [(f * 0.5 * 1e2 * w, t) for w, t in self.pseudo_label_terms(fake, hdr_input)]
+        terms.append((f * 0.2 * 1e5, L.tv_loss(fake)))
+        return L.weighted_sum(terms)
