@@ -244,6 +244,32 @@ def test_pipe_small_maps_whole_samples_per_tile(cin, cout, h, w, n, pad, res):
     assert (out[n] == 7.0).all()                                                        # nothing written past the batch
 
 
+def test_pipe_random_shapes_plain_layers():
+    """Seeded sweep over channel counts, odd map sizes (3..44), batch sizes and both paddings: rectangular tiles with ragged
+    borders, 8-row tiles, 64-channel tiles and the whole-samples-per-tile form all have to agree with the torch reference and
+    leave the sample behind the batch untouched."""
+    import random
+    rng = random.Random(20240807)
+    for it in range(24):
+        cin, cout = rng.choice([32, 64, 128, 256]), rng.choice([32, 64, 128, 256])
+        pad, h, w, n = rng.choice([0, 2]), rng.randint(3, 44), rng.randint(3, 44), rng.randint(1, 6)
+        x, b = q(rnd(n, cin, h, w, seed=300 + it), BF), rnd(cout, seed=400 + it)
+        if pad == 0:
+            wt = q(rnd(cout, cin, 3, 3, seed=500 + it, scale=0.05), BF)
+            y, packed = F.conv2d(x, wt, b), pack_weight(wt, BF)
+        else:
+            wt = q(rnd(cin, cout, 3, 3, seed=500 + it, scale=0.05), BF)
+            y, packed = F.conv_transpose2d(x, wt, b), pack_weight(wt, BF, transposed=True, flip=True)
+        ref = F.relu(y)
+        ho, wo = ref.shape[2], ref.shape[3]
+        out = torch.full((n + 1, ho, wo, cout), 7.0, dtype=torch.bfloat16, device="cuda")
+        run_pipe(dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=to_nhwc(x, BF),
+                 src0_H=h, src0_W=w, src0_C=cin, weight=packed, bias=b.cuda(), act=_hip.ACT_RELU, out=out, out_H=ho, out_W=wo,
+                 out_C=cout)
+        assert rel_l2(from_nhwc(out[:n]), ref) < TOL[BF], (cin, cout, pad, h, w, n)
+        assert (out[n] == 7.0).all(), (cin, cout, pad, h, w, n)
+
+
 def test_pipe_broadcast_residual_and_skip_store():
     cin, cout, h = 256, 256, 10
     x, wt, b = q(rnd(3, cin, h, h, seed=40), BF), q(rnd(cin, cout, 3, 3, seed=41, scale=0.05), BF), rnd(cout, seed=42)
