@@ -270,6 +270,37 @@ def test_pipe_random_shapes_plain_layers():
         assert (out[n] == 7.0).all(), (cin, cout, pad, h, w, n)
 
 
+def test_pipe_random_shapes_concat_loaders():
+    """Seeded sweep of the skip-concat loaders (square / square-root operator and plain two-way concat): channel counts, odd
+    sizes, both paddings, the up-sampled operand 0..2 pixels smaller than the skip (replicate padding, unet_parts.py:292-298)."""
+    import random
+    rng = random.Random(19690720)
+    for it in range(16):
+        c, cout = rng.choice([32, 64, 128]), rng.choice([32, 64, 128])
+        pad, h, w, n = rng.choice([0, 2, 2]), rng.randint(5, 40), rng.randint(5, 40), rng.randint(1, 4)
+        dy, dx, mode = rng.choice([0, 1, 2]), rng.choice([0, 1, 2]), rng.choice(["ssr", "ssr", "cat2"])
+        x2, x1 = q(rnd(n, c, h, w, seed=600 + it).abs(), BF), q(rnd(n, c, h - dy, w - dx, seed=700 + it), BF)
+        x1p = F.pad(x1, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2), mode="replicate")
+        groups = 4 if mode == "ssr" else 2
+        cat = torch.cat([x2, x1p, q(x2 ** 2, BF), q((x2 + 1e-8) ** 0.5, BF)], 1) if mode == "ssr" else torch.cat([x2, x1p], 1)
+        b = rnd(cout, seed=800 + it)
+        if pad == 0:
+            wt = q(rnd(cout, groups * c, 3, 3, seed=900 + it, scale=0.03), BF)
+            y, packed = F.conv2d(cat, wt, b), pack_weight(wt, BF)
+        else:
+            wt = q(rnd(groups * c, cout, 3, 3, seed=900 + it, scale=0.03), BF)
+            y, packed = F.conv_transpose2d(cat, wt, b), pack_weight(wt, BF, transposed=True, flip=True)
+        ref = F.relu(y)
+        ho, wo = ref.shape[2], ref.shape[3]
+        out = torch.full((n + 1, ho, wo, cout), 7.0, dtype=torch.bfloat16, device="cuda")
+        run_pipe(dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_CONCAT_SSR if mode == "ssr" else _hip.SRC_CONCAT2, N=n, H=h, W=w,
+                 Cin=groups * c, Cout=cout, src0=to_nhwc(x2, BF), src0_H=h, src0_W=w, src0_C=c, src1=to_nhwc(x1, BF),
+                 src1_H=h - dy, src1_W=w - dx, src1_C=c, weight=packed, bias=b.cuda(), act=_hip.ACT_RELU, out=out, out_H=ho,
+                 out_W=wo, out_C=cout)
+        assert rel_l2(from_nhwc(out[:n]), ref) < 2e-2, (mode, c, cout, pad, h, w, n, dy, dx)
+        assert (out[n] == 7.0).all(), (mode, c, cout, pad, h, w, n, dy, dx)
+
+
 def test_pipe_broadcast_residual_and_skip_store():
     cin, cout, h = 256, 256, 10
     x, wt, b = q(rnd(3, cin, h, h, seed=40), BF), q(rnd(cin, cout, 3, 3, seed=41, scale=0.05), BF), rnd(cout, seed=42)
