@@ -67,6 +67,41 @@ def test_wgrad3x3_transposed_concat_ssr():
     assert rel_l2(unpack(dw, cout, 4 * c, 3, True, True), wt.grad) < 3e-3
 
 
+def test_wgrad3x3_random_shapes():
+    """Seeded sweep of the nine-taps-per-workgroup weight gradient: channel counts, odd sizes (ragged 16 x 32 tiles and halo
+    rows), both paddings, plain and skip-concat inputs (up-sampled operand up to 2 pixels smaller: replicate padding)."""
+    import random
+    rng = random.Random(5551212)
+    for it in range(14):
+        cout = rng.choice([32, 64, 128])
+        pad, h, w, n = rng.choice([0, 2]), rng.randint(4, 44), rng.randint(4, 44), rng.randint(1, 4)
+        concat = rng.random() < 0.4
+        if concat:
+            c, dy, dx = rng.choice([32, 64]), rng.choice([0, 1, 2]), rng.choice([0, 1, 2])
+            x2, x1 = q(rnd(n, c, h, w, seed=40 + it).abs()), q(rnd(n, c, h - dy, w - dx, seed=60 + it))
+            x1p = F.pad(x1, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2), mode="replicate")
+            x = torch.cat([x2, x1p, q(x2 ** 2), q((x2 + 1e-8) ** 0.5)], 1)
+            cin = 4 * c
+            kw = dict(src_mode=_hip.SRC_CONCAT_SSR, src0=to_nhwc(x2, BF), src0_C=c, src1=to_nhwc(x1, BF), src1_H=h - dy,
+                      src1_W=w - dx, src1_C=c)
+        else:
+            cin = rng.choice([32, 64, 128])
+            x = q(rnd(n, cin, h, w, seed=40 + it))
+            kw = dict(src_mode=_hip.SRC_PLAIN, src0=to_nhwc(x, BF), src0_C=cin)
+        if pad == 0:
+            wt = rnd(cout, cin, 3, 3, seed=80 + it, scale=0.1).requires_grad_(True)
+            gy = q(rnd(n, cout, h - 2, w - 2, seed=90 + it))
+            F.conv2d(x, wt).backward(gy)
+        else:
+            wt = rnd(cin, cout, 3, 3, seed=80 + it, scale=0.1).requires_grad_(True)
+            gy = q(rnd(n, cout, h + 2, w + 2, seed=90 + it))
+            F.conv_transpose2d(x, wt).backward(gy)
+        dw = wgrad(to_nhwc(gy, BF), (9, cout, cin), dtype=BF, ksize=3, pad=pad, N=n, H=h, W=w, Cin=cin, Cout=cout, src0_H=h,
+                   src0_W=w, **kw)
+        got = unpack(dw, cout, cin, 3, pad == 2, pad == 2)
+        assert rel_l2(got, wt.grad) < 4e-3, (concat, cin, cout, pad, h, w, n)
+
+
 @pytest.mark.parametrize("n", [2, 3])
 def test_wgrad1x1(n):
     cin, cout = 256, 128
