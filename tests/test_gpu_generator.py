@@ -221,6 +221,21 @@ def test_tiler_real_generator(golden):
     assert rel_l2(y.cpu(), torch.from_numpy(g["tiler.realG.272"])) < 1e-4
 
 
+def test_tiled_forward_as_one_graph():
+    """tiler.TiledGraph: gather -> generator -> cross-fade captured once as a hipGraph (incl. the two-stream fork / join of
+    large batches) and replayed on new frames: bit-identical to the eager path."""
+    net = make_g("bf16")
+    for n_frames, h, w in ((1, 528, 784), (3, 1040, 1040)):             # 6 and 3 x 36 tiles (>= 64: two streams)
+        tg = tiler.TiledGraph(net, n_frames, h, w)
+        for salt in ("g1", "g2"):
+            fr = synth.hdr_frames(n_frames, h, w, salt=salt).cuda()
+            want = tiler.test_big_size_image2(fr, net, 0, 0, 0)
+            got = tg(fr)
+            assert torch.equal(got, want)
+        with pytest.raises(ValueError):
+            tg(torch.zeros(n_frames, 1, h + 1, w, device="cuda"))
+
+
 def test_tiler_full_size_properties():
     """1024^2 (25 tiles): with an identity 'model' the cross-fade must reproduce the frame exactly (the blend
     weights of every pixel sum to one), and tiling must commute with a per-pixel affine map."""

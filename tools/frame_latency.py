@@ -20,3 +20,13 @@ for (h, w) in ((1024, 1024), (2160, 3840)):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print("%dx%d: %.2f ms per frame (synchronous), %s" % (h, w, dt * 1e3, tuple(out.shape)))
+    tg = tiler.TiledGraph(net, 1, h, w)
+    ref = tiler.test_big_size_image2(fr, net, 0, 0, 0)
+    got = tg(fr)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = tg(fr)
+        torch.cuda.synchronize()
+    print("%dx%d: %.2f ms per frame as one hipGraph replay" % (h, w, (time.perf_counter() - t0) / n * 1e3))

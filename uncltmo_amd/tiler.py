@@ -77,3 +77,38 @@ def test_big_size_image(input_data, model, apply_crop, diffY, diffX, patch_h=256
         out, _ = model(clips, apply_crop=apply_crop, diffY=diffY, diffX=diffX)
     out = out.reshape(B, nt, T, 1, 256, 256).permute(0, 2, 1, 3, 4, 5).reshape(B * T * nt, 1, 256, 256).float().contiguous()
     return blend_tiles(out, B * T, H, W).reshape(B, T, 1, H, W)
+
+
+class TiledGraph:
+    """The whole tiled forward (gather -> generator -> cross-fade) of a FIXED frame batch shape as one hipGraph.
+
+    For streams of single frames (25 tiles at 1024^2) the ~35 launches of a forward are latency-, not throughput-bound;
+    replaying them as a graph removes the per-launch host cost and the gaps between dependent launches.  The graph owns
+    its input and output buffers: `graph(frames)` copies the frames in, replays, and returns the (re-used) output tensor --
+    clone it if it has to outlive the next call.  Weights are read through the pointers captured at construction: rebuild
+    the object after changing the model's parameters."""
+
+    def __init__(self, model, n_frames, H, W):
+        if not hasattr(model, "infer"):
+            raise TypeError("TiledGraph needs the HIP image generator (uncltmo_amd.generator.UNet)")
+        dev = next(model.parameters()).device
+        self.model = model
+        self.static_in = torch.zeros(n_frames, 1, H, W, dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # warm-up: kernel attributes, packed weights and workspaces exist before capture
+            for _ in range(2):
+                test_big_size_image2(self.static_in, model, 0, 0, 0)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._keep = model._packed_weights()    # the captured launches read these buffers
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = test_big_size_image2(self.static_in, model, 0, 0, 0)
+
+    def __call__(self, frames):
+        if frames.shape != self.static_in.shape:
+            raise ValueError("TiledGraph was captured for frames of shape %s, got %s" % (tuple(self.static_in.shape), tuple(frames.shape)))
+        self.static_in.copy_(frames)
+        self.graph.replay()
+        return self.static_out
