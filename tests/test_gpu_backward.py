@@ -342,8 +342,9 @@ def test_head_handoff_and_mix_kernels():
     assert torch.equal(mixed, refm)
 
 
-def test_gauss_stats_backward_vs_autograd():
-    n, h, c = 2, 40, 16
+@pytest.mark.parametrize("n,h,c,accumulate", [(2, 40, 16, 0), (3, 45, 32, 0), (2, 70, 32, 1), (1, 256, 32, 0)])
+def test_gauss_stats_backward_vs_autograd(n, h, c, accumulate):
+    """c == 32 takes the whole-pixel kernel (all channels of a 16 x 16 tile per workgroup), other widths the per-channel one."""
     x = q(rnd(n, c, h, h, seed=64).abs()).requires_grad_(True)
     gst = rnd(n, 2, c, seed=65)
     win = OG.gauss_window()
@@ -351,10 +352,12 @@ def test_gauss_stats_backward_vs_autograd():
     f2 = OG.local_variance(x, win).mean(dim=(2, 3))
     ((f1 * gst[:, 0]).sum() + (f2 * gst[:, 1]).sum()).backward()
     xd = to_nhwc(x.detach(), BF)
-    gx = torch.empty_like(xd)
-    _hip.check(_hip.lib().uncl_gauss_stats_backward(xd.data_ptr(), BF, gst.cuda().data_ptr(), gx.data_ptr(), n, h, h, c, 0,
+    prior = q(rnd(n, c, h, h, seed=66, scale=1e-4))
+    gx = to_nhwc(prior, BF).clone() if accumulate else torch.empty_like(xd)
+    _hip.check(_hip.lib().uncl_gauss_stats_backward(xd.data_ptr(), BF, gst.cuda().data_ptr(), gx.data_ptr(), n, h, h, c, accumulate,
                                                     _hip.stream_ptr()), "gsb")
-    assert rel_l2(from_nhwc(gx), x.grad) < 1e-2
+    want = x.grad + prior if accumulate else x.grad
+    assert rel_l2(from_nhwc(gx), want) < 1e-2
 
 
 def test_video_generator_backward_through_time_vs_oracle_autograd():

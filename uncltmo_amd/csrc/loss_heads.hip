@@ -702,6 +702,159 @@ extern "C" int uncl_gauss_var_backward(const float* x, const float* gscale, floa
   return UNCL_OK;
 }
 
+// The same backward for the case that matters (the generator's 32-channel bf16 feature map, five times per video step):
+// one workgroup per 16 x 16 pixel tile and ALL 32 channels.  The tile with its 10-pixel halo is read as whole 64-byte
+// pixels (the one-channel form above touches 2 of every 64 bytes it pulls in, and writes the same way: 440 us for 8 frames),
+// transposed into per-channel bf16 planes in LDS, each wave runs the four separable passes for eight channels in its own
+// scratch, and the result goes back through LDS as whole pixels.
+constexpr int HT = 16, HM = HT + GW - 1 /*26*/, HI = HM + GW - 1 /*36*/;
+__global__ __launch_bounds__(512) void gauss_stats_bwd32_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gst,
+                                                                bf16_t* __restrict__ gx, int H, int W, int tiles_x, GaussW gw,
+                                                                int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PS = HI * HI + 2;     // plane stride in elements: 649 dwords, so planes 8 apart sit 8 banks apart
+  bf16_t* sx = reinterpret_cast<bf16_t*>(smem);                               // [32][PS] input planes
+  float* tmp = reinterpret_cast<float*>(smem + 32 * PS * 2);                  // per wave: sh[HI*HM] (later sv[HT*HM]), smu[HM*HM]
+  constexpr int TMPW = HI * HM + HM * HM, NWAVE = 8, NTHR = NWAVE * 64;
+  bf16_t* so = reinterpret_cast<bf16_t*>(smem + 32 * PS * 2 + NWAVE * TMPW * 4);  // [HT*HT][32] results
+  const int n = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * HT, x0 = tx * HT;
+  const int Ho = H - (GW - 1), Wo = W - (GW - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* xn = x + (size_t)n * H * W * 32;
+  // two adjacent plane positions per thread: every LDS write is a whole dword (channel i of both pixels)
+  for (int v = tid; v < (HI * HI / 2) * 4; v += NTHR) {
+    const int pair = v >> 2, c8 = v & 3;
+    bf16x8 val[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int pix = 2 * pair + h2, ly = pix / HI, lx = pix - ly * HI;
+      const int gy = y0 - 10 + ly, gxx = x0 - 10 + lx;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) val[h2][i] = (bf16_t)0.f;
+      if (gy >= 0 && gy < H && gxx >= 0 && gxx < W)
+        val[h2] = *reinterpret_cast<const bf16x8*>(xn + ((size_t)gy * W + gxx) * 32 + c8 * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+      bf16x2_t pk;
+      pk[0] = val[0][i]; pk[1] = val[1][i];
+      *reinterpret_cast<bf16x2_t*>(sx + (c8 * 8 + i) * PS + 2 * pair) = pk;
+    }
+  }
+  __syncthreads();
+  // the passes of a channel run inside ONE wave on its private scratch: ordering between them needs the wave's own LDS
+  // operations to have completed, not a workgroup barrier
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+  float* sh = tmp + wave * TMPW;
+  float* smu = sh + HI * HM;
+  float* sv = sh;                    // the first pass's buffer is dead when the third pass writes
+  // Every pass computes runs of four outputs along the filter direction from 14 inputs held in registers (44 LDS reads
+  // become 14).  Unit -> (line, run) maps and the edge weights of the last pass are the same for every channel.
+  constexpr int R = 4, NRM = (HM + R - 1) / R /*7 runs across 26*/, NRT = HT / R /*4 runs across 16*/;
+  // last pass: this lane's run (row py, columns 4*pr .. +3) and the window-count weights wy, wx of its four pixels
+  const int py = lane / NRT, pr = lane - py * NRT;
+  float wy4 = 0.f, wx4[R] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int gyv = y0 + py;
+    if (gyv - t >= 0 && gyv - t < Ho) wy4 += gw.g[t];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int gxv = x0 + pr * R + r;
+      if (gxv - t >= 0 && gxv - t < Wo) wx4[r] += gw.g[t];
+    }
+  }
+  for (int ci = 0; ci < 32 / NWAVE; ++ci) {
+    const int ch = wave + NWAVE * ci;
+    const bf16_t* sc_ = sx + ch * PS;
+    // 1: sh[ly][lx] = sum_t g[t] x[ly][lx + t]                     (HI rows x HM columns)
+    for (int u = lane; u < HI * NRM; u += 64) {
+      const int ly = u / NRM, lx0 = (u - ly * NRM) * R;
+      float in[R + GW - 1];
+#pragma unroll
+      for (int j = 0; j < R + GW - 1; ++j) in[j] = (float)sc_[ly * HI + min(lx0 + j, HI - 1)];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < GW; ++t) acc = fmaf(gw.g[t], in[r + t], acc);
+        if (lx0 + r < HM) sh[ly * HM + lx0 + r] = acc;
+      }
+    }
+    WAVE_SYNC();
+    // 2: mu[ly][lx] = sum_t g[t] sh[ly + t][lx] at valid window positions, else 0        (HM x HM)
+    for (int u = lane; u < NRM * HM; u += 64) {
+      const int lr_ = u / HM, lx = u - lr_ * HM, ly0 = lr_ * R;
+      float in[R + GW - 1];
+#pragma unroll
+      for (int j = 0; j < R + GW - 1; ++j) in[j] = sh[min(ly0 + j, HI - 1) * HM + lx];
+      const int ox = x0 - 10 + lx;
+      const bool xok = ox >= 0 && ox < Wo;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < GW; ++t) acc = fmaf(gw.g[t], in[r + t], acc);
+        const int oy = y0 - 10 + ly0 + r;
+        if (ly0 + r < HM) smu[(ly0 + r) * HM + lx] = (xok && oy >= 0 && oy < Ho) ? acc : 0.f;
+      }
+    }
+    WAVE_SYNC();
+    // 3: sv[ly][lx] = sum_t g[t] mu[ly + 10 - t][lx]                (HT rows x HM columns)
+    for (int u = lane; u < NRT * HM; u += 64) {
+      const int lr_ = u / HM, lx = u - lr_ * HM, ly0 = lr_ * R;
+      float in[R + GW - 1];          // mu rows ly0 .. ly0 + 13
+#pragma unroll
+      for (int j = 0; j < R + GW - 1; ++j) in[j] = smu[(ly0 + j) * HM + lx];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < GW; ++t) acc = fmaf(gw.g[t], in[r + 10 - t], acc);
+        sv[(ly0 + r) * HM + lx] = acc;
+      }
+    }
+    WAVE_SYNC();
+    // 4: s[ly][lx] = sum_t g[t] sv[ly][lx + 10 - t]; gradient = g_mean + sc (x wy wx - s)
+    const float gm = gst[((size_t)n * 2 + 0) * 32 + ch] / ((float)H * (float)W);
+    const float scv = gst[((size_t)n * 2 + 1) * 32 + ch] * 2.f / ((float)Ho * (float)Wo);
+    {
+      float in[R + GW - 1];          // sv columns 4 pr .. 4 pr + 13 of row py
+#pragma unroll
+      for (int j = 0; j < R + GW - 1; ++j) in[j] = sv[py * HM + pr * R + j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < GW; ++t) acc = fmaf(gw.g[t], in[r + 10 - t], acc);
+        const int lx = pr * R + r;
+        so[(py * HT + lx) * 32 + ch] = (bf16_t)(gm + scv * ((float)sc_[(py + 10) * HI + lx + 10] * wy4 * wx4[r] - acc));
+      }
+    }
+    WAVE_SYNC();
+  }
+  __syncthreads();
+#undef WAVE_SYNC
+  for (int v = tid; v < HT * HT * 4; v += NTHR) {
+    const int pix = v >> 2, c8 = v & 3, ly = pix / HT, lx = pix - ly * HT;
+    const int gy = y0 + ly, gxx = x0 + lx;
+    if (gy < H && gxx < W) {
+      bf16_t* d = gx + ((size_t)n * H * W + (size_t)gy * W + gxx) * 32 + c8 * 8;
+      bf16x8 val = *reinterpret_cast<const bf16x8*>(so + pix * 32 + c8 * 8);
+      if (accumulate) {
+        const bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) val[i] = (bf16_t)((float)old[i] + (float)val[i]);
+      }
+      *reinterpret_cast<bf16x8*>(d) = val;
+    }
+  }
+}
+
 // x, gx: NHWC (N,H,W,C) in dtype; g_stats: fp32 (N,2,C) = [d/d mean, d/d mean-local-variance] per (sample, channel)
 extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* g_stats, void* gx, int N, int H, int W, int C,
                                          int accumulate, void* stream) {
@@ -713,7 +866,19 @@ extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* 
   for (int k = 0; k < GW; ++k) gw.g[k] = (float)(g[k] / s);
   const int tx = (W + GT - 1) / GT, ty = (H + GT - 1) / GT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == UNCL_BF16)
+  if (dtype == UNCL_BF16 && C == 32) {
+    constexpr size_t lds = (size_t)32 * (HI * HI + 2) * 2 + (size_t)8 * (HI * HM + HM * HM) * 4 + (size_t)HT * HT * 32 * 2;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_stats_bwd32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return UNCL_ERR_LAUNCH;
+      attr = true;
+    }
+    const int tx16 = (W + HT - 1) / HT, ty16 = (H + HT - 1) / HT;
+    hipLaunchKernelGGL(gauss_stats_bwd32_kernel, dim3(tx16 * ty16, N), dim3(512), lds, st, (const bf16_t*)x, g_stats, (bf16_t*)gx, H, W,
+                       tx16, gw, accumulate);
+  } else if (dtype == UNCL_BF16)
     hipLaunchKernelGGL(gauss_stats_bwd_kernel<bf16_t>, dim3(tx * ty, N, C), dim3(256), 0, st, (const bf16_t*)x, g_stats, (bf16_t*)gx,
                        H, W, C, tx, gw, accumulate);
   else
