@@ -146,7 +146,7 @@ __global__ void gauss_stats_final_kernel(const float* __restrict__ partial, floa
 }  // namespace
 
 extern "C" size_t uncl_gauss_stats_workspace_bytes(int N, int H, int C) {
-  const int band_rows = 32;
+  const int band_rows = 8;        // the thinnest band uncl_gauss_stats may choose
   const int n_bands = (H - 10 + band_rows - 1) / band_rows;
   return (size_t)N * (n_bands > 0 ? n_bands : 1) * 2 * C * sizeof(float);
 }
@@ -161,8 +161,11 @@ extern "C" int uncl_gauss_stats(const void* x, int dtype, float* out, int N, int
   double s = 0.0, g[GW];
   for (int k = 0; k < GW; ++k) { g[k] = exp(-((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); s += g[k]; }
   for (int k = 0; k < GW; ++k) gw.g[k] = (float)(g[k] / s);
-  const int band_rows = 32;
   const int Ho = H - (GW - 1), Wo = W - (GW - 1);
+  // bands of output rows per workgroup: 32 rows re-read 31 % of halo rows; small batches (the per-frame calls of the video
+  // generator: 8 samples) take thinner bands so that the launch has more workgroups than CUs
+  int band_rows = 32;
+  while (band_rows > 8 && (long long)((Ho + band_rows - 1) / band_rows) * (C >= 8 ? C / 8 : 1) * N < 768) band_rows /= 2;
   const int n_bands = (Ho + band_rows - 1) / band_rows;
   float* partial = reinterpret_cast<float*>(workspace);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
