@@ -15,6 +15,16 @@ opt = types.SimpleNamespace(device=dev, pyramid_weight_list=torch.tensor([1.0, 1
                             struct_method="gamma_ssim", add_frame=0, final_shape_addition=0, loss_g_d_factor=0.1,
                             adv_weight_list=torch.tensor([0.2, 0.2, 0.2]))
 tr = GanTrainer(opt, G, D, optG, optD, None, None)
+if os.environ.get("UNCL_SYNC_DEBUG"):      # list the host synchronisation points of one step
+    hdr = synth.smooth_hdr_frames(4, salt="h").reshape(2, 2, 1, 256, 256).to(dev)
+    pos = synth.ldr_frames(4, salt="p").reshape(2, 2, 1, 256, 256).to(dev)
+    neg = (synth.ldr_frames(4, salt="n") ** 2).reshape(2, 2, 1, 256, 256).to(dev)
+    tr.train_D(hdr, pos, neg, 0); tr.train_G(hdr, hdr, pos, neg, 0)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("warn")
+    tr.train_D(hdr, pos, neg, 0); tr.train_G(hdr, hdr, pos, neg, 0)
+    torch.cuda.set_sync_debug_mode("default")
+    sys.exit(0)
 for B in (1, 16):
     hdr = synth.smooth_hdr_frames(B * 2, salt="h").reshape(B, 2, 1, 256, 256).to(dev)
     pos = synth.ldr_frames(B * 2, salt="p").reshape(B, 2, 1, 256, 256).to(dev)

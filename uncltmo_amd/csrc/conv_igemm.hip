@@ -326,6 +326,146 @@ int dispatch(const ConvArgs& a, int ksize, int nt, dim3 grid, hipStream_t s) {
   return launch<T, 1, 1, 8, 4>(a, grid, s);
 }
 
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions of the graph block in bf16 (Grapher fc1 / fc2, the grouped graph conv, FFN fc1 / fc2: Unet_singleFrame.py:
+// 25-41, torch_vertex.py:190-199, torch_nn.py:58) -- plain GEMMs over 144 nodes per sample, a few GFLOP, LATENCY-bound: the
+// generic kernel above walks K in 32-channel steps with a load -> LDS -> barrier -> multiply round trip each (8-16 serial
+// memory latencies, 19-40 us per launch).  Here a workgroup stages its slice of the weights ([CT][CIN], swizzled) once, and
+// per 128-pixel tile every wave requests ALL of its K (one 16-byte B fragment per 16 channels, straight from global memory)
+// before the first multiply: one memory latency per tile.  Epilogue = the generic kernel's: act(acc + bias) * scale_n + res.
+// ------------------------------------------------------------------------------------------------------------------
+struct C1Args {
+  const bf16_t* x;      // pixels x ld_in
+  const bf16_t* w;      // [groups][Cout][CIN] packed
+  const float* bias;    // [groups * Cout] or NULL
+  const float* scale_n; // per sample or NULL
+  const bf16_t* res;    // same layout as out, or NULL
+  bf16_t* out;
+  int M, n_tiles, ld_in, ld_out, Cout, act, px_per_sample, res_b0, n_ct;
+};
+
+template <int CIN, int NT>
+__global__ __launch_bounds__(256) void conv1x1_direct_kernel(const C1Args a) {
+  using vec = bf16x8;
+  constexpr int KSTEPS = CIN / 16, S = CIN / 8, CT = NT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;                                   // [CT][CIN] bf16, 16-byte slots XOR row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ct = blockIdx.y % a.n_ct, grp = blockIdx.y / a.n_ct;
+  const int in_off = grp * CIN, out_off = grp * a.Cout + ct * CT;
+  const bf16_t* wg = a.w + ((size_t)grp * a.Cout + ct * CT) * CIN;
+  for (int v = tid; v < CT * S; v += 256) {
+    const int row = v / S, slot = v - row * S;
+    *reinterpret_cast<vec*>(sW + row * (CIN * 2) + ((slot ^ (row & (S - 1))) << 4)) =
+        *reinterpret_cast<const vec*>(wg + (size_t)row * CIN + slot * 8);
+  }
+  float bv[NT][16];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      bv[nt][i] = a.bias ? a.bias[out_off + nt * 32 + 8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f;
+  __syncthreads();
+  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const int m = t * 128 + wave * 32 + lr;
+    const bool valid = m < a.M;
+    const bf16_t* xp = a.x + (size_t)min(m, a.M - 1) * a.ld_in + in_off + lh * 8;
+    vec B[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) B[ks] = *reinterpret_cast<const vec*>(xp + ks * 16);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int row = nt * 32 + lr;
+        const vec A = *reinterpret_cast<const vec*>(sW + row * (CIN * 2) + (((2 * ks + lh) ^ (row & (S - 1))) << 4));
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[ks], acc[nt], 0, 0, 0);
+      }
+    if (valid) {
+      const int smp = m / a.px_per_sample;
+      const float sc = a.scale_n ? a.scale_n[smp] : 1.f;
+      const size_t opix = (size_t)m * a.ld_out + out_off;
+      const size_t rpix = (size_t)(a.res_b0 ? m - smp * a.px_per_sample : m) * a.ld_out + out_off;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cb = nt * 32 + 8 * q + 4 * lh;
+          float v4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v4[r] = uncl_act(acc[nt][4 * q + r] + bv[nt][4 * q + r], a.act) * sc;
+          if (a.res) {
+            float rr[4];
+            load4<bf16_t>(a.res, rpix + cb, rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] += rr[r];
+          }
+          store4<bf16_t>(a.out, opix + cb, v4);
+        }
+    }
+  }
+}
+
+template <int CIN, int NT>
+int launch_c1(const C1Args& a, int groups, hipStream_t s) {
+  constexpr size_t lds = (size_t)NT * 32 * CIN * 2;
+  auto kern = conv1x1_direct_kernel<CIN, NT>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr = true;
+  }
+  // every workgroup stages up to 64 KB of weights: a strided share of the tiles per resident slot, not one workgroup per tile
+  const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : ((int)(160 * 1024 / lds) > 4 ? 4 : (int)(160 * 1024 / lds));
+  int gx = (256 * per_cu) / (a.n_ct * groups);
+  if (gx < 1) gx = 1;
+  if (gx > a.n_tiles) gx = a.n_tiles;
+  hipLaunchKernelGGL(kern, dim3(gx, a.n_ct * groups), dim3(256), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// returns C1_NOT_MINE when the descriptor is outside this kernel's scope (the caller then takes the generic path)
+constexpr int C1_NOT_MINE = 1;
+int conv1x1_direct(const uncl_conv_desc* d, hipStream_t s) {
+  if (d->dtype != UNCL_BF16 || d->ksize != 1 || d->src_mode != UNCL_SRC_PLAIN || d->prev0 != nullptr || d->out1_w != nullptr ||
+      d->skip_main_store || d->src1 != nullptr)
+    return C1_NOT_MINE;
+  if (d->z_mode != UNCL_Z_NONE && d->z_mode != UNCL_Z_GROUPS) return C1_NOT_MINE;
+  const int groups = d->z_mode == UNCL_Z_GROUPS ? d->groups : 1;
+  if (d->Cin != 128 && d->Cin != 256 && d->Cin != 512) return C1_NOT_MINE;
+  const long long M = (long long)d->N * d->H * d->W;
+  if (M <= 0 || M > 0x7fffffffLL / 1024) return C1_NOT_MINE;
+  // output channels per workgroup: 128 (64 for K = 512: 64 KB of weights at most) when there are pixel tiles to amortise the
+  // weight staging over, 32 for the small batches of the training steps, where the launch is one workgroup's latency chain
+  const long long tiles = (M + 127) / 128;
+  // the latency regime only (training batches: a few dozen samples x 144 nodes): with hundreds of pixel tiles the generic
+  // kernel's small weight chunks win over staging a weight slice per workgroup (measured at 100 / 200 tiles: 25-40 us vs
+  // 40-70 us), here one memory latency per launch wins over eight (9 us vs 19 us)
+  if (tiles > 48) return C1_NOT_MINE;
+  int nt = d->Cin == 512 ? 2 : 4;
+  while (nt > 1 && tiles * (d->Cout / (nt * 32)) * groups < 256) nt /= 2;
+  if (d->Cout % (nt * 32) != 0) return C1_NOT_MINE;
+  if (d->res != nullptr && d->res_batch_stride0 && (d->out_H != d->H || d->out_W != d->W)) return C1_NOT_MINE;
+  C1Args a;
+  a.x = (const bf16_t*)d->src0; a.w = (const bf16_t*)d->weight; a.bias = d->bias; a.scale_n = d->scale_n;
+  a.res = (const bf16_t*)d->res; a.out = (bf16_t*)d->out;
+  a.M = (int)M; a.n_tiles = (int)((M + 127) / 128); a.ld_in = d->src0_C; a.ld_out = d->out_C; a.Cout = d->Cout; a.act = d->act;
+  a.px_per_sample = d->H * d->W; a.res_b0 = d->res_batch_stride0; a.n_ct = d->Cout / (nt * 32);
+  if (d->Cin == 128) return nt == 4 ? launch_c1<128, 4>(a, groups, s) : (nt == 2 ? launch_c1<128, 2>(a, groups, s) : launch_c1<128, 1>(a, groups, s));
+  if (d->Cin == 256) return nt == 4 ? launch_c1<256, 4>(a, groups, s) : (nt == 2 ? launch_c1<256, 2>(a, groups, s) : launch_c1<256, 1>(a, groups, s));
+  return nt == 2 ? launch_c1<512, 2>(a, groups, s) : launch_c1<512, 1>(a, groups, s);
+}
+
 }  // namespace
 
 extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
@@ -349,6 +489,10 @@ extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
   if (d->z_mode == UNCL_Z_UP2X2 && d->ksize != 1) return UNCL_ERR_ARG;
   if (d->z_mode == UNCL_Z_GROUPS && d->groups <= 0) return UNCL_ERR_ARG;
 
+  {
+    const int rc1 = conv1x1_direct(d, reinterpret_cast<hipStream_t>(stream));
+    if (rc1 != C1_NOT_MINE) return rc1;
+  }
   ConvArgs a;
   a.src0 = d->src0; a.src1 = d->src1; a.prev0 = d->prev0;
   a.weight = d->weight; a.bias = d->bias; a.scale_n = d->scale_n; a.res = d->res; a.out = d->out;

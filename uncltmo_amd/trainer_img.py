@@ -174,8 +174,9 @@ class GanTrainer:
         scores, bw = L.tmqi_naturalness(fake, patch=128)
         patches = fake.reshape(n, 1, 2, 128, 2, 128).permute(0, 2, 4, 1, 3, 5).reshape(4 * n, 1, 128, 128)
         m, v = L.frame_stats(patches)
-        best = bw[0].long()
-        return [(1.0, L.l1_mean(m, m[best].expand_as(m))), (1.0, L.l1_mean(v, v[best].expand_as(v)))]
+        best = bw[0:1].long()                 # a 1-element index tensor: m[0-dim tensor] would read the index back to the host
+        return [(1.0, L.l1_mean(m, m.index_select(0, best).expand_as(m))),
+                (1.0, L.l1_mean(v, v.index_select(0, best).expand_as(v)))]
 
     def pseudo_label_loss(self, fake, hdr_input):
         return L.weighted_sum(self.pseudo_label_terms(fake, hdr_input))
