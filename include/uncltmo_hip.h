@@ -448,6 +448,14 @@ int uncl_clamp01(const float* x, float* y, long long n, void* stream);
 /* (C,H,W) fp32 -> (H,W,C) uint8: clamp(x,0,1), (v - lo) / (hi - lo), clip to [0,1], truncate(v * 255)
  * (hdr_image_util.save_gray_tensor_as_numpy_stretch :237-241 with to_0_1_range_outlier :93-103) */
 int uncl_to_uint8(const float* x, unsigned char* out, int C, int H, int W, float lo, float hi, void* stream);
+/* Device-resident variants for a frame pipeline without host round trips: uncl_percentile_lerp finishes np.percentile's
+ * linear interpolation (numpy `_lerp`, every operation rounded separately, float32 or float64 as numpy's promotion gives) from
+ * the order statistics of uncl_order_stats; gamma / f64 are HOST arrays (n <= 8), pairs / out device.  uncl_color_finish_dev /
+ * uncl_to_uint8_dev read [lo, hi] from device memory (to_uint8: a zero span gets hi += 1e-8, hdr_image_util.py:98-99). */
+int uncl_percentile_lerp(const float* pairs, const double* gamma, const int* f64, int n, float* out, void* stream);
+int uncl_color_finish_dev(const float* rgb, const float* fake, float* out, int H1, int W1, int top, int left, int H, int W,
+                          const float* lohi, void* stream);
+int uncl_to_uint8_dev(const float* x, unsigned char* out, int C, int H, int W, const float* lohi, void* stream);
 
 #ifdef __cplusplus
 }

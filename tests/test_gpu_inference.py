@@ -43,6 +43,11 @@ def test_percentile_is_exactly_numpy(n):
     ref = [np.percentile(x.numpy(), q) for q in qs]
     for q, a, b in zip(qs, got, ref):
         assert a == b or (np.isnan(a) and np.isnan(b)), (n, q, a, b)
+    # the same interpolation finished on the device (no value crosses to the host): bit-identical
+    dev = frame_util.percentile(x.cuda(), qs, on_device=True)
+    assert dev.is_cuda and dev.dtype == torch.float32
+    for q, a, b in zip(qs, dev.cpu().numpy(), ref):
+        assert a == np.float32(b) or (np.isnan(a) and np.isnan(b)), (n, q, a, b)
 
 
 def test_post_processing_matches_reference_golden(golden):
@@ -55,6 +60,11 @@ def test_post_processing_matches_reference_golden(golden):
     col = frame_util.back_to_color_and_crop(rgb_p, fake.cuda(), min_p, max_p, dY, dX)
     check_summary(col, g, "inf.color", rtol=1e-6, atol=1e-7)
     im = frame_util.to_uint8_outlier(col).cpu().numpy()
+    # device-resident percentiles through the same two stages: identical results
+    lohi = frame_util.percentile(fake.cuda(), [0.5, 99.5], on_device=True)
+    col_d = frame_util.back_to_color_and_crop(rgb_p, fake.cuda(), lohi, None, dY, dX)
+    assert torch.equal(col_d, col)
+    assert np.array_equal(frame_util.to_uint8_outlier(col, on_device=True).cpu().numpy(), im)
     assert im.shape == (300, 280, 3) and im.dtype == np.uint8
     d = im.reshape(-1)[g["inf.uint8.pos"]].astype(np.int64) - g["inf.uint8.val"].astype(np.int64)
     # truncation to 8 bits: a last-bit difference of the fp32 stretch can move a value across an integer boundary

@@ -146,6 +146,10 @@ SIGNATURES = {
                                   C.c_void_p]),
     "uncl_gen_layer_name": (C.c_char_p, [C.c_int]),
     "uncl_gen_set_streams": (C.c_int, [C.c_int]),
+    "uncl_percentile_lerp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_color_finish_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    "uncl_to_uint8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uncl_rgbe_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     "uncl_rgbe_to_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_prof_enable": (C.c_int, [C.c_int, C.c_int]),

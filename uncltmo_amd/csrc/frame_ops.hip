@@ -156,8 +156,9 @@ __global__ void sel_init_kernel(SelState* __restrict__ st, int nr, const unsigne
 // over the cropped window (H x W inside the padded H1 x W1); model_save_util.py:393-401, hdr_image_util.py:120-131
 __global__ __launch_bounds__(256) void color_finish_kernel(const float* __restrict__ rgb, const float* __restrict__ fake,
                                                            float* __restrict__ out, int H1, int W1, int top, int left, int H,
-                                                           int W, float lo, float hi, float eps) {
+                                                           int W, float lo, float hi, float eps, const float* __restrict__ lohi) {
   const size_t hw1 = (size_t)H1 * W1, hw = (size_t)H * W;
+  if (lohi) { lo = lohi[0]; hi = lohi[1]; }     // percentiles left on the device (uncl_percentile_lerp)
   const float span = __fsub_rn(hi, lo);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
     const int r = i / W, c = i - r * W;
@@ -174,7 +175,11 @@ __global__ __launch_bounds__(256) void color_finish_kernel(const float* __restri
 // 8-bit image: clamp(x,0,1) -> (v - lo) / (hi - lo) -> clip(0,1) -> uint8(v * 255), CHW fp32 -> HWC uint8
 // (hdr_image_util.py:237-241 save_gray_tensor_as_numpy_stretch with to_0_1_range_outlier :93-103)
 __global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int C,
-                                                       size_t hw, float lo, float hi) {
+                                                       size_t hw, float lo, float hi, const float* __restrict__ lohi) {
+  if (lohi) {
+    lo = lohi[0]; hi = lohi[1];
+    if (__fsub_rn(hi, lo) == 0.f) hi = __fadd_rn(hi, 1e-8f);      // hdr_image_util.py:98-99
+  }
   const float span = __fsub_rn(hi, lo);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < hw * C; i += (size_t)gridDim.x * 256) {
     const size_t p = i / C;
@@ -252,7 +257,18 @@ extern "C" int uncl_color_finish(const float* rgb, const float* fake, float* out
   if (!rgb || !fake || !out || H <= 0 || W <= 0 || top < 0 || left < 0 || top + H > H1 || left + W > W1 || !(hi > lo))
     return UNCL_ERR_ARG;
   hipLaunchKernelGGL(color_finish_kernel, dim3(nb((size_t)H * W, 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rgb,
-                     fake, out, H1, W1, top, left, H, W, lo, hi, 1e-8f);
+                     fake, out, H1, W1, top, left, H, W, lo, hi, 1e-8f, (const float*)nullptr);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// the same with [lo, hi] read from device memory (uncl_percentile_lerp output): no host round trip between the tiled forward
+// and the colour step
+extern "C" int uncl_color_finish_dev(const float* rgb, const float* fake, float* out, int H1, int W1, int top, int left, int H, int W,
+                                     const float* lohi, void* stream) {
+  if (!rgb || !fake || !out || !lohi || H <= 0 || W <= 0 || top < 0 || left < 0 || top + H > H1 || left + W > W1) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(color_finish_kernel, dim3(nb((size_t)H * W, 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rgb,
+                     fake, out, H1, W1, top, left, H, W, 0.f, 1.f, 1e-8f, lohi);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
@@ -268,7 +284,68 @@ extern "C" int uncl_clamp01(const float* x, float* y, long long n, void* stream)
 extern "C" int uncl_to_uint8(const float* x, unsigned char* out, int C, int H, int W, float lo, float hi, void* stream) {
   if (!x || !out || C <= 0 || H <= 0 || W <= 0 || !(hi > lo)) return UNCL_ERR_ARG;
   hipLaunchKernelGGL(to_uint8_kernel, dim3(nb((size_t)C * H * W, 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out,
-                     C, (size_t)H * W, lo, hi);
+                     C, (size_t)H * W, lo, hi, (const float*)nullptr);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// [lo, hi] from device memory; a zero span gets the reference's +1e-8 on hi (hdr_image_util.py:98-99)
+extern "C" int uncl_to_uint8_dev(const float* x, unsigned char* out, int C, int H, int W, const float* lohi, void* stream) {
+  if (!x || !out || !lohi || C <= 0 || H <= 0 || W <= 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(to_uint8_kernel, dim3(nb((size_t)C * H * W, 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out,
+                     C, (size_t)H * W, 0.f, 1.f, lohi);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+namespace {
+struct LerpArgs {
+  double gamma[8];
+  int f64[8];
+  int n;
+};
+// numpy's _lerp (lib/_function_base_impl.py): a + (b - a) t, and b - (b - a)(1 - t) where t >= 0.5, every operation rounded
+// on its own, in the precision numpy's type promotion gives the expression (float32 values with a float32 or float64 gamma)
+__global__ void percentile_lerp_kernel(const float* __restrict__ pairs, const LerpArgs t, float* __restrict__ out) {
+#pragma clang fp contract(off)      // numpy rounds the product before the sum: no fused multiply-add here
+  const int i = threadIdx.x;
+  if (i >= t.n) return;
+  const float a = pairs[2 * i], b = pairs[2 * i + 1];
+  // plain operators under contract(off): the *_rn helpers are inlined with the translation unit's default (contraction on)
+  if (t.f64[i]) {
+    const double g = t.gamma[i], ad = (double)a, bd = (double)b;
+    const double d = bd - ad;
+    const double p1 = d * g;
+    double r = ad + p1;
+    if (g >= 0.5) {
+      const double omg = 1.0 - g;
+      const double p2 = d * omg;
+      r = bd - p2;
+    }
+    out[i] = (float)r;
+  } else {
+    const float g = (float)t.gamma[i];
+    const float d = b - a;
+    const float p1 = d * g;
+    float r = a + p1;
+    if (g >= 0.5f) {
+      const float omg = 1.f - g;
+      const float p2 = d * omg;
+      r = b - p2;
+    }
+    out[i] = r;
+  }
+}
+}  // namespace
+
+// out[i] = numpy-lerp(pairs[2i], pairs[2i+1], gamma[i]) on the device.  pairs: device order statistics (uncl_order_stats),
+// gamma / f64: HOST arrays (they depend on the element count and the percentile only), n <= 8.
+extern "C" int uncl_percentile_lerp(const float* pairs, const double* gamma, const int* f64, int n, float* out, void* stream) {
+  if (!pairs || !gamma || !f64 || !out || n <= 0 || n > 8) return UNCL_ERR_ARG;
+  LerpArgs t = {};
+  t.n = n;
+  for (int i = 0; i < n; ++i) { t.gamma[i] = gamma[i]; t.f64[i] = f64[i]; }
+  hipLaunchKernelGGL(percentile_lerp_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), pairs, t, out);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

@@ -80,11 +80,12 @@ def _numpy_percentile_plan(n, q):
         virt = np.asanyarray(props["get_virtual_index"](n, q_))
         if np.issubdtype(virt.dtype, np.integer):
             i = int(virt)
-            return i, i, (lambda a, b: np.float32(a))
+            return i, i, (lambda a, b: np.float32(a)), (0.0, False)
         prev, nxt = npf._get_indexes(np.empty(1, dtype=np.float32), virt, n)
         gamma = npf._get_gamma(virt, prev, props)
         fin = lambda a, b: npf._lerp(np.float32(a), np.float32(b), gamma)
-        return int(prev) % n, int(nxt) % n, fin
+        # (gamma, arithmetic in float64?) for the device form of the same interpolation (uncl_percentile_lerp)
+        return int(prev) % n, int(nxt) % n, fin, (float(gamma), np.asarray(gamma).dtype == np.float64)
     except (ImportError, AttributeError, KeyError, TypeError):
         pos = q / 100.0 * (n - 1)
         lo = int(np.floor(pos))
@@ -94,12 +95,14 @@ def _numpy_percentile_plan(n, q):
             a, b = np.float32(a), np.float32(b)
             d = b - a
             return np.float32(a + d * t if t < 0.5 else b - d * (1 - t))
-        return lo, min(lo + 1, n - 1), fin
+        return lo, min(lo + 1, n - 1), fin, None
 
 
-def percentile(x, qs):
+def percentile(x, qs, on_device=False):
     """np.percentile(x.cpu().numpy(), q) for each q (linear interpolation), from exact order statistics selected on the
     device: a few floats cross to the host instead of the image (model_save_util.py:389-390, hdr_image_util.py:93-97).
+    on_device=True: the interpolation runs on the device as well and a (len(qs),) fp32 device tensor is returned -- nothing
+    crosses to the host (same values bit for bit: numpy's `_lerp` restated with separately rounded operations).
     NaNs are not supported (the reference would return NaN)."""
     _need_gpu(x, "x")
     lib = _hip.lib()
@@ -107,7 +110,7 @@ def percentile(x, qs):
     n = xf.numel()
     plans = [_numpy_percentile_plan(n, q) for q in qs]
     ranks = []
-    for lo, hi, _ in plans:
+    for lo, hi, _, _ in plans:
         ranks += [lo, hi]
     out = torch.empty(len(ranks), dtype=torch.float32, device=xf.device)
     ws = _ws(xf.device)
@@ -116,8 +119,18 @@ def percentile(x, qs):
         arr = (C.c_ulonglong * len(part))(*part)
         _hip.check(lib.uncl_order_stats(xf.data_ptr(), n, arr, len(part), out.data_ptr() + 4 * i0, ws.data_ptr(),
                                         _hip.stream_ptr()), "uncl_order_stats")
+    if on_device and all(p[3] is not None for p in plans) and len(plans) <= 8:
+        k = len(plans)
+        gam = (C.c_double * k)(*[p[3][0] for p in plans])
+        f64 = (C.c_int * k)(*[int(p[3][1]) for p in plans])
+        res = torch.empty(k, dtype=torch.float32, device=xf.device)
+        _hip.check(lib.uncl_percentile_lerp(out.data_ptr(), gam, f64, k, res.data_ptr(), _hip.stream_ptr()), "uncl_percentile_lerp")
+        return res
     v = out.cpu().numpy()
-    return [fin(v[2 * i], v[2 * i + 1]) for i, (_, _, fin) in enumerate(plans)]
+    vals = [fin(v[2 * i], v[2 * i + 1]) for i, (_, _, fin, _) in enumerate(plans)]
+    if on_device:       # plans without numpy's helpers: finish on the host, hand back a device tensor all the same
+        return torch.tensor([float(np.float32(t)) for t in vals], dtype=torch.float32, device=xf.device)
+    return vals
 
 
 def back_to_color_and_crop(rgb_padded, fake, min_p, max_p, diffY, diffX):
@@ -130,13 +143,18 @@ def back_to_color_and_crop(rgb_padded, fake, min_p, max_p, diffY, diffX):
     rgb = rgb_padded.float().contiguous()
     f = fake.reshape(h1, w1).float().contiguous()
     out = torch.empty(3, h, w, dtype=torch.float32, device=f.device)
+    if torch.is_tensor(min_p):        # (2,) device tensor [min_p, max_p] from percentile(..., on_device=True); max_p unused
+        lohi = min_p.float().contiguous()
+        _hip.check(_hip.lib().uncl_color_finish_dev(rgb.data_ptr(), f.data_ptr(), out.data_ptr(), h1, w1, diffY // 2, diffX // 2, h, w,
+                                                    lohi.data_ptr(), _hip.stream_ptr()), "uncl_color_finish_dev")
+        return out
     _hip.check(_hip.lib().uncl_color_finish(rgb.data_ptr(), f.data_ptr(), out.data_ptr(), h1, w1, diffY // 2, diffX // 2, h, w,
                                             float(np.float32(min_p)), float(np.float32(max_p)), _hip.stream_ptr()),
                "uncl_color_finish")
     return out
 
 
-def to_uint8_outlier(color):
+def to_uint8_outlier(color, on_device=False):
     """hdr_image_util.save_gray_tensor_as_numpy_stretch up to the file write (:237-241): clamp(0,1), to_0_1_range_outlier
     (percentiles 0.1 / 99.0 over all channels, :93-103), *255, truncate.  (C,H,W) fp32 -> (H,W,C) uint8 on the device."""
     _need_gpu(color, "color")
@@ -145,10 +163,14 @@ def to_uint8_outlier(color):
     c, h, w = x.shape
     cl = torch.empty_like(x)
     _hip.check(lib.uncl_clamp01(x.data_ptr(), cl.data_ptr(), x.numel(), _hip.stream_ptr()), "uncl_clamp01")
+    out = torch.empty(h, w, c, dtype=torch.uint8, device=x.device)
+    if on_device:
+        lohi = percentile(cl, [0.1, 99.0], on_device=True)
+        _hip.check(lib.uncl_to_uint8_dev(cl.data_ptr(), out.data_ptr(), c, h, w, lohi.data_ptr(), _hip.stream_ptr()), "uncl_to_uint8_dev")
+        return out
     im_min, im_max = percentile(cl, [0.1, 99.0])
     if float(im_max) - float(im_min) == 0:
         im_max = np.float32(im_max) + np.float32(1e-08)
-    out = torch.empty(h, w, c, dtype=torch.uint8, device=x.device)
     _hip.check(lib.uncl_to_uint8(cl.data_ptr(), out.data_ptr(), c, h, w, float(im_min), float(im_max), _hip.stream_ptr()),
                "uncl_to_uint8")
     return out

@@ -21,9 +21,10 @@ def run_model_on_frame(G_net, rgb_img, f_factor, model_params=None, final_shape_
     rgb_img, diffY, diffX = frame_util.resize_im(rgb_img, add_frame, final_shape_addition)
     gray_im_log, diffY, diffX = frame_util.resize_im(gray_im_log, add_frame, final_shape_addition)
     fake = test_big_size_image2(input_data=gray_im_log.unsqueeze(0), model=G_net, apply_crop=add_frame, diffY=diffY, diffX=diffX)
-    min_p, max_p = frame_util.percentile(fake, [0.5, 99.5])
-    color = frame_util.back_to_color_and_crop(rgb_img, fake, min_p, max_p, diffY, diffX)
-    return color, frame_util.to_uint8_outlier(color)
+    # the four percentiles stay on the device: nothing between the file read and the 8-bit image waits for the host
+    lohi = frame_util.percentile(fake, [0.5, 99.5], on_device=True)
+    color = frame_util.back_to_color_and_crop(rgb_img, fake, lohi, None, diffY, diffX)
+    return color, frame_util.to_uint8_outlier(color, on_device=True)
 
 
 def load_inference2(im_path, f_factor_path, factor_coeff, device, scale=4):
