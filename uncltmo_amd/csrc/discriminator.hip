@@ -20,35 +20,56 @@ constexpr float SLOPE = 0.2f;
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : SLOPE * v; }
 
-// ---- conv1: one thread = one output pixel, all 16 channels
+// ---- conv1: one thread = two horizontally adjacent output pixels, all 16 channels (every weight vector read from LDS feeds
+// both pixels; the 4 x 6 input window is shared)
 __global__ __launch_bounds__(256) void d_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                       const float* __restrict__ b0, float* __restrict__ h1, int N) {
-  __shared__ float sw[16 * C1 + C1];  // [tap][co], then bias
+  __shared__ __attribute__((aligned(16))) float sw[16 * C1 + C1];  // [tap][co], then bias
   for (int i = threadIdx.x; i < 16 * C1; i += 256) {
     const int co = i % C1, tap = i / C1;
     sw[i] = w0[co * 16 + tap];  // reference layout (co, 1, 4, 4)
   }
   if (threadIdx.x < C1) sw[16 * C1 + threadIdx.x] = b0[threadIdx.x];
   __syncthreads();
-  const size_t total = (size_t)N * H1 * H1;
+  constexpr int HP = (H1 + 1) / 2;                         // pixel pairs per output row (the last pair of a row is half empty)
+  const size_t total = (size_t)N * H1 * HP;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ox = (int)(i % H1), oy = (int)((i / H1) % H1), n = (int)(i / ((size_t)H1 * H1));
+    const int pxp = (int)(i % HP), oy = (int)((i / HP) % H1), n = (int)(i / ((size_t)HP * H1));
+    const int ox = 2 * pxp;
+    const bool two = ox + 1 < H1;
     const float* xp = x + ((size_t)n * H0 + 2 * oy) * H0 + 2 * ox;
-    float acc[C1];
+    float in[4][6];
 #pragma unroll
-    for (int c = 0; c < C1; ++c) acc[c] = sw[16 * C1 + c];
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 6; ++kx) in[ky][kx] = (kx < 4 || two) ? xp[ky * H0 + kx] : 0.f;
+    float acc[2][C1];
+#pragma unroll
+    for (int c = 0; c < C1; ++c) acc[0][c] = acc[1][c] = sw[16 * C1 + c];
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx) {
-        const float v = xp[ky * H0 + kx];
+        const float v0 = in[ky][kx], v1 = in[ky][kx + 2];
 #pragma unroll
-        for (int c = 0; c < C1; ++c) acc[c] = fmaf(v, sw[(ky * 4 + kx) * C1 + c], acc[c]);
+        for (int c4 = 0; c4 < C1; c4 += 4) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(sw + (ky * 4 + kx) * C1 + c4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[0][c4 + e] = fmaf(v0, wv[e], acc[0][c4 + e]);
+            acc[1][c4 + e] = fmaf(v1, wv[e], acc[1][c4 + e]);
+          }
+        }
       }
-    float* o = h1 + i * C1;
+    float* o = h1 + (((size_t)n * H1 + oy) * H1 + ox) * C1;
 #pragma unroll
-    for (int c = 0; c < C1; c += 4)
-      *reinterpret_cast<f32x4*>(o + c) = f32x4{lrelu(acc[c]), lrelu(acc[c + 1]), lrelu(acc[c + 2]), lrelu(acc[c + 3])};
+    for (int p = 0; p < 2; ++p) {
+      if (p == 1 && !two) break;
+#pragma unroll
+      for (int c = 0; c < C1; c += 4)
+        *reinterpret_cast<f32x4*>(o + p * C1 + c) =
+            f32x4{lrelu(acc[p][c]), lrelu(acc[p][c + 1]), lrelu(acc[p][c + 2]), lrelu(acc[p][c + 3])};
+    }
   }
 }
 
@@ -468,7 +489,7 @@ extern "C" int uncl_simple_d_forward(const float* x, const float* w0, const floa
   if (!x || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !wl || !out || !workspace || N <= 0) return UNCL_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DBufs b = d_bufs(workspace, N);
-  const size_t t1 = (size_t)N * H1 * H1;
+  const size_t t1 = (size_t)N * H1 * ((H1 + 1) / 2);     // pixel pairs
   hipLaunchKernelGGL(d_conv1_kernel, dim3((unsigned)((t1 + 255) / 256 < 4096 ? (t1 + 255) / 256 : 4096)), dim3(256), 0, st, x,
                      w0, b0, b.h1, N);
   {
