@@ -111,7 +111,6 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   static_assert(HH % 2 == 0, "two halo rows per staging pass");
   constexpr int RS = HH / 2;   // regular slots: 32 columns x 2 rows x 4 vectors per pass
   constexpr int XV = RS + 1;   // + one slot for the two extra halo columns
-  constexpr int XV_ = XV;
   constexpr int WROWS = 9 * CT;
   constexpr int WVN = (WROWS + 63) / 64;
   constexpr bool W_RAGGED = WROWS % 64 != 0;
@@ -171,14 +170,14 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;  // + j * (64 / CT) * Cout * Cin
 
   // FLAT: source sample (or -1: zero padding / unused slot) and element offset inside the group for each staging slot
-  int flat_s[FLAT ? XV_ : 1];
-  unsigned flat_off[FLAT ? XV_ : 1];
+  int flat_s[FLAT ? XV : 1];
+  unsigned flat_off[FLAT ? XV : 1];
   int flat_lane[FLAT ? MPW : 1];     // byte address of the top-left input slot of this lane's output pixel, per M-tile
   if (FLAT) {
     const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad, hpwp = Hp * Wp;
 #pragma unroll
-    for (int j = 0; j < XV_; ++j) {
-      const int sl = j < XV_ - 1 ? pix_r0 + j * 2 * HW : pix_e;
+    for (int j = 0; j < XV; ++j) {
+      const int sl = j < XV - 1 ? pix_r0 + j * 2 * HW : pix_e;
       const int sj = sl / hpwp, r = sl - sj * hpwp;
       const int py = r / Wp, px = r - py * Wp;
       const int iy = py - a.pad, ix = px - a.pad;
