@@ -119,7 +119,6 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   // (64-channel tiles: 32 KB vs 27 KB) the weight image starts behind it, so that the weights of a single-chunk layer
   // (down_path.0.mpconv.1.conv, 32 -> 64) stay resident across tiles instead of being re-staged (37 KB) for every tile.
   constexpr int XIMG = NPIX * 80 > TH * TW * CT * 2 ? NPIX * 80 : TH * TW * CT * 2;
-  constexpr bool W_CLOBBERED = false;
   constexpr int ST_IT = (TH * TW * SLOTS) / NTHR;             // main-store passes
   constexpr int ROWS_PER_IT = NTHR / (TW * SLOTS);            // output rows covered per pass
   static_assert(ROWS_PER_IT * TW * SLOTS == NTHR, "store pass must cover whole rows");
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   int tile = (int)blockIdx.x * a.tiles_per_wg;
   const int tile_end = min(tile + a.tiles_per_wg, a.total_tiles);
   if (tile >= tile_end) return;
-  const bool w_static = (a.nk == 1 && a.n_ct == 1) && !W_CLOBBERED;
+  const bool w_static = a.nk == 1 && a.n_ct == 1;      // one weight chunk for the whole launch: staged once
 
   // ---- per-thread constants of the staging pattern (identical for every step)
   // regular slot j: halo pixel (hy0 + 2j, hx), vector ch; extra slot: halo pixel (ey, 32 + ec), vector ch
