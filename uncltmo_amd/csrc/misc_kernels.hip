@@ -41,19 +41,46 @@ extern "C" int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int
 struct PackBatch {
   uncl_pack_item it[UNCL_PACK_MAX_ITEMS];
 };
+// One workgroup = a 32 x 32 block of the two channel dimensions with all kk taps.  The source (reference layout
+// [A][B][kk]: A = Cout, B = Cin for Conv2d, A = Cin, B = Cout for ConvTranspose2d) is read as 32 runs of 32*kk contiguous
+// floats, the packed [tap][Cout][Cin] destination is written as runs of 32 contiguous channels; the transposition happens in
+// LDS (rows padded to an odd pitch).  The element-per-thread form read the source with a stride of kk floats.
 template <typename T>
-__global__ void pack_weight_batch_kernel(const PackBatch t) {
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch t) {
   const uncl_pack_item& e = t.it[blockIdx.y];
   const int kk = e.k * e.k, Cin = e.Cin, Cout = e.Cout;
-  const size_t total = (size_t)kk * Cout * Cin;
+  const int A = e.transposed ? Cin : Cout, B = e.transposed ? Cout : Cin;
+  const int tb = B >> 5, tiles = (A >> 5) * tb;
+  if ((A | B) & 31) {       // odd channel counts: element-wise
+    const size_t total = (size_t)kk * Cout * Cin;
+    T* dst = reinterpret_cast<T*>(e.dst);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((size_t)Cin * Cout));
+      const int ts = e.flip ? (kk - 1 - tap) : tap;
+      const size_t s = e.transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
+      dst[i] = (T)e.src[s];
+    }
+    return;
+  }
+  __shared__ float sm[32 * (32 * 9 + 1)];
+  const int pitch = 32 * kk + 1;
   T* dst = reinterpret_cast<T*>(e.dst);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Cin);
-    const int co = (int)((i / Cin) % Cout);
-    const int tap = (int)(i / ((size_t)Cin * Cout));
-    const int ts = e.flip ? (kk - 1 - tap) : tap;
-    const size_t s = e.transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
-    dst[i] = (T)e.src[s];
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int a0 = (tile / tb) << 5, b0 = (tile % tb) << 5;
+    __syncthreads();
+    for (int v = threadIdx.x; v < 32 * 32 * kk; v += 256) {
+      const int a = v / (32 * kk), r = v - a * (32 * kk);
+      sm[a * pitch + r] = e.src[((size_t)(a0 + a) * B + b0) * kk + r];
+    }
+    __syncthreads();
+    // destination runs: (tap, co, 32 x ci).  lane = ci within the run
+    for (int v = threadIdx.x; v < 32 * 32 * kk; v += 256) {
+      const int ci_l = v & 31, co_l = (v >> 5) & 31, tap = v >> 10;
+      const int ts = e.flip ? (kk - 1 - tap) : tap;
+      const int a = e.transposed ? ci_l : co_l, bb = e.transposed ? co_l : ci_l;
+      const int co = e.transposed ? b0 + co_l : a0 + co_l, ci = e.transposed ? a0 + ci_l : b0 + ci_l;
+      dst[((size_t)tap * Cout + co) * Cin + ci] = (T)sm[a * pitch + bb * kk + ts];
+    }
   }
 }
 

@@ -512,15 +512,41 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
 struct UnpackBatch {
   uncl_unpack_item it[UNCL_PACK_MAX_ITEMS];
 };
-__global__ void unpack_wgrad_batch_kernel(const UnpackBatch t) {
+// 32 x 32 channel blocks through LDS, the mirror image of pack_weight_batch_kernel: packed runs of 32 channels in, runs of
+// 32*kk contiguous reference-layout floats out
+__global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBatch t) {
   const uncl_unpack_item& e = t.it[blockIdx.y];
   const int kk = e.k * e.k, Cin = e.Cin, Cout = e.Cout;
-  const size_t total = (size_t)kk * Cout * Cin;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((size_t)Cin * Cout));
-    const int ts = e.flip ? (kk - 1 - tap) : tap;
-    const size_t d = e.transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
-    e.dst[d] = e.accumulate ? e.dst[d] + e.packed[i] : e.packed[i];
+  const int A = e.transposed ? Cin : Cout, B = e.transposed ? Cout : Cin;
+  const int tb = B >> 5, tiles = (A >> 5) * tb;
+  if ((A | B) & 31) {
+    const size_t total = (size_t)kk * Cout * Cin;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((size_t)Cin * Cout));
+      const int ts = e.flip ? (kk - 1 - tap) : tap;
+      const size_t d = e.transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
+      e.dst[d] = e.accumulate ? e.dst[d] + e.packed[i] : e.packed[i];
+    }
+    return;
+  }
+  __shared__ float sm[32 * (32 * 9 + 1)];
+  const int pitch = 32 * kk + 1;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int a0 = (tile / tb) << 5, b0 = (tile % tb) << 5;
+    __syncthreads();
+    for (int v = threadIdx.x; v < 32 * 32 * kk; v += 256) {
+      const int ci_l = v & 31, co_l = (v >> 5) & 31, tap = v >> 10;
+      const int ts = e.flip ? (kk - 1 - tap) : tap;
+      const int a = e.transposed ? ci_l : co_l, bb = e.transposed ? co_l : ci_l;
+      const int co = e.transposed ? b0 + co_l : a0 + co_l, ci = e.transposed ? a0 + ci_l : b0 + ci_l;
+      sm[a * pitch + bb * kk + ts] = e.packed[((size_t)tap * Cout + co) * Cin + ci];
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < 32 * 32 * kk; v += 256) {
+      const int a = v / (32 * kk), r = v - a * (32 * kk);
+      float* d = e.dst + ((size_t)(a0 + a) * B + b0) * kk + r;
+      *d = e.accumulate ? *d + sm[a * pitch + r] : sm[a * pitch + r];
+    }
   }
 }
 
