@@ -301,8 +301,9 @@ int uncl_prof_read(float* ms_host, int max_n);
 size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep_activations);
 int uncl_gen_forward(const uncl_gen_weights* wts, const uncl_gen_run* run, void* stream);
 /* uncl_gen_forward runs an un-chunked inference batch of >= 64 tiles as n contiguous parts on n streams (the caller's plus
- * internal ones, forked and joined with events, so the call keeps stream semantics): one part's launches fill the ramp-down
- * of the other's persistent grids.  Default 2 (measured best: 5.65 -> 5.25 ms per 200 tiles); 1 = the caller's stream only. */
+ * internal ones, forked and joined with events, so the call keeps stream semantics) up to the third decoder stage: one
+ * part's launches fill the ramp-down of the other's persistent grids; the last decoder stage then runs once for the whole
+ * batch on the caller's stream.  Default 2 (measured best: 5.65 -> 5.25 ms per 200 tiles); 1 = the caller's stream only. */
 int uncl_gen_set_streams(int n);
 
 /* ------------------------------------------------------------------------------------------------------
