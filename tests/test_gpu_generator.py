@@ -75,7 +75,7 @@ def test_large_batch_on_two_streams_equals_one_stream(dtype):
     with events).  Per-tile results do not depend on the split, and the call keeps the caller's stream semantics."""
     from uncltmo_amd import _hip
     net = make_g(dtype)
-    n = 71 if dtype == "bf16" else 65
+    n = 135 if dtype == "bf16" else 65
     x = synth.hdr_frames(n, 256, 256, salt="two-streams").cuda()
     lib = _hip.lib()
     try:
@@ -83,7 +83,7 @@ def test_large_batch_on_two_streams_equals_one_stream(dtype):
             _hip.check(lib.uncl_gen_set_streams(1), "set_streams")
             y1, k1 = net.infer(x, want_knn=True)
             y1 = y1.clone()
-            _hip.check(lib.uncl_gen_set_streams(2), "set_streams")
+            _hip.check(lib.uncl_gen_set_streams(4), "set_streams")
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                      # a non-default caller stream
@@ -93,7 +93,7 @@ def test_large_batch_on_two_streams_equals_one_stream(dtype):
             _hip.check(lib.uncl_gen_set_streams(3), "set_streams")
             y3, _ = net.infer(x, want_knn=True)
     finally:
-        lib.uncl_gen_set_streams(2)
+        lib.uncl_gen_set_streams(4)
     assert torch.equal(y1, y2) and torch.equal(k1, k2) and torch.equal(y1, y3)
     assert lib.uncl_gen_set_streams(0) != 0 and lib.uncl_gen_set_streams(5) != 0
 

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r1l}
+TAG=${1:-r1m}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R

@@ -562,7 +562,7 @@ int backward_all(const BCtx& c) {
 }  // namespace
 
 // streams an un-chunked inference batch of >= 64 tiles is spread over (1 = the caller's stream only), see uncl_gen_forward
-static int g_streams = 2;
+static int g_streams = 4;
 extern "C" int uncl_gen_set_streams(int n) {
   if (n < 1 || n > 4) return UNCL_ERR_ARG;
   g_streams = n;
@@ -612,17 +612,18 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   Layout L = make_layout(n_alloc, w->dtype);
   if (r->workspace_bytes < L.total) return UNCL_ERR_ARG;
   const size_t es = w->dtype == UNCL_BF16 ? 2 : 4;
-  // A large un-chunked inference batch runs as two halves on two streams (the caller's and an internal one, joined by
-  // events before returning): the launches of one half fill the ramp-down of the other's persistent grids and the gaps
-  // between dependent launches.  Every buffer is (N, ...), so the halves own disjoint slices of the same workspace.
+  // A large un-chunked inference batch runs as up to four contiguous parts on as many streams (the caller's and internal
+  // ones, joined by events): the launches of one part fill the ramp-down of the others' persistent grids and the gaps
+  // between dependent launches.  Every buffer is (N, ...), so the parts own disjoint slices of the same workspace.
   const int split_cfg = g_streams;
   const bool split2 = split_cfg >= 2 && chunk == r->N && r->N >= 64 && !r->keep_activations && !r->save_preact &&
                       r->prev_workspace == nullptr;
   constexpr int MAX_SIDE = 3;
-  static hipStream_t side[MAX_SIDE] = {nullptr, nullptr, nullptr};
-  static hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {nullptr, nullptr, nullptr};
+  static hipStream_t side[MAX_SIDE] = {};
+  static hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
   hipStream_t main_s = reinterpret_cast<hipStream_t>(stream);
-  const int parts = split2 ? (split_cfg > MAX_SIDE + 1 ? MAX_SIDE + 1 : split_cfg) : 1;
+  // at least 32 tiles per part
+  const int parts = split2 ? (r->N / 32 < split_cfg ? r->N / 32 : split_cfg) : 1;
   if (split2) {
     if (!ev_fork) {
       if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return UNCL_ERR_LAUNCH;
