@@ -70,8 +70,8 @@ def test_generator_bf16_vs_oracle():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_large_batch_on_two_streams_equals_one_stream(dtype):
-    """uncl_gen_forward spreads an un-chunked batch of >= 64 tiles over two streams (halves of the batch, forked and joined
+def test_large_batch_on_several_streams_equals_one_stream(dtype):
+    """uncl_gen_forward spreads an un-chunked batch of >= 64 tiles over up to four streams (contiguous parts, forked and joined
     with events).  Per-tile results do not depend on the split, and the call keeps the caller's stream semantics."""
     from uncltmo_amd import _hip
     net = make_g(dtype)
@@ -222,10 +222,10 @@ def test_tiler_real_generator(golden):
 
 
 def test_tiled_forward_as_one_graph():
-    """tiler.TiledGraph: gather -> generator -> cross-fade captured once as a hipGraph (incl. the two-stream fork / join of
+    """tiler.TiledGraph: gather -> generator -> cross-fade captured once as a hipGraph (incl. the multi-stream fork / join of
     large batches) and replayed on new frames: bit-identical to the eager path."""
     net = make_g("bf16")
-    for n_frames, h, w in ((1, 528, 784), (3, 1040, 1040)):             # 6 and 3 x 36 tiles (>= 64: two streams)
+    for n_frames, h, w in ((1, 528, 784), (3, 1040, 1040)):             # 6 and 3 x 36 tiles (>= 64: several streams)
         tg = tiler.TiledGraph(net, n_frames, h, w)
         for salt in ("g1", "g2"):
             fr = synth.hdr_frames(n_frames, h, w, salt=salt).cuda()
