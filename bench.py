@@ -7,18 +7,28 @@ One step = one pass of the hot path over one batch of synthetic frames that are 
 `value` is whole-job frames/s (all ranks); with --gpus N every rank runs its own 8 frames (weak scaling, the
 tiles are independent so there is no data-path collective) and the slowest rank's time is used.
 
+Ranks.  `python bench.py --gpus N` with no WORLD_SIZE in the environment is the LAUNCHER: before touching a GPU it starts N
+children of itself (one per LOCAL_RANK, 127.0.0.1 rendezvous), waits for them and exits with the worst exit code; asking for
+more GPUs than are visible is refused with a message and exit code 2.  Under `python -m torch.distributed.run ... bench.py
+--gpus N` the ranks already exist and RANK / LOCAL_RANK / WORLD_SIZE come from the environment.  Rank 0 prints the ONE JSON
+line; at N > 1 it carries `ranks_seen` (an all-gather of the rank numbers over RCCL) and the per-rank step times.
+
 Extra objects on the JSON line:
-  roofline     dense-bf16 MFMA roofline of the dominant kernel (the implicit-GEMM conv of up_path.3.conv.conv with
-               up_path.3.up recomputed in its loader, 26.3 % of the generator's FLOPs): algorithmic FLOPs per launch / mean launch duration measured
-               with HIP events inside the timed steps (`exclusive` = the same kernel in a single-stream forward, a
-               cross-check).
+  roofline     dense-bf16 MFMA roofline of the WHOLE forward (algorithmic 18.286 GFLOP per tile x tiles / step time); its
+               `dominant_kernel` sub-object is the same for the single largest launch (the implicit-GEMM conv of
+               up_path.3.conv.conv with up_path.3.up recomputed in its loader, 26.3 % of the generator's FLOPs): algorithmic
+               FLOPs per launch / mean launch duration measured with HIP events on the launch stream inside the timed steps.
   cpu_baseline the CPU oracle (a port, not the reference's own code) timed on this box's host cores on a bounded
                sample of the same workload (generator forward over 256^2 tiles), reported in the same unit.
+  train_step / train_video_step   BASELINE configs[2] / configs[3] measured after the headline region (same ranks, gradient
+               all-reduce over RCCL at N > 1): ms per step, frames/s and the generator's MFMA fraction in both FLOP conventions.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,38 +36,86 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 GFLOP_PER_TILE = 18.2858            # 2*MAC of the 27 conv layers, one 256^2 tile
 DOM_LAYER = 24                      # packed-weight index of up_path.3.conv.conv
 # 64516 px x 32 x 1152 x 2 (the 3x3 over the 128-channel concat) + 15876 px x 32 x 128 x 2 (up_path.3.up, computed inside
-# the same launch since r1g; the halo pixels it recomputes are not counted)
+# the same launch; the halo pixels it recomputes are not counted)
 DOM_GFLOP_PER_TILE = 4.6820 + 0.1300
 DOM_GFLOP_PER_TILE_F32 = 4.6820     # fp32 parity mode: separate up-conv launch
-PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_TFLOPS = 157.3
 FRAMES, H, W, TILES_PER_FRAME = 8, 1024, 1024, 25
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("UNCL_CHUNK", "0")))
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "train_video"],
-                    help="infer: BASELINE configs[1] (default, the headline metric); train: configs[2], one full "
-                         "GanTrainerImg step on 32 frames of 256x256; train_video: configs[3], one GanTrainer step on clips "
-                         "of T=5 (4 crops of 256x256 per 512x512 clip) -- both reported for DESIGN.md, not the headline")
+                    help="infer: BASELINE configs[1] (default, the headline metric; its line also carries train_step / "
+                         "train_video_step); train: configs[2] alone, one full GanTrainerImg step on 32 frames of 256x256 per "
+                         "GPU; train_video: configs[3] alone, one GanTrainer step on clips of T=5 (4 crops of 256x256 per "
+                         "512x512 clip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-train", action="store_true", help="infer mode: skip the train_step / train_video_step legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-exclusive", action="store_true",
                     help="skip the untimed single-stream pass that measures the dominant kernel alone (profiling runs: "
                          "keeps every launch of the trace in the product configuration)")
-    return ap.parse_args()
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU self-test of the launcher and the JSON contract: gloo backend, the step is a small host matmul, "
+                         "no GPU and no HIP library are touched (tests/test_bench_launcher.py)")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh children, started before this process has made any GPU call
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(a, argv):
+    """Parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): start one child per GPU, pass rank 0's stdout through."""
+    if not a.stub:
+        import torch    # device_count() enumerates without creating a HIP context in this process
+        have = torch.cuda.device_count()
+        if a.gpus > have:
+            sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run fewer ranks "
+                             "than asked for\n" % (a.gpus, have))
+            return 2
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(a.gpus),
+               LOCAL_WORLD_SIZE=str(a.gpus))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(a.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("UNCL_BENCH_TIMEOUT", "1500"))
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            code = 124
+            for q in procs:            # our own children, by PID
+                if q.poll() is None:
+                    q.kill()
+        rc = max(rc, abs(code))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------------------------
 def _flush_c_stdio():
     """RCCL prints its version banner through C stdio, which (piped) would otherwise be flushed at exit, after the JSON line."""
     try:
@@ -73,11 +131,13 @@ def pmc_traffic(dtype):
     if dtype != "bf16":
         return None, None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
     if not files:
         return None, None
     try:
         doc = json.load(open(files[-1]))
+        if "dominant" in doc and "hbm_bytes_per_launch" in doc["dominant"]:
+            return int(doc["dominant"]["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
         dom = doc["dominant"]
         for k in doc["kernels"]:
             if k["grid_x"] == dom["grid_x"] and "pipe_kernel<1, 4, 4, 4" in k["kernel"]:
@@ -89,6 +149,7 @@ def pmc_traffic(dtype):
 
 def cpu_baseline(seconds):
     """Oracle generator forward on the host cores, fp32, bounded to ~`seconds` of work."""
+    import torch
     from oracle.state import generator_state
     from oracle.generator import unet_image_forward
     from uncltmo_amd import synth
@@ -110,19 +171,94 @@ def cpu_baseline(seconds):
                                       "one 1024x1024 frame = 25 tiles" % (done, dt, tiles_per_s)}
 
 
-def train_bench(a, rank, world, dist):
-    """configs[2]: full image-trainer step (train_D + train_G, all losses, Adam) on N = 32 frames per rank;
-    configs[3] (--mode train_video): the video trainer on 2 clips x 4 crops x T=5 = 40 frames per rank."""
+class Ranks:
+    """The process group of this run: barrier, max-over-ranks timing and the self-check of who took part."""
+
+    def __init__(self, a):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.stub = a.stub
+        self.dist = self.world > 1 or os.environ.get("UNCL_FORCE_DIST") == "1"   # the override lets a 1-GPU box exercise RCCL
+        import torch
+        self.torch = torch
+        if not self.stub:
+            if self.local_rank >= torch.cuda.device_count():
+                raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible" % (self.local_rank, torch.cuda.device_count()))
+            torch.cuda.set_device(self.local_rank)
+        if self.dist:
+            import torch.distributed as td
+            self.td = td
+            if self.stub:
+                td.init_process_group("gloo")
+            else:
+                td.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        self.dev = torch.device("cpu") if self.stub else torch.device("cuda", self.local_rank)
+
+    def sync(self):
+        if self.dist:
+            self.td.barrier()
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def timed(self, step, steps, warmup):
+        """W untimed steps, then EXACTLY K steps between barrier + device sync on both sides; returns
+        (max-over-ranks seconds, per-rank seconds list, last step's result)."""
+        out = None
+        for _ in range(warmup):
+            out = step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        self.sync()
+        dt = time.perf_counter() - t0
+        per_rank = [dt]
+        if self.dist:
+            t = self.torch.tensor([dt], device=self.dev, dtype=self.torch.float64)
+            allt = [self.torch.zeros_like(t) for _ in range(self.world)]
+            self.td.all_gather(allt, t)
+            per_rank = [float(x.item()) for x in allt]
+        return max(per_rank), per_rank, out
+
+    def ranks_seen(self):
+        if not self.dist:
+            return [self.rank]
+        t = self.torch.tensor([self.rank], device=self.dev, dtype=self.torch.int64)
+        allr = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.td.all_gather(allr, t)
+        return sorted(int(x.item()) for x in allr)
+
+    def close(self):
+        if self.dist:
+            self.td.destroy_process_group()
+
+
+def common_fields(a, rk, dt, per_rank):
+    f = {"n_gpus": rk.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    if rk.dist:
+        seen = rk.ranks_seen()
+        f["ranks_seen"] = seen
+        f["per_rank_ms_per_step"] = [t / a.steps * 1e3 for t in per_rank]
+        assert seen == list(range(rk.world)), "ranks that took part %s != 0..%d" % (seen, rk.world - 1)
+    return f
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training steps (configs[2], configs[3])
+# ---------------------------------------------------------------------------------------------------------------------
+def make_trainer(rk, video):
     import types
+    import torch
     from uncltmo_amd import model_factory, synth
     from uncltmo_amd.distributed import DistributedOptimizer
     from uncltmo_amd.optim import Adam
-    video = a.mode == "train_video"
     if video:
         from uncltmo_amd.trainer_vid import GanTrainer
     else:
         from uncltmo_amd.trainer_img import GanTrainer
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = rk.dev
     make_g = model_factory.create_G_net if video else model_factory.create_G_net2
     G = make_g("unet", dev, False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, "none", "none", "relu",
                True, 1, 1, 0, "replicate", 2, 0, compute_dtype="bf16")
@@ -131,80 +267,101 @@ def train_bench(a, rank, world, dist):
     synth.fill_state_dict(D, "d0")
     G.train()
     optG, optD = Adam(G.parameters(), lr=1e-5, betas=(0.5, 0.999)), Adam(D.parameters(), lr=1.5e-5, betas=(0.5, 0.999))
-    if dist:
+    if rk.dist:
         optG, optD = DistributedOptimizer(optG), DistributedOptimizer(optD)
     opt = types.SimpleNamespace(device=dev, pyramid_weight_list=torch.tensor([1.0, 1.0, 1.0]), ssim_loss_factor=1.0,
                                 ssim_window_size=5, struct_method="gamma_ssim", add_frame=0, final_shape_addition=0,
                                 loss_g_d_factor=0.1, adv_weight_list=torch.tensor([0.2, 0.2, 0.2]))
     tr = GanTrainer(opt, G, D, optG, optD, None, None)
-    B, T = (8, 5) if video else (16, 2)     # video: 2 clips of 512x512 -> 4 spatial 256x256 crops each
-    hdr = synth.smooth_hdr_frames(B * T, salt="tr%d" % rank).reshape(B, T, 1, 256, 256).to(dev)
-    pos = synth.ldr_frames(B * T, salt="trp%d" % rank).reshape(B, T, 1, 256, 256).to(dev)
-    neg = (synth.ldr_frames(B * T, salt="trn%d" % rank) ** 2).reshape(B, T, 1, 256, 256).to(dev)
+    if video:
+        # configs[3]: 2 clips of T=5 at 512x512 per GPU -> four spatial 256x256 crops each = 8 clips of 256^2
+        from uncltmo_amd.frame_util import clip_to_crops
+        clips = synth.hdr_frames(2 * 5, 512, 512, salt="trv%d" % rk.rank).reshape(2, 5, 1, 512, 512)
+        pclips = synth.ldr_frames(2 * 5, 512, 512, salt="trvp%d" % rk.rank).reshape(2, 5, 1, 512, 512)
+        hdr = clip_to_crops(clips.to(dev))
+        pos = clip_to_crops(pclips.to(dev))
+        neg = pos ** 2
+        B, T = 8, 5
+    else:
+        B, T = 16, 2
+        hdr = synth.smooth_hdr_frames(B * T, salt="tr%d" % rk.rank).reshape(B, T, 1, 256, 256).to(dev)
+        pos = synth.ldr_frames(B * T, salt="trp%d" % rk.rank).reshape(B, T, 1, 256, 256).to(dev)
+        neg = (synth.ldr_frames(B * T, salt="trn%d" % rk.rank) ** 2).reshape(B, T, 1, 256, 256).to(dev)
 
     def step():
         tr.train_D(hdr, pos, neg, 0)
         tr.train_G(hdr, hdr, pos, neg, 0)
 
-    for _ in range(a.warmup):
-        step()
-    if dist:
-        import torch.distributed as td
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = t.item()
-    if rank == 0:
-        ms = dt / a.steps * 1e3
-        n = B * T
-        # per frame: 2 generator forwards + 1 (summed) backward = 2*18.286 + 36.572 GFLOP (the reference runs 2 backwards)
-        tfl = n * (2 * GFLOP_PER_TILE + 2 * GFLOP_PER_TILE) / ms
+    return tr, step, B * T
+
+
+def train_numbers(a, rk, video, steps, warmup):
+    tr, step, n = make_trainer(rk, video)
+    dt, per_rank, _ = rk.timed(step, steps, warmup)
+    ms = dt / steps * 1e3
+    # per frame: 2 generator forwards; backward = 2 x forward FLOPs per pass.  SURVEY §8(d) counts the reference's two
+    # backward passes (109.7 GFLOP per frame); this build feeds the summed output gradient through ONE pass (73.1 GFLOP).
+    tfl_1 = n * (2 * GFLOP_PER_TILE + 2 * GFLOP_PER_TILE) / ms
+    tfl_2 = n * (2 * GFLOP_PER_TILE + 4 * GFLOP_PER_TILE) / ms
+    return {"ms_per_step": ms, "frames_per_s": rk.world * n * steps / dt, "frames_per_step_per_gpu": n, "steps": steps,
+            "warmup": warmup, "dtype": "bf16",
+            "workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, Adam): 2 clips of "
+                         "512x512 x T=5 per GPU cut into 4 crops of 256x256 each, epoch regime 0 (BASELINE configs[3])") if video
+            else ("GanTrainerImg step (train_D + train_G, all losses, Adam): 32 frames of 256x256 per GPU, epoch regime 0 "
+                  "(BASELINE configs[2])"),
+            "generator_mfma": {"peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "achieved_executed": tfl_1, "frac_executed": tfl_1 / PEAK_BF16_TFLOPS,
+                               "achieved_survey_convention": tfl_2, "frac_survey_convention": tfl_2 / PEAK_BF16_TFLOPS,
+                               "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
+                                       "2 bwd (109.7 GFLOP, what the reference runs); both over the whole step time"},
+            "errD": float(tr.errD), "errG_d": float(tr.errG_d), "errG_struct": float(tr.errG_struct)}, per_rank
+
+
+def train_bench(a, rk):
+    video = a.mode == "train_video"
+    nums, per_rank = train_numbers(a, rk, video, a.steps, a.warmup)
+    if rk.rank == 0:
         name = "GanTrainer (video, T=5)" if video else "GanTrainerImg"
+        line = {"metric": "HDR frames/sec (256x256 full %s step)" % name, "value": nums["frames_per_s"], "unit": "frames/s"}
+        line.update(common_fields(a, rk, nums["ms_per_step"] * a.steps / 1e3, per_rank))
+        line.update({"dtype": "bf16",
+                     "config": {"workload": nums["workload"], "parallelism": "data-parallel x%d, gradient all-reduce" % rk.world},
+                     "generator_mfma": nums["generator_mfma"],
+                     "errD": nums["errD"], "errG_d": nums["errG_d"], "errG_struct": nums["errG_struct"]})
         _flush_c_stdio()
-        print(json.dumps({"metric": "HDR frames/sec (256x256 full %s step)" % name, "value": world * n * a.steps / dt,
-                          "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, "
-                                                  "Adam), 2 clips x 4 crops x 5 frames of 256x256 per GPU, epoch regime 0 "
-                                                  "(BASELINE.json configs[3])") if video else
-                                                 ("GanTrainerImg step (train_D + train_G, all losses, Adam), 32 frames of 256x256 "
-                                                  "per GPU, epoch regime 0 (BASELINE.json configs[2])"),
-                                     "parallelism": "data-parallel x%d, gradient all-reduce" % world},
-                          "generator_mfma": {"achieved": tfl, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                             "frac": tfl / PEAK_BF16_TFLOPS,
-                                             "note": "2 fwd + 1 summed bwd of G per frame, whole step time"},
-                          "errD": tr.errD.item(), "errG_d": tr.errG_d.item(), "errG_struct": tr.errG_struct.item()}), flush=True)
+        print(json.dumps(line), flush=True)
+    elif rk.dist:
+        rk.ranks_seen()
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = world > 1 or os.environ.get("UNCL_FORCE_DIST") == "1"   # the override lets a 1-GPU box exercise the RCCL path
-    torch.cuda.set_device(local_rank)
-    if dist:
-        import torch.distributed as td
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+# ---------------------------------------------------------------------------------------------------------------------
+# stub step (CPU tests of the launcher / JSON contract)
+# ---------------------------------------------------------------------------------------------------------------------
+def stub_bench(a, rk):
+    import torch
+    x = torch.ones(64, 64)
+
+    def step():
+        return (x @ x).sum()
+
+    dt, per_rank, _ = rk.timed(step, a.steps, a.warmup)
+    line = None
+    if rk.rank == 0:
+        line = {"metric": "stub steps/sec (launcher self-test, no GPU)", "value": rk.world * a.steps / dt, "unit": "steps/s"}
+        line.update(common_fields(a, rk, dt, per_rank))
+        line.update({"dtype": "f32", "config": {"workload": "stub", "parallelism": "x%d" % rk.world}})
+        print(json.dumps(line), flush=True)
+    elif rk.dist:
+        rk.ranks_seen()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# headline: tiled generator forward
+# ---------------------------------------------------------------------------------------------------------------------
+def infer_bench(a, rk):
+    import torch
     from uncltmo_amd import _hip, synth, tiler
     from uncltmo_amd.generator import UNet
-    if os.environ.get("UNCL_STREAMS"):        # experiments: 1 = everything on the caller's stream
-        _hip.check(_hip.lib().uncl_gen_set_streams(int(os.environ["UNCL_STREAMS"])), "uncl_gen_set_streams")
-    if a.mode in ("train", "train_video"):
-        train_bench(a, rank, world, dist)
-        if dist:
-            td.destroy_process_group()
-        return
-
     lib = _hip.lib()
     assert lib.uncl_device_ok() == 1, "bench needs an MI355X (gfx950)"
     net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
@@ -212,7 +369,7 @@ def main():
     synth.fill_state_dict(net, "g0")
     net = net.cuda().eval()
     # synthetic frames (seeded, heavy-tailed log-compressed radiance), resident in HBM before timing starts
-    frames = synth.hdr_frames(FRAMES, H, W, salt="bench%d" % rank).cuda()
+    frames = synth.hdr_frames(FRAMES, H, W, salt="bench%d" % rk.rank).cuda()
 
     def step():
         return tiler.test_big_size_image2(frames, net, 0, 0, 0)
@@ -220,24 +377,15 @@ def main():
     for _ in range(a.warmup):
         step()
     lib.uncl_prof_enable(DOM_LAYER, 4096)
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    dt = time.perf_counter() - t0
+    dt, per_rank, out = rk.timed(step, a.steps, 0)
     # per-launch durations of the dominant kernel, recorded by HIP events on the launch stream during the steps
     buf = (ctypes.c_float * 4096)()
     nrec = lib.uncl_prof_read(buf, 4096)
     dom_ms = sum(buf[i] for i in range(nrec)) / max(nrec, 1)
     tiles_per_launch = FRAMES * TILES_PER_FRAME * a.steps / max(nrec, 1)
-    # The timed steps run the product configuration: four parts on four streams up to the third decoder stage, then the last
-    # stage (the dominant launch) for all 200 tiles on one stream.  The same kernel in a purely single-stream forward is
-    # measured separately (untimed) as a cross-check of the live figure.
+    # The timed steps run the product configuration (several parts on several streams up to the third decoder stage, then the
+    # last stage for all 200 tiles on one stream).  The same kernel in a purely single-stream forward is measured separately
+    # (untimed) as a cross-check of the live figure.
     excl_ms, excl_tiles = 0.0, 0.0
     if not a.no_exclusive:
         lib.uncl_gen_set_streams(1)
@@ -250,56 +398,89 @@ def main():
         nx = lib.uncl_prof_read(buf, 4096)
         excl_ms = sum(buf[i] for i in range(nx)) / max(nx, 1)
         excl_tiles = FRAMES * TILES_PER_FRAME * 3 / max(nx, 1)
-        lib.uncl_gen_set_streams(4)
+        lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "4")))
     lib.uncl_prof_enable(-1, 0)
-    if dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = t.item()
     assert torch.isfinite(out).all()
 
-    if rank == 0:
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        ms = dt / a.steps * 1e3
-        fps = world * FRAMES * a.steps / dt
-        dom_gflop = DOM_GFLOP_PER_TILE if a.dtype == "bf16" else DOM_GFLOP_PER_TILE_F32
-        dom_tflops = dom_gflop * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
-        excl_tflops = dom_gflop * excl_tiles / excl_ms if excl_ms > 0 else 0.0
-        fwd_tflops = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / ms          # per GPU
-        traffic, traffic_src = pmc_traffic(a.dtype)
-        line = {
-            "metric": "HDR frames/sec (1024x1024 generator forward, tiled)", "value": fps, "unit": "frames/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "UNet generator forward, batch 8 x 1024x1024 synthetic HDR -> 200 overlap tiles "
-                                   "of 256x256 per GPU, eval mode, random-init weights (BASELINE.json configs[1])",
-                       "frames_per_step_per_gpu": FRAMES, "tiles_per_frame": TILES_PER_FRAME, "chunk": a.chunk,
-                       "parallelism": "frame-parallel x%d, no collective" % world},
-            "roofline": {"bound": "mfma", "achieved": dom_tflops, "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom_tflops / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
+    train = {}
+    if not a.no_train and a.dtype == "bf16":
+        del out
+        for key, video in (("train_step", False), ("train_video_step", True)):
+            train[key], _ = train_numbers(a, rk, video, 10, 3)
+            torch.cuda.empty_cache()
+
+    if rk.rank != 0:
+        if rk.dist:
+            rk.ranks_seen()
+        return
+    peak = PEAK_F32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS
+    ms = dt / a.steps * 1e3
+    fps = rk.world * FRAMES * a.steps / dt
+    dom_gflop = DOM_GFLOP_PER_TILE_F32 if a.dtype == "fp32" else DOM_GFLOP_PER_TILE
+    dom_tflops = dom_gflop * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
+    excl_tflops = dom_gflop * excl_tiles / excl_ms if excl_ms > 0 else 0.0
+    fwd_tflops = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / ms          # per GPU
+    traffic, traffic_src = pmc_traffic(a.dtype)
+    mfma_name = {"bf16": "conv3x3 implicit-GEMM (bf16 MFMA)", "fp16": "conv3x3 implicit-GEMM (f16 MFMA)",
+                 "fp32": "conv_igemm_kernel<float,3,8,1,1>"}[a.dtype]
+    line = {"metric": "HDR frames/sec (1024x1024 generator forward, tiled)", "value": fps, "unit": "frames/s"}
+    line.update(common_fields(a, rk, dt, per_rank))
+    line.update({
+        "dtype": a.dtype,
+        "config": {"workload": "UNet generator forward, batch 8 x 1024x1024 synthetic HDR -> 200 overlap tiles "
+                               "of 256x256 per GPU, eval mode, random-init weights (BASELINE.json configs[1])",
+                   "frames_per_step_per_gpu": FRAMES, "tiles_per_frame": TILES_PER_FRAME, "chunk": a.chunk,
+                   "parallelism": "frame-parallel x%d, no collective" % rk.world},
+        "roofline": {"bound": "mfma", "achieved": fwd_tflops, "peak": peak, "unit": "TFLOP/s", "frac": fwd_tflops / peak,
+                     "scope": "whole forward: 18.2858 GFLOP per tile x 200 tiles / ms_per_step (tiler included), per GPU",
+                     "traffic": traffic, "traffic_unit": "bytes/launch of the dominant kernel",
+                     "traffic_source": traffic_src,
+                     "dominant_kernel": {
+                         "kernel": mfma_name + " @ up_path.3.conv.conv (+ up_path.3.up in its loader)",
+                         "achieved": dom_tflops, "frac": dom_tflops / peak,
                          # skip 252^2 + coarse map 126^2 in, 254^2 out, 32 bf16 channels each
                          "algorithmic_bytes": int(tiles_per_launch * (252 * 252 + 126 * 126 + 254 * 254) * 64),
                          "hbm_gbps": (traffic / dom_ms / 1e6 if traffic and dom_ms > 0 else None),
-                         "kernel": ("conv3x3_pipe_kernel<1,4,4,4,false,false>" if a.dtype == "bf16" else "conv_igemm_kernel<float,3,8,1,1>")
-                                   + " @ up_path.3.conv.conv",
                          "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
                          "gflop_per_tile": dom_gflop,
-                         "concurrency": "the network up to the third decoder stage runs as four parts on four streams; the "
-                                        "last stage (this launch) covers all tiles on one stream, nothing else in flight",
                          "exclusive": {"achieved": excl_tflops, "frac": excl_tflops / peak, "avg_launch_ms": excl_ms,
                                        "tiles_per_launch": excl_tiles,
-                                       "note": "same kernel, single stream, 3 untimed steps after the timed region"}},
-            "forward_mfma": {"achieved": fwd_tflops, "peak": peak, "unit": "TFLOP/s", "frac": fwd_tflops / peak,
-                             "gflop_per_tile": GFLOP_PER_TILE, "note": "whole step incl. tiler, per GPU"},
-        }
-        if world == 1 and not a.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
-        _flush_c_stdio()
-        print(json.dumps(line), flush=True)
-    if dist:
-        td.destroy_process_group()
+                                       "note": "same kernel, single stream, 3 untimed steps after the timed region"}}},
+    })
+    line.update(train)
+    if rk.world == 1 and not a.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+    _flush_c_stdio()
+    print(json.dumps(line), flush=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            return launch(a, argv)
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; the launcher's world size is used\n"
+                         % (a.gpus, os.environ["WORLD_SIZE"]))
+    rk = Ranks(a)
+    try:
+        if a.stub:
+            stub_bench(a, rk)
+        else:
+            from uncltmo_amd import _hip
+            if os.environ.get("UNCL_STREAMS"):        # experiments: 1 = everything on the caller's stream
+                _hip.check(_hip.lib().uncl_gen_set_streams(int(os.environ["UNCL_STREAMS"])), "uncl_gen_set_streams")
+            if a.mode in ("train", "train_video"):
+                train_bench(a, rk)
+            else:
+                infer_bench(a, rk)
+    finally:
+        rk.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,62 @@
+"""bench.py's rank launcher and JSON contract, on CPU (gloo, stubbed step): `--gpus N` must really run N ranks, rank 0 must
+print exactly one JSON line that says so, and asking for GPUs that are not there must fail loudly.
+Replaces the reference's nn.DataParallel wrapping (utils/model_save_util.py:50-54) as the way N GPUs are driven."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return e
+
+
+def _json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+
+
+def test_launcher_spawns_n_ranks_and_prints_one_line():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and len(d["per_rank_ms_per_step"]) == 2
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) < 1e-9        # MAX over ranks
+    for k in ("metric", "value", "unit", "vs_baseline", "dtype", "data", "config"):
+        assert k in d
+
+
+def test_single_rank_line_has_no_rank_fields():
+    p = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "0", "--stub"], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    (d,) = _json_lines(p.stdout)
+    assert d["n_gpus"] == 1 and "ranks_seen" not in d
+
+
+def test_torchrun_style_ranks_from_environment():
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), BENCH, "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--stub"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    (d,) = _json_lines(p.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1]
+
+
+def test_more_gpus_than_visible_is_refused():
+    """No silent single-rank run: the container has no GPU, so --gpus 2 without --stub must exit non-zero with a message."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("box has >= 2 GPUs")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 2
+    assert "refusing" in p.stderr and not _json_lines(p.stdout)

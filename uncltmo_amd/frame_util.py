@@ -52,6 +52,27 @@ def crop_input_hdr_batch(input_hdr_batch, diffY, diffX):
     return input_hdr_batch[:, :, i:i + th, j:j + tw]
 
 
+def clip_to_crops(clips, crop=256):
+    """(B,T,C,H,W) clips with H, W multiples of `crop` -> (B*(H/crop)*(W/crop), T, C, crop, crop): every spatial window of a
+    clip becomes a clip of its own (row-major window order inside each source clip), so that a T-frame sequence stays one
+    recurrent unit.  The published generator only accepts 256x256 inputs (gcn.pos_embed is (1,256,12,12): Unet.py:66,94),
+    so the 512x512 training clips of BASELINE configs[3] enter the video trainer (GanTrainer.py:263-291) as four crops each."""
+    B, T, Cc, H, W = clips.shape
+    if H % crop or W % crop:
+        raise ValueError("clip_to_crops needs H and W to be multiples of %d (got %dx%d)" % (crop, H, W))
+    ny, nx = H // crop, W // crop
+    x = clips.reshape(B, T, Cc, ny, crop, nx, crop).permute(0, 3, 5, 1, 2, 4, 6)
+    return x.reshape(B * ny * nx, T, Cc, crop, crop).contiguous()
+
+
+def crops_to_clip(crops, ny, nx):
+    """Inverse of clip_to_crops: (B*ny*nx, T, C, h, w) -> (B, T, C, ny*h, nx*w)."""
+    n, T, Cc, h, w = crops.shape
+    B = n // (ny * nx)
+    x = crops.reshape(B, ny, nx, T, Cc, h, w).permute(0, 3, 4, 1, 5, 2, 6)
+    return x.reshape(B, T, Cc, ny * h, nx * w).contiguous()
+
+
 def hdr_log_gray(rgb_img, f_factor):
     """The tensor arithmetic of load_inference / load_inference2 (model_save_util.py:209-217): (3,H,W) linear radiance ->
     (rgb shifted to be non-negative (3,H,W), log-compressed luminance in [0,1] (1,H,W))."""
