@@ -395,3 +395,114 @@ def test_pipe_transposed_plain_layers_zero_borders(cin, cout, h, w, n, act):
              src0=to_nhwc(x, BF), src0_H=h, src0_W=w, src0_C=cin, weight=pack_weight(wt, BF, transposed=True, flip=True),
              bias=b.cuda(), act=code, out=out, out_H=h + 2, out_W=w + 2, out_C=cout)
     assert rel_l2(from_nhwc(out), ref) < TOL[BF]
+
+
+# ---- producer / consumer kernel (csrc/conv3x3_pc.hip) against the four-wave kernel: same tiles, same MFMA order per
+# ---- accumulator, so every stored element must be IDENTICAL (the torch comparisons above already run through it by default)
+def _both_structures(fn):
+    lib = _hip.lib()
+    old = lib.uncl_conv3x3_set_pc(0)
+    try:
+        ref = fn()
+        lib.uncl_conv3x3_set_pc(1)
+        got = fn()
+    finally:
+        lib.uncl_conv3x3_set_pc(old)
+    return ref, got
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n,pad,pool,act", [
+    (64, 64, 124, 124, 3, 0, True, _hip.ACT_RELU),      # down_path.0 second conv: two chunks, pooled copy
+    (64, 128, 61, 61, 2, 0, False, _hip.ACT_RELU),      # two cout tiles, ragged 59 x 59 output
+    (128, 128, 59, 59, 2, 0, True, _hip.ACT_LRELU),     # odd output 57: floor pooling
+    (256, 256, 26, 26, 5, 0, True, _hip.ACT_RELU),      # eight chunks, four cout tiles
+    (128, 128, 26, 26, 3, 2, False, _hip.ACT_RELU),     # transposed (pad 2): zero borders
+    (64, 32, 33, 70, 2, 2, False, _hip.ACT_NONE),       # 32-channel tiles (16 x 32), plain source
+    (96, 64, 17, 40, 1, 0, False, _hip.ACT_RELU),       # three chunks: odd chunk count flips the stage parity per tile
+])
+def test_pc_plain_layers_bitwise(cin, cout, h, w, n, pad, pool, act):
+    x, wt, b = q(rnd(n, cin, h, w, seed=201), BF), q(rnd(cout, cin, 3, 3, seed=202, scale=0.1), BF), rnd(cout, seed=203)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    xd, wd, bd = to_nhwc(x, BF), pack_weight(wt, BF), b.cuda()
+
+    def run():
+        out = torch.zeros(n, ho, wo, cout, dtype=torch.bfloat16, device="cuda")
+        pl = torch.zeros(n, ho // 2, wo // 2, cout, dtype=torch.bfloat16, device="cuda") if pool else None
+        run_pipe(pool_out=pl, dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=xd,
+                 src0_H=h, src0_W=w, src0_C=cin, weight=wd, bias=bd, act=act, out=out, out_H=ho, out_W=wo, out_C=cout)
+        return out, pl
+
+    (ro, rp), (go, gp) = _both_structures(run)
+    assert torch.equal(ro, go)
+    if pool:
+        assert torch.equal(rp, gp)
+    ref = F.conv2d(F.pad(x, (pad,) * 4), wt, b)
+    ref = {_hip.ACT_RELU: F.relu, _hip.ACT_LRELU: lambda t: F.leaky_relu(t, 0.2), _hip.ACT_NONE: lambda t: t}[act](ref)
+    assert rel_l2(from_nhwc(go), ref) < TOL[BF]
+
+
+@pytest.mark.parametrize("c,cout,h,w,n,short", [(32, 32, 37, 45, 2, 1), (64, 32, 124, 124, 2, 0), (128, 64, 57, 57, 2, 1),
+                                                (256, 128, 24, 24, 3, 0)])
+def test_pc_concat_ssr_bitwise(c, cout, h, w, n, short):
+    x2 = q(rnd(n, c, h, w, seed=211).abs(), BF)
+    x1 = q(rnd(n, c, h - short, w - short, seed=212), BF)
+    wt, b = q(rnd(4 * c, cout, 3, 3, seed=213, scale=0.05), BF), rnd(cout, seed=214)
+    x2d, x1d, wd, bd = to_nhwc(x2, BF), to_nhwc(x1, BF), pack_weight(wt, BF, transposed=True, flip=True), b.cuda()
+
+    def run():
+        out = torch.zeros(n, h + 2, w + 2, cout, dtype=torch.bfloat16, device="cuda")
+        run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR, N=n, H=h, W=w, Cin=4 * c, Cout=cout, src0=x2d, src0_H=h,
+                 src0_W=w, src0_C=c, src1=x1d, src1_H=h - short, src1_W=w - short, src1_C=c, weight=wd, bias=bd,
+                 act=_hip.ACT_RELU, out=out, out_H=h + 2, out_W=w + 2, out_C=cout)
+        return out
+
+    ro, go = _both_structures(run)
+    assert torch.equal(ro, go)
+    cat = torch.cat([x2, F.pad(x1, (0, short, 0, short), mode="replicate"), x2 ** 2, (x2 + 1e-8) ** 0.5], 1)
+    assert rel_l2(from_nhwc(go), F.relu(F.conv_transpose2d(cat, wt, b))) < 2e-2
+
+
+@pytest.mark.parametrize("h,w,n", [(9, 13, 3), (23, 40, 2), (126, 126, 2)])
+def test_pc_fused_upconv_bitwise(h, w, n):
+    c = 32
+    H, W = 2 * h, 2 * w
+    x2d = to_nhwc(q(rnd(n, c, H, W, seed=221).abs(), BF), BF)
+    xsd = to_nhwc(q(rnd(n, c, h, w, seed=222), BF), BF)
+    wud, bud = pack_weight(q(rnd(c, c, 2, 2, seed=223, scale=0.1), BF), BF, transposed=True), rnd(c, seed=224).cuda()
+    wd, bd = pack_weight(q(rnd(4 * c, 32, 3, 3, seed=225, scale=0.05), BF), BF, transposed=True, flip=True), rnd(32, seed=226).cuda()
+
+    def run():
+        out = torch.zeros(n, H + 2, W + 2, 32, dtype=torch.bfloat16, device="cuda")
+        run_pipe(dtype=BF, ksize=3, pad=2, N=n, H=H, W=W, Cin=4 * c, Cout=32, src0=x2d, src0_H=H, src0_W=W, src0_C=c, weight=wd,
+                 bias=bd, act=_hip.ACT_RELU, out_H=H + 2, out_W=W + 2, out_C=32, src_mode=_hip.SRC_CONCAT_SSR_UP, src1=xsd,
+                 src1_H=h, src1_W=w, src1_C=c, up_w=wud, up_b=bud, out=out)
+        return out
+
+    ro, go = _both_structures(run)
+    assert torch.equal(ro, go)
+
+
+@pytest.mark.parametrize("gc,cd,gh,pad_d,n,accumulate,use_mask", [(64, 64, 122, 2, 2, 0, True), (128, 64, 59, 2, 2, 1, True),
+                                                                  (32, 128, 254, 0, 1, 0, False), (256, 256, 24, 2, 2, 1, False)])
+def test_pc_dgrad_store_bitwise(gc, cd, gh, pad_d, n, accumulate, use_mask):
+    """Gradient mode of the epilogue (ReLU mask of the producing layer, accumulation into an existing gradient)."""
+    oh = gh + 2 * pad_d - 2
+    gy = to_nhwc(q(rnd(n, gc, gh, gh, seed=231), BF), BF)
+    wd = pack_weight(q(rnd(cd, gc, 3, 3, seed=232, scale=0.1), BF), BF)
+    mask = to_nhwc(q(rnd(n, cd, oh, oh, seed=233), BF), BF)
+    init = to_nhwc(q(rnd(n, cd, oh, oh, seed=234), BF), BF)
+
+    def run():
+        out = init.clone()
+        d = _hip.ConvDesc()
+        for k_, v in dict(dtype=BF, ksize=3, pad=pad_d, src_mode=_hip.SRC_PLAIN, N=n, H=gh, W=gh, Cin=gc, Cout=cd,
+                          src0=gy.data_ptr(), src0_H=gh, src0_W=gh, src0_C=gc, weight=wd.data_ptr(), act=_hip.ACT_NONE,
+                          out=out.data_ptr(), out_H=oh, out_W=oh, out_C=cd).items():
+            setattr(d, k_, v)
+        _hip.check(_hip.lib().uncl_conv3x3_dgrad(C.byref(d), mask.data_ptr() if use_mask else None, 0.0, accumulate,
+                                                 _hip.stream_ptr()), "dgrad")
+        torch.cuda.synchronize()
+        return out
+
+    ro, go = _both_structures(run)
+    assert torch.equal(ro, go)

@@ -96,6 +96,7 @@ SIGNATURES = {
     "uncl_device_ok": (C.c_int, []),
     "uncl_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "uncl_conv3x3_pipe": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p]),
+    "uncl_conv3x3_set_pc": (C.c_int, [C.c_int]),
     "uncl_upconv2x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_conv_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,64 @@
+// Launch descriptor and load helpers shared by the two bf16 3x3 implicit-GEMM kernels (conv3x3_pipe.hip: four waves that
+// stage and multiply in turn, two workgroups per CU; conv3x3_pc.hip: four multiplying + four staging waves, one per CU).
+#pragma once
+#include "common.h"
+
+struct PipeArgs {
+  const bf16_t* src0;
+  const bf16_t* src1;
+  const bf16_t* prev0;
+  const bf16_t* weight;
+  const float* bias;
+  const bf16_t* res;
+  const bf16_t* mask;   // backward: stored value is zeroed where mask <= 0 (ReLU of the layer that produced `mask`)
+  int accumulate;       // backward: add to what `out` already holds
+  float mask_slope;     // backward: derivative on the non-positive side (0 ReLU, 0.2 LeakyReLU)
+  bf16_t* out;
+  bf16_t* pool_out;
+  const float* out1_w;
+  const float* out1_b;
+  float* out1;
+  int H, W, Cin, Cout, pad;
+  int s0H, s0W, s0C, s1H, s1W, s1C, prev_ch;
+  float slope;  // activation as max(t,0) + slope*min(t,0): 0 relu, 0.2 leaky, 1 identity
+  int res_b0;
+  int Hout, Wout, oC;
+  int pH, pW;
+  int tiles_x, tiles_y, n_ct, total_tiles, tiles_per_wg, nk;
+  int out1_act, skip_main;
+  const float* img;     // MODE 3: fp32 one-channel image (N, imgH, imgW); x = act(conv3x3_valid(img; pre_w, pre_b))
+  const float* pre_w;   // (32,1,3,3)
+  const float* pre_b;   // (32) or NULL
+  int imgH, imgW;
+  int flat_S, flat_hw, flat_N;  // FLAT: whole samples per tile, output pixels per sample, samples in the batch
+  const bf16_t* up_w;   // MODE 4: packed [4 taps][32 cout][32 cin] weights of the 2x2 stride-2 transposed conv
+  const float* up_b;    // MODE 4: its bias (32) or NULL
+  int pc_prio;          // conv3x3_pc: 0 no priorities, 1 multiplying waves raised, 2 staging waves raised
+};
+
+// conv3x3_pc.hip: the producer / consumer kernel for the multi-chunk layers; returns UNCL_ERR_ARG when (nt, mpw, mode) is not built
+int uncl_conv3x3_pc_launch(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s);
+
+namespace {
+
+__device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// wave-uniform base + 32-bit per-lane BYTE offset: lowers to global_load_dwordx4 v, v_off, s[base] (no address VGPR pair)
+__device__ __forceinline__ bf16x8 ld16o(const bf16_t* base, unsigned byte_off) {
+  // The empty asm keeps the zero-extension of the offset next to the load: hoisted out of the loop it turns the access
+  // into a 64-bit VGPR address that the compiler builds inside the destination registers, and the write-after-write
+  // hazard check then waits (vmcnt) for every load issued so far before the next one can go out.
+  asm volatile("" : "+v"(byte_off));
+  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+
+template <int V>
+struct IntTag { static constexpr int value = V; };
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off) {
+  asm volatile("" : "+v"(byte_off));
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+}  // namespace

@@ -1,0 +1,673 @@
+// Producer / consumer 3x3 implicit-GEMM convolution for gfx950 (bf16): the multi-chunk (Cin >= 64) layers of the generator.
+//
+// conv3x3_pipe.hip runs four waves that take turns loading, staging and multiplying, two workgroups per CU; its waves spend
+// two thirds of their time outside the MFMA phase and the matrix pipe of a SIMD idles whenever both of its waves are there.
+// Here the roles are split instead, ONE 512-thread workgroup per CU:
+//
+//   waves 0-3  (one per SIMD, raised priority): nothing but LDS fragment reads + v_mfma_f32_32x32x16_bf16 over the staged
+//              K-chunk, and the tile's epilogue (bias, activation, wave-private LDS transposition, 1-KiB row stores, fused
+//              2x2 max-pool copy).  They never touch global loads or staging writes.
+//   waves 4-7  (their SIMD partners): global loads of chunk s+2 into registers, LDS staging of chunk s+1 (square / square-root
+//              of the skip slice, replicate padding, zero borders, the 2x2 transposed conv of MODE 4 straight from global
+//              fragments), one chunk ahead of the multiplying waves in a two-stage LDS ring.
+//
+// One s_barrier per K-chunk hands a stage from the producers to the consumers and the previous one back; global loads stay
+// in flight across it (raw s_barrier + lgkmcnt only).  Same tiles, same LDS images (80-byte padded rows), same MFMA order per
+// accumulator as conv3x3_pipe -> bit-identical results; tests/test_gpu_conv.py compares the two kernels element for element.
+//
+// LDS (one workgroup per CU): 2 stages x (halo tile + 9 taps of weights) + 4 x 4 KiB wave-private epilogue images + biases of
+// two tiles = 160 640 B (32-channel tiles, 16 x 32 pixels) / 163 456 B (64-channel tiles, 8 x 32 pixels) of 163 840.
+#include <cstdlib>
+
+#include "conv3x3_args.h"
+
+namespace {
+
+__device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Phase timing (measurement builds only, -DUNCL_PC_TIMING; tools/pc_phase_timing.py): wave 0 (consumer) and wave 4 (producer) of
+// every workgroup accumulate s_memtime deltas per loop phase into g_pc_t[]; the product library compiles all of this away.
+#ifdef UNCL_PC_TIMING
+__device__ unsigned long long g_pc_t[16];
+__device__ __forceinline__ unsigned long long pct_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define PCT_DECL unsigned long long pct_acc[4] = {}; unsigned long long pct_last = pct_now();
+#define PCT(i) { const unsigned long long pct_t = pct_now(); pct_acc[i] += pct_t - pct_last; pct_last = pct_t; }
+#define PCT_FLUSH(base) if ((threadIdx.x & 255) == 0) { for (int i = 0; i < 4; ++i) atomicAdd(&g_pc_t[base + i], pct_acc[i]); atomicAdd(&g_pc_t[8 + base / 4], 1ull); }
+#else
+#define PCT_DECL
+#define PCT(i)
+#define PCT_FLUSH(base)
+#endif
+
+struct TileCur { int tile, ct, tx, ty, n, kc; };
+
+__device__ __forceinline__ void cur_init(TileCur& c, int tile, const PipeArgs& a) {
+  int r = tile;
+  c.tile = tile;
+  c.ct = r % a.n_ct; r /= a.n_ct;
+  c.tx = r % a.tiles_x; r /= a.tiles_x;
+  c.ty = r % a.tiles_y; r /= a.tiles_y;
+  c.n = r;
+  c.kc = 0;
+}
+// one K-chunk further; false past the end of this workgroup's tile range
+__device__ __forceinline__ bool cur_next(TileCur& c, const PipeArgs& a, int tile_end) {
+  if (++c.kc < a.nk) return true;
+  c.kc = 0;
+  if (++c.tile >= tile_end) return false;
+  if (++c.ct == a.n_ct) {
+    c.ct = 0;
+    if (++c.tx == a.tiles_x) {
+      c.tx = 0;
+      if (++c.ty == a.tiles_y) { c.ty = 0; ++c.n; }
+    }
+  }
+  return true;
+}
+
+// MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) computed by the
+//       producers (32 channels, same extent as the skip)
+template <int NT, int MPW, int MODE, int PW>
+__global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_kernel(const PipeArgs a) {
+  static_assert(PW == 4 || PW == 8, "four or eight staging waves");
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int TH = MPW * 4, TW = 32;
+  constexpr int HH = TH + 2, HW = TW + 2;
+  constexpr int NPIX = HH * HW;
+  constexpr int CT = NT * 32;
+  constexpr int WROWS = 9 * CT;
+  constexpr int SLOTS = CT / 8;
+  constexpr int RP = 80;                      // padded LDS row (64 bytes of channels), see conv3x3_pipe.hip
+  constexpr int XBYTES = NPIX * RP, WBYTES = WROWS * RP, STAGE = XBYTES + WBYTES;
+  constexpr int EW = 4096;                    // wave-private epilogue image
+  constexpr int RG = EW / (TW * CT * 2);      // output rows per epilogue group (2 for 32-channel tiles, 1 for 64)
+  static_assert(RG >= 1 && MPW % RG == 0, "epilogue groups cover the wave's rows");
+  static_assert(MODE != 4 || (NT == 1 && MPW == 4), "fused up-conv: 16 x 32 tiles of 32 channels");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sE = smem + 2 * STAGE;
+  float* const sBias = reinterpret_cast<float*>(sE + 4 * EW);   // [2 tiles][CT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tile0 = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile0 + a.tiles_per_wg, a.total_tiles);
+  if (tile0 >= tile_end) return;
+
+  if (wave < 4) {
+    // =================================================================================================================
+    // consumers
+    // =================================================================================================================
+    if ((a.pc_prio & 3) == 1) __builtin_amdgcn_s_setprio(2);
+    f32x16 acc[MPW][NT];
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+    // fragment bases of this lane (stage 0): A = weights row lr, B = halo pixel (wave*MPW) * HW + lr, 16-byte half lh
+    const int aoff = XBYTES + lr * RP + (lh << 4);
+    const int boff = (wave * MPW * HW + lr) * RP + (lh << 4);
+
+    // One staged K-chunk = six (ks, tx) tap columns of 12 MFMAs each.  The fragments of column i + 1 are read while the MFMAs
+    // of column i issue (two register sets, one DS read per MFMA gap pinned with sched_group_barrier): a single wave per SIMD
+    // has nobody to cover its LDS latency, and left to itself the compiler emits "9 reads, wait, 12 MFMAs" per column.
+    // The accumulators are zeroed after each tile's epilogue, so the phase has no branch and is one scheduling region.
+    constexpr int NRD = 3 * NT + MPW + 2;      // DS reads per column
+    constexpr int NMM = 3 * NT * MPW;          // MFMAs per column
+    auto mfma_phase = [&](const char* st) __attribute__((always_inline)) {
+      const char* pa = st + aoff;
+      const char* pb = st + boff;
+      vec A[2][3][NT], B[2][MPW + 2];
+      auto rd = [&](int set, int col) __attribute__((always_inline)) {
+        const int ks = col / 3, tx = col - 3 * ks;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            A[set][ty][nt] = *reinterpret_cast<const vec*>(pa + ((ty * 3 + tx) * CT + nt * 32) * RP + (ks << 5));
+#pragma unroll
+        for (int r = 0; r < MPW + 2; ++r) B[set][r] = *reinterpret_cast<const vec*>(pb + (r * HW + tx) * RP + (ks << 5));
+      };
+      rd(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);     // column 0's own fragments first
+#pragma unroll
+      for (int col = 0; col < 6; ++col) {
+        const int set = col & 1;
+        if (col + 1 < 6) rd(set ^ 1, col + 1);
+        if (col == 0) {
+          // same order as conv3x3_pipe's first column: tap row 0 of every output row, then rows 1 and 2
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][nt], B[set][m], acc[m][nt], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 1; ty < 3; ++ty)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][ty][nt], B[set][m + ty], acc[m][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][ty][nt], B[set][m + ty], acc[m][nt], 0, 0, 0);
+        }
+        if (col + 1 < 6) {
+#pragma unroll
+          for (int k = 0; k < NRD; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read of the next column ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... per MFMA of this one
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+        }
+      }
+    };
+
+    // epilogue addressing that does not change between tiles
+    char* const sEw = sE + wave * EW;
+    const int sw_e = (lr >> 1) & (SLOTS - 1);
+    const int ew_base = lr * (CT * 2) + (lh << 3);                    // + r*TW*CT*2 + ((slot ^ sw_e) << 4)
+    const int rd_pl = lane / SLOTS, rd_sl = lane - rd_pl * SLOTS;     // read-back pass 0: pixel / slot
+    constexpr int PX_PER_PASS = 64 / SLOTS;                           // pixels per read-back pass (16 / 8)
+    constexpr int PASSES = RG * TW / PX_PER_PASS;                     // 4
+
+    // ACT 0: ReLU on the rounded bf16 pair (signed 16-bit max against zero; rounding is sign-symmetric); 1: identity
+    // (gradient mode); 2: max(t,0) + slope*min(t,0)
+    auto epilogue = [&](const TileCur& c, int tpar, auto act_tag) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_tag)::value;
+      const float* sBt = sBias + tpar * CT;
+      const int y0 = c.ty * TH + wave * MPW, x0 = c.tx * TW, co = c.ct * CT;
+      f32x4 bq[NT][4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[nt][q] = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 8 * q + 4 * lh);
+      auto act_pack = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = v[4 * q + r] + b[r];
+          o[r] = (bf16_t)(ACT == 2 ? fmaxf(t, 0.f) + a.slope * fminf(t, 0.f) : t);
+        }
+        if (ACT == 0) {
+          s16x4 si = __builtin_bit_cast(s16x4, o);
+          si = __builtin_elementwise_max(si, s16x4{0, 0, 0, 0});
+          o = __builtin_bit_cast(bf16x4, si);
+        }
+        return o;
+      };
+#pragma unroll
+      for (int g = 0; g < MPW / RG; ++g) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+              *reinterpret_cast<bf16x4*>(sEw + ew_base + r * (TW * CT * 2) + (((nt * 4 + q) ^ sw_e) << 4)) =
+                  act_pack(acc[g * RG + r][nt], q, bq[nt][q]);
+        asm volatile("" ::: "memory");     // the wave reads back what its other lanes wrote (DS operations of a wave are in order)
+        if (!a.skip_main) {
+          vec v[PASSES];
+#pragma unroll
+          for (int it = 0; it < PASSES; ++it) {
+            const int pl = rd_pl + it * PX_PER_PASS;
+            v[it] = *reinterpret_cast<const vec*>(sEw + pl * (CT * 2) + ((rd_sl ^ ((pl >> 1) & (SLOTS - 1))) << 4));
+          }
+          const bool plain = a.mask == nullptr && !a.accumulate;     // wave-uniform
+#pragma unroll
+          for (int it = 0; it < PASSES; ++it) {
+            const int pl = rd_pl + it * PX_PER_PASS;
+            const int oy = y0 + g * RG + pl / TW, ox = x0 + (pl & (TW - 1));
+            if (oy < a.Hout && ox < a.Wout) {
+              const size_t e = (((size_t)c.n * a.Hout + oy) * a.Wout + ox) * a.oC + co + rd_sl * 8;
+              if (plain) {
+                *reinterpret_cast<vec*>(a.out + e) = v[it];
+              } else {
+                // gradient store: ReLU mask of the producing layer and / or accumulation into an existing gradient
+                float f[8];
+                E::unpack(v[it], f);
+                if (a.mask) {
+                  float m[8];
+                  E::unpack(ld16(a.mask + e), m);
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) f[i] = m[i] > 0.f ? f[i] : a.mask_slope * f[i];
+                }
+                if (a.accumulate) {
+                  float o[8];
+                  E::unpack(ld16(a.out + e), o);
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) f[i] += o[i];
+                }
+                *reinterpret_cast<vec*>(a.out + e) = E::pack(f);
+              }
+            }
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+      if (NT == 2 && a.pool_out != nullptr) {
+        // MaxPool2d(2) of the wave's two rows (unet_parts.py:212,233): vertical max in registers, horizontal max between
+        // neighbouring lanes, the 16 pooled pixels transposed through the wave's LDS image like the rows above
+        static_assert(NT != 2 || MPW == 2, "one pooled row per wave");
+        const int pp = lr >> 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bf16x4 r0 = act_pack(acc[0][nt], q, bq[nt][q]), r1 = act_pack(acc[MPW - 1][nt], q, bq[nt][q]);
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float m = fmaxf((float)r0[r], (float)r1[r]);
+              o[r] = (bf16_t)fmaxf(m, __shfl_xor(m, 1, 64));
+            }
+            if ((lr & 1) == 0)
+              *reinterpret_cast<bf16x4*>(sEw + pp * (CT * 2) + (((nt * 4 + q) ^ ((pp >> 1) & (SLOTS - 1))) << 4) + (lh << 3)) = o;
+          }
+        asm volatile("" ::: "memory");
+        const int gy = (c.ty * TH >> 1) + wave;
+#pragma unroll
+        for (int it = 0; it < (TW / 2) / PX_PER_PASS; ++it) {
+          const int pl = rd_pl + it * PX_PER_PASS;
+          const vec val = *reinterpret_cast<const vec*>(sEw + pl * (CT * 2) + ((rd_sl ^ ((pl >> 1) & (SLOTS - 1))) << 4));
+          const int gx = (x0 >> 1) + pl;
+          if (gy < a.pH && gx < a.pW)
+            *reinterpret_cast<vec*>(a.pool_out + (((size_t)c.n * a.pH + gy) * a.pW + gx) * a.oC + co + rd_sl * 8) = val;
+        }
+        asm volatile("" ::: "memory");
+      }
+    };
+
+    TileCur cc;
+    cur_init(cc, tile0, a);
+    int tpar = 0;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
+    PCT_DECL
+    pc_barrier();     // stage 0 is staged
+    PCT(2)
+    for (int s = 0;; ++s) {
+      mfma_phase(smem + (s & 1) * STAGE);
+      PCT(0)
+      if (cc.kc == a.nk - 1) {
+        if (a.slope == 0.f) epilogue(cc, tpar, IntTag<0>{});
+        else if (a.slope == 1.f) epilogue(cc, tpar, IntTag<1>{});
+        else epilogue(cc, tpar, IntTag<2>{});
+#pragma unroll
+        for (int m = 0; m < MPW; ++m)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
+        PCT(1)
+      }
+      pc_barrier();   // done with stage s & 1; stage (s + 1) & 1 is staged
+      PCT(2)
+      const int t_old = cc.tile;
+      if (!cur_next(cc, a, tile_end)) break;
+      if (cc.tile != t_old) tpar ^= 1;
+    }
+    PCT_FLUSH(0)
+    return;
+  }
+
+  // ===================================================================================================================
+  // producers
+  // ===================================================================================================================
+  if ((a.pc_prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
+  const int ptid = tid - 256;
+  const int pwave = wave - 4;
+  // per-thread constants of the staging pattern (identical for every step): regular slot j = halo pixel (hy0 + RSTEP*j, hx),
+  // vector ch; extra slot = halo pixel (ey, 32 + ec), vector ch
+  constexpr int NPROD = PW * 64;
+  constexpr int RSTEP = NPROD / 128;                 // halo rows covered per regular pass (2 or 4)
+  constexpr int RSN = (HH + RSTEP - 1) / RSTEP;      // regular passes
+  constexpr bool R_RAGGED = HH % RSTEP != 0;
+  constexpr int XV = RSN + 1;
+  constexpr int WPP = NPROD / 4;                     // weight rows per pass
+  static_assert(WPP % CT == 0, "a weight pass covers whole taps");
+  constexpr int WVN = (WROWS + WPP - 1) / WPP;
+  constexpr bool W_RAGGED = WROWS % WPP != 0;
+  static_assert(NPROD >= HH * 8, "extra-column slot");
+  const int ch = ptid & 3, p0 = ptid >> 2;
+  const int hx = p0 & 31, hy0 = p0 >> 5;
+  const int ey = ptid >> 3, ec = (ptid >> 2) & 1;
+  const bool e_on = ptid < HH * 8;
+  const bool r_last_on = !R_RAGGED || hy0 + RSTEP * (RSN - 1) < HH;   // the ragged last regular pass
+  const int row_el = a.s0W * a.s0C;
+  const int xoff_r = (hy0 * a.s0W + hx) * a.s0C + ch * 8;
+  const int xoff_e = (ey * a.s0W + 32 + ec) * a.s0C + ch * 8;
+  const int pix_r0 = hy0 * HW + hx;
+  const int pix_e = ey * HW + 32 + ec;
+  const int lds_w0 = XBYTES + p0 * RP + (ch << 4);
+  const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;
+
+  vec xr[XV];
+  vec wr[WVN];
+  f32x4 br = {0.f, 0.f, 0.f, 0.f};
+  unsigned xvalid = 0;
+  int g_pending = 0, bpar_pending = 0;
+  bool b_pending = false;
+  int u_iy0 = 0, u_ix0 = 0;
+  int ppar = 0;                 // parity of the tile the producers are loading
+
+  // MODE 4: this wave is tap (dy, dx) of the 2x2 stride-2 transposed conv (and, with eight staging waves, one half of the
+  // M-tiles).  Its weight fragment (A rows in the order cout(r) = 16*bit2(r) + 4*(r >> 3) + (r & 3), which makes a lane's D
+  // registers 16 consecutive output channels of its pixel) and the bias it starts the accumulation from stay in registers
+  // for the whole launch.
+  constexpr int UPH = HH / 2, UPW = HW / 2, UPN = UPH * UPW, MTU = (UPN + 31) / 32;
+  constexpr int MT_STEP = PW / 4;                       // M-tiles are dealt round-robin over the waves of a tap
+  constexpr int MT_PER = (MTU + MT_STEP - 1) / MT_STEP;
+  static_assert(MODE != 4 || 2 * MT_PER <= XV, "the up-conv's source fragments fit in the staging registers");
+  const int tap = pwave & 3, mt0 = pwave >> 2;
+  vec ua[2];
+  f32x16 cb;
+  if (MODE == 4) {
+    const int arow = tap * 32 + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) ua[ks] = ld16(a.up_w + arow * 32 + (2 * ks + lh) * 8);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cb[i] = a.up_b ? a.up_b[16 * lh + i] : 0.f;
+  }
+
+  auto load_regs = [&](const TileCur& c) {
+    const int n = c.n, y0 = c.ty * TH, x0 = c.tx * TW, cout0 = c.ct * CT, kc = c.kc;
+    int g = 0, cbase = kc * 32, wk = kc;
+    bool reuse = false;
+    if (MODE == 1 || MODE == 4) {
+      // each 32-channel slice of the skip is walked as [x1, x2, x2^2, sqrt(x2)]; the x2 registers are re-staged (squared,
+      // square-rooted) for the third and fourth chunk; `wk` = the chunk's position in the weight's K layout [x2|x1|x2^2|sqrt]
+      const int ph = kc & 3;
+      cbase = (kc >> 2) * 32;
+      g = ph == 0 ? 1 : (ph == 1 ? 0 : ph);
+      wk = g * (a.s0C >> 5) + (kc >> 2);
+      reuse = ph >= 2;
+    }
+    g_pending = g;
+    b_pending = kc == 0;
+    bpar_pending = ppar;
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    const bool same_ext = a.s1H == a.s0H && a.s1W == a.s0W;
+    const bf16_t* xsrc = (MODE != 0 && g == 1) ? a.src1 : a.src0;
+    if (reuse) {
+      // xr / xvalid still hold this tile's x2 slice
+    } else if (MODE == 4 && g == 1) {
+      // B fragments of the up-conv straight from global memory: source pixel sp = 32 mt + lr of the 9 x 17 patch under the
+      // 18 x 34 halo tile, channels 8 (2 ks + lh) .. +7; out-of-image source pixels are clamped (their outputs are outside the
+      // image too and are staged as zeros)
+      const int sy0 = iy0 >> 1, sx0 = ix0 >> 1;
+      u_iy0 = iy0; u_ix0 = ix0;
+      const bf16_t* ub = a.src1 + (size_t)n * a.s1H * a.s1W * 32;
+#pragma unroll
+      for (int i = 0; i < MT_PER; ++i) {
+        const int mt = mt0 + MT_STEP * i;
+        const int spc = min(mt * 32 + lr, UPN - 1);
+        const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;     // / 17 for spc < 1024
+        const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          xr[2 * i + ks] = ld16o(ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
+      }
+      xvalid = 0xffffffffu;
+    } else if (MODE != 0 && MODE != 4 && g == 1 && !same_ext) {
+      // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
+      const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
+      const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
+      unsigned valid = 0;
+      const int ix = ix0 + hx;
+      const bool xok = (unsigned)ix < (unsigned)a.W;
+      const int sx = min(max(ix - dx, 0), a.s1W - 1);
+#pragma unroll
+      for (int j = 0; j < RSN; ++j) {
+        const int iy = iy0 + hy0 + RSTEP * j;
+        const bool ok = xok && (unsigned)iy < (unsigned)a.H && (j < RSN - 1 || r_last_on);
+        const int sy = min(max(iy - dy, 0), a.s1H - 1);
+        valid |= (ok ? 1u : 0u) << j;
+        xr[j] = ld16o(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
+      }
+      {
+        const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
+        const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
+        const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
+        valid |= (ok ? 1u : 0u) << RSN;
+        xr[RSN] = ld16o(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
+      }
+      xvalid = valid;
+    } else {
+      const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
+      if (interior) {
+        const bf16_t* base = xsrc + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
+#pragma unroll
+        for (int j = 0; j < RSN; ++j)
+          xr[j] = ld16o(base + j * RSTEP * row_el, (unsigned)((j < RSN - 1 || r_last_on) ? xoff_r : 0) * 2u);
+        xr[RSN] = ld16o(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
+        xvalid = 0xffffffffu;
+      } else {
+        const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+        const int toff = (iy0 * a.s0W + ix0) * a.s0C;  // may be negative on the border; masked below
+        unsigned valid = 0;
+        const bool xok = (unsigned)(ix0 + hx) < (unsigned)a.W;
+#pragma unroll
+        for (int j = 0; j <= RSN; ++j) {
+          bool ok;
+          int eoff;
+          if (j < RSN) {
+            ok = xok && (unsigned)(iy0 + hy0 + RSTEP * j) < (unsigned)a.H && (j < RSN - 1 || r_last_on);
+            eoff = xoff_r + j * RSTEP * row_el;
+          } else {
+            ok = e_on && (unsigned)(iy0 + ey) < (unsigned)a.H && (unsigned)(ix0 + 32 + ec) < (unsigned)a.W;
+            eoff = xoff_e;
+          }
+          valid |= (ok ? 1u : 0u) << j;
+          const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
+          xr[j] = ld16o(base, off * 2u);
+        }
+        xvalid = valid;
+      }
+    }
+    {
+      const bf16_t* wb = a.weight + (size_t)cout0 * a.Cin + wk * 32;
+      const int wstride = (WPP / CT) * a.Cout * a.Cin;  // taps per pass x one tap
+#pragma unroll
+      for (int j = 0; j < WVN; ++j) {
+        unsigned off = (unsigned)woff0;
+        if (W_RAGGED && j == WVN - 1) off = (p0 + WPP * j < WROWS) ? off : 0u;
+        wr[j] = ld16o(wb + j * wstride, off * 2u);
+      }
+    }
+    if (b_pending && ptid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
+  };
+
+  auto write_lds = [&](char* st) {
+    const bool all_ok = xvalid == 0xffffffffu;
+    if (MODE == 4 && g_pending == 1) {
+      // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: per 32 source pixels two MFMAs (K = 32 input channels),
+      // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image in the D layout they already have
+      const int iy0h = u_iy0 + (tap >> 1), ix0h = u_ix0 + (tap & 1);
+#pragma unroll
+      for (int i = 0; i < MT_PER; ++i) {
+        const int mt = mt0 + MT_STEP * i;
+        if (mt < MTU) {       // wave-uniform
+          const int sp = mt * 32 + lr, spc = min(sp, UPN - 1);
+          const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;
+          f32x16 cu = cb;
+          cu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[0], xr[2 * i], cu, 0, 0, 0);
+          cu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[1], xr[2 * i + 1], cu, 0, 0, 0);
+          const bool in_img = (unsigned)(iy0h + 2 * spy) < (unsigned)a.H && (unsigned)(ix0h + 2 * spx) < (unsigned)a.W;
+          char* dst = st + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * RP + (lh << 5);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = cu[8 * h + e];
+            vec o = E::pack(f);
+            if (!in_img) o = E::zero();
+            if (sp < UPN) *reinterpret_cast<vec*>(dst + (h << 4)) = o;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j <= RSN; ++j) {
+        if (j == RSN && !e_on) continue;
+        if (R_RAGGED && j == RSN - 1 && !r_last_on) continue;
+        vec v = xr[j];
+#ifdef UNCL_PC_TIMING
+        if ((MODE == 1 || MODE == 4) && g_pending >= 2 && !(a.pc_prio & 32)) {   // experiment: bit 5 skips the transforms
+#else
+        if ((MODE == 1 || MODE == 4) && g_pending >= 2) {
+#endif
+          float f[8];
+          E::unpack(v, f);
+          if (g_pending == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f);
+          }
+          v = E::pack(f);
+        }
+        if (!all_ok && !((xvalid >> j) & 1u)) v = E::zero();
+        const int pix = j < RSN ? pix_r0 + j * RSTEP * HW : pix_e;
+#ifdef UNCL_PC_TIMING
+        if (a.pc_prio & 16) { asm volatile("" ::"v"(v)); continue; }      // experiment: no staging writes (wrong results)
+#endif
+        *reinterpret_cast<vec*>(st + pix * RP + (ch << 4)) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WVN; ++j) {
+      if (W_RAGGED && j == WVN - 1 && p0 + WPP * j >= WROWS) continue;
+#ifdef UNCL_PC_TIMING
+      if (a.pc_prio & 16) continue;
+#endif
+      *reinterpret_cast<vec*>(st + lds_w0 + j * WPP * RP) = wr[j];
+    }
+    if (b_pending && ptid < CT / 4) *reinterpret_cast<f32x4*>(sBias + bpar_pending * CT + ptid * 4) = br;
+    // name every prefetch register as consumed on every path (path-insensitive waitcnt insertion, see conv3x3_pipe.hip)
+#pragma unroll
+    for (int j = 0; j < XV; ++j) asm volatile("" ::"v"(xr[j]));
+#pragma unroll
+    for (int j = 0; j < WVN; ++j) asm volatile("" ::"v"(wr[j]));
+    asm volatile("" ::"v"(br));
+  };
+
+  TileCur pc;
+  cur_init(pc, tile0, a);
+  auto step_next = [&]() {
+    const int t_old = pc.tile;
+    const bool more = cur_next(pc, a, tile_end);
+    if (more && pc.tile != t_old) ppar ^= 1;
+    return more;
+  };
+  load_regs(pc);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  write_lds(smem);
+  bool more = step_next();
+  if (more) load_regs(pc);
+  PCT_DECL
+  pc_barrier();                         // stage 0 is staged
+  PCT(3)
+  for (int s = 0;; ++s) {
+    if (!more) {
+      pc_barrier();                     // the consumers' last chunk
+      break;
+    }
+    // chunk s + 1 (in registers since the previous iteration) into the stage the consumers left at the last barrier
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    PCT(0)
+    write_lds(smem + ((s + 1) & 1) * STAGE);
+    PCT(1)
+    more = step_next();
+    if (more) load_regs(pc);            // chunk s + 2: in flight across the barrier, lands during the next multiply phase
+    PCT(2)
+    pc_barrier();
+    PCT(3)
+  }
+  PCT_FLUSH(4)
+}
+
+template <int NT, int MPW, int MODE, int PW>
+int launch_pc(PipeArgs& a, hipStream_t s) {
+  constexpr int TH = MPW * 4, CT = NT * 32;
+  constexpr size_t lds = 2 * ((size_t)(TH + 2) * 34 * 80 + (size_t)9 * CT * 80) + 4 * 4096 + 2 * CT * 4;
+  static_assert(lds <= 163840, "one workgroup's LDS");
+  auto kern = conv3x3_pc_kernel<NT, MPW, MODE, PW>;
+  static bool attr_done = false;
+  static int n_cu = 0;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return UNCL_ERR_LAUNCH;
+    n_cu = p.multiProcessorCount;
+    attr_done = true;
+  }
+  int grid = a.total_tiles < n_cu ? a.total_tiles : n_cu;
+  a.tiles_per_wg = (a.total_tiles + grid - 1) / grid;
+  grid = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((4 + PW) * 64), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+}  // namespace
+
+#ifdef UNCL_PC_TIMING
+// measurement builds only: copy (and optionally clear) the per-phase cycle counters
+extern "C" int uncl_pc_timing_read(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pc_t), sizeof(unsigned long long) * 16) != hipSuccess) return UNCL_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pc_t), z, sizeof(z)) != hipSuccess) return UNCL_ERR_LAUNCH;
+  }
+  return UNCL_OK;
+}
+#endif
+
+int uncl_conv3x3_pc_launch(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
+  if (a.nk < 2 || a.res != nullptr || a.out1_w != nullptr || a.flat_S != 0) return UNCL_ERR_ARG;
+  static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
+  a.pc_prio = prio;
+  static const int pw = [] { const char* e = getenv("UNCL_PC_PW"); return e ? atoi(e) : 8; }();
+  if (nt == 1 && mpw == 4) {
+    if (a.pool_out != nullptr) return UNCL_ERR_ARG;
+    if (pw == 4) {
+      if (mode == 0) return launch_pc<1, 4, 0, 4>(a, s);
+      if (mode == 1) return launch_pc<1, 4, 1, 4>(a, s);
+      if (mode == 4) return launch_pc<1, 4, 4, 4>(a, s);
+    } else {
+      if (mode == 0) return launch_pc<1, 4, 0, 8>(a, s);
+      if (mode == 1) return launch_pc<1, 4, 1, 8>(a, s);
+      if (mode == 4) return launch_pc<1, 4, 4, 8>(a, s);
+    }
+    return UNCL_ERR_ARG;
+  }
+  if (nt == 2 && mpw == 2) {
+    // 64-channel tiles: the multiplying waves need 234 registers (two fragment sets of ten vectors), which leaves room for two
+    // waves per SIMD, i.e. four staging waves
+    if (mode == 0) return launch_pc<2, 2, 0, 4>(a, s);
+    if (mode == 1) return launch_pc<2, 2, 1, 4>(a, s);
+    return UNCL_ERR_ARG;
+  }
+  return UNCL_ERR_ARG;
+}

@@ -16,51 +16,11 @@
 //    and read back row-wise, so every global store instruction writes 1 KiB of contiguous NHWC bytes; the same
 //    image feeds the fused 2x2 max-pool output (unet_parts.py:212,233) and the fused 1-channel 1x1 + sigmoid
 //    (outconv, Unet_singleFrame.py:207-209).
-#include "common.h"
+#include <cstdlib>
+
+#include "conv3x3_args.h"
 
 namespace {
-
-struct PipeArgs {
-  const bf16_t* src0;
-  const bf16_t* src1;
-  const bf16_t* prev0;
-  const bf16_t* weight;
-  const float* bias;
-  const bf16_t* res;
-  const bf16_t* mask;   // backward: stored value is zeroed where mask <= 0 (ReLU of the layer that produced `mask`)
-  int accumulate;       // backward: add to what `out` already holds
-  float mask_slope;     // backward: derivative on the non-positive side (0 ReLU, 0.2 LeakyReLU)
-  bf16_t* out;
-  bf16_t* pool_out;
-  const float* out1_w;
-  const float* out1_b;
-  float* out1;
-  int H, W, Cin, Cout, pad;
-  int s0H, s0W, s0C, s1H, s1W, s1C, prev_ch;
-  float slope;  // activation as max(t,0) + slope*min(t,0): 0 relu, 0.2 leaky, 1 identity
-  int res_b0;
-  int Hout, Wout, oC;
-  int pH, pW;
-  int tiles_x, tiles_y, n_ct, total_tiles, tiles_per_wg, nk;
-  int out1_act, skip_main;
-  const float* img;     // MODE 3: fp32 one-channel image (N, imgH, imgW); x = act(conv3x3_valid(img; pre_w, pre_b))
-  const float* pre_w;   // (32,1,3,3)
-  const float* pre_b;   // (32) or NULL
-  int imgH, imgW;
-  int flat_S, flat_hw, flat_N;  // FLAT: whole samples per tile, output pixels per sample, samples in the batch
-  const bf16_t* up_w;   // MODE 4: packed [4 taps][32 cout][32 cin] weights of the 2x2 stride-2 transposed conv
-  const float* up_b;    // MODE 4: its bias (32) or NULL
-};
-
-__device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
-// wave-uniform base + 32-bit per-lane BYTE offset: lowers to global_load_dwordx4 v, v_off, s[base] (no address VGPR pair)
-__device__ __forceinline__ bf16x8 ld16o(const bf16_t* base, unsigned byte_off) {
-  // The empty asm keeps the zero-extension of the offset next to the load: hoisted out of the loop it turns the access
-  // into a 64-bit VGPR address that the compiler builds inside the destination registers, and the write-after-write
-  // hazard check then waits (vmcnt) for every load issued so far before the next one can go out.
-  asm volatile("" : "+v"(byte_off));
-  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) + byte_off);
-}
 
 // Phase timing (measurement builds only, -DUNCL_PIPE_TIMING; tools/pipe_phase_timing.py): wave 0 of every workgroup
 // accumulates s_memtime deltas per loop phase into g_pipe_t[]; the product library compiles all of this away.
@@ -79,15 +39,6 @@ __device__ __forceinline__ unsigned long long pt_now() {
 #define PT(i)
 #define PT_FLUSH()
 #endif
-
-template <int V>
-struct IntTag { static constexpr int value = V; };
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off) {
-  asm volatile("" : "+v"(byte_off));
-  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 2 concat [x2, x1], 3 first layer recomputed from the image,
 //       4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) recomputed inside the loader (32 channels, same extent as the skip)
@@ -874,6 +825,13 @@ int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
 
 }  // namespace
 
+static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 0; }();
+extern "C" int uncl_conv3x3_set_pc(int on) {
+  const int old = g_use_pc;
+  g_use_pc = on ? 1 : 0;
+  return old;
+}
+
 // Same descriptor as uncl_conv_igemm; handles bf16 3x3 with src_mode PLAIN / CONCAT_SSR / CONCAT2.
 // `pool_out` (optional) receives maxpool2x2(out) as NHWC (N, Hout/2, Wout/2, Cout).
 static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void* mask, float mask_slope, int accumulate,
@@ -935,6 +893,10 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   a.nk = d->Cin / 32;
   const bool prev = d->prev0 != nullptr && d->prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // multi-chunk layers: producer / consumer workgroups (conv3x3_pc.hip); everything it does not build falls through
+  const int pc_mode = d->src_mode == UNCL_SRC_PLAIN ? (prev ? -1 : 0)
+                      : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? 4 : -1;
+  const bool pc_ok = g_use_pc && pc_mode >= 0 && a.nk >= 2 && d->res == nullptr && d->out1_w == nullptr && !d->skip_main_store;
   if (d->Cout == 32) {
     // 8-row tiles at three workgroups per CU (50 KB LDS, 168 VGPRs) overlap the serial load / stage / store phases of the
     // single-chunk 32 -> 32 transposed layers better than 16-row tiles at two (measured: up_path.{2,3}.conv.conv1 -9 %);
@@ -949,6 +911,10 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     a.n_ct = 1;
     a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
     a.total_tiles = d->N * a.tiles_x * a.tiles_y;
+    if (pc_ok && pool_out == nullptr) {
+      const int rc = uncl_conv3x3_pc_launch(a, 1, 4, pc_mode, s);
+      if (rc != UNCL_ERR_ARG) return rc;
+    }
     return dispatch_mode<1, 4>(a, d->src_mode, prev, s);
   }
   if (d->Cout % 64 != 0) return UNCL_ERR_ARG;
@@ -972,6 +938,10 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   }
   a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
   a.total_tiles = d->N * a.tiles_x * a.tiles_y * a.n_ct;
+  if (pc_ok) {
+    const int rc = uncl_conv3x3_pc_launch(a, 2, 2, pc_mode, s);
+    if (rc != UNCL_ERR_ARG) return rc;
+  }
   return dispatch_mode<2, 2>(a, d->src_mode, prev, s);
 }
 
