@@ -404,7 +404,7 @@ def _both_structures(fn):
     old = lib.uncl_conv3x3_set_pc(0)
     try:
         ref = fn()
-        lib.uncl_conv3x3_set_pc(1)
+        lib.uncl_conv3x3_set_pc(2)
         got = fn()
     finally:
         lib.uncl_conv3x3_set_pc(old)

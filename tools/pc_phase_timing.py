@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CONS = ["MFMA phase", "epilogue", "barrier wait", "-"]
-PROD = ["vmcnt wait", "LDS staging writes", "cursor + load issue", "barrier wait"]
+PROD = ["-", "register wait + LDS staging", "cursor + load issue", "barrier wait"]
 
 
 def build():

@@ -15,8 +15,9 @@
 // in flight across it (raw s_barrier + lgkmcnt only).  Same tiles, same LDS images (80-byte padded rows), same MFMA order per
 // accumulator as conv3x3_pipe -> bit-identical results; tests/test_gpu_conv.py compares the two kernels element for element.
 //
-// LDS (one workgroup per CU): 2 stages x (halo tile + 9 taps of weights) + 4 x 4 KiB wave-private epilogue images + biases of
-// two tiles = 160 640 B (32-channel tiles, 16 x 32 pixels) / 163 456 B (64-channel tiles, 8 x 32 pixels) of 163 840.
+// LDS (one workgroup per CU): 2 stages x (halo tile + 9 taps of weights) + the biases of two tiles = 144 256 B (32-channel
+// tiles, 16 x 32 pixels) / 147 072 B (64-channel tiles, 8 x 32 pixels) of 163 840; the epilogue needs none (lane-widening
+// v_permlane32_swap instead of a transposition).
 #include <cstdlib>
 
 #include "conv3x3_args.h"
@@ -84,14 +85,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   constexpr int SLOTS = CT / 8;
   constexpr int RP = 80;                      // padded LDS row (64 bytes of channels), see conv3x3_pipe.hip
   constexpr int XBYTES = NPIX * RP, WBYTES = WROWS * RP, STAGE = XBYTES + WBYTES;
-  constexpr int EW = 4096;                    // wave-private epilogue image
-  constexpr int RG = EW / (TW * CT * 2);      // output rows per epilogue group (2 for 32-channel tiles, 1 for 64)
-  static_assert(RG >= 1 && MPW % RG == 0, "epilogue groups cover the wave's rows");
   static_assert(MODE != 4 || (NT == 1 && MPW == 4), "fused up-conv: 16 x 32 tiles of 32 channels");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sE = smem + 2 * STAGE;
-  float* const sBias = reinterpret_cast<float*>(sE + 4 * EW);   // [2 tiles][CT]
+  float* const sBias = reinterpret_cast<float*>(smem + 2 * STAGE);   // [2 tiles][CT]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -177,16 +174,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       }
     };
 
-    // epilogue addressing that does not change between tiles
-    char* const sEw = sE + wave * EW;
-    const int sw_e = (lr >> 1) & (SLOTS - 1);
-    const int ew_base = lr * (CT * 2) + (lh << 3);                    // + r*TW*CT*2 + ((slot ^ sw_e) << 4)
-    const int rd_pl = lane / SLOTS, rd_sl = lane - rd_pl * SLOTS;     // read-back pass 0: pixel / slot
-    constexpr int PX_PER_PASS = 64 / SLOTS;                           // pixels per read-back pass (16 / 8)
-    constexpr int PASSES = RG * TW / PX_PER_PASS;                     // 4
-
+    // Epilogue without an LDS round trip.  A lane holds four consecutive channels (8q + 4 lh ..) of its pixel per register
+    // quad; v_permlane32_swap between the two half-waves turns the bf16 pairs of quads (2 qp, 2 qp + 1) into EIGHT consecutive
+    // channels per lane (lower half-wave: quad 2 qp, upper: quad 2 qp + 1), i.e. one 16-byte store per lane and a wave
+    // instruction that writes 32 contiguous bytes of each of its 32 pixels.
     // ACT 0: ReLU on the rounded bf16 pair (signed 16-bit max against zero; rounding is sign-symmetric); 1: identity
     // (gradient mode); 2: max(t,0) + slope*min(t,0)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto epilogue = [&](const TileCur& c, int tpar, auto act_tag) __attribute__((always_inline)) {
       constexpr int ACT = decltype(act_tag)::value;
       const float* sBt = sBias + tpar * CT;
@@ -210,86 +205,80 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         }
         return o;
       };
+      // two quads of four channels -> this lane's eight consecutive channels (8 (2 qp + lh) ..)
+      auto widen = [&](const bf16x4& o0, const bf16x4& o1) __attribute__((always_inline)) {
+        const u32x2 d0 = __builtin_bit_cast(u32x2, o0), d1 = __builtin_bit_cast(u32x2, o1);
+        const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
+        const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
+        return __builtin_bit_cast(vec, w);
+      };
+      const int ox = x0 + lr;
+      const bool plain = a.mask == nullptr && !a.accumulate;     // wave-uniform
+      if (!a.skip_main) {
 #pragma unroll
-      for (int g = 0; g < MPW / RG; ++g) {
+        for (int m = 0; m < MPW; ++m) {
+          const int oy = y0 + m;
+          const bool in = oy < a.Hout && ox < a.Wout;
+          const size_t e0 = (((size_t)c.n * a.Hout + oy) * a.Wout + ox) * a.oC + co + 8 * lh;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+            for (int qp = 0; qp < 2; ++qp) {
+              vec v = widen(act_pack(acc[m][nt], 2 * qp, bq[nt][2 * qp]), act_pack(acc[m][nt], 2 * qp + 1, bq[nt][2 * qp + 1]));
+              const size_t e = e0 + nt * 32 + 16 * qp;
+              if (in) {
+                if (!plain) {
+                  // gradient store: ReLU mask of the producing layer and / or accumulation into an existing gradient
+                  float f[8];
+                  E::unpack(v, f);
+                  if (a.mask) {
+                    float mk[8];
+                    E::unpack(ld16(a.mask + e), mk);
 #pragma unroll
-            for (int r = 0; r < RG; ++r)
-              *reinterpret_cast<bf16x4*>(sEw + ew_base + r * (TW * CT * 2) + (((nt * 4 + q) ^ sw_e) << 4)) =
-                  act_pack(acc[g * RG + r][nt], q, bq[nt][q]);
-        asm volatile("" ::: "memory");     // the wave reads back what its other lanes wrote (DS operations of a wave are in order)
-        if (!a.skip_main) {
-          vec v[PASSES];
+                    for (int i = 0; i < 8; ++i) f[i] = mk[i] > 0.f ? f[i] : a.mask_slope * f[i];
+                  }
+                  if (a.accumulate) {
+                    float o[8];
+                    E::unpack(ld16(a.out + e), o);
 #pragma unroll
-          for (int it = 0; it < PASSES; ++it) {
-            const int pl = rd_pl + it * PX_PER_PASS;
-            v[it] = *reinterpret_cast<const vec*>(sEw + pl * (CT * 2) + ((rd_sl ^ ((pl >> 1) & (SLOTS - 1))) << 4));
-          }
-          const bool plain = a.mask == nullptr && !a.accumulate;     // wave-uniform
-#pragma unroll
-          for (int it = 0; it < PASSES; ++it) {
-            const int pl = rd_pl + it * PX_PER_PASS;
-            const int oy = y0 + g * RG + pl / TW, ox = x0 + (pl & (TW - 1));
-            if (oy < a.Hout && ox < a.Wout) {
-              const size_t e = (((size_t)c.n * a.Hout + oy) * a.Wout + ox) * a.oC + co + rd_sl * 8;
-              if (plain) {
-                *reinterpret_cast<vec*>(a.out + e) = v[it];
-              } else {
-                // gradient store: ReLU mask of the producing layer and / or accumulation into an existing gradient
-                float f[8];
-                E::unpack(v[it], f);
-                if (a.mask) {
-                  float m[8];
-                  E::unpack(ld16(a.mask + e), m);
-#pragma unroll
-                  for (int i = 0; i < 8; ++i) f[i] = m[i] > 0.f ? f[i] : a.mask_slope * f[i];
+                    for (int i = 0; i < 8; ++i) f[i] += o[i];
+                  }
+                  v = E::pack(f);
                 }
-                if (a.accumulate) {
-                  float o[8];
-                  E::unpack(ld16(a.out + e), o);
-#pragma unroll
-                  for (int i = 0; i < 8; ++i) f[i] += o[i];
-                }
-                *reinterpret_cast<vec*>(a.out + e) = E::pack(f);
+#ifdef UNCL_PC_TIMING
+                if (a.pc_prio & 64) { asm volatile("" ::"v"(v)); continue; }     // experiment: no output stores (wrong results)
+#endif
+                *reinterpret_cast<vec*>(a.out + e) = v;
               }
             }
-          }
         }
-        asm volatile("" ::: "memory");
       }
       if (NT == 2 && a.pool_out != nullptr) {
-        // MaxPool2d(2) of the wave's two rows (unet_parts.py:212,233): vertical max in registers, horizontal max between
-        // neighbouring lanes, the 16 pooled pixels transposed through the wave's LDS image like the rows above
+        // MaxPool2d(2) of the wave's two rows (unet_parts.py:212,233): vertical max in registers, horizontal max with the
+        // neighbouring pixel's lane through DPP quad_perm [1,0,3,2]; the even lanes store the 16 pooled pixels
         static_assert(NT != 2 || MPW == 2, "one pooled row per wave");
-        const int pp = lr >> 1;
+        const int gy = (c.ty * TH >> 1) + wave, gx = (x0 >> 1) + (lr >> 1);
+        const bool in = (lr & 1) == 0 && gy < a.pH && gx < a.pW;
+        const size_t e0 = (((size_t)c.n * a.pH + gy) * a.pW + gx) * a.oC + co + 8 * lh;
+        auto pooled = [&](int nt, int q) __attribute__((always_inline)) {
+          const bf16x4 r0 = act_pack(acc[0][nt], q, bq[nt][q]), r1 = act_pack(acc[MPW - 1][nt], q, bq[nt][q]);
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float mv = fmaxf((float)r0[r], (float)r1[r]);
+            const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mv), 0xB1, 0xF, 0xF, true));
+            o[r] = (bf16_t)fmaxf(mv, other);
+          }
+          return o;
+        };
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bf16x4 r0 = act_pack(acc[0][nt], q, bq[nt][q]), r1 = act_pack(acc[MPW - 1][nt], q, bq[nt][q]);
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float m = fmaxf((float)r0[r], (float)r1[r]);
-              o[r] = (bf16_t)fmaxf(m, __shfl_xor(m, 1, 64));
-            }
-            if ((lr & 1) == 0)
-              *reinterpret_cast<bf16x4*>(sEw + pp * (CT * 2) + (((nt * 4 + q) ^ ((pp >> 1) & (SLOTS - 1))) << 4) + (lh << 3)) = o;
+          for (int qp = 0; qp < 2; ++qp) {
+            const vec v = widen(pooled(nt, 2 * qp), pooled(nt, 2 * qp + 1));
+            if (in) *reinterpret_cast<vec*>(a.pool_out + e0 + nt * 32 + 16 * qp) = v;
           }
-        asm volatile("" ::: "memory");
-        const int gy = (c.ty * TH >> 1) + wave;
-#pragma unroll
-        for (int it = 0; it < (TW / 2) / PX_PER_PASS; ++it) {
-          const int pl = rd_pl + it * PX_PER_PASS;
-          const vec val = *reinterpret_cast<const vec*>(sEw + pl * (CT * 2) + ((rd_sl ^ ((pl >> 1) & (SLOTS - 1))) << 4));
-          const int gx = (x0 >> 1) + pl;
-          if (gy < a.pH && gx < a.pW)
-            *reinterpret_cast<vec*>(a.pool_out + (((size_t)c.n * a.pH + gy) * a.pW + gx) * a.oC + co + rd_sl * 8) = val;
-        }
-        asm volatile("" ::: "memory");
       }
     };
 
@@ -357,12 +346,19 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   const int lds_w0 = XBYTES + p0 * RP + (ch << 4);
   const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;
 
-  vec xr[XV];
-  vec wr[WVN];
-  f32x4 br = {0.f, 0.f, 0.f, 0.f};
-  unsigned xvalid = 0;
-  int g_pending = 0, bpar_pending = 0;
-  bool b_pending = false;
+  // Register sets.  A chunk is loaded THREE steps before the multiplying waves reach it and written to LDS one step before:
+  // two chunks are always in flight in registers, so the memory latency of a load is covered by a whole step of the
+  // workgroup instead of sitting in the staging waves' serial chain (load -> wait -> write -> barrier).
+  //   plain source:   xa / xb and wa / wb alternate with the step's parity
+  //   concat source:  steps of a 32-channel slice are [x1, x2, x2^2, sqrt(x2)] (phase = step & 3, nk is a multiple of 4):
+  //                   xa holds the x1 chunk (MODE 4: the up-conv's source fragments), xb the x2 slice, which is staged three
+  //                   times (as is, squared, square-rooted) and so read from memory once; weights alternate as above
+  vec xa[XV], xb[XV];
+  vec wa[WVN], wb[WVN];
+  f32x4 bra = {0.f, 0.f, 0.f, 0.f}, brb = {0.f, 0.f, 0.f, 0.f};
+  unsigned xvalid_a = 0, xvalid_b = 0;
+  int bpar_a = 0, bpar_b = 0;
+  bool bp_a = false, bp_b = false;
   int u_iy0 = 0, u_ix0 = 0;
   int ppar = 0;                 // parity of the tile the producers are loading
 
@@ -385,28 +381,32 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     for (int i = 0; i < 16; ++i) cb[i] = a.up_b ? a.up_b[16 * lh + i] : 0.f;
   }
 
-  auto load_regs = [&](const TileCur& c) {
+  // loads of the chunk the cursor points at; P = step index & 3 (compile time): which register set, and for the concat
+  // sources which member of [x1, x2, x2^2, sqrt] the chunk is
+  auto load_step = [&](const TileCur& c, auto p_tag) __attribute__((always_inline)) {
+    constexpr int P = decltype(p_tag)::value;
+    constexpr bool CAT = MODE == 1 || MODE == 4;
+    constexpr bool SET_A = CAT ? P == 0 : (P & 1) == 0;     // X registers this chunk loads into (if it loads any)
+    constexpr bool X_LOAD = !CAT || P < 2;
+    constexpr bool W_A = (P & 1) == 0;
+    vec (&xr)[XV] = SET_A ? xa : xb;
+    vec (&wr)[WVN] = W_A ? wa : wb;
     const int n = c.n, y0 = c.ty * TH, x0 = c.tx * TW, cout0 = c.ct * CT, kc = c.kc;
     int g = 0, cbase = kc * 32, wk = kc;
-    bool reuse = false;
-    if (MODE == 1 || MODE == 4) {
-      // each 32-channel slice of the skip is walked as [x1, x2, x2^2, sqrt(x2)]; the x2 registers are re-staged (squared,
-      // square-rooted) for the third and fourth chunk; `wk` = the chunk's position in the weight's K layout [x2|x1|x2^2|sqrt]
-      const int ph = kc & 3;
+    if (CAT) {
       cbase = (kc >> 2) * 32;
-      g = ph == 0 ? 1 : (ph == 1 ? 0 : ph);
-      wk = g * (a.s0C >> 5) + (kc >> 2);
-      reuse = ph >= 2;
+      g = P == 0 ? 1 : (P == 1 ? 0 : P);
+      wk = g * (a.s0C >> 5) + (kc >> 2);     // the chunk's position in the weight's K layout [x2 | x1 | x2^2 | sqrt]
     }
-    g_pending = g;
-    b_pending = kc == 0;
-    bpar_pending = ppar;
+    const bool bp = kc == 0;
+    if (W_A) { bp_a = bp; bpar_a = ppar; } else { bp_b = bp; bpar_b = ppar; }
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
     const bool same_ext = a.s1H == a.s0H && a.s1W == a.s0W;
     const bf16_t* xsrc = (MODE != 0 && g == 1) ? a.src1 : a.src0;
-    if (reuse) {
-      // xr / xvalid still hold this tile's x2 slice
-    } else if (MODE == 4 && g == 1) {
+    unsigned valid = 0xffffffffu;
+    if (!X_LOAD) {
+      // x2^2 / sqrt(x2): staged from the x2 registers
+    } else if (MODE == 4 && P == 0) {
       // B fragments of the up-conv straight from global memory: source pixel sp = 32 mt + lr of the 9 x 17 patch under the
       // 18 x 34 halo tile, channels 8 (2 ks + lh) .. +7; out-of-image source pixels are clamped (their outputs are outside the
       // image too and are staged as zeros)
@@ -423,12 +423,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         for (int ks = 0; ks < 2; ++ks)
           xr[2 * i + ks] = ld16o(ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
       }
-      xvalid = 0xffffffffu;
-    } else if (MODE != 0 && MODE != 4 && g == 1 && !same_ext) {
+    } else if (MODE == 1 && P == 0 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
       const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
       const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
-      unsigned valid = 0;
+      valid = 0;
       const int ix = ix0 + hx;
       const bool xok = (unsigned)ix < (unsigned)a.W;
       const int sx = min(max(ix - dx, 0), a.s1W - 1);
@@ -447,7 +446,6 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         valid |= (ok ? 1u : 0u) << RSN;
         xr[RSN] = ld16o(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
       }
-      xvalid = valid;
     } else {
       const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
       if (interior) {
@@ -456,11 +454,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         for (int j = 0; j < RSN; ++j)
           xr[j] = ld16o(base + j * RSTEP * row_el, (unsigned)((j < RSN - 1 || r_last_on) ? xoff_r : 0) * 2u);
         xr[RSN] = ld16o(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
-        xvalid = 0xffffffffu;
       } else {
         const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
         const int toff = (iy0 * a.s0W + ix0) * a.s0C;  // may be negative on the border; masked below
-        unsigned valid = 0;
+        valid = 0;
         const bool xok = (unsigned)(ix0 + hx) < (unsigned)a.W;
 #pragma unroll
         for (int j = 0; j <= RSN; ++j) {
@@ -477,25 +474,37 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
           xr[j] = ld16o(base, off * 2u);
         }
-        xvalid = valid;
       }
     }
+    if (X_LOAD) {
+      if (SET_A) xvalid_a = valid; else xvalid_b = valid;
+    }
     {
-      const bf16_t* wb = a.weight + (size_t)cout0 * a.Cin + wk * 32;
+      const bf16_t* wb_ = a.weight + (size_t)cout0 * a.Cin + wk * 32;
       const int wstride = (WPP / CT) * a.Cout * a.Cin;  // taps per pass x one tap
 #pragma unroll
       for (int j = 0; j < WVN; ++j) {
         unsigned off = (unsigned)woff0;
         if (W_RAGGED && j == WVN - 1) off = (p0 + WPP * j < WROWS) ? off : 0u;
-        wr[j] = ld16o(wb + j * wstride, off * 2u);
+        wr[j] = ld16o(wb_ + j * wstride, off * 2u);
       }
     }
-    if (b_pending && ptid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
+    if (bp && ptid < CT / 4 && a.bias != nullptr) {
+      const f32x4 v = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
+      if (W_A) bra = v; else brb = v;
+    }
   };
 
-  auto write_lds = [&](char* st) {
+  auto write_step = [&](char* st, auto p_tag) __attribute__((always_inline)) {
+    constexpr int P = decltype(p_tag)::value;
+    constexpr bool CAT = MODE == 1 || MODE == 4;
+    constexpr bool SET_A = CAT ? P == 0 : (P & 1) == 0;
+    constexpr bool W_A = (P & 1) == 0;
+    vec (&xr)[XV] = SET_A ? xa : xb;
+    vec (&wr)[WVN] = W_A ? wa : wb;
+    const unsigned xvalid = SET_A ? xvalid_a : xvalid_b;
     const bool all_ok = xvalid == 0xffffffffu;
-    if (MODE == 4 && g_pending == 1) {
+    if (MODE == 4 && P == 0) {
       // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: per 32 source pixels two MFMAs (K = 32 input channels),
       // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image in the D layout they already have
       const int iy0h = u_iy0 + (tap >> 1), ix0h = u_ix0 + (tap & 1);
@@ -527,14 +536,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         if (j == RSN && !e_on) continue;
         if (R_RAGGED && j == RSN - 1 && !r_last_on) continue;
         vec v = xr[j];
-#ifdef UNCL_PC_TIMING
-        if ((MODE == 1 || MODE == 4) && g_pending >= 2 && !(a.pc_prio & 32)) {   // experiment: bit 5 skips the transforms
-#else
-        if ((MODE == 1 || MODE == 4) && g_pending >= 2) {
-#endif
+        if (CAT && P >= 2) {
           float f[8];
           E::unpack(v, f);
-          if (g_pending == 2) {
+          if (P == 2) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
           } else {
@@ -545,60 +550,68 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         }
         if (!all_ok && !((xvalid >> j) & 1u)) v = E::zero();
         const int pix = j < RSN ? pix_r0 + j * RSTEP * HW : pix_e;
-#ifdef UNCL_PC_TIMING
-        if (a.pc_prio & 16) { asm volatile("" ::"v"(v)); continue; }      // experiment: no staging writes (wrong results)
-#endif
         *reinterpret_cast<vec*>(st + pix * RP + (ch << 4)) = v;
       }
     }
 #pragma unroll
     for (int j = 0; j < WVN; ++j) {
       if (W_RAGGED && j == WVN - 1 && p0 + WPP * j >= WROWS) continue;
-#ifdef UNCL_PC_TIMING
-      if (a.pc_prio & 16) continue;
-#endif
       *reinterpret_cast<vec*>(st + lds_w0 + j * WPP * RP) = wr[j];
     }
-    if (b_pending && ptid < CT / 4) *reinterpret_cast<f32x4*>(sBias + bpar_pending * CT + ptid * 4) = br;
-    // name every prefetch register as consumed on every path (path-insensitive waitcnt insertion, see conv3x3_pipe.hip)
+    if ((W_A ? bp_a : bp_b) && ptid < CT / 4)
+      *reinterpret_cast<f32x4*>(sBias + (W_A ? bpar_a : bpar_b) * CT + ptid * 4) = W_A ? bra : brb;
+    // name the registers this step read as consumed on every path (path-insensitive waitcnt insertion, see conv3x3_pipe.hip)
+    if (!CAT || P < 2 || P == 3) {
 #pragma unroll
-    for (int j = 0; j < XV; ++j) asm volatile("" ::"v"(xr[j]));
+      for (int j = 0; j < XV; ++j) asm volatile("" ::"v"(xr[j]));
+    }
 #pragma unroll
     for (int j = 0; j < WVN; ++j) asm volatile("" ::"v"(wr[j]));
-    asm volatile("" ::"v"(br));
+    asm volatile("" ::"v"(W_A ? bra : brb));
   };
 
   TileCur pc;
   cur_init(pc, tile0, a);
-  auto step_next = [&]() {
-    const int t_old = pc.tile;
-    const bool more = cur_next(pc, a, tile_end);
-    if (more && pc.tile != t_old) ppar ^= 1;
-    return more;
+  const int total = (tile_end - tile0) * a.nk;     // chunks this workgroup walks
+  int loaded = 0;                                  // chunks handed to load_step so far; the cursor points at chunk `loaded`
+  auto load_next = [&](auto p_tag) __attribute__((always_inline)) {
+    if (loaded < total) {
+      load_step(pc, p_tag);
+      ++loaded;
+      const int t_old = pc.tile;
+      if (cur_next(pc, a, tile_end) && pc.tile != t_old) ppar ^= 1;
+    }
   };
-  load_regs(pc);
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  write_lds(smem);
-  bool more = step_next();
-  if (more) load_regs(pc);
+  load_next(IntTag<0>{});
+  write_step(smem, IntTag<0>{});
+  load_next(IntTag<1>{});
+  load_next(IntTag<2>{});
   PCT_DECL
   pc_barrier();                         // stage 0 is staged
   PCT(3)
-  for (int s = 0;; ++s) {
-    if (!more) {
+  // iteration s (the consumers multiply chunk s): chunk s + 1 goes from registers to the stage the consumers left at the
+  // last barrier, then the loads of chunk s + 3 are issued into the registers that just became free
+  int s = 0;
+  auto iter = [&](auto q_tag) __attribute__((always_inline)) {
+    constexpr int Q = decltype(q_tag)::value;
+    if (s + 1 >= total) {
       pc_barrier();                     // the consumers' last chunk
-      break;
+      return true;
     }
-    // chunk s + 1 (in registers since the previous iteration) into the stage the consumers left at the last barrier
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    PCT(0)
-    write_lds(smem + ((s + 1) & 1) * STAGE);
+    write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
     PCT(1)
-    more = step_next();
-    if (more) load_regs(pc);            // chunk s + 2: in flight across the barrier, lands during the next multiply phase
+    load_next(IntTag<(Q + 3) & 3>{});
     PCT(2)
     pc_barrier();
     PCT(3)
+    ++s;
+    return false;
+  };
+  for (;;) {
+    if (iter(IntTag<0>{})) break;
+    if (iter(IntTag<1>{})) break;
+    if (iter(IntTag<2>{})) break;
+    if (iter(IntTag<3>{})) break;
   }
   PCT_FLUSH(4)
 }
@@ -606,7 +619,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 template <int NT, int MPW, int MODE, int PW>
 int launch_pc(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * 4, CT = NT * 32;
-  constexpr size_t lds = 2 * ((size_t)(TH + 2) * 34 * 80 + (size_t)9 * CT * 80) + 4 * 4096 + 2 * CT * 4;
+  constexpr size_t lds = 2 * ((size_t)(TH + 2) * 34 * 80 + (size_t)9 * CT * 80) + 2 * CT * 4;
   static_assert(lds <= 163840, "one workgroup's LDS");
   auto kern = conv3x3_pc_kernel<NT, MPW, MODE, PW>;
   static bool attr_done = false;

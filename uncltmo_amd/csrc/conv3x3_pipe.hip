@@ -825,10 +825,11 @@ int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
 
 }  // namespace
 
-static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 0; }();
+// 1 (default): the layers where the producer / consumer structure measured faster (concat sources); 2: every layer it builds
+static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 1; }();
 extern "C" int uncl_conv3x3_set_pc(int on) {
   const int old = g_use_pc;
-  g_use_pc = on ? 1 : 0;
+  g_use_pc = on < 0 ? 0 : (on > 2 ? 2 : on);
   return old;
 }
 
@@ -896,7 +897,10 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   // multi-chunk layers: producer / consumer workgroups (conv3x3_pc.hip); everything it does not build falls through
   const int pc_mode = d->src_mode == UNCL_SRC_PLAIN ? (prev ? -1 : 0)
                       : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? 4 : -1;
-  const bool pc_ok = g_use_pc && pc_mode >= 0 && a.nk >= 2 && d->res == nullptr && d->out1_w == nullptr && !d->skip_main_store;
+  // measured per layer at bench size (tools/pc_phase_timing.py): the concat layers (deep K, transforms in the staging waves)
+  // gain 3 - 13 %, the plain 64-channel-tile layers (two to eight chunks per tile, pooled copy) lose 10 - 20 %
+  const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc == 2 ? 0 : 1) && a.nk >= 2 && d->res == nullptr && d->out1_w == nullptr &&
+                     !d->skip_main_store;
   if (d->Cout == 32) {
     // 8-row tiles at three workgroups per CU (50 KB LDS, 168 VGPRs) overlap the serial load / stage / store phases of the
     // single-chunk 32 -> 32 transposed layers better than 16-row tiles at two (measured: up_path.{2,3}.conv.conv1 -9 %);
