@@ -430,8 +430,9 @@ size_t uncl_frame_workspace_bytes(void);
 /* Radiance .hdr (RGBE) input (replaces imageio's FreeImage reader behind hdr_image_util.read_hdr_image,
  * utils/hdr_image_util.py:35-39).  uncl_rgbe_decode: HOST function, run-length / flat scanline decode of the bytes after
  * the resolution line into H*W*4 RGBE bytes.  uncl_rgbe_to_planes: device kernel, RGBE bytes -> (3, H/scale, W/scale) fp32
- * (value = mantissa * 2^(E-136)); scale 1, or an even factor reproducing cv2.resize(img, (W//s, H//s)) of
- * load_inference2 (utils/model_save_util.py:225-226). */
+ * (value = mantissa * 2^(E-136)); scale 1, or any factor s > 1 reproducing cv2.resize(img, (W//s, H//s)) (INTER_LINEAR) of
+ * load_inference2 (utils/model_save_util.py:225-226) for ANY H, W: source coordinate (d + 0.5) * (W / (W//s)) - 0.5 per axis,
+ * fractional weights, clamped at the borders, horizontal pass first. */
 int uncl_rgbe_decode(const uint8_t* data, size_t n, int H, int W, uint8_t* out);
 int uncl_rgbe_to_planes(const uint8_t* rgbe, float* out, int H, int W, int scale, void* stream);
 

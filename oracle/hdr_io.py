@@ -122,14 +122,29 @@ def write_hdr(rgbe, rle=True, extra_header=b"EXPOSURE=          1.0000000000000\
     return head + bytes(body)
 
 
+def _lin_coord(n_dst, n_src):
+    """cv2 INTER_LINEAR sample positions along one axis (imgproc/resize.cpp): fx = float32((d + 0.5) * scale - 0.5) with
+    scale = 1 / (n_dst / n_src) in double, s = floor(fx), weight of the right / lower neighbour fx - s, clamped to the ends."""
+    scale = 1.0 / (float(n_dst) / float(n_src))
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    w = (f - s.astype(np.float32)).astype(np.float32)
+    lo, hi = s < 0, s >= n_src - 1
+    s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+    w = np.where(lo | hi, np.float32(0), w).astype(np.float32)
+    return s, np.minimum(s + 1, n_src - 1), w
+
+
 def downscale_linear(img, s):
-    """cv2.resize(img, (W//s, H//s)) with INTER_LINEAR for an even integer s: (H, W, C) float32 -> (H//s, W//s, C)"""
+    """cv2.resize(img, (W//s, H//s)) with the default INTER_LINEAR (utils/model_save_util.py:225-226): (H, W, C) float32 ->
+    (H//s, W//s, C).  The ratio per axis is W / (W // s), not s: for sizes that are not multiples of s (the reference's own
+    sample belgium.hdr is 769 x 1025) the sample point drifts by up to a source pixel across the image."""
     H, W = img.shape[:2]
     Ho, Wo = H // s, W // s
-    y0 = np.arange(Ho) * s + s // 2 - 1
-    x0 = np.arange(Wo) * s + s // 2 - 1
-    y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
-    half = np.float32(0.5)
-    top = img[y0][:, x0] * half + img[y0][:, x1] * half
-    bot = img[y1][:, x0] * half + img[y1][:, x1] * half
-    return (top * half + bot * half).astype(np.float32)
+    y0, y1, fy = _lin_coord(Ho, H)
+    x0, x1, fx = _lin_coord(Wo, W)
+    img = img.astype(np.float32)
+    ax, ay = (np.float32(1) - fx)[None, :, None], (np.float32(1) - fy)[:, None, None]
+    fxb, fyb = fx[None, :, None], fy[:, None, None]
+    rows = img[:, x0] * ax + img[:, x1] * fxb           # horizontal pass on every source row (float32 products and sum)
+    return (rows[y0] * ay + rows[y1] * fyb).astype(np.float32)

@@ -52,6 +52,45 @@ def test_oracle_round_trip_and_downscale():
     np.testing.assert_array_equal(y[..., 0], np.array([[19.5, 23.5, 27.5], [67.5, 71.5, 75.5]], np.float32))
 
 
+def _cv2_axis_by_hand(n_src, n_dst):
+    """cv2's INTER_LINEAR taps along one axis in exact rational arithmetic (independent of oracle/hdr_io.py's float code):
+    source position (d + 1/2) * n_src / n_dst - 1/2 -> (left index, right index, weight of the right tap)."""
+    from fractions import Fraction
+    taps = []
+    for d in range(n_dst):
+        f = (Fraction(2 * d + 1, 2)) * Fraction(n_src, n_dst) - Fraction(1, 2)
+        s = f.numerator // f.denominator
+        w = f - s
+        if s < 0:
+            s, w = 0, Fraction(0)
+        if s >= n_src - 1:
+            s, w = n_src - 1, Fraction(0)
+        taps.append((s, min(s + 1, n_src - 1), w))
+    return taps
+
+
+def test_oracle_downscale_not_divisible_sizes_belgium():
+    """The reference's own sample, belgium.hdr, is 769 x 1025: cv2.resize(img, (1025 // 4, 769 // 4)) samples at
+    (d + 0.5) * 1025 / 256 - 0.5, not at 4 d + 1.5 (utils/model_save_util.py:225-226).  Expected values of the last column / row
+    and of a mid-image pixel are computed here by hand from the rational tap positions."""
+    H, W, s = 769, 1025, 4
+    xt, yt = _cv2_axis_by_hand(W, W // s), _cv2_axis_by_hand(H, H // s)
+    # the drift: last column sits at 1022.498..., i.e. between source 1022 and 1023 (the integer-scale rule said 1021 / 1022)
+    assert xt[-1][:2] == (1022, 1023) and abs(float(xt[-1][2]) - 0.498046875) < 1e-12
+    assert yt[-1][:2] == (766, 767) and abs(float(yt[-1][2]) - (191.5 * 769 / 192 - 0.5 - 766)) < 1e-9
+    assert xt[0][:2] == (1, 2) and abs(float(xt[0][2]) - 0.501953125) < 1e-12      # 0.5 * 1025 / 256 - 0.5 = 1.50195...
+    img = synthetic(H, W, 11)[..., :1]
+    y = OH.downscale_linear(img, s)
+    assert y.shape == (192, 256, 1)
+    for oy, ox in [(0, 0), (191, 255), (191, 0), (0, 255), (100, 128), (57, 200)]:
+        (x0, x1, fx), (y0, y1, fy) = xt[ox], yt[oy]
+        fx, fy = float(fx), float(fy)
+        top = float(img[y0, x0, 0]) * (1 - fx) + float(img[y0, x1, 0]) * fx
+        bot = float(img[y1, x0, 0]) * (1 - fx) + float(img[y1, x1, 0]) * fx
+        want = top * (1 - fy) + bot * fy
+        assert abs(float(y[oy, ox, 0]) - want) <= 4e-6 * abs(want) + 1e-12, (oy, ox)
+
+
 def test_host_decoder_equals_oracle_and_rejects_bad_streams():
     from uncltmo_amd import hdr_io
     for h, w, seed in [(13, 70, 2), (5, 7, 3), (3, 300, 4)]:
@@ -78,10 +117,10 @@ def test_host_decoder_equals_oracle_and_rejects_bad_streams():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scale", [1, 2, 4])
-def test_device_conversion_and_downscale(scale):
+@pytest.mark.parametrize("scale,h,w", [(1, 37, 91), (2, 37, 91), (4, 37, 91), (4, 769, 1025), (3, 50, 64), (4, 64, 128)])
+def test_device_conversion_and_downscale(scale, h, w):
     from uncltmo_amd import hdr_io
-    x = synthetic(37, 91, 6)
+    x = synthetic(h, w, 6)
     rg = OH.float_to_rgbe(x)
     buf = OH.write_hdr(rg, True)
     got = hdr_io.read_hdr(buf, scale=scale).cpu().numpy()
@@ -89,8 +128,18 @@ def test_device_conversion_and_downscale(scale):
     if scale > 1:
         want = OH.downscale_linear(want, scale)
     np.testing.assert_array_equal(got, want.transpose(2, 0, 1))
+    if (h, w, scale) == (769, 1025, 4):
+        # belgium.hdr's size: last column / row against the hand-computed taps, so that oracle and kernel cannot share a mistake
+        xt, yt = _cv2_axis_by_hand(w, w // scale), _cv2_axis_by_hand(h, h // scale)
+        src = OH.rgbe_to_float(rg).astype(np.float64)
+        for oy, ox in [(191, 255), (0, 255), (191, 0), (96, 255)]:
+            (x0, x1, fx), (y0, y1, fy) = xt[ox], yt[oy]
+            fx, fy = float(fx), float(fy)
+            top = src[y0, x0] * (1 - fx) + src[y0, x1] * fx
+            bot = src[y1, x0] * (1 - fx) + src[y1, x1] * fx
+            np.testing.assert_allclose(got[:, oy, ox], top * (1 - fy) + bot * fy, rtol=4e-6)
     with pytest.raises(ValueError):
-        hdr_io.read_hdr(buf, scale=3)
+        hdr_io.read_hdr(buf, scale=0)
 
 
 @pytest.mark.gpu

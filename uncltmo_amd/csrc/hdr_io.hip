@@ -63,29 +63,50 @@ __device__ __forceinline__ void rgbe_px(const uint8_t* q, float& r, float& g, fl
   r = (float)v.x * f; g = (float)v.y * f; b = (float)v.z * f;
 }
 
-// out: (3, Ho, Wo) fp32 planes.  scale 1: the image itself.  Even scale s: cv2.resize(img, (W//s, H//s)) with its default
-// INTER_LINEAR, whose sample point (d + 0.5) s - 0.5 lies midway between source pixels s d + s/2 - 1 and s d + s/2 on both
-// axes: horizontal pass 0.5 a + 0.5 b per row, then the same vertically (model_save_util.py:226).
+// cv2's INTER_LINEAR source coordinate for destination index d (resize.cpp: fx = (float)((d + 0.5) * scale - 0.5) with
+// scale = 1 / ((double)n_dst / n_src); s = floor(fx), fx -= s; clamped to the first / last source sample)
+__device__ __forceinline__ void lin_coord(int d, double scale, int n_src, int& s0, int& s1, float& w1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { s = 0; f = 0.f; }
+  if (s >= n_src - 1) { s = n_src - 1; f = 0.f; }
+  s0 = s; s1 = min(s + 1, n_src - 1); w1 = f;
+}
+
+// out: (3, Ho, Wo) fp32 planes.  scale 1: the image itself.  Otherwise cv2.resize(img, (W//scale, H//scale)) with its default
+// INTER_LINEAR (model_save_util.py:225-226): the per-axis ratio is W / (W // scale), NOT `scale`, so for sizes that are not
+// multiples of `scale` (belgium.hdr is 769 x 1025) the sample point drifts across the image; horizontal pass first
+// (a (1 - fx) + b fx per source row), then the same vertically, every product and sum rounded separately like cv2's float path.
 __global__ __launch_bounds__(256) void rgbe_to_planes_kernel(const uint8_t* __restrict__ rgbe, float* __restrict__ out, int H, int W,
                                                              int Ho, int Wo, int scale) {
   const size_t total = (size_t)Ho * Wo;
+  const double sc_x = 1.0 / ((double)Wo / (double)W), sc_y = 1.0 / ((double)Ho / (double)H);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int oy = (int)(i / Wo), ox = (int)(i - (size_t)oy * Wo);
     float r, g, b;
     if (scale == 1) {
       rgbe_px(rgbe + ((size_t)oy * W + ox) * 4, r, g, b);
     } else {
-      const int y0 = oy * scale + scale / 2 - 1, x0 = ox * scale + scale / 2 - 1;
+      int x0, x1, y0, y1;
+      float fx, fy;
+      lin_coord(ox, sc_x, W, x0, x1, fx);
+      lin_coord(oy, sc_y, H, y0, y1, fy);
+      const float ax = 1.f - fx, ay = 1.f - fy;
       float c[2][3];
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy) {
         float r0, g0, b0, r1, g1, b1;
-        const int yy = min(y0 + dy, H - 1);
+        const int yy = dy ? y1 : y0;
         rgbe_px(rgbe + ((size_t)yy * W + x0) * 4, r0, g0, b0);
-        rgbe_px(rgbe + ((size_t)yy * W + min(x0 + 1, W - 1)) * 4, r1, g1, b1);
-        c[dy][0] = r0 * 0.5f + r1 * 0.5f; c[dy][1] = g0 * 0.5f + g1 * 0.5f; c[dy][2] = b0 * 0.5f + b1 * 0.5f;
+        rgbe_px(rgbe + ((size_t)yy * W + x1) * 4, r1, g1, b1);
+        c[dy][0] = __fadd_rn(__fmul_rn(r0, ax), __fmul_rn(r1, fx));
+        c[dy][1] = __fadd_rn(__fmul_rn(g0, ax), __fmul_rn(g1, fx));
+        c[dy][2] = __fadd_rn(__fmul_rn(b0, ax), __fmul_rn(b1, fx));
       }
-      r = c[0][0] * 0.5f + c[1][0] * 0.5f; g = c[0][1] * 0.5f + c[1][1] * 0.5f; b = c[0][2] * 0.5f + c[1][2] * 0.5f;
+      r = __fadd_rn(__fmul_rn(c[0][0], ay), __fmul_rn(c[1][0], fy));
+      g = __fadd_rn(__fmul_rn(c[0][1], ay), __fmul_rn(c[1][1], fy));
+      b = __fadd_rn(__fmul_rn(c[0][2], ay), __fmul_rn(c[1][2], fy));
     }
     out[i] = r; out[total + i] = g; out[2 * total + i] = b;
   }
@@ -93,9 +114,9 @@ __global__ __launch_bounds__(256) void rgbe_to_planes_kernel(const uint8_t* __re
 
 }  // namespace
 
-// rgbe: device (H, W, 4) bytes; out: device (3, H/scale, W/scale) fp32; scale 1 or an even factor
+// rgbe: device (H, W, 4) bytes; out: device (3, H/scale, W/scale) fp32; scale >= 1 (H, W need not be multiples of it)
 extern "C" int uncl_rgbe_to_planes(const uint8_t* rgbe, float* out, int H, int W, int scale, void* stream) {
-  if (!rgbe || !out || H <= 0 || W <= 0 || scale < 1 || (scale > 1 && (scale & 1))) return UNCL_ERR_ARG;
+  if (!rgbe || !out || H <= 0 || W <= 0 || scale < 1) return UNCL_ERR_ARG;
   const int Ho = H / scale, Wo = W / scale;
   if (Ho <= 0 || Wo <= 0) return UNCL_ERR_ARG;
   const size_t total = (size_t)Ho * Wo;

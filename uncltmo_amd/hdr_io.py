@@ -1,7 +1,7 @@
 """Radiance .hdr (RGBE) reader for the inference entry: replaces `hdr_image_util.read_hdr_image` for '.hdr' files
 (utils/hdr_image_util.py:35-39, imageio's FreeImage plugin in the reference) and the cv2.resize of `load_inference2`
 (utils/model_save_util.py:225-226).  The header is parsed here, the run-length scanlines are decoded by the library's host
-function, and the RGBE -> fp32 conversion (with the optional integer down-scale) runs on the MI355X: the image never exists
+function, and the RGBE -> fp32 conversion (with cv2's INTER_LINEAR down-scale to (W//scale, H//scale), any H and W) runs on the MI355X: the image never exists
 as host floats."""
 import ctypes as C
 
@@ -51,8 +51,8 @@ def read_hdr(path_or_bytes, device="cuda", scale=1):
     buf = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
     rgbe = torch.from_numpy(decode_rgbe(bytes(buf))).to(device)
     H, W = rgbe.shape[0], rgbe.shape[1]
-    if scale < 1 or (scale > 1 and scale % 2):
-        raise ValueError("scale must be 1 or an even integer")
+    if scale < 1:
+        raise ValueError("scale must be >= 1")
     out = torch.empty(3, H // scale, W // scale, dtype=torch.float32, device=rgbe.device)
     _hip.check(_hip.lib().uncl_rgbe_to_planes(_hip.ptr(rgbe), out.data_ptr(), H, W, scale, _hip.stream_ptr()), "uncl_rgbe_to_planes")
     return out
