@@ -88,7 +88,9 @@ def test_oracle_downscale_not_divisible_sizes_belgium():
         top = float(img[y0, x0, 0]) * (1 - fx) + float(img[y0, x1, 0]) * fx
         bot = float(img[y1, x0, 0]) * (1 - fx) + float(img[y1, x1, 0]) * fx
         want = top * (1 - fy) + bot * fy
-        assert abs(float(y[oy, ox, 0]) - want) <= 4e-6 * abs(want) + 1e-12, (oy, ox)
+        # cv2 rounds the source coordinate to float32 (half an ulp at 766 is 3e-5 of a pixel): the taps agree to that, and a
+        # sample point off by a whole pixel (the integer-scale rule) would be an O(1) error on this noise image
+        assert abs(float(y[oy, ox, 0]) - want) <= 2e-4 * abs(want) + 1e-12, (oy, ox)
 
 
 def test_host_decoder_equals_oracle_and_rejects_bad_streams():
@@ -137,7 +139,7 @@ def test_device_conversion_and_downscale(scale, h, w):
             fx, fy = float(fx), float(fy)
             top = src[y0, x0] * (1 - fx) + src[y0, x1] * fx
             bot = src[y1, x0] * (1 - fx) + src[y1, x1] * fx
-            np.testing.assert_allclose(got[:, oy, ox], top * (1 - fy) + bot * fy, rtol=4e-6)
+            np.testing.assert_allclose(got[:, oy, ox], top * (1 - fy) + bot * fy, rtol=2e-4)
     with pytest.raises(ValueError):
         hdr_io.read_hdr(buf, scale=0)
 
