@@ -366,7 +366,9 @@ int uncl_patch_d_forward(const float* x, const float* const* w, const float* b_f
 int uncl_cgan_loss(const float* real, const float* fake, int N, float w, float* loss, float* g_real, float* g_fake,
                    int accumulate_loss, void* stream);
 /* w * mean_n CE([s(a,p), s(a,q)], 0), s(a,b) = mean_hw sum_c a b / (c + k|a-b|) (GanTrainerImg.py:410-439); pos/neg may be
- * one row shared by all samples (infoNCE2, :401-402).  E = elements per sample, hw = spatial positions. */
+ * one row shared by all samples (infoNCE2, :401-402).  E = elements per sample, hw = spatial positions.
+ * accumulate_loss: bit 0 = add to *loss instead of overwriting it; bit 1 = the LMCL form (lmcl_loss, :441-450) instead of the
+ * cross-entropy: w * mean_n (s(a,q) - s(a,p)), i.e. -log(exp(s_pos) / exp(s_neg)) with its one negative. */
 size_t uncl_nce_workspace_bytes(int N);
 int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
                   int neg_shared, float k, float c, float w, float* loss, float* g_anchor, float* g_pos, float* g_neg,

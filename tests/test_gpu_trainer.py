@@ -132,3 +132,110 @@ def test_video_step_matches_reference_golden(golden, epoch):
             continue
         got, ref = v.double().sum().item(), float(g[tag + ".G_after." + k])
         assert abs(got - ref) <= 2e-5 * (0.05 * v.numel() + 3) + 1e-6, (k, got, ref)
+
+
+# ---- the reference's own call sequence: two backward passes over one generator graph (GanTrainerImg.py:338-339, GanTrainer.py:
+# ---- 338,461: errG_d.backward(retain_graph=True), then the structural loss) must leave the same .grad as the summed pass
+def _two_pass_case(video):
+    from uncltmo_amd.unet_multi_filters import Unet, Unet_singleFrame
+    cls = Unet.UNet if video else Unet_singleFrame.UNet
+    assert cls.__name__ in ("UNetVideo", "UNet")
+    G = cls(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0,
+            compute_dtype="bf16")
+    synth.fill_state_dict(G, "g0")
+    G = G.cuda().train()
+    G.drop_path_prob = 0.0
+    n = 2
+    x = synth.smooth_hdr_frames(2 * n, salt="twopass").cuda()
+    x = x.reshape(n, 2, 1, 256, 256) if video else x[:n]
+    t1 = synth.ldr_frames(2 * n, salt="tw1").cuda().reshape(-1)
+    t2 = synth.ldr_frames(2 * n, salt="tw2").cuda().reshape(-1)
+
+    def losses():
+        out, fea = G(x)
+        o = out.reshape(-1)
+        l1 = ((o - t1[:o.numel()]) ** 2).mean() + 1e-3 * fea.float().pow(2).mean()     # "through D": output and features
+        l2 = (o - t2[:o.numel()]).abs().mean()                                          # "structural": output only
+        return l1, l2
+
+    G.zero_grad()
+    l1, l2 = losses()
+    (l1 + l2).backward()
+    ref = {k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None}
+    G.zero_grad()
+    l1, l2 = losses()
+    l1.backward(retain_graph=True)
+    l2.backward()
+    got = {k: p.grad for k, p in G.named_parameters() if p.grad is not None}
+    assert set(ref) == set(got) and len(ref) == 57          # 58 state_dict tensors, one of them the fixed relative_pos buffer
+    worst = max(((got[k] - ref[k]).double().norm() / ref[k].double().norm().clamp_min(1e-30)).item() for k in ref)
+    return worst
+
+
+@pytest.mark.parametrize("video", [False, True])
+def test_two_backward_passes_equal_the_summed_pass(video):
+    # activation gradients are rounded to bf16 per pass: g1 and g2 separately vs (g1 + g2) once
+    assert _two_pass_case(video) < 3e-2
+
+
+def test_trainer_two_pass_option_matches_summed_step():
+    """opt.two_pass_backward = 1 runs train_G exactly as the reference does; the resulting gradients equal the default's."""
+    grads = []
+    for two in (0, 1):
+        tr, G, D = make_trainer()
+        tr.two_pass_backward = two
+        hdr, pos, neg = step_inputs()
+        tr.train_D(hdr, pos, neg, 0)
+        G.zero_grad()
+        tr.optimizerG = types.SimpleNamespace(step=lambda: None)      # look at the gradients, not at the update
+        tr.train_G(hdr, hdr.clone(), pos, neg, 0)
+        grads.append({k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None})
+        assert len(grads[-1]) == 57
+    worst = max(((grads[1][k] - grads[0][k]).double().norm() / grads[0][k].double().norm().clamp_min(1e-30)).item()
+                for k in grads[0])
+    assert worst < 3e-2
+
+
+def test_adam_bias_correction_follows_each_tensors_own_step():
+    a = torch.nn.Parameter(torch.ones(64, device="cuda"))
+    b = torch.nn.Parameter(torch.ones(64, device="cuda"))
+    ra, rb = torch.nn.Parameter(a.detach().clone()), torch.nn.Parameter(b.detach().clone())
+    mine, ref = Adam([a, b], lr=1e-2, betas=(0.5, 0.999)), torch.optim.Adam([ra, rb], lr=1e-2, betas=(0.5, 0.999))
+    for step in range(4):
+        for p, r in ((a, ra), (b, rb)):
+            p.grad = r.grad = None
+        g = torch.full((64,), 0.1 * (step + 1), device="cuda")
+        a.grad, ra.grad = g.clone(), g.clone()
+        if step >= 2:                              # b gets its first gradient two steps later
+            b.grad, rb.grad = 2 * g, 2 * g
+        mine.step()
+        ref.step()
+    np.testing.assert_allclose(a.detach().cpu().numpy(), ra.detach().cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(b.detach().cpu().numpy(), rb.detach().cpu().numpy(), rtol=1e-6)
+
+
+def test_save_model_round_trip_and_lmcl(tmp_path):
+    tr, G, D = make_trainer()
+    hdr, pos, neg = step_inputs()
+    tr.train_D(hdr, pos, neg, 0)
+    tr.train_G(hdr, hdr.clone(), pos, neg, 0)
+    path = model_factory.save_model("models", 3, 7, str(tmp_path), G, tr.optimizerG, D, tr.optimizerD)
+    assert path.endswith("net_epoch3_iter7.pth")
+    tr2, G2, D2 = make_trainer()
+    assert model_factory.load_checkpoint(path, torch.device("cuda"), G2, tr2.optimizerG, D2, tr2.optimizerD) == 3
+    for (k, v), (_, v2) in zip(G.state_dict().items(), G2.state_dict().items()):
+        assert torch.equal(v, v2), k
+    st, st2 = tr.optimizerG.state_dict()["state"], tr2.optimizerG.state_dict()["state"]
+    assert st.keys() == st2.keys() and all(torch.equal(st[i]["exp_avg"], st2[i]["exp_avg"]) for i in st)
+    # LMCL form of nce (GanTrainerImg.py:434-450) against the formula on the similarities
+    g = torch.Generator().manual_seed(5)
+    a_, p_, q_ = (torch.rand(4, 2, 1, 1, generator=g).cuda().requires_grad_(True) for _ in range(3))
+    loss = tr.nce(a_, [p_], [q_], "LMCL", 1, 1e-2)
+    sim = lambda u, v: ((u * v) / (1e-2 + (u - v).abs())).sum(1).mean(dim=[-1, -2]).unsqueeze(1)
+    ref = tr.lmcl_loss([sim(a_, p_), sim(a_, q_)])
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    ga = torch.autograd.grad(loss, a_, retain_graph=True)[0]
+    gr = torch.autograd.grad(ref, a_)[0]
+    np.testing.assert_allclose(ga.cpu().numpy(), gr.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    with pytest.raises(TypeError):
+        tr.nce(a_, [p_], [q_], "other", 1, 1e-2)

@@ -161,7 +161,8 @@ class _VideoGeneratorFn(torch.autograd.Function):
             gs.run(xf, out, up, ws, ds, go, gup, accumulate=(t != T - 1), prev_ws=frames[t - 1][3] if t > 0 else None,
                    carry_in=carry_in, carry_out=carry_out)
         grads = gs.unpack()
-        ctx.frames = None
+        # the saved activations stay with the graph node: the reference calls backward twice on it
+        # (errG_d.backward(retain_graph=True), then the structural loss; GanTrainer.py:338,461)
         return (None, None) + tuple(grads.get(k) for k in ctx.pnames)
 
 

@@ -4,6 +4,9 @@
 //
 // Tiles are processed in chunks sized so that a layer's output is still resident in the 256 MiB Infinity
 // Cache when the next layer reads it; skip tensors and (optionally) all activations stay in the workspace.
+#include <map>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -603,6 +606,31 @@ extern "C" size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep
   return make_layout(keep_activations ? N : chunk, dtype).total;
 }
 
+// Side streams and fork / join events of the multi-stream forward, one set per device (a process may drive several GPUs, and
+// two host threads may call uncl_gen_forward at once: creation is under a lock; calls on ONE device from several threads
+// share the set and must be serialised by the caller, like any use of one stream).
+struct SideStreams {
+  static constexpr int MAX_SIDE = 3;
+  hipStream_t side[MAX_SIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
+};
+static std::mutex g_side_mu;
+static std::map<int, SideStreams> g_side;
+static SideStreams* side_streams_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  auto it = g_side.find(dev);
+  if (it != g_side.end()) return &it->second;
+  SideStreams ss;
+  if (hipEventCreateWithFlags(&ss.ev_fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+  for (int i = 0; i < SideStreams::MAX_SIDE; ++i)
+    if (hipStreamCreateWithFlags(&ss.side[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.ev_join[i], hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+  return &(g_side[dev] = ss);
+}
+
 extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r, void* stream) {
   if (!w || !r || !r->x || !r->out || !r->workspace || r->N <= 0) return UNCL_ERR_ARG;
   if (w->dtype != UNCL_F32 && w->dtype != UNCL_BF16) return UNCL_ERR_ARG;
@@ -618,25 +646,29 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   const int split_cfg = g_streams;
   const bool split2 = split_cfg >= 2 && chunk == r->N && r->N >= 64 && !r->keep_activations && !r->save_preact &&
                       r->prev_workspace == nullptr;
-  constexpr int MAX_SIDE = 3;
-  static hipStream_t side[MAX_SIDE] = {};
-  static hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
+  constexpr int MAX_SIDE = SideStreams::MAX_SIDE;
   hipStream_t main_s = reinterpret_cast<hipStream_t>(stream);
   // at least 32 tiles per part
   const int parts = split2 ? (r->N / 32 < split_cfg ? r->N / 32 : split_cfg) : 1;
+  SideStreams* ss = nullptr;
   if (split2) {
-    if (!ev_fork) {
-      if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return UNCL_ERR_LAUNCH;
-      for (int i = 0; i < MAX_SIDE; ++i)
-        if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess)
-          return UNCL_ERR_LAUNCH;
-    }
-    if (hipEventRecord(ev_fork, main_s) != hipSuccess) return UNCL_ERR_LAUNCH;
+    ss = side_streams_for_current_device();     // one set per device, created under a lock on first use
+    if (!ss) return UNCL_ERR_LAUNCH;
+    if (hipEventRecord(ss->ev_fork, main_s) != hipSuccess) return UNCL_ERR_LAUNCH;
     for (int i = 0; i < parts - 1; ++i)
-      if (hipStreamWaitEvent(side[i], ev_fork, 0) != hipSuccess) return UNCL_ERR_LAUNCH;
+      if (hipStreamWaitEvent(ss->side[i], ss->ev_fork, 0) != hipSuccess) return UNCL_ERR_LAUNCH;
     chunk = (r->N + parts - 1) / parts;
   }
+  // whatever happens after the fork, the caller's stream waits for the side streams before this call returns: the caller may
+  // free the workspace as soon as its own stream is done
+  auto join_sides = [&]() {
+    int rc = UNCL_OK;
+    if (!ss) return rc;
+    for (int i = 0; i < parts - 1; ++i)
+      if (hipEventRecord(ss->ev_join[i], ss->side[i]) != hipSuccess || hipStreamWaitEvent(main_s, ss->ev_join[i], 0) != hipSuccess)
+        rc = UNCL_ERR_LAUNCH;
+    return rc;
+  };
   for (int n0 = 0; n0 < r->N; n0 += chunk) {
     Ctx c;
     c.w = w;
@@ -646,7 +678,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     // the backward pass reads inc.conv.conv's output (ReLU mask, weight gradient), the video path hands its channels on
     c.fuse_in = w->dtype == UNCL_BF16 && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr;
     c.fuse_up = c.fuse_in;
-    c.s = (split2 && n0 > 0) ? side[n0 / chunk - 1] : main_s;
+    c.s = (split2 && n0 > 0) ? ss->side[n0 / chunk - 1] : main_s;
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
     Layout Lc = L;
@@ -655,7 +687,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.L = Lc;
     c.ws = reinterpret_cast<char*>(r->workspace);
     c.prev = reinterpret_cast<const char*>(r->prev_workspace);
-    if (c.prev && !r->keep_activations) return UNCL_ERR_ARG;
+    if (c.prev && !r->keep_activations) { (void)join_sides(); return UNCL_ERR_ARG; }
     void* up = r->up_x ? reinterpret_cast<char*>(r->up_x) + (size_t)n0 * 256 * 256 * 32 * es : nullptr;
     // split mode: the halves run everything up to the third decoder stage; the last stage (a quarter of the step in its two
     // largest launches, which fill the chip on their own) then runs once for the whole batch on the caller's stream
@@ -665,12 +697,10 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
                        r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr,
                        r->drop_scale ? r->drop_scale + n0 : nullptr,
                        r->drop_scale ? r->drop_scale + r->N + n0 : nullptr, tail_whole ? 1 : 0);
-    if (rc != UNCL_OK) return rc;
+    if (rc != UNCL_OK) { (void)join_sides(); return rc; }
     if (tail_whole && n0 + chunk >= r->N) {
       // join, then the last decoder stage for the whole batch on the caller's stream
-      for (int i = 0; i < parts - 1; ++i)
-        if (hipEventRecord(ev_join[i], side[i]) != hipSuccess || hipStreamWaitEvent(main_s, ev_join[i], 0) != hipSuccess)
-          return UNCL_ERR_LAUNCH;
+      if (join_sides() != UNCL_OK) return UNCL_ERR_LAUNCH;
       Ctx cw = c;
       cw.n = r->N; cw.L = L; cw.s = main_s;
       return run_chunk(cw, r->x, r->out, r->up_x, nullptr, nullptr, nullptr, 2);

@@ -66,6 +66,7 @@ __device__ __forceinline__ void rgbe_px(const uint8_t* q, float& r, float& g, fl
 // cv2's INTER_LINEAR source coordinate for destination index d (resize.cpp: fx = (float)((d + 0.5) * scale - 0.5) with
 // scale = 1 / ((double)n_dst / n_src); s = floor(fx), fx -= s; clamped to the first / last source sample)
 __device__ __forceinline__ void lin_coord(int d, double scale, int n_src, int& s0, int& s1, float& w1) {
+#pragma clang fp contract(off)
   float f = (float)(((double)d + 0.5) * scale - 0.5);
   int s = (int)floorf(f);
   f -= (float)s;
@@ -80,6 +81,7 @@ __device__ __forceinline__ void lin_coord(int d, double scale, int n_src, int& s
 // (a (1 - fx) + b fx per source row), then the same vertically, every product and sum rounded separately like cv2's float path.
 __global__ __launch_bounds__(256) void rgbe_to_planes_kernel(const uint8_t* __restrict__ rgbe, float* __restrict__ out, int H, int W,
                                                              int Ho, int Wo, int scale) {
+#pragma clang fp contract(off)      // cv2 (and the oracle) round every product before the sum: no fused multiply-add here
   const size_t total = (size_t)Ho * Wo;
   const double sc_x = 1.0 / ((double)Wo / (double)W), sc_y = 1.0 / ((double)Ho / (double)H);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -100,13 +102,15 @@ __global__ __launch_bounds__(256) void rgbe_to_planes_kernel(const uint8_t* __re
         const int yy = dy ? y1 : y0;
         rgbe_px(rgbe + ((size_t)yy * W + x0) * 4, r0, g0, b0);
         rgbe_px(rgbe + ((size_t)yy * W + x1) * 4, r1, g1, b1);
-        c[dy][0] = __fadd_rn(__fmul_rn(r0, ax), __fmul_rn(r1, fx));
-        c[dy][1] = __fadd_rn(__fmul_rn(g0, ax), __fmul_rn(g1, fx));
-        c[dy][2] = __fadd_rn(__fmul_rn(b0, ax), __fmul_rn(b1, fx));
+        // plain operators: the contract(off) pragma governs THESE instructions (the __fmul_rn / __fadd_rn wrappers are inlined
+        // with their header's own floating-point options and fuse again)
+        c[dy][0] = r0 * ax + r1 * fx;
+        c[dy][1] = g0 * ax + g1 * fx;
+        c[dy][2] = b0 * ax + b1 * fx;
       }
-      r = __fadd_rn(__fmul_rn(c[0][0], ay), __fmul_rn(c[1][0], fy));
-      g = __fadd_rn(__fmul_rn(c[0][1], ay), __fmul_rn(c[1][1], fy));
-      b = __fadd_rn(__fmul_rn(c[0][2], ay), __fmul_rn(c[1][2], fy));
+      r = c[0][0] * ay + c[1][0] * fy;
+      g = c[0][1] * ay + c[1][1] * fy;
+      b = c[0][2] * ay + c[1][2] * fy;
     }
     out[i] = r; out[total + i] = g; out[2 * total + i] = b;
   }

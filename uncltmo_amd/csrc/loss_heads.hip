@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void nce_sim_kernel(const T* __restrict__ a, c
 
 // pass 2: finish the sums, the 2-way cross-entropy and d loss / d s_pos, d loss / d s_neg.  single block
 __global__ void nce_ce_kernel(const float* __restrict__ partial, int blocks, int N, double inv_hw, float w, float* loss,
-                              float* __restrict__ gs /* [N][2] */, int accumulate_loss) {
+                              float* __restrict__ gs /* [N][2] */, int accumulate_loss /* bit 0: add to loss, bit 1: LMCL */) {
   __shared__ double sl;
   if (threadIdx.x == 0) sl = 0.0;
   __syncthreads();
@@ -109,14 +109,21 @@ __global__ void nce_ce_kernel(const float* __restrict__ partial, int blocks, int
       sq += (double)partial[((size_t)n * blocks + b) * 2 + 1];
     }
     const float fp = (float)(sp * inv_hw), fq = (float)(sq * inv_hw);
-    const float mx = fmaxf(fp, fq);
-    const float lse = mx + logf(expf(fp - mx) + expf(fq - mx));
-    atomicAdd(&sl, (double)(lse - fp));
-    gs[2 * n] = w / (float)N * (expf(fp - lse) - 1.f);
-    gs[2 * n + 1] = w / (float)N * expf(fq - lse);
+    if (accumulate_loss & 2) {
+      // LMCL with one negative (GanTrainerImg.py:441-450): -log(exp(s_pos) / exp(s_neg)) = s_neg - s_pos
+      atomicAdd(&sl, (double)(fq - fp));
+      gs[2 * n] = -w / (float)N;
+      gs[2 * n + 1] = w / (float)N;
+    } else {
+      const float mx = fmaxf(fp, fq);
+      const float lse = mx + logf(expf(fp - mx) + expf(fq - mx));
+      atomicAdd(&sl, (double)(lse - fp));
+      gs[2 * n] = w / (float)N * (expf(fp - lse) - 1.f);
+      gs[2 * n + 1] = w / (float)N * expf(fq - lse);
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (accumulate_loss ? loss[0] : 0.f) + (float)(sl * (double)w / (double)N);
+  if (threadIdx.x == 0) loss[0] = ((accumulate_loss & 1) ? loss[0] : 0.f) + (float)(sl * (double)w / (double)N);
 }
 
 // pass 3: gradients.  One thread per element e, looping over the samples, so that a positive / negative that is

@@ -65,7 +65,7 @@ class _NceFn(torch.autograd.Function):
     (infoNCE2): they are then not separate autograd inputs and the anchor receives the complete gradient."""
 
     @staticmethod
-    def forward(ctx, anchor, pos, neg, hw, k, c, pos_shared, neg_shared, pos_row, neg_row, rows_dev=None):
+    def forward(ctx, anchor, pos, neg, hw, k, c, pos_shared, neg_shared, pos_row, neg_row, rows_dev=None, lmcl=False):
         lib = _hip.lib()
         n = anchor.shape[0]
         E = anchor.numel() // n
@@ -102,7 +102,7 @@ class _NceFn(torch.autograd.Function):
             gq = torch.empty(q.shape, dtype=torch.float32, device=dev) if need[2] else None
         P = lambda t: t.data_ptr() if t is not None else None
         _hip.check(lib.uncl_nce_loss(a.data_ptr(), p.data_ptr(), q.data_ptr(), code, n, E, hw, int(pos_shared), int(neg_shared),
-                                     float(k), float(c), 1.0, loss.data_ptr(), P(ga), P(gp), P(gq), 0, 0, ws.data_ptr(),
+                                     float(k), float(c), 1.0, loss.data_ptr(), P(ga), P(gp), P(gq), 2 if lmcl else 0, 0, ws.data_ptr(),
                                      P(rows_dev), _hip.stream_ptr()), "uncl_nce_loss")
         ctx.rows_dev = rows_dev
         ctx.g = (ga, gp, gq)
@@ -115,7 +115,7 @@ class _NceFn(torch.autograd.Function):
     def backward(ctx, g):
         if not ctx.deferred:
             out = [None if t is None else (t * g).to(dt) for t, dt in zip(ctx.g, ctx.dt)]
-            return (out[0], out[1], out[2]) + (None,) * 8
+            return (out[0], out[1], out[2]) + (None,) * 9
         lib = _hip.lib()
         a, p, q, ws, perm = ctx.saved
         code, n, E, hw, ps, qs, k, c, pos_row, neg_row = ctx.args
@@ -132,7 +132,7 @@ class _NceFn(torch.autograd.Function):
                    "uncl_nce_backward")
         if perm is not None:
             ga, gp, gq = [None if t is None else t.permute(*perm) for t in (ga, gp, gq)]
-        return (ga, gp, gq) + (None,) * 8
+        return (ga, gp, gq) + (None,) * 9
 
 
 def nce_rows(anchor, rows, k, c, hw=None):
@@ -145,7 +145,7 @@ def nce_rows(anchor, rows, k, c, hw=None):
     return _NceFn.apply(anchor, dummy, dummy, hw, k, c, True, True, -1, -1, rows)
 
 
-def nce(anchor, positive, negative, k, c, hw=None):
+def nce(anchor, positive, negative, k, c, hw=None, form="InfoNCE"):
     """2-way InfoNCE with s(a,b) = mean_hw sum_c a b / (c + k|a-b|).  Tensors are (N,C,H,W)-shaped (any memory layout
     shared by the three); `positive` / `negative` may have a leading dim of 1 (one row shared by all samples), and may be
     rows of `anchor` itself (infoNCE2, GanTrainerImg.py:398-402): the anchor then gets their gradient as well."""
@@ -162,7 +162,7 @@ def nce(anchor, positive, negative, k, c, hw=None):
     # a row of the anchor is passed as a detached tensor: its gradient is folded into the anchor's inside the kernel
     pos_in = positive.detach() if pos_row >= 0 else positive
     neg_in = negative.detach() if neg_row >= 0 else negative
-    return _NceFn.apply(anchor, pos_in, neg_in, hw, k, c, pos_shared, neg_shared, pos_row, neg_row)
+    return _NceFn.apply(anchor, pos_in, neg_in, hw, k, c, pos_shared, neg_shared, pos_row, neg_row, None, form == "LMCL")
 
 
 class _FrameStatsFn(torch.autograd.Function):

@@ -75,3 +75,30 @@ def load_g_model(model_params, device, net_path, compute_dtype="bf16"):
     g.to(device)
     g.eval()
     return g
+
+
+def save_model(path, epoch, epoch_iter, output_dir, netG, optimizerG, netD, optimizerD):
+    """reference: model_save_util.py:121-131 -- same file name, same five keys, so a checkpoint written here loads in the
+    reference (`load_g_model`, :177-201) and the other way round (state_dict keys / shapes are the reference's)."""
+    import os
+    path = os.path.join(output_dir, path, "net_epoch" + str(epoch) + "_iter" + str(epoch_iter) + ".pth")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"epoch": epoch,
+                "modelD_state_dict": netD.state_dict(), "modelG_state_dict": netG.state_dict(),
+                "optimizerD_state_dict": optimizerD.state_dict(), "optimizerG_state_dict": optimizerG.state_dict()}, path)
+    return path
+
+
+def load_checkpoint(net_path, device, netG, optimizerG=None, netD=None, optimizerD=None):
+    """Resume: the inverse of save_model (the reference's trainers restore the same keys, GanTrainerImg.py:484-493, where
+    the epoch counter restarts from the checkpoint's `epoch`).  Returns the stored epoch."""
+    ck = torch.load(net_path, map_location=device)
+    strip = lambda sd: {k[7:]: v for k, v in sd.items()} if sd and "module" in list(sd.keys())[0] else sd
+    netG.load_state_dict(strip(ck["modelG_state_dict"]))
+    if netD is not None and "modelD_state_dict" in ck:
+        netD.load_state_dict(strip(ck["modelD_state_dict"]))
+    if optimizerG is not None and "optimizerG_state_dict" in ck:
+        optimizerG.load_state_dict(ck["optimizerG_state_dict"])
+    if optimizerD is not None and "optimizerD_state_dict" in ck:
+        optimizerD.load_state_dict(ck["optimizerD_state_dict"])
+    return ck.get("epoch", 0)

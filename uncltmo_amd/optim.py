@@ -29,15 +29,20 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
                 st["step"] += 1
-            step = self.state[ps[0]]["step"]
-            grads = [p.grad.float().contiguous() for p in ps]
             arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-            n = (C.c_int * len(ps))(*[p.numel() for p in ps])
             b1, b2 = group["betas"]
-            _hip.check(lib.uncl_adam_step(arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
-                                          arr([self.state[p]["exp_avg_sq"] for p in ps]), n, len(ps), float(group["lr"]),
-                                          float(b1), float(b2), float(group["eps"]), int(step), _hip.stream_ptr()),
-                       "uncl_adam_step")
+            # the bias corrections depend on each tensor's OWN step count (torch.optim.Adam): tensors that got their first
+            # gradient later, or a loaded optimizer state with uneven steps, go in a launch of their own
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(int(self.state[p]["step"]), []).append(p)
+            for step, sub in sorted(by_step.items()):
+                grads = [p.grad.float().contiguous() for p in sub]
+                n = (C.c_int * len(sub))(*[p.numel() for p in sub])
+                _hip.check(lib.uncl_adam_step(arr(sub), arr(grads), arr([self.state[p]["exp_avg"] for p in sub]),
+                                              arr([self.state[p]["exp_avg_sq"] for p in sub]), n, len(sub), float(group["lr"]),
+                                              float(b1), float(b2), float(group["eps"]), int(step), _hip.stream_ptr()),
+                           "uncl_adam_step")
             # parameters changed behind autograd's back (no ._version bump): mark THESE tensors so that the module that owns
             # them re-packs its weights -- and only that module (the discriminator's step leaves the generator's packs valid)
             for p in ps:

@@ -102,13 +102,21 @@ class TiledGraph:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._keep = model._packed_weights()    # the captured launches read these buffers
+        self._pack_key = model._pack_key        # ... of THIS parameter version
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = test_big_size_image2(self.static_in, model, 0, 0, 0)
+        # the captured launches also hold raw pointers into the generator's workspace: keep those tensors alive even if a later
+        # call with a larger batch makes the model replace its cached workspace
+        self._ws_keep = [t for k, t in model._ws.items() if isinstance(k, tuple) and k[-1] == dev]
 
     def __call__(self, frames):
         if frames.shape != self.static_in.shape:
             raise ValueError("TiledGraph was captured for frames of shape %s, got %s" % (tuple(self.static_in.shape), tuple(frames.shape)))
+        self.model._packed_weights()
+        if self.model._pack_key != self._pack_key:
+            raise RuntimeError("TiledGraph: the model's parameters changed after capture (optimizer step / load_state_dict); "
+                               "the captured launches still read the old packed weights -- build a new TiledGraph")
         self.static_in.copy_(frames)
         self.graph.replay()
         return self.static_out

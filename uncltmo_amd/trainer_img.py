@@ -38,6 +38,8 @@ class GanTrainer:
         self.pre_train_mode = False
         self.manual_d_training = getattr(opt, "manual_d_training", 0)
         self.train_with_D = getattr(opt, "train_with_D", 1)
+        # 0 (default): errG_d + errG_struct go through ONE generator backward; 1: the reference's two backward calls
+        self.two_pass_backward = getattr(opt, "two_pass_backward", 0)
         self.pyramid_weight_list = opt.pyramid_weight_list
         self.struct_loss_factor = opt.ssim_loss_factor
         if opt.ssim_loss_factor:
@@ -136,10 +138,16 @@ class GanTrainer:
                 for p, r in zip(d_params, req):
                     p.requires_grad_(r)
             total = self.errG_d
+            if self.two_pass_backward:
+                # the reference's own sequence (GanTrainerImg.py:338-339 / GanTrainer.py:338): a backward pass per loss group,
+                # gradients accumulate in .grad; twice the generator-backward work of the summed form below
+                self.errG_d.backward(retain_graph=True)
+                total = None
         self.update_struct_loss(hdr_flat, _flat(hdr_original_gray_norm), fake)
         if self.struct_loss_factor:
             total = self.errG_struct if total is None else total + self.errG_struct
-        total.backward()
+        if total is not None:           # train_with_D = 0 and ssim_loss_factor = 0: nothing to optimise (the reference steps anyway)
+            total.backward()
         self.optimizerG.step()
 
     def update_g_d_loss(self, d_fake_bp, d_real_pos_bp, d_real_neg_bp, d_fea_fake, d_fea_real_pos, d_fea_real_neg, d_fea_input,
@@ -191,9 +199,19 @@ class GanTrainer:
         return L.nce_rows(fea_fake, bw, k, constant)
 
     def nce(self, fea_anchor, feas_positive, feas_negative, cl_loss_type, k, constant):
-        if cl_loss_type != "InfoNCE" or len(feas_positive) != 1 or len(feas_negative) != 1:
-            raise NotImplementedError("HIP nce covers the published InfoNCE form with one positive and one negative")
-        return L.nce(fea_anchor, feas_positive[0], feas_negative[0], k, constant)
+        """GanTrainerImg.py:410-439 with one positive and one negative (every published call site); cl_loss_type 'InfoNCE'
+        (2-way cross-entropy) or 'LMCL' (lmcl_loss, :441-450: -log(exp(s_pos) / exp(s_neg)) = s_neg - s_pos)."""
+        if cl_loss_type not in ("InfoNCE", "LMCL"):
+            raise TypeError("%s is not found in loss/adversarial.py" % cl_loss_type)        # the reference's message (:437)
+        if len(feas_positive) != 1 or len(feas_negative) != 1:
+            raise NotImplementedError("HIP nce covers one positive and one negative (all call sites of the published trainers)")
+        return L.nce(fea_anchor, feas_positive[0], feas_negative[0], k, constant, form=cl_loss_type)
+
+    def lmcl_loss(self, logits):
+        """GanTrainerImg.py:441-450 on a list of (B,1) similarity tensors, the first one positive: tiny host-side tensor
+        algebra on device tensors (the fused form is nce(..., 'LMCL'))."""
+        neg = torch.cat(logits[1:], dim=1)
+        return -torch.log(logits[0].exp() / neg.exp().sum(dim=1, keepdim=True)).mean()
 
     def update_struct_loss(self, hdr_input, hdr_input_original_gray_norm, fake):
         if self.struct_loss_factor:
