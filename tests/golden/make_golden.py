@@ -273,6 +273,46 @@ def capture_step(out, video, epochs):
         print("captured", tag, out[tag + ".errD"], out[tag + ".errG_d"], out[tag + ".errG_struct"], flush=True)
 
 
+def c4_inputs():
+    """BASELINE configs[3] at test size: ONE clip of T = 5 frames at 512 x 512 -> four spatial 256 x 256 crops (the published
+    generator only ingests 256 x 256) = the loader tensors (4, 5, 1, 256, 256) of one video step."""
+    from uncltmo_amd.frame_util import clip_to_crops
+    hdr = clip_to_crops(synth.hdr_frames(5, 512, 512, salt="c4hdr").reshape(1, 5, 1, 512, 512))
+    pos = clip_to_crops(synth.ldr_frames(5, 512, 512, salt="c4pos").reshape(1, 5, 1, 512, 512))
+    neg = clip_to_crops(synth.ldr_frames(5, 512, 512, salt="c4neg").reshape(1, 5, 1, 512, 512)) ** 2
+    return hdr, hdr.clone(), pos, neg
+
+
+def capture_step_c4(out):
+    """One reference video-trainer step (GanTrainer.py:202-338) on the C4-shaped batch, epoch regime 0.  Besides the norms
+    the fixture keeps 64 hashed elements of every gradient tensor, so that a test can check DIRECTION, not only length."""
+    tr, mod = make_trainer(True)
+    tr.netG.train()
+    tr.netD.train()
+    DropPath.forced_mask = None
+    for m in tr.netG.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    hdr, gray, pos, neg = c4_inputs()
+    tag = "vid_c4_e0"
+    tr.train_D(hdr, pos, neg, 0)
+    out[tag + ".errD"] = np.float64(tr.errD.item())
+    tr.train_G(hdr, gray, pos, neg, 0)
+    out[tag + ".errG_d"] = np.float64(tr.errG_d.item())
+    out[tag + ".errG_struct"] = np.float64(tr.errG_struct.item())
+    for k, v in tr.netG.named_parameters():
+        if v.grad is not None:
+            g = v.grad.double().reshape(-1)
+            out[tag + ".gradG." + k] = np.float64(g.norm().item())
+            n = g.numel()
+            pos_ = (synth.hash_uniform("gpos:" + k, min(64, n)) * n).astype(np.int64) % n
+            out[tag + ".gradGpos." + k] = pos_
+            out[tag + ".gradGval." + k] = g[torch.from_numpy(pos_)].numpy()
+    for k, v in tr.netG.state_dict().items():
+        out[tag + ".G_after." + k] = np.float64(v.double().sum().item())
+    print("captured", tag, out[tag + ".errD"], out[tag + ".errG_d"], out[tag + ".errG_struct"], flush=True)
+
+
 def capture_tiler(out):
     from utils import model_save_util
     torch.Tensor.cuda = lambda self, *a, **k: self          # the tiler hard-codes .cuda() (model_save_util.py:414)
@@ -373,11 +413,13 @@ def capture_tmqi(out):
 
 
 def main():
-    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "tiler", "inference", "tmqi"]
+    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler", "inference",
+                             "tmqi"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
-            "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "tiler": lambda o: capture_tiler(o),
+            "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "vid_c4": lambda o: capture_step_c4(o),
+            "tiler": lambda o: capture_tiler(o),
             "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o)}
     for name in which:
         out = {}
