@@ -31,6 +31,7 @@ extern "C" {
 
 #define UNCL_F32 0
 #define UNCL_BF16 1
+#define UNCL_F16 2   /* IEEE half: the inference forward (generator, tiler) only; same kernels as UNCL_BF16 on the f16 MFMA */
 
 #define UNCL_ACT_NONE 0
 #define UNCL_ACT_RELU 1
@@ -128,6 +129,9 @@ int uncl_conv3x3_set_pc(int on);
  * generator's channel hand-off (Unet.py:270), NULL/0 otherwise. */
 int uncl_upconv2x2(const void* x, const void* prev, int prev_ch, const void* w, const float* bias, void* out, int N,
                    int H, int W, int C, int Cout, void* stream);
+/* the same with the element type stated (UNCL_BF16 or, inference, UNCL_F16) */
+int uncl_upconv2x2_dt(const void* x, const void* prev, int prev_ch, const void* w, const float* bias, void* out, int dtype,
+                      int N, int H, int W, int C, int Cout, void* stream);
 
 /* Weight gradient of a 3x3 / 1x1 convolution (bf16 operands, fp32 accumulation, transposing LDS reads):
  * dw_packed[tap][Cout][Cin] += sum_p gy[p][co] * X[p + tap][ci].  Descriptor: ksize, pad, src_mode (PLAIN / CONCAT_SSR),

@@ -69,6 +69,22 @@ def test_generator_bf16_vs_oracle():
     assert rel_l2(up.float().cpu(), up_ref) < 5e-2
 
 
+def test_generator_fp16_vs_oracle_and_training_is_refused():
+    """UNCL_F16 (BASELINE configs[4], "tiled UNet forward fp16"): the same kernels on v_mfma_f32_32x32x16_f16.  Ten mantissa
+    bits instead of bf16's seven: the stated tolerance is 4x tighter.  fp16 is an inference dtype: asking for gradients raises."""
+    net = make_g("fp16")
+    x = golden_input()
+    with torch.no_grad():
+        y, up = net(x.cuda())
+        y_ref, up_ref = OG.unet_image_forward(cpu_sd(net), x)
+    assert up.dtype == torch.float16
+    assert rel_l2(y.cpu(), y_ref) < 7e-3
+    assert rel_l2(up.float().cpu(), up_ref) < 1.2e-2
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(x.cuda())
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_large_batch_on_several_streams_equals_one_stream(dtype):
     """uncl_gen_forward spreads an un-chunked batch of >= 64 tiles over up to four streams (contiguous parts, forked and joined

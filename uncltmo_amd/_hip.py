@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNCL_HIP_LIB points measurement tools at another build of the same ABI (same-box A/B runs); the product uses the in-tree one
 LIB_PATH = os.environ.get("UNCL_HIP_LIB") or os.path.join(_HERE, "libuncltmo_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_TANH, ACT_MSIG = 0, 1, 2, 3, 4, 5, 6
 SRC_PLAIN, SRC_MAXPOOL2, SRC_CONCAT_SSR, SRC_CONCAT2, SRC_IMAGE1, SRC_CONCAT_SSR_UP = 0, 1, 2, 3, 4, 5
 Z_NONE, Z_GROUPS, Z_UP2X2 = 0, 1, 2
@@ -99,6 +99,8 @@ SIGNATURES = {
     "uncl_conv3x3_set_pc": (C.c_int, [C.c_int]),
     "uncl_upconv2x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uncl_upconv2x2_dt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_conv_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "uncl_unpack_conv_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p]),
@@ -244,10 +246,12 @@ def ptr(t):
 def dtype_code(dt):
     if dt in ("bf16", torch.bfloat16):
         return BF16
+    if dt in ("fp16", "f16", "half", torch.float16):
+        return F16
     if dt in ("fp32", "f32", torch.float32):
         return F32
-    raise ValueError("compute dtype must be 'bf16' or 'fp32', got %r" % (dt,))
+    raise ValueError("compute dtype must be 'bf16', 'fp16' (inference) or 'fp32', got %r" % (dt,))
 
 
 def torch_dtype(code):
-    return torch.bfloat16 if code == BF16 else torch.float32
+    return torch.bfloat16 if code == BF16 else (torch.float16 if code == F16 else torch.float32)

@@ -9,6 +9,9 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -43,6 +46,7 @@ struct Elem<float> {
 template <>
 struct Elem<bf16_t> {
   typedef bf16x8 vec;
+  typedef bf16x4 vec4;
   static constexpr int EPV = 8;
   static constexpr int KC = 32;
   static __device__ __forceinline__ void unpack(const vec& v, float* f) {
@@ -62,6 +66,41 @@ struct Elem<bf16_t> {
     return v;
   }
 };
+
+// fp16 (BASELINE configs[4]: 4K inference): same 16-byte vectors, same kernels, v_mfma_f32_32x32x16_f16
+template <>
+struct Elem<f16_t> {
+  typedef f16x8 vec;
+  typedef f16x4 vec4;
+  static constexpr int EPV = 8;
+  static constexpr int KC = 32;
+  static __device__ __forceinline__ void unpack(const vec& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ vec pack(const float* f) {
+    vec v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (f16_t)f[i];
+    return v;
+  }
+  static __device__ __forceinline__ vec zero() {
+    vec v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (f16_t)0.f;
+    return v;
+  }
+};
+
+// one 32x32x16 matrix instruction on eight 16-bit elements per lane and operand, fp32 accumulators
+__device__ __forceinline__ f32x16 mfma32x16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32x16(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// 16-bit dtype code -> is it one of the two MFMA element types
+static inline bool uncl_is_h16(int dtype) { return dtype == UNCL_BF16 || dtype == UNCL_F16; }
 
 __device__ __forceinline__ float uncl_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float uncl_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }

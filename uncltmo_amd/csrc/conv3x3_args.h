@@ -37,11 +37,19 @@ struct PipeArgs {
 };
 
 // conv3x3_pc.hip: the producer / consumer kernel for the multi-chunk layers; returns UNCL_ERR_ARG when (nt, mpw, mode) is not built
-int uncl_conv3x3_pc_launch(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s);
+int uncl_conv3x3_pc_launch(PipeArgs& a, int dtype, int nt, int mpw, int mode, hipStream_t s);
 
 namespace {
 
+// the descriptor's 16-bit tensors are typed bf16_t for addressing only; the kernels read them as their own element type T
 __device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+template <typename V>
+__device__ __forceinline__ V ld16v(const bf16_t* p) { return *reinterpret_cast<const V*>(p); }
+template <typename V>
+__device__ __forceinline__ V ld16ov(const bf16_t* base, unsigned byte_off) {
+  asm volatile("" : "+v"(byte_off));     // see ld16o
+  return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 // wave-uniform base + 32-bit per-lane BYTE offset: lowers to global_load_dwordx4 v, v_off, s[base] (no address VGPR pair)
 __device__ __forceinline__ bf16x8 ld16o(const bf16_t* base, unsigned byte_off) {
   // The empty asm keeps the zero-extension of the offset next to the load: hoisted out of the loop it turns the access

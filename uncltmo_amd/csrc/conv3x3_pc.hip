@@ -72,11 +72,12 @@ __device__ __forceinline__ bool cur_next(TileCur& c, const PipeArgs& a, int tile
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) computed by the
 //       producers (32 channels, same extent as the skip)
-template <int NT, int MPW, int MODE, int PW>
+template <typename T, int NT, int MPW, int MODE, int PW>
 __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_kernel(const PipeArgs a) {
   static_assert(PW == 4 || PW == 8, "four or eight staging waves");
-  using E = Elem<bf16_t>;
-  using vec = bf16x8;
+  using E = Elem<T>;
+  using vec = typename Elem<T>::vec;
+  using vec4 = typename Elem<T>::vec4;
   constexpr int TH = MPW * 4, TW = 32;
   constexpr int HH = TH + 2, HW = TW + 2;
   constexpr int NPIX = HH * HW;
@@ -144,14 +145,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           for (int m = 0; m < MPW; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][nt], B[set][m], acc[m][nt], 0, 0, 0);
+              acc[m][nt] = mfma32x16(A[set][0][nt], B[set][m], acc[m][nt]);
 #pragma unroll
           for (int m = 0; m < MPW; ++m)
 #pragma unroll
             for (int ty = 1; ty < 3; ++ty)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][ty][nt], B[set][m + ty], acc[m][nt], 0, 0, 0);
+                acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
         } else {
 #pragma unroll
           for (int m = 0; m < MPW; ++m)
@@ -159,7 +160,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][ty][nt], B[set][m + ty], acc[m][nt], 0, 0, 0);
+                acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
         }
         if (col + 1 < 6) {
 #pragma unroll
@@ -192,21 +193,21 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[nt][q] = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 8 * q + 4 * lh);
       auto act_pack = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
-        bf16x4 o;
+        vec4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float t = v[4 * q + r] + b[r];
-          o[r] = (bf16_t)(ACT == 2 ? fmaxf(t, 0.f) + a.slope * fminf(t, 0.f) : t);
+          o[r] = (T)(ACT == 2 ? fmaxf(t, 0.f) + a.slope * fminf(t, 0.f) : t);
         }
         if (ACT == 0) {
           s16x4 si = __builtin_bit_cast(s16x4, o);
           si = __builtin_elementwise_max(si, s16x4{0, 0, 0, 0});
-          o = __builtin_bit_cast(bf16x4, si);
+          o = __builtin_bit_cast(vec4, si);
         }
         return o;
       };
       // two quads of four channels -> this lane's eight consecutive channels (8 (2 qp + lh) ..)
-      auto widen = [&](const bf16x4& o0, const bf16x4& o1) __attribute__((always_inline)) {
+      auto widen = [&](const vec4& o0, const vec4& o1) __attribute__((always_inline)) {
         const u32x2 d0 = __builtin_bit_cast(u32x2, o0), d1 = __builtin_bit_cast(u32x2, o1);
         const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
         const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
@@ -234,13 +235,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
                   E::unpack(v, f);
                   if (a.mask) {
                     float mk[8];
-                    E::unpack(ld16(a.mask + e), mk);
+                    E::unpack(ld16v<vec>(a.mask + e), mk);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) f[i] = mk[i] > 0.f ? f[i] : a.mask_slope * f[i];
                   }
                   if (a.accumulate) {
                     float o[8];
-                    E::unpack(ld16(a.out + e), o);
+                    E::unpack(ld16v<vec>(a.out + e), o);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) f[i] += o[i];
                   }
@@ -262,13 +263,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         const bool in = (lr & 1) == 0 && gy < a.pH && gx < a.pW;
         const size_t e0 = (((size_t)c.n * a.pH + gy) * a.pW + gx) * a.oC + co + 8 * lh;
         auto pooled = [&](int nt, int q) __attribute__((always_inline)) {
-          const bf16x4 r0 = act_pack(acc[0][nt], q, bq[nt][q]), r1 = act_pack(acc[MPW - 1][nt], q, bq[nt][q]);
-          bf16x4 o;
+          const vec4 r0 = act_pack(acc[0][nt], q, bq[nt][q]), r1 = act_pack(acc[MPW - 1][nt], q, bq[nt][q]);
+          vec4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float mv = fmaxf((float)r0[r], (float)r1[r]);
             const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mv), 0xB1, 0xF, 0xF, true));
-            o[r] = (bf16_t)fmaxf(mv, other);
+            o[r] = (T)fmaxf(mv, other);
           }
           return o;
         };
@@ -376,7 +377,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   if (MODE == 4) {
     const int arow = tap * 32 + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) ua[ks] = ld16(a.up_w + arow * 32 + (2 * ks + lh) * 8);
+    for (int ks = 0; ks < 2; ++ks) ua[ks] = ld16v<vec>(a.up_w + arow * 32 + (2 * ks + lh) * 8);
 #pragma unroll
     for (int i = 0; i < 16; ++i) cb[i] = a.up_b ? a.up_b[16 * lh + i] : 0.f;
   }
@@ -421,7 +422,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-          xr[2 * i + ks] = ld16o(ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
+          xr[2 * i + ks] = ld16ov<vec>(ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
       }
     } else if (MODE == 1 && P == 0 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
@@ -437,14 +438,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         const bool ok = xok && (unsigned)iy < (unsigned)a.H && (j < RSN - 1 || r_last_on);
         const int sy = min(max(iy - dy, 0), a.s1H - 1);
         valid |= (ok ? 1u : 0u) << j;
-        xr[j] = ld16o(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
+        xr[j] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
       }
       {
         const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
         const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
         valid |= (ok ? 1u : 0u) << RSN;
-        xr[RSN] = ld16o(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
+        xr[RSN] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
       }
     } else {
       const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
@@ -452,8 +453,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         const bf16_t* base = xsrc + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
 #pragma unroll
         for (int j = 0; j < RSN; ++j)
-          xr[j] = ld16o(base + j * RSTEP * row_el, (unsigned)((j < RSN - 1 || r_last_on) ? xoff_r : 0) * 2u);
-        xr[RSN] = ld16o(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
+          xr[j] = ld16ov<vec>(base + j * RSTEP * row_el, (unsigned)((j < RSN - 1 || r_last_on) ? xoff_r : 0) * 2u);
+        xr[RSN] = ld16ov<vec>(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
       } else {
         const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
         const int toff = (iy0 * a.s0W + ix0) * a.s0C;  // may be negative on the border; masked below
@@ -472,7 +473,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           }
           valid |= (ok ? 1u : 0u) << j;
           const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
-          xr[j] = ld16o(base, off * 2u);
+          xr[j] = ld16ov<vec>(base, off * 2u);
         }
       }
     }
@@ -486,7 +487,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       for (int j = 0; j < WVN; ++j) {
         unsigned off = (unsigned)woff0;
         if (W_RAGGED && j == WVN - 1) off = (p0 + WPP * j < WROWS) ? off : 0u;
-        wr[j] = ld16o(wb_ + j * wstride, off * 2u);
+        wr[j] = ld16ov<vec>(wb_ + j * wstride, off * 2u);
       }
     }
     if (bp && ptid < CT / 4 && a.bias != nullptr) {
@@ -515,8 +516,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           const int sp = mt * 32 + lr, spc = min(sp, UPN - 1);
           const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;
           f32x16 cu = cb;
-          cu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[0], xr[2 * i], cu, 0, 0, 0);
-          cu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[1], xr[2 * i + 1], cu, 0, 0, 0);
+          cu = mfma32x16(ua[0], xr[2 * i], cu);
+          cu = mfma32x16(ua[1], xr[2 * i + 1], cu);
           const bool in_img = (unsigned)(iy0h + 2 * spy) < (unsigned)a.H && (unsigned)(ix0h + 2 * spx) < (unsigned)a.W;
           char* dst = st + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * RP + (lh << 5);
 #pragma unroll
@@ -616,12 +617,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   PCT_FLUSH(4)
 }
 
-template <int NT, int MPW, int MODE, int PW>
+template <typename T, int NT, int MPW, int MODE, int PW>
 int launch_pc(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * 4, CT = NT * 32;
   constexpr size_t lds = 2 * ((size_t)(TH + 2) * 34 * 80 + (size_t)9 * CT * 80) + 2 * CT * 4;
   static_assert(lds <= 163840, "one workgroup's LDS");
-  auto kern = conv3x3_pc_kernel<NT, MPW, MODE, PW>;
+  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW>;
   static bool attr_done = false;
   static int n_cu = 0;
   if (!attr_done) {
@@ -657,7 +658,8 @@ extern "C" int uncl_pc_timing_read(unsigned long long* out16, int reset) {
 }
 #endif
 
-int uncl_conv3x3_pc_launch(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
+template <typename T>
+static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
   if (a.nk < 2 || a.res != nullptr || a.out1_w != nullptr || a.flat_S != 0) return UNCL_ERR_ARG;
   static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
   a.pc_prio = prio;
@@ -665,22 +667,27 @@ int uncl_conv3x3_pc_launch(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s
   if (nt == 1 && mpw == 4) {
     if (a.pool_out != nullptr) return UNCL_ERR_ARG;
     if (pw == 4) {
-      if (mode == 0) return launch_pc<1, 4, 0, 4>(a, s);
-      if (mode == 1) return launch_pc<1, 4, 1, 4>(a, s);
-      if (mode == 4) return launch_pc<1, 4, 4, 4>(a, s);
+      if (mode == 0) return launch_pc<T, 1, 4, 0, 4>(a, s);
+      if (mode == 1) return launch_pc<T, 1, 4, 1, 4>(a, s);
+      if (mode == 4) return launch_pc<T, 1, 4, 4, 4>(a, s);
     } else {
-      if (mode == 0) return launch_pc<1, 4, 0, 8>(a, s);
-      if (mode == 1) return launch_pc<1, 4, 1, 8>(a, s);
-      if (mode == 4) return launch_pc<1, 4, 4, 8>(a, s);
+      if (mode == 0) return launch_pc<T, 1, 4, 0, 8>(a, s);
+      if (mode == 1) return launch_pc<T, 1, 4, 1, 8>(a, s);
+      if (mode == 4) return launch_pc<T, 1, 4, 4, 8>(a, s);
     }
     return UNCL_ERR_ARG;
   }
   if (nt == 2 && mpw == 2) {
     // 64-channel tiles: the multiplying waves need 234 registers (two fragment sets of ten vectors), which leaves room for two
     // waves per SIMD, i.e. four staging waves
-    if (mode == 0) return launch_pc<2, 2, 0, 4>(a, s);
-    if (mode == 1) return launch_pc<2, 2, 1, 4>(a, s);
+    if (mode == 0) return launch_pc<T, 2, 2, 0, 4>(a, s);
+    if (mode == 1) return launch_pc<T, 2, 2, 1, 4>(a, s);
     return UNCL_ERR_ARG;
   }
   return UNCL_ERR_ARG;
+}
+
+int uncl_conv3x3_pc_launch(PipeArgs& a, int dtype, int nt, int mpw, int mode, hipStream_t s) {
+  if (dtype == UNCL_F16) return pc_launch_t<f16_t>(a, nt, mpw, mode, s);
+  return pc_launch_t<bf16_t>(a, nt, mpw, mode, s);
 }

@@ -48,11 +48,12 @@ __device__ __forceinline__ unsigned long long pt_now() {
 // the store loop sees a 32-pixel-wide image), the staging area holds their zero-padded input maps back to back, and every
 // lane reads its own window: fragment address = lane base (its pixel's top-left input slot) + tap offset.  A 10 x 10 map
 // fills 78 % of the tile instead of 20 % of a 16 x 32 rectangle.
-template <int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
+template <typename T, int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
 __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void conv3x3_pipe_kernel(const PipeArgs a) {
   static_assert(!FLAT || (MODE == 0 && !PREV), "flat tiles: plain source only");
-  using E = Elem<bf16_t>;
-  using vec = bf16x8;
+  using E = Elem<T>;
+  using vec = typename Elem<T>::vec;
+  using vec4 = typename Elem<T>::vec4;
   static_assert(WAVES == 4, "staging pattern below is written for 256 threads");
   constexpr int NTHR = WAVES * 64;
   constexpr int TH = MPW * WAVES, TW = 32;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * lh + j;
-      preA[j] = (bf16_t)(k < 9 ? a.pre_w[lr * 9 + k] : 0.f);
+      preA[j] = (T)(k < 9 ? a.pre_w[lr * 9 + k] : 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) preB[i] = a.pre_b ? a.pre_b[8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f;
@@ -233,10 +234,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const int sp = v >> 2, sl = v & 3;
         const int spy = sp / UPW, spx = sp - spy * UPW;
         const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
-        xr[k] = ld16o(ub, (unsigned)(((yy * a.s1W + xx) * 32 + sl * 8) * 2));
+        xr[k] = ld16ov<vec>(ub, (unsigned)(((yy * a.s1W + xx) * 32 + sl * 8) * 2));
       }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) xr[3 + k] = ld16o(a.up_w, (unsigned)((t4 + k * NTHR) * 16));
+      for (int k = 0; k < 2; ++k) xr[3 + k] = ld16ov<vec>(a.up_w, (unsigned)((t4 + k * NTHR) * 16));
       xvalid = 0xffffffffu;
     } else if (MODE != 0 && MODE != 4 && g == 1 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
@@ -252,14 +253,14 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const bool ok = xok && (unsigned)iy < (unsigned)a.H;
         const int sy = min(max(iy - dy, 0), a.s1H - 1);
         valid |= (ok ? 1u : 0u) << j;
-        xr[j] = ld16o(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
+        xr[j] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
       }
       {
         const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
         const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
         valid |= (ok ? 1u : 0u) << RS;
-        xr[RS] = ld16o(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
+        xr[RS] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
       }
       xvalid = valid;
     } else if (FLAT) {
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const int sj = flat_s[j];
         const bool ok = sj >= 0 && sj < left && (j < RS || e_on);
         valid |= (ok ? 1u : 0u) << j;
-        xr[j] = ld16o(base, ok ? flat_off[j] * 2u : 0u);
+        xr[j] = ld16ov<vec>(base, ok ? flat_off[j] * 2u : 0u);
       }
       xvalid = valid;
     } else {
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const bf16_t* base = xsrc + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
         // the stride between slots goes into the scalar base, so one offset VGPR serves all regular slots
 #pragma unroll
-        for (int j = 0; j < RS; ++j) xr[j] = ld16o(base + j * 2 * row_el, (unsigned)xoff_r * 2u);
-        xr[RS] = ld16o(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
+        for (int j = 0; j < RS; ++j) xr[j] = ld16ov<vec>(base + j * 2 * row_el, (unsigned)xoff_r * 2u);
+        xr[RS] = ld16ov<vec>(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
         xvalid = 0xffffffffu;
       } else {
         const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
@@ -308,11 +309,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
           }
           valid |= (ok ? 1u : 0u) << j;
           const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
-          xr[j] = ld16o(base, off * 2u);
+          xr[j] = ld16ov<vec>(base, off * 2u);
           if (PREV) {
             const int c = cbase + ch * 8;
             if (c < a.prev_ch) {
-              const vec p = ld16(a.prev0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase + off);
+              const vec p = ld16v<vec>(a.prev0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase + off);
 #pragma unroll
               for (int i = 0; i < 8; ++i)
                 if (c + i < a.prev_ch) xr[j][i] = p[i];
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       for (int j = 0; j < WVN; ++j) {
         unsigned off = (unsigned)woff0;
         if (W_RAGGED && j == WVN - 1) off = (p0 + 64 * j < WROWS) ? off : 0u;
-        wr[j] = ld16o(wb + j * wstride, off * 2u);
+        wr[j] = ld16ov<vec>(wb + j * wstride, off * 2u);
       }
     }
     // last on purpose: the alternative x paths above are laid out one after the other, and the hazard check of a later
@@ -374,21 +375,21 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             const int o0 = (j / 3) * PW3 + j % 3;  // tap j (lower half-wave)
             float v = pp[lh ? 2 * PW3 + 2 : o0];   // upper half-wave: tap 8 in slot 0
             if (j > 0) v = lh ? 0.f : v;
-            const bf16_t hi = (bf16_t)v;
+            const T hi = (T)v;
             Bh[j] = hi;
-            Bl[j] = (bf16_t)(v - (float)hi);
+            Bl[j] = (T)(v - (float)hi);
           }
-          f32x16 c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bh, z16, 0, 0, 0);
-          c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preA, Bl, c3, 0, 0, 0);
+          f32x16 c3 = mfma32x16(preA, Bh, z16);
+          c3 = mfma32x16(preA, Bl, c3);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            bf16x4 o;
+            vec4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float t = c3[4 * q + e] + preB[4 * q + e];
-              o[e] = (bf16_t)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+              o[e] = (T)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
             }
-            if (p < NPIX) *reinterpret_cast<bf16x4*>(sX + p * RP + (q << 4) + (lh << 3)) = o;
+            if (p < NPIX) *reinterpret_cast<vec4*>(sX + p * RP + (q << 4) + (lh << 3)) = o;
           }
         }
       }
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const vec Bu = *reinterpret_cast<const vec*>(sU + spc * 64 + (((2 * ks + lh) ^ ((spc >> 2) & 3)) << 4));
-          cu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Au[ks], Bu, cu, 0, 0, 0);
+          cu = mfma32x16(Au[ks], Bu, cu);
         }
         const bool in_img = (unsigned)(iy0h + 2 * spy) < (unsigned)a.H && (unsigned)(ix0h + 2 * spx) < (unsigned)a.W;
         char* dst = sX + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * RP + (lh << 5);
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ty][nt], Bf[ty], (ks == 0 && tx == 0 && ty == 0 && c_kc == 0) ? zero16 : acc[m][nt], 0, 0, 0);
+                acc[m][nt] = mfma32x16(A[ty][nt], Bf[ty], (ks == 0 && tx == 0 && ty == 0 && c_kc == 0) ? zero16 : acc[m][nt]);
           }
           continue;
         }
@@ -572,13 +573,13 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             for (int m = 0; m < MPW; ++m)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][nt], B[m], zero16, 0, 0, 0);
+                acc[m][nt] = mfma32x16(A[0][nt], B[m], zero16);
           } else {
 #pragma unroll
             for (int m = 0; m < MPW; ++m)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][nt], B[m], acc[m][nt], 0, 0, 0);
+                acc[m][nt] = mfma32x16(A[0][nt], B[m], acc[m][nt]);
           }
 #pragma unroll
           for (int m = 0; m < MPW; ++m)
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             for (int ty = 1; ty < 3; ++ty)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ty][nt], B[m + ty], acc[m][nt], 0, 0, 0);
+                acc[m][nt] = mfma32x16(A[ty][nt], B[m + ty], acc[m][nt]);
         } else {
 #pragma unroll
           for (int m = 0; m < MPW; ++m)
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ty][nt], B[m + ty], acc[m][nt], 0, 0, 0);
+                acc[m][nt] = mfma32x16(A[ty][nt], B[m + ty], acc[m][nt]);
         }
       }
     }
@@ -631,18 +632,18 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             const f32x4 b = *reinterpret_cast<const f32x4*>(sB + (nt * 32 + 8 * q + 4 * lh) * 4);
 #pragma unroll
             for (int m = 0; m < MPW; ++m) {
-              bf16x4 o;
+              vec4 o;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float t = acc[m][nt][4 * q + r] + b[r];
-                o[r] = (bf16_t)(ACT == 2 ? fmaxf(t, 0.f) + a.slope * fminf(t, 0.f) : t);
+                o[r] = (T)(ACT == 2 ? fmaxf(t, 0.f) + a.slope * fminf(t, 0.f) : t);
               }
               if (ACT == 0) {
                 s16x4 si = __builtin_bit_cast(s16x4, o);
                 si = __builtin_elementwise_max(si, s16x4{0, 0, 0, 0});
-                o = __builtin_bit_cast(bf16x4, si);
+                o = __builtin_bit_cast(vec4, si);
               }
-              *reinterpret_cast<bf16x4*>(sO + eo_base + m * (TW * CT * 2) + (((nt * 4 + q) ^ sw_e) << 4)) = o;
+              *reinterpret_cast<vec4*>(sO + eo_base + m * (TW * CT * 2) + (((nt * 4 + q) ^ sw_e) << 4)) = o;
             }
           }
         }
@@ -687,13 +688,13 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
                 E::unpack(VAL(it), f);
                 if (mb) {
                   float m[8];
-                  E::unpack(ld16(mb + it * row_stride), m);
+                  E::unpack(ld16v<vec>(mb + it * row_stride), m);
 #pragma unroll
                   for (int i = 0; i < 8; ++i) f[i] = m[i] > 0.f ? f[i] : a.mask_slope * f[i];
                 }
                 if (a.accumulate) {
                   float o[8];
-                  E::unpack(ld16(ob + it * row_stride), o);
+                  E::unpack(ld16v<vec>(ob + it * row_stride), o);
 #pragma unroll
                   for (int i = 0; i < 8; ++i) f[i] += o[i];
                 }
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
               if (it * ROWS_PER_IT < rows_left) {
                 float f[8], g[8];
                 E::unpack(VAL(it), f);
-                E::unpack(ld16(rb + it * row_stride), g);
+                E::unpack(ld16v<vec>(rb + it * row_stride), g);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) f[i] += g[i];
                 *reinterpret_cast<vec*>(ob + it * row_stride) = E::pack(f);
@@ -775,13 +776,13 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   PT_FLUSH()
 }
 
-template <int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
+template <typename T, int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
 int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
   constexpr size_t ximg = (size_t)(TH + 2) * 34 * 80 > (size_t)TH * 32 * NT * 32 * 2 ? (size_t)(TH + 2) * 34 * 80 : (size_t)TH * 32 * NT * 32 * 2;
   constexpr size_t lds = ximg + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
                          (MODE == 3 ? (size_t)((TH + 4) * 36 + 32) * 4 : 0);
-  auto kern = conv3x3_pipe_kernel<NT, MPW, WAVES, MODE, PREV, FLAT>;
+  auto kern = conv3x3_pipe_kernel<T, NT, MPW, WAVES, MODE, PREV, FLAT>;
   static bool attr_done = false;
   static int max_blocks = 0;
   if (!attr_done) {
@@ -808,19 +809,26 @@ int launch_pipe(PipeArgs& a, hipStream_t s) {
   return UNCL_OK;
 }
 
-template <int NT, int MPW>
+template <typename T, int NT, int MPW>
 int dispatch_mode(PipeArgs& a, int mode, bool prev, hipStream_t s) {
   if (mode == UNCL_SRC_IMAGE1) {
-    if constexpr (NT == 1 && MPW == 4) return launch_pipe<1, 4, 4, 3, false>(a, s);
+    if constexpr (NT == 1 && MPW == 4) return launch_pipe<T, 1, 4, 4, 3, false>(a, s);
     return UNCL_ERR_ARG;
   }
-  if (mode == UNCL_SRC_PLAIN) return prev ? launch_pipe<NT, MPW, 4, 0, true>(a, s) : launch_pipe<NT, MPW, 4, 0, false>(a, s);
-  if (mode == UNCL_SRC_CONCAT_SSR) return launch_pipe<NT, MPW, 4, 1, false>(a, s);
+  if (mode == UNCL_SRC_PLAIN) return prev ? launch_pipe<T, NT, MPW, 4, 0, true>(a, s) : launch_pipe<T, NT, MPW, 4, 0, false>(a, s);
+  if (mode == UNCL_SRC_CONCAT_SSR) return launch_pipe<T, NT, MPW, 4, 1, false>(a, s);
   if (mode == UNCL_SRC_CONCAT_SSR_UP) {
-    if constexpr (NT == 1 && MPW == 4) return launch_pipe<1, 4, 4, 4, false>(a, s);
+    if constexpr (NT == 1 && MPW == 4) return launch_pipe<T, 1, 4, 4, 4, false>(a, s);
     return UNCL_ERR_ARG;
   }
-  return launch_pipe<NT, MPW, 4, 2, false>(a, s);
+  return launch_pipe<T, NT, MPW, 4, 2, false>(a, s);
+}
+
+// element type of the launch: bf16 or (inference) fp16
+template <int NT, int MPW>
+int dispatch_type(PipeArgs& a, int dtype, int mode, bool prev, hipStream_t s) {
+  if (dtype == UNCL_F16) return dispatch_mode<f16_t, NT, MPW>(a, mode, prev, s);
+  return dispatch_mode<bf16_t, NT, MPW>(a, mode, prev, s);
 }
 
 }  // namespace
@@ -837,7 +845,8 @@ extern "C" int uncl_conv3x3_set_pc(int on) {
 // `pool_out` (optional) receives maxpool2x2(out) as NHWC (N, Hout/2, Wout/2, Cout).
 static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void* mask, float mask_slope, int accumulate,
                              void* stream) {
-  if (d == nullptr || d->dtype != UNCL_BF16 || d->ksize != 3) return UNCL_ERR_ARG;
+  if (d == nullptr || !uncl_is_h16(d->dtype) || d->ksize != 3) return UNCL_ERR_ARG;
+  if (d->dtype == UNCL_F16 && (mask != nullptr || accumulate)) return UNCL_ERR_ARG;    // fp16: forward only
   if (d->pad != 0 && d->pad != 2) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_MAXPOOL2 || d->src_mode < 0 || d->src_mode > UNCL_SRC_CONCAT_SSR_UP) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_IMAGE1) {
@@ -909,17 +918,17 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
       a.n_ct = 1;
       a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + 7) / 8;
       a.total_tiles = d->N * a.tiles_x * a.tiles_y;
-      return dispatch_mode<1, 2>(a, d->src_mode, prev, s);
+      return dispatch_type<1, 2>(a, d->dtype, d->src_mode, prev, s);
     }
     constexpr int TH = 16;
     a.n_ct = 1;
     a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
     a.total_tiles = d->N * a.tiles_x * a.tiles_y;
     if (pc_ok && pool_out == nullptr) {
-      const int rc = uncl_conv3x3_pc_launch(a, 1, 4, pc_mode, s);
+      const int rc = uncl_conv3x3_pc_launch(a, d->dtype, 1, 4, pc_mode, s);
       if (rc != UNCL_ERR_ARG) return rc;
     }
-    return dispatch_mode<1, 4>(a, d->src_mode, prev, s);
+    return dispatch_type<1, 4>(a, d->dtype, d->src_mode, prev, s);
   }
   if (d->Cout % 64 != 0) return UNCL_ERR_ARG;
   constexpr int TH = 8;
@@ -937,16 +946,16 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
       a.Hout = 8; a.Wout = 32;      // the store loop's view of the tile: 256 consecutive pixels
       a.tiles_x = a.tiles_y = 1;
       a.total_tiles = ((d->N + S - 1) / S) * a.n_ct;
-      return launch_pipe<2, 2, 4, 0, false, true>(a, s);
+      return d->dtype == UNCL_F16 ? launch_pipe<f16_t, 2, 2, 4, 0, false, true>(a, s) : launch_pipe<bf16_t, 2, 2, 4, 0, false, true>(a, s);
     }
   }
   a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
   a.total_tiles = d->N * a.tiles_x * a.tiles_y * a.n_ct;
   if (pc_ok) {
-    const int rc = uncl_conv3x3_pc_launch(a, 2, 2, pc_mode, s);
+    const int rc = uncl_conv3x3_pc_launch(a, d->dtype, 2, 2, pc_mode, s);
     if (rc != UNCL_ERR_ARG) return rc;
   }
-  return dispatch_mode<2, 2>(a, d->src_mode, prev, s);
+  return dispatch_type<2, 2>(a, d->dtype, d->src_mode, prev, s);
 }
 
 #ifdef UNCL_PIPE_TIMING

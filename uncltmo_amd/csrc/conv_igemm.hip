@@ -113,6 +113,10 @@ __device__ __forceinline__ f32x16 mma<bf16_t>(const bf16x8& a, const bf16x8& b, 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 template <>
+__device__ __forceinline__ f32x16 mma<f16_t>(const f16x8& a, const f16x8& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <>
 __device__ __forceinline__ f32x16 mma<float>(const f32x4& a, const f32x4& b, f32x16 c) {
   // exact fp32: four K=2 steps; lane half h supplies channel 4h+j of the 8-channel group for step j
 #pragma unroll
@@ -133,8 +137,21 @@ __device__ __forceinline__ void store4<bf16_t>(void* base, size_t off, const flo
   for (int i = 0; i < 4; ++i) o[i] = (bf16_t)v[i];
   *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(base) + off) = o;
 }
+template <>
+__device__ __forceinline__ void store4<f16_t>(void* base, size_t off, const float* v) {
+  f16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (f16_t)v[i];
+  *reinterpret_cast<f16x4*>(reinterpret_cast<f16_t*>(base) + off) = o;
+}
 template <typename T>
 __device__ __forceinline__ void load4(const void* base, size_t off, float* v);
+template <>
+__device__ __forceinline__ void load4<f16_t>(const void* base, size_t off, float* v) {
+  f16x4 t = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16_t*>(base) + off);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
+}
 template <>
 __device__ __forceinline__ void load4<float>(const void* base, size_t off, float* v) {
   f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
@@ -470,9 +487,9 @@ int conv1x1_direct(const uncl_conv_desc* d, hipStream_t s) {
 
 extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
   if (d == nullptr) return UNCL_ERR_ARG;
-  if (d->dtype != UNCL_F32 && d->dtype != UNCL_BF16) return UNCL_ERR_ARG;
+  if (d->dtype != UNCL_F32 && !uncl_is_h16(d->dtype)) return UNCL_ERR_ARG;
   if (d->ksize != 3 && d->ksize != 1) return UNCL_ERR_ARG;
-  const int KC = d->dtype == UNCL_BF16 ? 32 : 16;
+  const int KC = uncl_is_h16(d->dtype) ? 32 : 16;
   if (d->Cin <= 0 || d->Cin % KC != 0 || d->Cout <= 0 || d->Cout % 32 != 0) return UNCL_ERR_ARG;
   if (d->ksize == 3 && d->pad != 0 && d->pad != 2) return UNCL_ERR_ARG;
   if (d->src_mode < UNCL_SRC_PLAIN || d->src_mode > UNCL_SRC_CONCAT2) return UNCL_ERR_ARG;
@@ -508,7 +525,7 @@ extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
   int nt = d->Cout >= 128 ? 4 : (d->Cout == 64 ? 2 : (d->Cout % 128 == 0 ? 4 : (d->Cout % 64 == 0 ? 2 : 1)));
   // bf16 1x1 layers (the graph block: a few GFLOP on 144 nodes per sample) are launch-parallelism bound, not tile-efficiency
   // bound: 128 pixels x 64 channels per workgroup gives 4x the workgroups of the 256 x 128 tile
-  const bool small_1x1 = d->ksize == 1 && d->dtype == UNCL_BF16 && d->z_mode != UNCL_Z_UP2X2 && nt >= 2;
+  const bool small_1x1 = d->ksize == 1 && uncl_is_h16(d->dtype) && d->z_mode != UNCL_Z_UP2X2 && nt >= 2;
   if (small_1x1) nt = 2;
   const int CT = nt * 32;
   if (d->Cout % CT != 0) return UNCL_ERR_ARG;
@@ -540,7 +557,8 @@ extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
     grid = dim3(a.tiles_x, 1, a.n_ct * zcount);
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (small_1x1) return launch<bf16_t, 1, 1, 4, 2>(a, grid, s);
+  if (small_1x1) return d->dtype == UNCL_F16 ? launch<f16_t, 1, 1, 4, 2>(a, grid, s) : launch<bf16_t, 1, 1, 4, 2>(a, grid, s);
   if (d->dtype == UNCL_BF16) return dispatch<bf16_t>(a, d->ksize, nt, grid, s);
+  if (d->dtype == UNCL_F16) return dispatch<f16_t>(a, d->ksize, nt, grid, s);
   return dispatch<float>(a, d->ksize, nt, grid, s);
 }

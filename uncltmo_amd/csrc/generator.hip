@@ -45,7 +45,7 @@ struct Layout {
 };
 
 Layout make_layout(int n_alloc, int dtype) {
-  const size_t es = dtype == UNCL_BF16 ? 2 : 4;
+  const size_t es = uncl_is_h16(dtype) ? 2 : 4;
   Layout L;
   size_t o = 0;
   for (int b = 0; b < B_COUNT; ++b) {
@@ -135,7 +135,7 @@ void set_out(uncl_conv_desc& d, void* p, int b) {
 }
 
 // bf16 runs the pipelined kernel (producer-side pooling); fp32 the generic one (loader-side pooling)
-inline bool use_pipe(const Ctx& c) { return c.w->dtype == UNCL_BF16; }
+inline bool use_pipe(const Ctx& c) { return uncl_is_h16(c.w->dtype); }
 
 int run3(const Ctx& c, int wi, uncl_conv_desc& d, void* pool_out) {
   ProfScope ps(wi, c.s);
@@ -179,8 +179,8 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
     ProfScope ps(wi_up, c.s);
     const int h = kDims[x1].h == 1 ? 12 : kDims[x1].h, w = kDims[x1].h == 1 ? 12 : kDims[x1].w;
     const bool pv = prev_ch > 0 && c.prev;
-    if ((rc = uncl_upconv2x2(c.ptr(x1), pv ? c.pptr(x1) : nullptr, pv ? prev_ch : 0, c.w->w[wi_up], c.w->b[wi_up],
-                             c.ptr(upbuf), c.n, h, w, ch, ch, c.s)) != UNCL_OK)
+    if ((rc = uncl_upconv2x2_dt(c.ptr(x1), pv ? c.pptr(x1) : nullptr, pv ? prev_ch : 0, c.w->w[wi_up], c.w->b[wi_up],
+                                c.ptr(upbuf), c.w->dtype, c.n, h, w, ch, ch, c.s)) != UNCL_OK)
       return rc;
   } else {
     uncl_conv_desc d = base_desc(c, wi_up, 1, 0, ch, ch, UNCL_ACT_NONE);
@@ -633,13 +633,15 @@ static SideStreams* side_streams_for_current_device() {
 
 extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r, void* stream) {
   if (!w || !r || !r->x || !r->out || !r->workspace || r->N <= 0) return UNCL_ERR_ARG;
-  if (w->dtype != UNCL_F32 && w->dtype != UNCL_BF16) return UNCL_ERR_ARG;
+  if (w->dtype != UNCL_F32 && !uncl_is_h16(w->dtype)) return UNCL_ERR_ARG;
+  // fp16 is the inference dtype (BASELINE configs[4]): no kept activations for a backward pass, no clip recurrence
+  if (w->dtype == UNCL_F16 && (r->keep_activations || r->save_preact || r->prev_workspace != nullptr)) return UNCL_ERR_ARG;
   int chunk = r->chunk;
   if (chunk <= 0 || chunk > r->N) chunk = r->N;
   const int n_alloc = r->keep_activations ? r->N : chunk;
   Layout L = make_layout(n_alloc, w->dtype);
   if (r->workspace_bytes < L.total) return UNCL_ERR_ARG;
-  const size_t es = w->dtype == UNCL_BF16 ? 2 : 4;
+  const size_t es = uncl_is_h16(w->dtype) ? 2 : 4;
   // A large un-chunked inference batch runs as up to four contiguous parts on as many streams (the caller's and internal
   // ones, joined by events): the launches of one part fill the ramp-down of the others' persistent grids and the gaps
   // between dependent launches.  Every buffer is (N, ...), so the parts own disjoint slices of the same workspace.
@@ -676,7 +678,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.n = (r->N - n0 < chunk) ? r->N - n0 : chunk;
     c.save_preact = r->save_preact;
     // the backward pass reads inc.conv.conv's output (ReLU mask, weight gradient), the video path hands its channels on
-    c.fuse_in = w->dtype == UNCL_BF16 && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr;
+    c.fuse_in = uncl_is_h16(w->dtype) && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr;
     c.fuse_up = c.fuse_in;
     c.s = (split2 && n0 > 0) ? ss->side[n0 / chunk - 1] : main_s;
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.

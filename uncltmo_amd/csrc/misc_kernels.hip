@@ -28,6 +28,9 @@ extern "C" int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int
   if (dtype == UNCL_BF16)
     hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, src, (bf16_t*)dst, Cout, Cin, k * k,
                        transposed, flip);
+  else if (dtype == UNCL_F16)
+    hipLaunchKernelGGL(pack_weight_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, src, (f16_t*)dst, Cout, Cin, k * k,
+                       transposed, flip);
   else if (dtype == UNCL_F32)
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, Cout, Cin, k * k,
                        transposed, flip);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch 
 
 extern "C" int uncl_pack_conv_weights(const uncl_pack_item* items, int n_items, int dtype, void* stream) {
   if (n_items == 0) return UNCL_OK;
-  if (!items || n_items < 0 || (dtype != UNCL_BF16 && dtype != UNCL_F32)) return UNCL_ERR_ARG;
+  if (!items || n_items < 0 || (!uncl_is_h16(dtype) && dtype != UNCL_F32)) return UNCL_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   for (int i0 = 0; i0 < n_items; i0 += UNCL_PACK_MAX_ITEMS) {
     const int n = n_items - i0 < UNCL_PACK_MAX_ITEMS ? n_items - i0 : UNCL_PACK_MAX_ITEMS;
@@ -97,6 +100,7 @@ extern "C" int uncl_pack_conv_weights(const uncl_pack_item* items, int n_items, 
       t.it[i] = e;
     }
     if (dtype == UNCL_BF16) hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, s, t);
+    else if (dtype == UNCL_F16) hipLaunchKernelGGL(pack_weight_batch_kernel<f16_t>, dim3(96, n), dim3(256), 0, s, t);
     else hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(96, n), dim3(256), 0, s, t);
   }
   UNCL_CHECK_LAUNCH();
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(256) void conv_in_c1_kernel(const float* __restrict
     for (int c = 0; c < 8; ++c) { v0[c] = uncl_act(v0[c], act); v1[c] = uncl_act(v1[c], act); }
     T* o = out + (((size_t)n * Ho + oy) * Wo + ox) * Cout + g * 8;
     if constexpr (sizeof(T) == 2) {
-      *reinterpret_cast<bf16x8*>(o) = Elem<bf16_t>::pack(v0);
-      if (two) *reinterpret_cast<bf16x8*>(o + (size_t)Wo * Cout) = Elem<bf16_t>::pack(v1);
+      *reinterpret_cast<typename Elem<T>::vec*>(o) = Elem<T>::pack(v0);
+      if (two) *reinterpret_cast<typename Elem<T>::vec*>(o + (size_t)Wo * Cout) = Elem<T>::pack(v1);
     } else {
       *reinterpret_cast<f32x4*>(o) = f32x4{v0[0], v0[1], v0[2], v0[3]};
       *reinterpret_cast<f32x4*>(o + 4) = f32x4{v0[4], v0[5], v0[6], v0[7]};
@@ -270,6 +274,9 @@ extern "C" int uncl_conv_in_c1(const float* x, const float* w, const float* b, v
   }
   if (dtype == UNCL_BF16)
     hipLaunchKernelGGL(conv_in_c1_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, x, w, b, (bf16_t*)out, N, H, W, Cout,
+                       act);
+  else if (dtype == UNCL_F16)
+    hipLaunchKernelGGL(conv_in_c1_kernel<f16_t>, dim3(blocks), dim3(256), lds, s, x, w, b, (f16_t*)out, N, H, W, Cout,
                        act);
   else if (dtype == UNCL_F32)
     hipLaunchKernelGGL(conv_in_c1_kernel<float>, dim3(blocks), dim3(256), lds, s, x, w, b, (float*)out, N, H, W, Cout,
@@ -412,8 +419,16 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // one workgroup per CU (the sample fills the LDS): with a CU per sample to spare the rows are not split
   const int split = N * KNN_SPLIT <= 256 ? KNN_SPLIT : 1;
-  static bool attr[2] = {false, false};
-  if (dtype == UNCL_BF16) {
+  static bool attr[3] = {false, false, false};
+  if (dtype == UNCL_F16) {
+    if (!attr[2]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_kernel<f16_t>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
+      attr[2] = true;
+    }
+    hipLaunchKernelGGL(gcn_knn_kernel<f16_t>, dim3(N, split), dim3(1024), lds, s, (const f16_t*)x, relative_pos, idx, dist_out,
+                       n, k);
+  } else if (dtype == UNCL_BF16) {
     if (!attr[1]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_kernel<bf16_t>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
@@ -476,7 +491,11 @@ extern "C" int uncl_gcn_maxrel(const void* x, const int32_t* idx, void* out, int
                                void* stream) {
   if (!x || !idx || !out || N <= 0 || n <= 0 || C % 8 != 0 || k <= 0) return UNCL_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == UNCL_BF16) {
+  if (dtype == UNCL_F16) {
+    const size_t total = (size_t)N * n * (C / 8);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gcn_maxrel_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, (const f16_t*)x, idx, (f16_t*)out, N, n, C, k);
+  } else if (dtype == UNCL_BF16) {
     const size_t total = (size_t)N * n * (C / 8);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(gcn_maxrel_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, idx, (bf16_t*)out, N, n,

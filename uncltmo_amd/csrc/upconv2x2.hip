@@ -26,10 +26,11 @@ struct UpArgs {
   int n_tiles;          // ceil(M / 128)
 };
 
-template <int CIN, bool PREV>
+template <typename T, int CIN, bool PREV>
 __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
-  using E = Elem<bf16_t>;
-  using vec = bf16x8;
+  using E = Elem<T>;
+  using vec = typename Elem<T>::vec;
+  using vec4 = typename Elem<T>::vec4;
   constexpr int KS = CIN / 16;           // MFMA k-steps
   constexpr int S = CIN / 8;             // 16-byte slots per weight row
   constexpr int CT = 128;                // virtual output channels (tap-major) per workgroup
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
       for (int nt = 0; nt < 4; ++nt) {
         const int row = nt * 32 + lr;
         const vec A = *reinterpret_cast<const vec*>(sW + row * (CIN * 2) + (wswz(row, 2 * ks + lh) << 4));
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[ks], ks == 0 ? zero16 : acc[nt], 0, 0, 0);
+        acc[nt] = mfma32x16(A, B[ks], ks == 0 ? zero16 : acc[nt]);
       }
     }
     // ---- transpose through LDS: image [pixel (128)][virtual channel (128)], 16-byte slots XOR pixel
@@ -102,10 +103,10 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bf16x4 o;
+        vec4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[nt][4 * q + r] + bv[nt][4 * q + r]);
-        *reinterpret_cast<bf16x4*>(sO + pl * 256 + (((nt * 4 + q) ^ (pl & 15)) << 4) + (lh << 3)) = o;
+        for (int r = 0; r < 4; ++r) o[r] = (T)(acc[nt][4 * q + r] + bv[nt][4 * q + r]);
+        *reinterpret_cast<vec4*>(sO + pl * 256 + (((nt * 4 + q) ^ (pl & 15)) << 4) + (lh << 3)) = o;
       }
     __syncthreads();
     // ---- coalesced stores.  A run = the channels of one (pixel, tap-row) that are contiguous in the output:
@@ -143,12 +144,12 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
   }
 }
 
-template <int CIN>
+template <typename T, int CIN>
 int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
   constexpr size_t lds = (size_t)128 * CIN * 2 + 128 * 256;
   static bool attr_done[2] = {false, false};
-  auto k0 = upconv2x2_kernel<CIN, false>;
-  auto k1 = upconv2x2_kernel<CIN, true>;
+  auto k0 = upconv2x2_kernel<T, CIN, false>;
+  auto k1 = upconv2x2_kernel<T, CIN, true>;
   const void* kp = prev ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0);
   if (!attr_done[prev]) {
     if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UNCL_ERR_LAUNCH;
@@ -176,6 +177,13 @@ int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
 // prev / prev_ch: video recurrence (first prev_ch input channels come from `prev`, Unet.py:270).
 extern "C" int uncl_upconv2x2(const void* x, const void* prev, int prev_ch, const void* w, const float* bias, void* out,
                               int N, int H, int W, int C, int Cout, void* stream) {
+  return uncl_upconv2x2_dt(x, prev, prev_ch, w, bias, out, UNCL_BF16, N, H, W, C, Cout, stream);
+}
+
+// the same with the element type stated: UNCL_BF16 or UNCL_F16 (inference)
+extern "C" int uncl_upconv2x2_dt(const void* x, const void* prev, int prev_ch, const void* w, const float* bias, void* out,
+                                 int dtype, int N, int H, int W, int C, int Cout, void* stream) {
+  if (!uncl_is_h16(dtype)) return UNCL_ERR_ARG;
   if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0) return UNCL_ERR_ARG;
   if (Cout % 32 != 0 || (C != 32 && C != 64 && C != 128 && C != 256)) return UNCL_ERR_ARG;
   const long long M = (long long)N * H * W;
@@ -185,11 +193,19 @@ extern "C" int uncl_upconv2x2(const void* x, const void* prev, int prev_ch, cons
   a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.prev_ch = prev_ch; a.M = (int)M; a.n_tiles = (int)((M + 127) / 128);
   const bool pv = prev != nullptr && prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == UNCL_F16) {
+    switch (C) {
+      case 32: return launch_up<f16_t, 32>(a, pv, s);
+      case 64: return launch_up<f16_t, 64>(a, pv, s);
+      case 128: return launch_up<f16_t, 128>(a, pv, s);
+      default: return launch_up<f16_t, 256>(a, pv, s);
+    }
+  }
   switch (C) {
-    case 32: return launch_up<32>(a, pv, s);
-    case 64: return launch_up<64>(a, pv, s);
-    case 128: return launch_up<128>(a, pv, s);
-    default: return launch_up<256>(a, pv, s);
+    case 32: return launch_up<bf16_t, 32>(a, pv, s);
+    case 64: return launch_up<bf16_t, 64>(a, pv, s);
+    case 128: return launch_up<bf16_t, 128>(a, pv, s);
+    default: return launch_up<bf16_t, 256>(a, pv, s);
   }
 }
 
