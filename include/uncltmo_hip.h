@@ -299,6 +299,12 @@ typedef struct uncl_gen_bwd {
 } uncl_gen_bwd;
 size_t uncl_gen_backward_workspace_bytes(int N);
 size_t uncl_gen_carry_bytes(int N);
+/* The backward pass runs in the element type of `wts`: UNCL_BF16 (training: matrix-core kernels, fp32 atomics for the weight
+ * gradients) or UNCL_F32, the PARITY mode -- activations, gradients, `wd` and `g_upx` in fp32, every weight gradient summed in a
+ * fixed order by plain fp32 kernels (csrc/bwd_f32.hip; deterministic, an order of magnitude slower), so that a whole trainer step
+ * can be checked against the CPU oracle at fp32 tolerances.  The two sizes above are the bf16 ones; `_dt` state the type. */
+size_t uncl_gen_backward_workspace_bytes_dt(int N, int dtype);
+size_t uncl_gen_carry_bytes_dt(int N, int dtype);
 int uncl_gen_backward(const uncl_gen_weights* wts, const uncl_gen_bwd* b, void* stream);
 
 const char* uncl_gen_layer_name(int i); /* state_dict prefix of packed weight i, NULL past the end */

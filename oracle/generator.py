@@ -61,6 +61,7 @@ def local_variance(x, win=None):
         win = gauss_window()
     b, c, h, w = x.shape
     xr = x.reshape(b * c, 1, h, w)
+    win = win.to(x.dtype)           # the fp64 evaluation used as the ground truth of the fp32 parity tests
     mu = F.conv2d(xr, win)
     var = F.conv2d(xr * xr, win) - mu.pow(2)
     return var.reshape(b, c, var.shape[2], var.shape[3])

@@ -104,7 +104,7 @@ def struct_loss_level(img1, img2, window_size=5):
     """models/struct_loss.py:57-87: every 5x5 window is normalised by its own box-filter mean / std and the
     two normalised window stacks are compared by MSE."""
     ws = window_size
-    win = torch.ones((1, 1, ws, ws)) / (ws * ws)
+    win = torch.ones((1, 1, ws, ws), dtype=img1.dtype) / (ws * ws)     # dtype follows the inputs (fp64 ground-truth runs)
     win = win / win.sum()
 
     def stats(img):

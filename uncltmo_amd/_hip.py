@@ -137,6 +137,8 @@ SIGNATURES = {
     "uncl_gcn_maxrel_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "uncl_conv_in_c1_wgrad": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "uncl_gen_backward_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "uncl_gen_backward_workspace_bytes_dt": (C.c_size_t, [C.c_int, C.c_int]),
+    "uncl_gen_carry_bytes_dt": (C.c_size_t, [C.c_int, C.c_int]),
     "uncl_gen_backward": (C.c_int, [C.POINTER(GenWeights), C.POINTER(GenBwd), C.c_void_p]),
     "uncl_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),

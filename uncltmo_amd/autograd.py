@@ -1,6 +1,9 @@
 """Autograd bridge of the image and video generators: forward = uncl_gen_forward with activations kept, backward = ONE call of
 uncl_gen_backward (hand-written HIP dgrad / wgrad / element-wise kernels), then the packed weight gradients are
-re-laid-out into the reference parameter layout.  bf16 compute, fp32 accumulation and fp32 parameter gradients."""
+re-laid-out into the reference parameter layout.  compute_dtype 'bf16' is the training path (bf16 activations and activation
+gradients, fp32 accumulation, fp32 parameter gradients); 'fp32' is the PARITY mode: everything in fp32, weight gradients by
+deterministic fixed-order kernels (csrc/bwd_f32.hip) -- slower, used to check a trainer step against the CPU oracle at fp32
+tolerances (tests/test_gpu_trainer.py, tests/test_gpu_backward.py)."""
 import ctypes as C
 
 import torch
@@ -33,7 +36,7 @@ class _GradSet:
         module = self.module
         gwts, _keep = module._packed_weights()
         n = xf.shape[0]
-        gbytes = lib.uncl_gen_backward_workspace_bytes(n)
+        gbytes = lib.uncl_gen_backward_workspace_bytes_dt(n, module._dtype_code())
         if self.gws is None or self.gws.numel() < gbytes:
             self.gws = torch.empty(gbytes, dtype=torch.uint8, device=self.dev)
         b = _hip.GenBwd()
@@ -105,7 +108,7 @@ class _GeneratorFn(torch.autograd.Function):
         g_out = torch.zeros_like(out) if g_out is None else g_out.reshape(n, 1, 256, 256).float().contiguous()
         gup = None
         if g_upx is not None:
-            gup = g_upx.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+            gup = g_upx.permute(0, 2, 3, 1).to(_hip.torch_dtype(module._dtype_code())).contiguous()
         gs = _GradSet(module, xf.device)
         gs.run(xf, out, up, ws, ds, g_out, gup)
         grads = gs.unpack()
@@ -145,7 +148,8 @@ class _VideoGeneratorFn(torch.autograd.Function):
         B = frames[0][0].shape[0]
         dev = frames[0][0].device
         gs = _GradSet(module, dev)
-        cbytes = lib.uncl_gen_carry_bytes(B)
+        code = module._dtype_code()
+        cbytes = lib.uncl_gen_carry_bytes_dt(B, code)
         carries = [torch.empty(cbytes, dtype=torch.uint8, device=dev) for _ in range(2)] if T > 1 else []
         for t in range(T - 1, -1, -1):
             xf, out, up, ws, ds = frames[t]
@@ -154,7 +158,7 @@ class _VideoGeneratorFn(torch.autograd.Function):
             if g_feats is not None:
                 gst = g_feats[:, t].reshape(B, 2, 32).float().contiguous()
                 gup = torch.empty_like(up)
-                _hip.check(lib.uncl_gauss_stats_backward(up.data_ptr(), _hip.BF16, gst.data_ptr(), gup.data_ptr(), B, 256, 256, 32, 0,
+                _hip.check(lib.uncl_gauss_stats_backward(up.data_ptr(), code, gst.data_ptr(), gup.data_ptr(), B, 256, 256, 32, 0,
                                                          _hip.stream_ptr()), "uncl_gauss_stats_backward")
             carry_in = carries[(t + 1) % 2] if t < T - 1 else None      # written by frame t+1
             carry_out = carries[t % 2] if t > 0 else None               # read by frame t-1
@@ -167,9 +171,9 @@ class _VideoGeneratorFn(torch.autograd.Function):
 
 
 def generator_image_apply(module, x):
-    if module._dtype_code() != _hip.BF16:
-        raise NotImplementedError("uncltmo_amd: the HIP backward path is built for compute_dtype='bf16' (fp32 is the "
-                                  "inference parity mode)")
+    if module._dtype_code() not in (_hip.BF16, _hip.F32):
+        raise NotImplementedError("uncltmo_amd: the HIP backward path is built for compute_dtype 'bf16' (training) and 'fp32' "
+                                  "(parity mode); 'fp16' is an inference dtype")
     named = [(k, p) for k, p in module.named_parameters() if p.requires_grad]
     _GeneratorFn_pnames = [k for k, _ in named]
 
@@ -183,9 +187,9 @@ def generator_image_apply(module, x):
 
 
 def generator_video_apply(module, x):
-    if module._dtype_code() != _hip.BF16:
-        raise NotImplementedError("uncltmo_amd: the HIP backward path is built for compute_dtype='bf16' (fp32 is the "
-                                  "inference parity mode)")
+    if module._dtype_code() not in (_hip.BF16, _hip.F32):
+        raise NotImplementedError("uncltmo_amd: the HIP backward path is built for compute_dtype 'bf16' (training) and 'fp32' "
+                                  "(parity mode); 'fp16' is an inference dtype")
     named = [(k, p) for k, p in module.named_parameters() if p.requires_grad]
     pnames = [k for k, _ in named]
 

@@ -8,6 +8,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "bwd_internal.h"
 
 namespace {
 
@@ -156,7 +157,11 @@ int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, boo
   d.W = pool ? kDims[in].w / 2 : kDims[in].w;
   if (prev_ch > 0 && c.prev) { d.prev0 = c.pptr(src); d.prev_ch = prev_ch; }
   set_out(d, c.ptr(out), out);
-  return run3(c, wi, d, (pipe && out_pooled >= 0) ? c.ptr(out_pooled) : nullptr);
+  const int rc = run3(c, wi, d, (pipe && out_pooled >= 0) ? c.ptr(out_pooled) : nullptr);
+  // fp32 training (parity) mode: the next stage pools inside its loader, but the backward pass reads the pooled tensor itself
+  if (rc == UNCL_OK && !pipe && out_pooled >= 0 && c.save_preact)
+    return bwd_maxpool2_f32(c.ptr(out), c.ptr(out_pooled), c.n, kDims[out].h, kDims[out].w, kDims[out].c, c.s);
+  return rc;
 }
 
 // decoder stage: ConvT2x2(s2) of `x1` -> up buffer; concat-ssr(skip, up) -> ConvT3x3 -> ConvT3x3
@@ -276,16 +281,16 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   if (knn_out && hipMemcpyAsync(knn_out, knn, (size_t)c.n * NODES * 9 * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
     return UNCL_ERR_LAUNCH;
   RUN(uncl_gcn_maxrel(c.ptr(B_GFC1), knn, c.ptr(B_GMR), w->dtype, c.n, NODES, 256, 9, c.s));
-  if (c.save_preact && use_pipe(c)) {
+  if (c.save_preact) {
     RUN(conv1(c, W_GGC, B_GMR, B_GGCZ, 512, 512, UNCL_ACT_NONE, nullptr, 0, nullptr, 4));
-    RUN(uncl_gelu_forward(c.ptr(B_GGCZ), c.ptr(B_GGC), (long long)c.n * NODES * 512, c.s));
+    RUN(bwd_gelu_forward(w->dtype, c.ptr(B_GGCZ), c.ptr(B_GGC), (long long)c.n * NODES * 512, c.s));
   } else {
     RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_GELU, nullptr, 0, nullptr, 4));
   }
   RUN(conv1(c, W_GFC2, B_GGC, B_GX1, 512, 256, UNCL_ACT_NONE, c.ptr(B_X4), 0, drop0));
-  if (c.save_preact && use_pipe(c)) {
+  if (c.save_preact) {
     RUN(conv1(c, W_FFC1, B_GX1, B_FHZ, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
-    RUN(uncl_gelu_forward(c.ptr(B_FHZ), c.ptr(B_FH), (long long)c.n * NODES * 256, c.s));
+    RUN(bwd_gelu_forward(w->dtype, c.ptr(B_FHZ), c.ptr(B_FH), (long long)c.n * NODES * 256, c.s));
   } else {
     RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
   }
@@ -310,6 +315,7 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
 // every stored gradient already carries the activation derivative of the layer that produced b.
 // ------------------------------------------------------------------------------------------------------------------
 struct BwdScratch {
+  char* tmp;     // fp32 mode only, (N,252,252,128): a data gradient before its masked / accumulating store
   char* gcat;    // (N,252,252,128) bf16: gradient of a decoder stage's concat input
   char* gpool;   // (N,126,126,32) bf16: gradient of a pooled encoder input
   char* tA;      // (N,144,512) bf16 x 4 temporaries of the graph block
@@ -334,19 +340,20 @@ struct ColsumQueue {
 struct CarrySlot { int buf, pix, pc; };
 const CarrySlot kCarry[8] = {{B_X0P, 126 * 126, 1}, {B_X1P, 61 * 61, 2}, {B_X2P, 28 * 28, 4}, {B_X3P, 12 * 12, 8},
                              {B_GOUT, 144, 8},      {B_U0, 28 * 28, 4},  {B_U1, 61 * 61, 2},  {B_U2, 126 * 126, 1}};
-size_t carry_off(int slot, int N) {
+size_t carry_off(int slot, int N, size_t es = 2) {
   size_t o = 0;
-  for (int i = 0; i < slot; ++i) o += ((size_t)N * kCarry[i].pix * kCarry[i].pc * 2 + 255) & ~(size_t)255;
+  for (int i = 0; i < slot; ++i) o += ((size_t)N * kCarry[i].pix * kCarry[i].pc * es + 255) & ~(size_t)255;
   return o;
 }
 
-size_t bwd_scratch_bytes(int N) {
+size_t bwd_scratch_bytes(int N, size_t es = 2) {
   size_t b = 0;
-  b += (size_t)N * 252 * 252 * 128 * 2;
-  b += (size_t)N * 126 * 126 * 32 * 2;
-  b += 4 * (size_t)N * 144 * 512 * 2;
+  if (es == 4) b += (size_t)N * 252 * 252 * 128 * 4;     // tmp
+  b += (size_t)N * 252 * 252 * 128 * es;
+  b += (size_t)N * 126 * 126 * 32 * es;
+  b += 4 * (size_t)N * 144 * 512 * es;
   b += (size_t)N * 144 * 256 * 4;
-  b += (size_t)N * 126 * 126 * 32 * 2;
+  b += (size_t)N * 126 * 126 * 32 * es;
   b += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
   b += (size_t)CS_CHANNELS * 512 * 4;
   return b + 4096;
@@ -361,6 +368,8 @@ struct BCtx {
   Layout L;
   BwdScratch sc;
   int n;
+  int dt;        // UNCL_BF16 (training) or UNCL_F32 (parity mode: deterministic plain-fp32 kernels, bwd_f32.hip)
+  size_t es;
   float slope;
   hipStream_t s;
   ColsumQueue* q;
@@ -368,6 +377,7 @@ struct BCtx {
   void* G(int buf) const { return gws + L.off[buf]; }
   // out[c] (+)= sum_rows x[row][c], finished by flush_colsums()
   int colsum(const void* x, long long rows, int C, float* out) const {
+    if (dt == UNCL_F32) return bwd_colsum_f32(x, rows, C, C, out, b->accumulate, s);
     for (int c0 = 0; c0 < C; c0 += 256) {
       const int cw = C - c0 < 256 ? C - c0 : 256;
       if (q->n >= UNCL_COLSUM_MAX_ITEMS || q->channels + cw > CS_CHANNELS) return UNCL_ERR_ARG;
@@ -384,27 +394,33 @@ struct BCtx {
     return rc;
   }
   bool video() const { return b->carry_in != nullptr || b->carry_out != nullptr; }
-  const void* cin(int slot) const { return b->carry_in ? (const char*)b->carry_in + carry_off(slot, n) : nullptr; }
-  void* cout(int slot) const { return b->carry_out ? (char*)b->carry_out + carry_off(slot, n) : nullptr; }
+  const void* cin(int slot) const { return b->carry_in ? (const char*)b->carry_in + carry_off(slot, n, es) : nullptr; }
+  void* cout(int slot) const { return b->carry_out ? (char*)b->carry_out + carry_off(slot, n, es) : nullptr; }
   // the tensor a hand-off stage actually read: this frame's buffer with the previous frame's head channels
   const void* mixed(int slot) const {
     const CarrySlot& k = kCarry[slot];
     if (!pws) return F(k.buf);
-    if (uncl_mix_heads(F(k.buf), pws + L.off[k.buf], sc.mix, (long long)n * k.pix, kDims[k.buf].c, k.pc, s) != UNCL_OK) return nullptr;
+    if (bwd_mix_heads(dt, F(k.buf), pws + L.off[k.buf], sc.mix, (long long)n * k.pix, kDims[k.buf].c, k.pc, s) != UNCL_OK) return nullptr;
     return sc.mix;
   }
   int handoff(int slot, void* g, const void* mask) const {
     if (!video()) return UNCL_OK;
     const CarrySlot& k = kCarry[slot];
-    return uncl_head_handoff(g, mask, slope, cin(slot), cout(slot), (long long)n * k.pix, kDims[k.buf].c, k.pc, s);
+    return bwd_head_handoff(dt, g, mask, slope, cin(slot), cout(slot), (long long)n * k.pix, kDims[k.buf].c, k.pc, s);
   }
 };
 
 uncl_conv_desc bdesc(const BCtx& c, int ks, int pad, int h, int w, int cin, int cout) {
   uncl_conv_desc d = {};
-  d.dtype = UNCL_BF16; d.ksize = ks; d.pad = pad; d.N = c.n; d.H = h; d.W = w; d.Cin = cin; d.Cout = cout;
+  d.dtype = c.dt; d.ksize = ks; d.pad = pad; d.N = c.n; d.H = h; d.W = w; d.Cin = cin; d.Cout = cout;
   d.src_mode = UNCL_SRC_PLAIN; d.act = UNCL_ACT_NONE;
   return d;
+}
+
+// weight gradient in the pass's element type: matrix-core kernel with fp32 atomics (bf16) or the deterministic fp32 kernel
+int conv_wgrad(const BCtx& c, const uncl_conv_desc& d, const void* gy, float* gw) {
+  if (c.dt == UNCL_F32) return bwd_wgrad_f32(&d, gy, gw, c.s);
+  return uncl_conv_wgrad(&d, gy, gw, c.s);
 }
 
 // weight + bias gradient of a 3x3 layer whose input is buffer `xin` (plain) and whose output gradient is gy
@@ -412,7 +428,7 @@ int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const voi
            const void* src = nullptr) {
   uncl_conv_desc d = bdesc(c, 3, pad, kDims[xin].h, kDims[xin].w, cin, cout);
   d.src0 = src ? src : c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
-  int rc = uncl_conv_wgrad(&d, gy, c.b->gw[wi], c.s);
+  int rc = conv_wgrad(c, d, gy, c.b->gw[wi]);
   if (rc != UNCL_OK) return rc;
   return c.colsum(gy, (long long)c.n * oh * ow, cout, c.b->gb[wi]);
 }
@@ -424,6 +440,14 @@ int dgrad3(const BCtx& c, int wi, const void* gy, int gh, int gw, int gc, int pa
   d.src0 = gy; d.src0_H = gh; d.src0_W = gw; d.src0_C = gc;
   d.weight = c.b->wd[wi];
   d.out = out; d.out_H = oh; d.out_W = ow; d.out_C = cout_d;
+  if (c.dt == UNCL_F32) {
+    // exact-fp32 implicit GEMM, then the gradient-mode store (ReLU mask of the producing layer / accumulation) as its own pass
+    const bool post = mask != nullptr || accumulate;
+    if (post) d.out = c.sc.tmp;
+    const int rc = uncl_conv_igemm(&d, c.s);
+    if (rc != UNCL_OK || !post) return rc;
+    return bwd_mask_acc_f32(c.sc.tmp, mask, c.slope, out, accumulate, (long long)c.n * oh * ow * cout_d, c.s);
+  }
   return uncl_conv3x3_dgrad(&d, mask, c.slope, accumulate, c.s);
 }
 
@@ -433,7 +457,7 @@ int wgrad1(const BCtx& c, int wi, const void* x, int xc_total, int cin, const vo
   uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, cin, cout);
   d.src0 = x; d.src0_H = 12; d.src0_W = 12; d.src0_C = xc_total;
   d.out_C = gy_total;  // leading dimension of gy
-  int rc = uncl_conv_wgrad(&d, gy, gw, c.s);
+  int rc = conv_wgrad(c, d, gy, gw);
   if (rc != UNCL_OK || !bias) return rc;
   return c.colsum(gy, (long long)c.n * NODES, gy_total, c.b->gb[wi]);
 }
@@ -452,7 +476,7 @@ int backward_all(const BCtx& c) {
   int rc;
 #define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
   // ---- tail: outconv + sigmoid
-  RUN(uncl_outc_backward(b->g_out, b->x_out, b->g_upx, b->up_x, c.w->outc_w, c.G(B_UPX), b->g_outc_w, b->g_outc_b,
+  RUN(bwd_outc_backward(c.dt, b->g_out, b->x_out, b->g_upx, b->up_x, c.w->outc_w, c.G(B_UPX), b->g_outc_w, b->g_outc_b,
                          (long long)c.n * 256 * 256, c.w->last_act, c.slope, b->accumulate, c.sc.misc, c.s));
   // ---- decoder stages 3..0
   struct Stage { int wi, x1, skip, up, a, out, ch, cout; };
@@ -473,23 +497,28 @@ int backward_all(const BCtx& c) {
       d.src_mode = UNCL_SRC_CONCAT_SSR;
       d.src0 = c.F(q.skip); d.src0_H = sh; d.src0_W = sw; d.src0_C = q.ch;
       d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
-      RUN(uncl_conv_wgrad(&d, c.G(q.a), b->gw[q.wi + 1], c.s));
+      RUN(conv_wgrad(c, d, c.G(q.a), b->gw[q.wi + 1]));
       RUN(c.colsum(c.G(q.a), (long long)c.n * ah * aw, q.cout, b->gb[q.wi + 1]));
     }
     RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
-    RUN(uncl_ssr_backward(c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
+    RUN(bwd_ssr_backward(c.dt, c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
     // up (ConvT 2x2 s2, ch -> ch): input x1
     const int xh = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].h, xw = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].w;
     const int slot = 4 + i;  // hand-off slot of this stage's input (video): GOUT, U0, U1, U2
     const void* x1m = c.mixed(slot);
     if (!x1m) return UNCL_ERR_LAUNCH;
-    RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
+    if (c.dt == UNCL_F32) RUN(bwd_upconv2x2_wgrad_f32(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
+    else RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
     RUN(c.colsum(c.G(q.up), (long long)c.n * uh * uw, q.ch, b->gb[q.wi]));
     // the ReLU derivative of the layer that produced x1 is applied by the dgrad kernel (single frames) or, for clips,
     // by the hand-off kernel after the head channels have been exchanged between frames
     const void* x1mask = i == 0 ? nullptr : c.F(q.x1);
-    RUN(uncl_upconv2x2_dgrad(c.G(q.up), b->wd[q.wi], c.video() ? nullptr : x1mask, c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
-                             c.s));
+    if (c.dt == UNCL_F32)
+      RUN(bwd_upconv2x2_dgrad_f32(c.G(q.up), b->wd[q.wi], c.video() ? nullptr : x1mask, c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
+                                  c.s));
+    else
+      RUN(uncl_upconv2x2_dgrad(c.G(q.up), b->wd[q.wi], c.video() ? nullptr : x1mask, c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
+                               c.s));
     RUN(c.handoff(slot, c.G(q.x1), x1mask));
   }
   // ---- graph block
@@ -497,33 +526,33 @@ int backward_all(const BCtx& c) {
   const float* drop1 = b->drop_scale ? b->drop_scale + c.n : nullptr;
   const long long per256 = (long long)NODES * 256, per512 = (long long)NODES * 512;
   // FFN: GOUT = drop1 * fc2(gelu(fc1(GX1))) + GX1
-  RUN(uncl_scale_rows(c.G(B_GOUT), drop1, c.sc.tA, c.n, per256, c.s));
+  RUN(bwd_scale_rows(c.dt, c.G(B_GOUT), drop1, c.sc.tA, c.n, per256, c.s));
   RUN(wgrad1(c, W_FFC2, c.F(B_FH), 256, 256, c.sc.tA, 256, 256, b->gw[W_FFC2], true));
   RUN(dgrad1(c, W_FFC2, c.sc.tA, 256, 256, c.sc.tB, nullptr));
-  RUN(uncl_gelu_backward(c.sc.tB, c.F(B_FHZ), c.sc.tB, (long long)c.n * per256, c.s));
+  RUN(bwd_gelu_backward(c.dt, c.sc.tB, c.F(B_FHZ), c.sc.tB, (long long)c.n * per256, c.s));
   RUN(wgrad1(c, W_FFC1, c.F(B_GX1), 256, 256, c.sc.tB, 256, 256, b->gw[W_FFC1], true));
   RUN(dgrad1(c, W_FFC1, c.sc.tB, 256, 256, c.G(B_GX1), c.G(B_GOUT)));
   // Grapher: GX1 = drop0 * fc2(gelu(gconv(maxrel(fc1(X4))))) + X4
-  RUN(uncl_scale_rows(c.G(B_GX1), drop0, c.sc.tA, c.n, per256, c.s));
+  RUN(bwd_scale_rows(c.dt, c.G(B_GX1), drop0, c.sc.tA, c.n, per256, c.s));
   RUN(wgrad1(c, W_GFC2, c.F(B_GGC), 512, 512, c.sc.tA, 256, 256, b->gw[W_GFC2], true));
   RUN(dgrad1(c, W_GFC2, c.sc.tA, 256, 512, c.sc.tC, nullptr));
-  RUN(uncl_gelu_backward(c.sc.tC, c.F(B_GGCZ), c.sc.tC, (long long)c.n * per512, c.s));
+  RUN(bwd_gelu_backward(c.dt, c.sc.tC, c.F(B_GGCZ), c.sc.tC, (long long)c.n * per512, c.s));
   {  // grouped 1x1: four independent 128 -> 128 blocks, one launch (grid.y = group)
     uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, 128, 128);
     d.src0 = c.F(B_GMR); d.src0_H = 12; d.src0_W = 12; d.src0_C = 512;
     d.out_C = 512;
     d.z_mode = UNCL_Z_GROUPS; d.groups = 4;
-    RUN(uncl_conv_wgrad(&d, c.sc.tC, b->gw[W_GGC], c.s));
+    RUN(conv_wgrad(c, d, c.sc.tC, b->gw[W_GGC]));
   }
   RUN(c.colsum(c.sc.tC, (long long)c.n * NODES, 512, b->gb[W_GGC]));
   RUN(dgrad1(c, W_GGC, c.sc.tC, 512, 512, c.sc.tD, nullptr, 4));
   if (hipMemsetAsync(c.sc.f32, 0, (size_t)c.n * per256 * 4, c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
-  RUN(uncl_gcn_maxrel_backward(c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, c.sc.tB, c.n, NODES,
+  RUN(bwd_gcn_maxrel_backward(c.dt, c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, c.sc.tB, c.n, NODES,
                                256, 9, c.s));
   RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, c.sc.tB, 256, 256, b->gw[W_GFC1], true));
   RUN(dgrad1(c, W_GFC1, c.sc.tB, 256, 256, c.G(B_X4), c.G(B_GX1)));
-  RUN(uncl_sum_samples(c.G(B_X4), b->g_pos_embed, c.n, per256, b->accumulate, c.s));
-  RUN(uncl_mask_minus(c.G(B_X4), c.F(B_X4), c.w->pos_embed, c.sc.tA, c.n, per256, c.slope, c.s));
+  RUN(bwd_sum_samples(c.dt, c.G(B_X4), b->g_pos_embed, c.n, per256, b->accumulate, c.s));
+  RUN(bwd_mask_minus(c.dt, c.G(B_X4), c.F(B_X4), c.w->pos_embed, c.sc.tA, c.n, per256, c.slope, c.s));
   // ---- encoder
   // down3: conv (valid, pooled X3 -> D3A), ConvT (D3A -> X4)
   RUN(wgrad3(c, W_D3B, B_D3A, 2, 256, 256, c.sc.tA, 12, 12));
@@ -541,7 +570,7 @@ int backward_all(const BCtx& c) {
   }
   RUN(dgrad3(c, W_D3A, c.G(B_D3A), 10, 10, 256, 2, 256, c.sc.gpool, 12, 12, nullptr, 0));
   RUN(c.handoff(3, c.sc.gpool, nullptr));
-  RUN(uncl_pool_backward(c.sc.gpool, c.F(B_X3), c.G(B_X3), c.n, 24, 24, 256, c.slope, 1, c.s));
+  RUN(bwd_pool_backward(c.dt, c.sc.gpool, c.F(B_X3), c.G(B_X3), c.n, 24, 24, 256, c.slope, 1, c.s));
   for (int i = 0; i < 3; ++i) {
     const Enc& e = en[i];
     const int oh = kDims[e.out].h, mh = kDims[e.mid].h, ph = kDims[e.pooled].h, xh = kDims[e.xin].h;
@@ -552,12 +581,12 @@ int backward_all(const BCtx& c) {
     RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh, xm));
     RUN(dgrad3(c, e.wa, c.G(e.mid), mh, mh, e.cout, 2, e.cin, c.sc.gpool, ph, ph, nullptr, 0));
     RUN(c.handoff(2 - i, c.sc.gpool, nullptr));
-    RUN(uncl_pool_backward(c.sc.gpool, c.F(e.xin), c.G(e.xin), c.n, xh, xh, e.cin, c.slope, 1, c.s));
+    RUN(bwd_pool_backward(c.dt, c.sc.gpool, c.F(e.xin), c.G(e.xin), c.n, xh, xh, e.cin, c.slope, 1, c.s));
   }
   // inc: conv1 (INC0 -> X0), conv (image -> INC0)
   RUN(wgrad3(c, W_INC1, B_INC0, 0, 32, 32, c.G(B_X0), 252, 252));
   RUN(dgrad3(c, W_INC1, c.G(B_X0), 252, 252, 32, 2, 32, c.G(B_INC0), 254, 254, c.F(B_INC0), 0));
-  RUN(uncl_conv_in_c1_wgrad(c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, b->accumulate, c.sc.misc, c.s));
+  RUN(bwd_conv_in_c1_wgrad(c.dt, c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, b->accumulate, c.sc.misc, c.s));
 #undef RUN
   return UNCL_OK;
 }
@@ -711,27 +740,31 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   return UNCL_OK;
 }
 
-extern "C" size_t uncl_gen_backward_workspace_bytes(int N) {
-  if (N <= 0) return 0;
-  return make_layout(N, UNCL_BF16).total + bwd_scratch_bytes(N);
+extern "C" size_t uncl_gen_backward_workspace_bytes(int N) { return uncl_gen_backward_workspace_bytes_dt(N, UNCL_BF16); }
+extern "C" size_t uncl_gen_backward_workspace_bytes_dt(int N, int dtype) {
+  if (N <= 0 || (dtype != UNCL_BF16 && dtype != UNCL_F32)) return 0;
+  return make_layout(N, dtype).total + bwd_scratch_bytes(N, dtype == UNCL_F32 ? 4 : 2);
 }
 
-extern "C" size_t uncl_gen_carry_bytes(int N) {
+extern "C" size_t uncl_gen_carry_bytes(int N) { return uncl_gen_carry_bytes_dt(N, UNCL_BF16); }
+extern "C" size_t uncl_gen_carry_bytes_dt(int N, int dtype) {
   if (N <= 0) return 0;
-  return carry_off(8, N);
+  return carry_off(8, N, dtype == UNCL_F32 ? 4 : 2);
 }
 
 extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* b, void* stream) {
-  if (!w || !b || w->dtype != UNCL_BF16 || b->N <= 0) return UNCL_ERR_ARG;
+  if (!w || !b || (w->dtype != UNCL_BF16 && w->dtype != UNCL_F32) || b->N <= 0) return UNCL_ERR_ARG;
   if (!b->x || !b->x_out || !b->g_out || !b->up_x || !b->workspace || !b->grad_workspace) return UNCL_ERR_ARG;
-  if (b->grad_workspace_bytes < uncl_gen_backward_workspace_bytes(b->N)) return UNCL_ERR_ARG;
+  if (b->grad_workspace_bytes < uncl_gen_backward_workspace_bytes_dt(b->N, w->dtype)) return UNCL_ERR_ARG;
   for (int i = 0; i < UNCL_G_NUM_WEIGHTS; ++i)
     if (!b->wd[i] || !b->gw[i] || !b->gb[i]) return UNCL_ERR_ARG;
   if (!b->g_inc0_w || !b->g_inc0_b || !b->g_outc_w || !b->g_outc_b || !b->g_pos_embed) return UNCL_ERR_ARG;
   if ((b->prev_workspace != nullptr) != (b->carry_out != nullptr)) return UNCL_ERR_ARG;
   BCtx c;
   c.w = w; c.b = b; c.n = b->N;
-  c.L = make_layout(b->N, UNCL_BF16);
+  c.dt = w->dtype;
+  c.es = w->dtype == UNCL_F32 ? 4 : 2;
+  c.L = make_layout(b->N, w->dtype);
   c.fws = reinterpret_cast<char*>(b->workspace);
   c.pws = reinterpret_cast<const char*>(b->prev_workspace);
   c.gws = reinterpret_cast<char*>(b->grad_workspace);
@@ -739,14 +772,17 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   c.s = reinterpret_cast<hipStream_t>(stream);
   char* p = c.gws + c.L.total;
   const int N = b->N;
-  c.sc.gcat = p; p += (size_t)N * 252 * 252 * 128 * 2;
-  c.sc.gpool = p; p += (size_t)N * 126 * 126 * 32 * 2;
-  c.sc.tA = p; p += (size_t)N * 144 * 512 * 2;
-  c.sc.tB = p; p += (size_t)N * 144 * 512 * 2;
-  c.sc.tC = p; p += (size_t)N * 144 * 512 * 2;
-  c.sc.tD = p; p += (size_t)N * 144 * 512 * 2;
+  const size_t es = c.es;
+  c.sc.tmp = nullptr;
+  if (es == 4) { c.sc.tmp = p; p += (size_t)N * 252 * 252 * 128 * 4; }
+  c.sc.gcat = p; p += (size_t)N * 252 * 252 * 128 * es;
+  c.sc.gpool = p; p += (size_t)N * 126 * 126 * 32 * es;
+  c.sc.tA = p; p += (size_t)N * 144 * 512 * es;
+  c.sc.tB = p; p += (size_t)N * 144 * 512 * es;
+  c.sc.tC = p; p += (size_t)N * 144 * 512 * es;
+  c.sc.tD = p; p += (size_t)N * 144 * 512 * es;
   c.sc.f32 = reinterpret_cast<float*>(p); p += (size_t)N * 144 * 256 * 4;
-  c.sc.mix = p; p += (size_t)N * 126 * 126 * 32 * 2;
+  c.sc.mix = p; p += (size_t)N * 126 * 126 * 32 * es;
   c.sc.misc = reinterpret_cast<float*>(p); p += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
   c.sc.cs = reinterpret_cast<float*>(p);
   ColsumQueue q;

@@ -185,8 +185,8 @@ class _GeneratorBase(nn.Module):
             src = sd[name + ".weight"].detach().float()
             fwd_off.append(job(src, src.numel(), cout, cin, k, int(transposed), 1 if (transposed and k == 3) else 0))
             gw.b[i] = f32(name + ".bias")
-        # weights re-packed for the data-gradient convolutions (bf16 training path only)
-        if code == _hip.BF16:
+        # weights re-packed for the data-gradient convolutions (the two training dtypes: bf16, and fp32 = parity mode)
+        if code in (_hip.BF16, _hip.F32):
             for i in range(_hip.G_NUM_WEIGHTS):
                 name = lib.uncl_gen_layer_name(i).decode()
                 shape, kind = spec[name + ".weight"]
