@@ -252,6 +252,9 @@ typedef struct uncl_gen_weights {
   const float* outc_b;            /* (1) fp32                                               */
   int act;                        /* UNCL_ACT_RELU or UNCL_ACT_LRELU (generator activation) */
   int last_act;                   /* UNCL_ACT_SIGMOID / TANH / MSIG / NONE (Unet_singleFrame.py:207-212) */
+  int norm;                       /* 0: none (published model); 1: nn.InstanceNorm2d between every 3x3 conv and its activation
+                                     (unet_norm = 'instance_norm', unet_parts.py:20-29).  Workspaces of such a model are sized
+                                     with uncl_gen_workspace_bytes_ex(..., norm = 1).                                          */
 } uncl_gen_weights;
 
 typedef struct uncl_gen_run {
@@ -315,6 +318,13 @@ const char* uncl_gen_layer_name(int i); /* state_dict prefix of packed weight i,
 int uncl_prof_enable(int layer, int max_records);
 int uncl_prof_read(float* ms_host, int max_n);
 size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep_activations);
+/* the same for a generator with uncl_gen_weights.norm = `norm` (training keeps the normalised pre-activations and 1/std) */
+size_t uncl_gen_workspace_bytes_ex(int N, int chunk, int dtype, int keep_activations, int norm);
+/* InstanceNorm2d (no affine, eps 1e-5) + activation of an NHWC tensor x (N, HW, C), in place, and its backward; stand-alone
+ * forms of what the generator runs per layer when norm = 1.  zhat / rstd (optional) receive the normalised pre-activation and
+ * 1/std [N][C] that uncl_inorm_backward needs: g (dL/dzhat, in place) -> dL/dz. */
+int uncl_inorm_act(void* x, void* zhat, float* rstd, int dtype, int N, int HW, int C, float slope, void* stream);
+int uncl_inorm_backward(void* g, const void* zhat, const float* rstd, int dtype, int N, int HW, int C, void* stream);
 int uncl_gen_forward(const uncl_gen_weights* wts, const uncl_gen_run* run, void* stream);
 /* uncl_gen_forward runs an un-chunked inference batch of >= 64 tiles as n contiguous parts on n streams (the caller's plus
  * internal ones, forked and joined with events, so the call keeps stream semantics) up to the third decoder stage: one

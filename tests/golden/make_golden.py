@@ -41,10 +41,10 @@ def summarize(t, key, nsamp=256):
             key + ".shape": np.array(t.shape, dtype=np.int64)}
 
 
-def build_ref_models(video=False):
+def build_ref_models(video=False, unet_norm="none"):
     from utils import model_save_util
     mk = model_save_util.create_G_net if video else model_save_util.create_G_net2
-    G = mk("unet", DEV, False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, "none", "none", "relu", True, 1,
+    G = mk("unet", DEV, False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, unet_norm, "none", "relu", True, 1,
            1, 0, "replicate", 2, 0)
     D = model_save_util.create_D_net(1, 16, DEV, False, "none", True, "simpleD", 3, "none", 3, 0, 0, 0)
     synth.fill_state_dict(G, "g0")
@@ -313,6 +313,32 @@ def capture_step_c4(out):
     print("captured", tag, out[tag + ".errD"], out[tag + ".errG_d"], out[tag + ".errG_struct"], flush=True)
 
 
+def capture_generator_inorm(out):
+    """The reference generator built with unet_norm='instance_norm' (unet_parts.py:20-29): eval forward on two frames and the
+    parameter gradients of a smooth loss (norm + 64 hashed elements per tensor)."""
+    G, _ = build_ref_models(unet_norm="instance_norm")
+    assert len(G.state_dict()) == 58          # InstanceNorm2d without affine / running stats adds no state
+    G.eval()
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    y, up = G(x)
+    out["inorm.x_out"] = y.detach().numpy().copy()
+    summarize(up.detach(), "inorm.up_x")
+    for k, v in summarize(up.detach(), "inorm.up_x").items():
+        out[k] = v
+    wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
+    G.zero_grad()
+    ((y * wy).sum() + 1e-3 * up.sum()).backward()
+    for k, v in G.named_parameters():
+        if v.grad is None:
+            continue
+        g = v.grad.double().reshape(-1)
+        n = g.numel()
+        pos_ = (synth.hash_uniform("gpos:" + k, min(64, n)) * n).astype(np.int64) % n
+        out["inorm.grad." + k] = np.float64(g.norm().item())
+        out["inorm.gradpos." + k] = pos_
+        out["inorm.gradval." + k] = g[torch.from_numpy(pos_)].numpy()
+
+
 def capture_tiler(out):
     from utils import model_save_util
     torch.Tensor.cuda = lambda self, *a, **k: self          # the tiler hard-codes .cuda() (model_save_util.py:414)
@@ -413,12 +439,13 @@ def capture_tmqi(out):
 
 
 def main():
-    which = sys.argv[1:] or ["generator", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler", "inference",
-                             "tmqi"]
+    which = sys.argv[1:] or ["generator", "generator_inorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
+                             "inference", "tmqi"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
             "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "vid_c4": lambda o: capture_step_c4(o),
+            "generator_inorm": lambda o: capture_generator_inorm(o),
             "tiler": lambda o: capture_tiler(o),
             "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o)}
     for name in which:

@@ -47,7 +47,7 @@ class GenWeights(C.Structure):
         ("dtype", C.c_int), ("inc0_w", C.c_void_p), ("inc0_b", C.c_void_p),
         ("w", C.c_void_p * G_NUM_WEIGHTS), ("b", C.c_void_p * G_NUM_WEIGHTS),
         ("pos_embed", C.c_void_p), ("relative_pos", C.c_void_p), ("outc_w", C.c_void_p), ("outc_b", C.c_void_p),
-        ("act", C.c_int), ("last_act", C.c_int),
+        ("act", C.c_int), ("last_act", C.c_int), ("norm", C.c_int),
     ]
 
 
@@ -160,6 +160,9 @@ SIGNATURES = {
     "uncl_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "uncl_prof_read": (C.c_int, [C.c_void_p, C.c_int]),
     "uncl_gen_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "uncl_gen_workspace_bytes_ex": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "uncl_inorm_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "uncl_inorm_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_gen_forward": (C.c_int, [C.POINTER(GenWeights), C.POINTER(GenRun), C.c_void_p]),
     "uncl_gauss_stats_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "uncl_gauss_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

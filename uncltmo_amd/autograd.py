@@ -170,7 +170,16 @@ class _VideoGeneratorFn(torch.autograd.Function):
         return (None, None) + tuple(grads.get(k) for k in ctx.pnames)
 
 
+def _warn_bf16_norm(module):
+    if module._dtype_code() == _hip.BF16 and getattr(module, "unet_norm", "none") == "instance_norm":
+        import warnings
+        warnings.warn("uncltmo_amd: training with unet_norm='instance_norm' in bf16 loses the gradient below the per-channel "
+                      "mean that the norm's backward subtracts (activation gradients are stored in bf16); use "
+                      "compute_dtype='fp32' for this configuration", UserWarning, stacklevel=3)
+
+
 def generator_image_apply(module, x):
+    _warn_bf16_norm(module)
     if module._dtype_code() not in (_hip.BF16, _hip.F32):
         raise NotImplementedError("uncltmo_amd: the HIP backward path is built for compute_dtype 'bf16' (training) and 'fp32' "
                                   "(parity mode); 'fp16' is an inference dtype")
@@ -187,6 +196,7 @@ def generator_image_apply(module, x):
 
 
 def generator_video_apply(module, x):
+    _warn_bf16_norm(module)
     if module._dtype_code() not in (_hip.BF16, _hip.F32):
         raise NotImplementedError("uncltmo_amd: the HIP backward path is built for compute_dtype 'bf16' (training) and 'fp32' "
                                   "(parity mode); 'fp16' is an inference dtype")

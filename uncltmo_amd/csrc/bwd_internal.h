@@ -24,3 +24,10 @@ int bwd_upconv2x2_dgrad_f32(const void* gy, const void* wt, const void* mask, fl
 int bwd_mask_acc_f32(const void* src, const void* mask, float slope, void* dst, int accumulate, long long n, hipStream_t s);
 int bwd_colsum_f32(const void* x, long long rows, int C, int ld, float* out, int accumulate, hipStream_t s);
 int bwd_maxpool2_f32(const void* x, void* y, int N, int H, int W, int C, hipStream_t s);
+
+// generator InstanceNorm (inorm.hip)
+int bwd_inorm_forward(int dtype, void* x, void* zhat, float* rstd, const void* res, int res_b0, int N, int P, int C, float slope,
+                      hipStream_t s);
+int bwd_inorm_backward(int dtype, void* g, const void* zhat, const float* rstd, int N, int P, int C, hipStream_t s);
+int bwd_maxpool2(int dtype, const void* x, void* y, int N, int H, int W, int C, hipStream_t s);
+int bwd_outc_forward(int dtype, const void* up, const float* w, const float* b, float* out, long long P, int act, hipStream_t s);

@@ -25,8 +25,20 @@ enum Buf {
   B_INC0, B_X0, B_D0A, B_X1, B_D1A, B_X2, B_D2A, B_X3, B_D3A, B_X4,
   B_GFC1, B_GMR, B_GGC, B_GX1, B_FH, B_GOUT,
   B_U0UP, B_U0A, B_U0, B_U1UP, B_U1A, B_U1, B_U2UP, B_U2A, B_U2, B_U3UP, B_U3A, B_UPX,
-  B_KNN, B_X0P, B_X1P, B_X2P, B_X3P, B_GGCZ, B_FHZ, B_COUNT
+  B_KNN, B_X0P, B_X1P, B_X2P, B_X3P, B_GGCZ, B_FHZ,
+  // InstanceNorm training mode only: the normalised pre-activation of every 3x3 conv output (same extent as that output) and
+  // 1/std per (sample, channel) of the 18 conv layers, fp32
+  B_ZN0, B_ZN_END = B_ZN0 + 18, B_RSTD = B_ZN_END, B_COUNT
 };
+// the 18 convolutions that a norm follows, as the activation buffer each writes
+constexpr int kNormBuf[18] = {B_INC0, B_X0, B_D0A, B_X1, B_D1A, B_X2, B_D2A, B_X3, B_D3A, B_X4,
+                              B_U0A, B_U0, B_U1A, B_U1, B_U2A, B_U2, B_U3A, B_UPX};
+constexpr int RSTD_FLOATS = 32 + 32 + 64 + 64 + 128 + 128 + 256 + 256 + 256 + 256 + 128 + 128 + 64 + 64 + 32 + 32 + 32 + 32;
+inline int norm_index(int buf) {
+  for (int i = 0; i < 18; ++i)
+    if (kNormBuf[i] == buf) return i;
+  return -1;
+}
 
 struct BufDim { int h, w, c; };
 const BufDim kDims[B_COUNT] = {
@@ -37,7 +49,12 @@ const BufDim kDims[B_COUNT] = {
     {122, 122, 64}, {124, 124, 32}, {126, 126, 32}, {252, 252, 32}, {254, 254, 32}, {256, 256, 32},
     {1, 144, 9},
     {126, 126, 32}, {61, 61, 64}, {28, 28, 128}, {12, 12, 256},
-    {1, 144, 512}, {1, 144, 256}};
+    {1, 144, 512}, {1, 144, 256},
+    // B_ZN0 ..: dims of kNormBuf[i]
+    {254, 254, 32}, {252, 252, 32}, {124, 124, 64}, {122, 122, 64}, {59, 59, 128}, {57, 57, 128}, {26, 26, 256}, {24, 24, 256},
+    {10, 10, 256}, {12, 12, 256}, {26, 26, 128}, {28, 28, 128}, {59, 59, 64}, {61, 61, 64}, {124, 124, 32}, {126, 126, 32},
+    {254, 254, 32}, {256, 256, 32},
+    {1, RSTD_FLOATS, 1}};
 
 struct Layout {
   size_t off[B_COUNT];
@@ -45,13 +62,14 @@ struct Layout {
   size_t total;
 };
 
-Layout make_layout(int n_alloc, int dtype) {
+Layout make_layout(int n_alloc, int dtype, int norm_train = 0) {
   const size_t es = uncl_is_h16(dtype) ? 2 : 4;
   Layout L;
   size_t o = 0;
   for (int b = 0; b < B_COUNT; ++b) {
-    const size_t e = b == B_KNN ? 4 : es;
+    const size_t e = (b == B_KNN || b == B_RSTD) ? 4 : es;
     L.per_n[b] = (size_t)kDims[b].h * kDims[b].w * kDims[b].c * e;
+    if (b >= B_ZN0 && b < B_ZN_END && !norm_train) L.per_n[b] = 0;
     L.off[b] = o;
     o += (L.per_n[b] * n_alloc + 255) & ~(size_t)255;
   }
@@ -107,7 +125,23 @@ struct Ctx {
   int save_preact;   // keep pre-GELU values (training)
   int fuse_up;       // inference: up_path.3.up is recomputed inside up_path.3.conv.conv's loader (same idea, last decoder level)
   int fuse_in;       // inference: inc.conv.conv is recomputed inside inc.conv.conv1's loader (its output never goes to HBM)
+  int norm;          // InstanceNorm between conv and activation (unet_norm = 'instance_norm')
+  int norm_keep;     // ... and keep zhat / rstd for the backward pass
   hipStream_t s;
+  float slope() const { return w->act == UNCL_ACT_LRELU ? 0.2f : 0.f; }
+  // norm + activation (+ residual) of the conv output just written to `p` (the buffer `buf`'s extent), in place
+  int post_norm(void* p, int buf, const void* res = nullptr, int res_b0 = 0) const {
+    const int li = norm_index(buf);
+    if (li < 0) return UNCL_ERR_ARG;
+    int roff = 0;
+    for (int i = 0; i < li; ++i) roff += kDims[kNormBuf[i]].c;
+    void* z = norm_keep ? ws + L.off[B_ZN0 + li] : nullptr;
+    // 1/std: every layer owns a contiguous [N_total][C] block of the B_RSTD area; this chunk's rows start at n0
+    float* rs = norm_keep ? rstd_base + (size_t)roff * n_total + (size_t)n0 * kDims[buf].c : nullptr;
+    return bwd_inorm_forward(w->dtype, p, z, rs, res, res_b0, n, kDims[buf].h * kDims[buf].w, kDims[buf].c, slope(), s);
+  }
+  float* rstd_base;  // start of the B_RSTD area of the WHOLE call's layout
+  int n_total, n0;   // tiles of the whole call, first tile of this chunk
   void* ptr(int b) const { return ws + L.off[b]; }
   const void* pptr(int b) const { return prev ? prev + L.off[b] : nullptr; }
 };
@@ -148,7 +182,7 @@ int run3(const Ctx& c, int wi, uncl_conv_desc& d, void* pool_out) {
 // `pooled` >= 0 names the buffer that holds / receives the pooled copy in the bf16 path
 int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, bool pool, int prev_ch = 0,
           int in_pooled = -1, int out_pooled = -1) {
-  uncl_conv_desc d = base_desc(c, wi, 3, pad, cin, cout, c.w->act);
+  uncl_conv_desc d = base_desc(c, wi, 3, pad, cin, cout, c.norm ? UNCL_ACT_NONE : c.w->act);
   const bool pipe = use_pipe(c);
   const int src = (pool && pipe) ? in_pooled : in;
   set_src0(d, c, src);
@@ -157,11 +191,19 @@ int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, boo
   d.W = pool ? kDims[in].w / 2 : kDims[in].w;
   if (prev_ch > 0 && c.prev) { d.prev0 = c.pptr(src); d.prev_ch = prev_ch; }
   set_out(d, c.ptr(out), out);
-  const int rc = run3(c, wi, d, (pipe && out_pooled >= 0) ? c.ptr(out_pooled) : nullptr);
+  int rc = run3(c, wi, d, (pipe && out_pooled >= 0 && !c.norm) ? c.ptr(out_pooled) : nullptr);
+  if (rc != UNCL_OK) return rc;
+  if (c.norm) {
+    // conv -> InstanceNorm -> activation (unet_parts.py:57-75); the pooled copy can only be taken after the norm
+    if ((rc = c.post_norm(c.ptr(out), out)) != UNCL_OK) return rc;
+    if (out_pooled >= 0 && (pipe || c.save_preact))
+      return bwd_maxpool2(c.w->dtype, c.ptr(out), c.ptr(out_pooled), c.n, kDims[out].h, kDims[out].w, kDims[out].c, c.s);
+    return UNCL_OK;
+  }
   // fp32 training (parity) mode: the next stage pools inside its loader, but the backward pass reads the pooled tensor itself
-  if (rc == UNCL_OK && !pipe && out_pooled >= 0 && c.save_preact)
+  if (!pipe && out_pooled >= 0 && c.save_preact)
     return bwd_maxpool2_f32(c.ptr(out), c.ptr(out_pooled), c.n, kDims[out].h, kDims[out].w, kDims[out].c, c.s);
-  return rc;
+  return UNCL_OK;
 }
 
 // decoder stage: ConvT2x2(s2) of `x1` -> up buffer; concat-ssr(skip, up) -> ConvT3x3 -> ConvT3x3
@@ -200,7 +242,7 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
     if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
   }
   if (!fuse_up) {
-    uncl_conv_desc d = base_desc(c, wi_up + 1, 3, 2, 4 * ch, cout, c.w->act);
+    uncl_conv_desc d = base_desc(c, wi_up + 1, 3, 2, 4 * ch, cout, c.norm ? UNCL_ACT_NONE : c.w->act);
     set_src0(d, c, skip);
     d.src1 = c.ptr(upbuf);
     d.src1_H = kDims[upbuf].h; d.src1_W = kDims[upbuf].w; d.src1_C = kDims[upbuf].c;
@@ -208,18 +250,27 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
     d.H = kDims[skip].h; d.W = kDims[skip].w;
     set_out(d, c.ptr(abuf), abuf);
     if ((rc = run3(c, wi_up + 1, d, nullptr)) != UNCL_OK) return rc;
+    if (c.norm && (rc = c.post_norm(c.ptr(abuf), abuf)) != UNCL_OK) return rc;
   }
   {
-    uncl_conv_desc d = base_desc(c, wi_up + 2, 3, 2, cout, cout, c.w->act);
+    uncl_conv_desc d = base_desc(c, wi_up + 2, 3, 2, cout, cout, c.norm ? UNCL_ACT_NONE : c.w->act);
     set_src0(d, c, abuf);
     d.src_mode = UNCL_SRC_PLAIN;
     d.H = kDims[abuf].h; d.W = kDims[abuf].w;
-    set_out(d, final_out ? final_out : c.ptr(outbuf), outbuf);
-    if (tail) {
+    void* outp = final_out ? final_out : c.ptr(outbuf);
+    set_out(d, outp, outbuf);
+    if (tail && !c.norm) {
       d.out1_w = tail->out1_w; d.out1_b = tail->out1_b; d.out1 = tail->out1; d.out1_act = tail->out1_act;
       d.skip_main_store = tail->skip_main_store;
     }
     if ((rc = run3(c, wi_up + 2, d, nullptr)) != UNCL_OK) return rc;
+    if (c.norm) {
+      if ((rc = c.post_norm(outp, outbuf)) != UNCL_OK) return rc;
+      // the 1x1 outconv + last activation reads the normalised features (it is fused into the conv's epilogue otherwise)
+      if (tail)
+        return bwd_outc_forward(c.w->dtype, outp, tail->out1_w, tail->out1_b, tail->out1, (long long)c.n * 256 * 256, tail->out1_act,
+                                c.s);
+    }
   }
   return UNCL_OK;
 }
@@ -255,7 +306,8 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
     set_out(d, c.ptr(B_X0), B_X0);
     RUN(run3(c, W_INC1, d, c.ptr(B_X0P)));
   } else {
-    RUN(uncl_conv_in_c1(x, w->inc0_w, w->inc0_b, c.ptr(B_INC0), w->dtype, c.n, S_IN, S_IN, 32, w->act, c.s));
+    RUN(uncl_conv_in_c1(x, w->inc0_w, w->inc0_b, c.ptr(B_INC0), w->dtype, c.n, S_IN, S_IN, 32, c.norm ? UNCL_ACT_NONE : w->act, c.s));
+    if (c.norm) RUN(c.post_norm(c.ptr(B_INC0), B_INC0));
     RUN(conv3(c, W_INC1, B_INC0, B_X0, 32, 32, 0, false, 0, -1, B_X0P));
   }
   RUN(conv3(c, W_D0A, B_X0, B_D0A, 32, 64, 0, true, 1, B_X0P));
@@ -267,12 +319,13 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   RUN(conv3(c, W_D3A, B_X3, B_D3A, 256, 256, 0, true, 8, B_X3P));
   {
     // transposed 3x3 back to 12x12, ReLU, then + pos_embed (Unet_singleFrame.py:94) fused as a broadcast residual
-    uncl_conv_desc d = base_desc(c, W_D3B, 3, 2, 256, 256, w->act);
+    uncl_conv_desc d = base_desc(c, W_D3B, 3, 2, 256, 256, c.norm ? UNCL_ACT_NONE : w->act);
     set_src0(d, c, B_D3A);
     d.H = S_D3A; d.W = S_D3A;
-    d.res = w->pos_embed; d.res_batch_stride0 = 1;
+    if (!c.norm) { d.res = w->pos_embed; d.res_batch_stride0 = 1; }
     set_out(d, c.ptr(B_X4), B_X4);
     RUN(run3(c, W_D3B, d, nullptr));
+    if (c.norm) RUN(c.post_norm(c.ptr(B_X4), B_X4, w->pos_embed, 1));
   }
   // graph block: Grapher (fc1 -> kNN -> max-relative -> grouped 1x1 + GELU -> fc2, residual) then FFN
   RUN(conv1(c, W_GFC1, B_X4, B_GFC1, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
@@ -304,7 +357,7 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   uncl_conv_desc tail = {};
   tail.out1_w = w->outc_w; tail.out1_b = w->outc_b; tail.out1 = out; tail.out1_act = w->last_act;
   tail.skip_main_store = up_x == nullptr ? 1 : 0;
-  RUN(up_stage(c, W_U3UP, B_U2, B_X0, B_U3UP, B_U3A, B_UPX, 32, 32, 1, up_x, &tail));
+  RUN(up_stage(c, W_U3UP, B_U2, B_X0, B_U3UP, B_U3A, B_UPX, 32, 32, 1, (c.norm && !up_x) ? c.ptr(B_UPX) : up_x, &tail));
 #undef RUN
   return UNCL_OK;
 }
@@ -392,6 +445,18 @@ struct BCtx {
     const int rc = uncl_colsum_finish(q->it, q->n, s);
     q->n = 0; q->channels = 0;
     return rc;
+  }
+  // InstanceNorm models: dL/dzhat (what arrives, already masked by the activation derivative) -> dL/dz of the conv output
+  // that activation buffer `buf` holds, in place, before that conv's weight / data gradients are taken
+  Layout LZ;     // the forward workspace's layout incl. the zhat / rstd buffers
+  int unnorm(void* g, int buf) const {
+    if (!w->norm) return UNCL_OK;
+    const int li = norm_index(buf);
+    if (li < 0) return UNCL_ERR_ARG;
+    int roff = 0;
+    for (int i = 0; i < li; ++i) roff += kDims[kNormBuf[i]].c;
+    const float* rs = reinterpret_cast<const float*>(fws + LZ.off[B_RSTD]) + (size_t)roff * n;
+    return bwd_inorm_backward(dt, g, fws + LZ.off[B_ZN0 + li], rs, n, kDims[buf].h * kDims[buf].w, kDims[buf].c, s);
   }
   bool video() const { return b->carry_in != nullptr || b->carry_out != nullptr; }
   const void* cin(int slot) const { return b->carry_in ? (const char*)b->carry_in + carry_off(slot, n, es) : nullptr; }
@@ -489,9 +554,11 @@ int backward_all(const BCtx& c) {
     const int oh = kDims[q.out].h, ow = kDims[q.out].w, ah = kDims[q.a].h, aw = kDims[q.a].w;
     const int sh = kDims[q.skip].h, sw = kDims[q.skip].w, uh = kDims[q.up].h, uw = kDims[q.up].w;
     // conv b (ConvT 3x3, cout -> cout): input = buffer a
+    RUN(c.unnorm(c.G(q.out), q.out));
     RUN(wgrad3(c, q.wi + 2, q.a, 2, q.cout, q.cout, c.G(q.out), oh, ow));
     RUN(dgrad3(c, q.wi + 2, c.G(q.out), oh, ow, q.cout, 0, q.cout, c.G(q.a), ah, aw, c.F(q.a), 0));
     // conv a (ConvT 3x3 on the concat, 4ch -> cout)
+    RUN(c.unnorm(c.G(q.a), q.a));
     {
       uncl_conv_desc d = bdesc(c, 3, 2, sh, sw, 4 * q.ch, q.cout);
       d.src_mode = UNCL_SRC_CONCAT_SSR;
@@ -555,6 +622,7 @@ int backward_all(const BCtx& c) {
   RUN(bwd_mask_minus(c.dt, c.G(B_X4), c.F(B_X4), c.w->pos_embed, c.sc.tA, c.n, per256, c.slope, c.s));
   // ---- encoder
   // down3: conv (valid, pooled X3 -> D3A), ConvT (D3A -> X4)
+  RUN(c.unnorm(c.sc.tA, B_X4));
   RUN(wgrad3(c, W_D3B, B_D3A, 2, 256, 256, c.sc.tA, 12, 12));
   RUN(dgrad3(c, W_D3B, c.sc.tA, 12, 12, 256, 0, 256, c.G(B_D3A), 10, 10, c.F(B_D3A), 0));
   struct Enc { int wa, wb, xin, pooled, mid, out, cin, cout; };
@@ -563,6 +631,7 @@ int backward_all(const BCtx& c) {
                      {W_D1A, W_D1B, B_X1, B_X1P, B_D1A, B_X2, 64, 128},
                      {W_D0A, W_D0B, B_X0, B_X0P, B_D0A, B_X1, 32, 64}};
   // down3's first conv reads pooled X3
+  RUN(c.unnorm(c.G(B_D3A), B_D3A));
   {
     const void* xm = c.mixed(3);
     if (!xm) return UNCL_ERR_LAUNCH;
@@ -574,18 +643,22 @@ int backward_all(const BCtx& c) {
   for (int i = 0; i < 3; ++i) {
     const Enc& e = en[i];
     const int oh = kDims[e.out].h, mh = kDims[e.mid].h, ph = kDims[e.pooled].h, xh = kDims[e.xin].h;
+    RUN(c.unnorm(c.G(e.out), e.out));
     RUN(wgrad3(c, e.wb, e.mid, 0, e.cout, e.cout, c.G(e.out), oh, oh));
     RUN(dgrad3(c, e.wb, c.G(e.out), oh, oh, e.cout, 2, e.cout, c.G(e.mid), mh, mh, c.F(e.mid), 0));
     const void* xm = c.mixed(2 - i);
     if (!xm) return UNCL_ERR_LAUNCH;
+    RUN(c.unnorm(c.G(e.mid), e.mid));
     RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh, xm));
     RUN(dgrad3(c, e.wa, c.G(e.mid), mh, mh, e.cout, 2, e.cin, c.sc.gpool, ph, ph, nullptr, 0));
     RUN(c.handoff(2 - i, c.sc.gpool, nullptr));
     RUN(bwd_pool_backward(c.dt, c.sc.gpool, c.F(e.xin), c.G(e.xin), c.n, xh, xh, e.cin, c.slope, 1, c.s));
   }
   // inc: conv1 (INC0 -> X0), conv (image -> INC0)
+  RUN(c.unnorm(c.G(B_X0), B_X0));
   RUN(wgrad3(c, W_INC1, B_INC0, 0, 32, 32, c.G(B_X0), 252, 252));
   RUN(dgrad3(c, W_INC1, c.G(B_X0), 252, 252, 32, 2, 32, c.G(B_INC0), 254, 254, c.F(B_INC0), 0));
+  RUN(c.unnorm(c.G(B_INC0), B_INC0));
   RUN(bwd_conv_in_c1_wgrad(c.dt, c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, b->accumulate, c.sc.misc, c.s));
 #undef RUN
   return UNCL_OK;
@@ -630,9 +703,12 @@ extern "C" const char* uncl_gen_layer_name(int i) {
 }
 
 extern "C" size_t uncl_gen_workspace_bytes(int N, int chunk, int dtype, int keep_activations) {
+  return uncl_gen_workspace_bytes_ex(N, chunk, dtype, keep_activations, 0);
+}
+extern "C" size_t uncl_gen_workspace_bytes_ex(int N, int chunk, int dtype, int keep_activations, int norm) {
   if (N <= 0) return 0;
   if (chunk <= 0 || chunk > N) chunk = N;
-  return make_layout(keep_activations ? N : chunk, dtype).total;
+  return make_layout(keep_activations ? N : chunk, dtype, norm && keep_activations).total;
 }
 
 // Side streams and fork / join events of the multi-stream forward, one set per device (a process may drive several GPUs, and
@@ -668,7 +744,8 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   int chunk = r->chunk;
   if (chunk <= 0 || chunk > r->N) chunk = r->N;
   const int n_alloc = r->keep_activations ? r->N : chunk;
-  Layout L = make_layout(n_alloc, w->dtype);
+  if (w->norm != 0 && w->norm != 1) return UNCL_ERR_ARG;
+  Layout L = make_layout(n_alloc, w->dtype, w->norm && r->keep_activations);
   if (r->workspace_bytes < L.total) return UNCL_ERR_ARG;
   const size_t es = uncl_is_h16(w->dtype) ? 2 : 4;
   // A large un-chunked inference batch runs as up to four contiguous parts on as many streams (the caller's and internal
@@ -707,8 +784,13 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.n = (r->N - n0 < chunk) ? r->N - n0 : chunk;
     c.save_preact = r->save_preact;
     // the backward pass reads inc.conv.conv's output (ReLU mask, weight gradient), the video path hands its channels on
-    c.fuse_in = uncl_is_h16(w->dtype) && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr;
+    // a norm sits between the fused layers' convolution and activation: no loader-side recomputation then
+    c.fuse_in = uncl_is_h16(w->dtype) && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr && !w->norm;
     c.fuse_up = c.fuse_in;
+    c.norm = w->norm;
+    c.norm_keep = w->norm && r->keep_activations;
+    c.rstd_base = reinterpret_cast<float*>(reinterpret_cast<char*>(r->workspace) + L.off[B_RSTD]);
+    c.n_total = r->N; c.n0 = n0;
     c.s = (split2 && n0 > 0) ? ss->side[n0 / chunk - 1] : main_s;
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
@@ -733,7 +815,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
       // join, then the last decoder stage for the whole batch on the caller's stream
       if (join_sides() != UNCL_OK) return UNCL_ERR_LAUNCH;
       Ctx cw = c;
-      cw.n = r->N; cw.L = L; cw.s = main_s;
+      cw.n = r->N; cw.L = L; cw.s = main_s; cw.n0 = 0;
       return run_chunk(cw, r->x, r->out, r->up_x, nullptr, nullptr, nullptr, 2);
     }
   }
@@ -765,6 +847,7 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   c.dt = w->dtype;
   c.es = w->dtype == UNCL_F32 ? 4 : 2;
   c.L = make_layout(b->N, w->dtype);
+  c.LZ = make_layout(b->N, w->dtype, w->norm);
   c.fws = reinterpret_cast<char*>(b->workspace);
   c.pws = reinterpret_cast<const char*>(b->prev_workspace);
   c.gws = reinterpret_cast<char*>(b->grad_workspace);

@@ -75,8 +75,9 @@ class _GeneratorBase(nn.Module):
             unsupported.append("decoder must be doubleConvTranspose=1, up_mode=0, bilinear=0, convtranspose_kernel=2")
         if n_channels != 1 or output_dim != 1:
             unsupported.append("n_channels/output_dim must be 1")
-        if unet_norm not in ("none", None):
-            unsupported.append("unet_norm=%s (HIP path covers 'none')" % unet_norm)
+        if unet_norm not in ("none", None, "instance_norm"):
+            # batch_norm would need running statistics in the state_dict; no published configuration uses it
+            unsupported.append("unet_norm=%s (HIP path covers 'none' and 'instance_norm')" % unet_norm)
         if last_layer not in _LAST:
             unsupported.append("last_layer=%s" % last_layer)
         if stretch_g not in ("none", None):
@@ -84,6 +85,7 @@ class _GeneratorBase(nn.Module):
         if unsupported:
             raise NotImplementedError("generator configuration outside the published topology: " + "; ".join(unsupported))
         self.to_crop = to_crop
+        self.unet_norm = unet_norm if unet_norm not in (None,) else "none"
         self.con_operator = con_operator
         self.network = network
         self.depth = depth
@@ -221,6 +223,7 @@ class _GeneratorBase(nn.Module):
         gw.relative_pos = f32("gcn.module.0.0.relative_pos")
         gw.outc_w, gw.outc_b = f32("outc.conv.weight"), f32("outc.conv.bias")
         gw.act = _ACT[self.activation]
+        gw.norm = 1 if self.unet_norm == "instance_norm" else 0
         gw.last_act = _LAST[self.last_layer]
         self._packed = (gw, keep)
         self._pack_key = key
@@ -229,7 +232,7 @@ class _GeneratorBase(nn.Module):
     def _workspace(self, n, chunk, keep_act, dev, slot=0):
         lib = _hip.lib()
         code = self._dtype_code()
-        nbytes = lib.uncl_gen_workspace_bytes(n, chunk, code, int(keep_act))
+        nbytes = lib.uncl_gen_workspace_bytes_ex(n, chunk, code, int(keep_act), 1 if self.unet_norm == "instance_norm" else 0)
         k = (slot, dev)
         ws = self._ws.get(k)
         if ws is None or ws.numel() < nbytes:
