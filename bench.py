@@ -268,7 +268,7 @@ def make_trainer(rk, video):
     G.train()
     optG, optD = Adam(G.parameters(), lr=1e-5, betas=(0.5, 0.999)), Adam(D.parameters(), lr=1.5e-5, betas=(0.5, 0.999))
     if rk.dist:
-        optG, optD = DistributedOptimizer(optG), DistributedOptimizer(optD)
+        optG, optD = DistributedOptimizer(optG, module=G), DistributedOptimizer(optD)
     opt = types.SimpleNamespace(device=dev, pyramid_weight_list=torch.tensor([1.0, 1.0, 1.0]), ssim_loss_factor=1.0,
                                 ssim_window_size=5, struct_method="gamma_ssim", add_frame=0, final_shape_addition=0,
                                 loss_g_d_factor=0.1, adv_weight_list=torch.tensor([0.2, 0.2, 0.2]))

@@ -299,6 +299,9 @@ typedef struct uncl_gen_bwd {
   const void* prev_workspace;/* forward workspace of frame k-1 (NULL for the first frame of a clip)           */
   const void* carry_in;      /* uncl_gen_carry_bytes(N): head gradients sent back by frame k+1, or NULL        */
   void* carry_out;           /* receives the head gradients of frame k-1; required iff prev_workspace != NULL */
+  void* ev_decoder_done;     /* optional hipEvent_t, recorded on the stream once the weight gradients of the decoder (packed
+                                weights 14..25, outc) are complete while the graph block and the encoder are still to run: a data-
+                                parallel caller starts the all-reduce of that half there (uncltmo_amd/distributed.py)            */
 } uncl_gen_bwd;
 size_t uncl_gen_backward_workspace_bytes(int N);
 size_t uncl_gen_carry_bytes(int N);

@@ -333,3 +333,34 @@ def test_fp32_step_vs_reference_golden_and_oracle(golden, video, epoch):
         diff = (v.cpu()[sel] - ref_p[sel]).abs()
         flips = (diff > 2e-7).float().mean().item() if diff.numel() else 0.0
         assert flips <= (0.05 if loose(k) or k.startswith("down_path.2.") else 0.02), (k, flips)
+
+
+def test_overlapped_in_place_gradient_allreduce_matches_plain_step():
+    """DistributedOptimizer(module=G): the generator's flat gradient buffers are all-reduced in place over RCCL (decoder half on
+    a side stream from its event on), .grad is re-pointed at the reduced views.  On one GPU (world size 1 with the forced
+    data-parallel path) the step must leave exactly the parameters of the plain step."""
+    import os
+    import torch.distributed as td
+    from uncltmo_amd.distributed import DistributedOptimizer
+    os.environ["UNCL_FORCE_DIST"] = "1"
+    td.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29700 + os.getpid() % 200), rank=0, world_size=1,
+                          device_id=torch.device("cuda", 0))
+    try:
+        after = []
+        for wrap in (False, True):
+            tr, G, D = _fp32_trainer(False)             # fp32 mode: deterministic, so the two runs can be compared exactly
+            if wrap:
+                tr.optimizerG = DistributedOptimizer(tr.optimizerG, module=G)
+                tr.optimizerD = DistributedOptimizer(tr.optimizerD)
+                assert G._grad_reducer.active()
+            hdr, pos, neg = step_inputs()
+            for _ in range(2):
+                tr.train_D(hdr, pos, neg, 0)
+                tr.train_G(hdr, hdr.clone(), pos, neg, 0)
+            torch.cuda.synchronize()
+            after.append({k: v.clone() for k, v in G.state_dict().items()})
+        for k in after[0]:
+            assert torch.equal(after[0][k], after[1][k]), k
+    finally:
+        td.destroy_process_group()
+        os.environ.pop("UNCL_FORCE_DIST", None)

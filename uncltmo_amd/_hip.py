@@ -69,6 +69,7 @@ class GenBwd(C.Structure):
         ("g_inc0_w", C.c_void_p), ("g_inc0_b", C.c_void_p), ("g_outc_w", C.c_void_p), ("g_outc_b", C.c_void_p),
         ("g_pos_embed", C.c_void_p),
         ("accumulate", C.c_int), ("prev_workspace", C.c_void_p), ("carry_in", C.c_void_p), ("carry_out", C.c_void_p),
+        ("ev_decoder_done", C.c_void_p),
     ]
 
 

@@ -22,15 +22,27 @@ class _GradSet:
         self.names = [lib.uncl_gen_layer_name(i).decode() for i in range(_hip.G_NUM_WEIGHTS)]
         self.sizes = [int(torch.tensor(self.spec[nm + ".weight"][0]).prod()) for nm in self.names]
         self.gw_flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)   # packed, accumulated with atomics
-        self.gb = [torch.empty(self.spec[nm + ".bias"][0], dtype=torch.float32, device=dev) for nm in self.names]
-        self.g_inc_w = torch.empty(32, 1, 3, 3, dtype=torch.float32, device=dev)
-        self.g_inc_b = torch.empty(32, dtype=torch.float32, device=dev)
-        self.g_oc_w = torch.empty(32, dtype=torch.float32, device=dev)
-        self.g_oc_b = torch.empty(1, dtype=torch.float32, device=dev)
-        self.g_pe = torch.empty(144, 256, dtype=torch.float32, device=dev)
+        # every other gradient (biases, first layer, outconv, pos_embed) is a view of ONE flat buffer, the unpacked weights of
+        # another: a data-parallel step all-reduces two or three flat tensors in place instead of concatenating 57 of them
+        bsz = [int(torch.tensor(self.spec[nm + ".bias"][0]).prod()) for nm in self.names]
+        extra = [288, 32, 32, 1, 144 * 256]
+        self.small = torch.empty(sum(bsz) + sum(extra), dtype=torch.float32, device=dev)
+        off, self.gb = 0, []
+        for n_ in bsz:
+            self.gb.append(self.small[off:off + n_])
+            off += n_
+        self.g_inc_w = self.small[off:off + 288].view(32, 1, 3, 3); off += 288
+        self.g_inc_b = self.small[off:off + 32]; off += 32
+        self.g_oc_w = self.small[off:off + 32]; off += 32
+        self.g_oc_b = self.small[off:off + 1]; off += 1
+        self.g_pe = self.small[off:off + 144 * 256].view(144, 256)
+        self.flat = torch.empty(sum(self.sizes), dtype=torch.float32, device=dev)      # unpacked weights, layer order
+        self.w_off = [sum(self.sizes[:i]) for i in range(len(self.sizes) + 1)]
+        self.DEC0 = 14            # packed weights 14..25 are the decoder's (uncl_gen_layer_name order)
+        self.ev_half = None
         self.gws = None
 
-    def run(self, xf, out, up, ws, ds, g_out, gup, accumulate=False, prev_ws=None, carry_in=None, carry_out=None):
+    def run(self, xf, out, up, ws, ds, g_out, gup, accumulate=False, prev_ws=None, carry_in=None, carry_out=None, ev_half=None):
         """One uncl_gen_backward call over the n samples of (xf, out, up, ws)."""
         lib = _hip.lib()
         module = self.module
@@ -57,33 +69,64 @@ class _GradSet:
         b.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
         b.carry_in = carry_in.data_ptr() if carry_in is not None else None
         b.carry_out = carry_out.data_ptr() if carry_out is not None else None
+        b.ev_decoder_done = None
+        if ev_half is not None:
+            h = ev_half.cuda_event
+            b.ev_decoder_done = h.value if hasattr(h, "value") else int(h)
+            if not b.ev_decoder_done:
+                raise _hip.HipError("the decoder-done event has no HIP handle yet (record it once before the call)")
         _hip.check(lib.uncl_gen_backward(C.byref(gwts), C.byref(b), _hip.stream_ptr()), "uncl_gen_backward")
 
-    def unpack(self):
-        """packed [tap][Cout][Cin] -> reference parameter layout, keyed by state_dict name"""
+    def unpack(self, lo=0, hi=None):
+        """packed [tap][Cout][Cin] -> reference parameter layout for the layers lo <= i < hi (views of self.flat), one launch"""
         lib = _hip.lib()
-        st = _hip.stream_ptr()
-        grads = {"inc.conv.conv.weight": self.g_inc_w, "inc.conv.conv.bias": self.g_inc_b,
-                 "outc.conv.weight": self.g_oc_w.reshape(1, 32, 1, 1), "outc.conv.bias": self.g_oc_b,
-                 "gcn.pos_embed": self.g_pe.t().reshape(1, 256, 12, 12).contiguous()}
-        off = 0
-        items = (_hip.UnpackItem * len(self.names))()
-        flat = torch.empty(sum(self.sizes), dtype=torch.float32, device=self.dev)      # one allocation, one launch
-        for i, nm in enumerate(self.names):
-            shape, kind = self.spec[nm + ".weight"]
+        hi = len(self.names) if hi is None else hi
+        items = (_hip.UnpackItem * (hi - lo))()
+        for j, i in enumerate(range(lo, hi)):
+            shape, kind = self.spec[self.names[i] + ".weight"]
             transposed = kind == "convT"
             k = shape[2]
             cout, cin = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
-            dst = flat[off:off + self.sizes[i]].view(shape)
-            it = items[i]
-            it.packed, it.dst = self.gw_flat.data_ptr() + off * 4, dst.data_ptr()
+            it = items[j]
+            it.packed, it.dst = self.gw_flat.data_ptr() + self.w_off[i] * 4, self.flat.data_ptr() + self.w_off[i] * 4
             it.Cout, it.Cin, it.k, it.transposed, it.flip, it.accumulate = cout, cin, k, int(transposed), \
                 (1 if (transposed and k == 3) else 0), 0
-            grads[nm + ".weight"] = dst
-            grads[nm + ".bias"] = self.gb[i]
-            off += self.sizes[i]
-        _hip.check(lib.uncl_unpack_conv_wgrads(items, len(self.names), st), "uncl_unpack_conv_wgrads")
-        return grads
+        _hip.check(lib.uncl_unpack_conv_wgrads(items, hi - lo, _hip.stream_ptr()), "uncl_unpack_conv_wgrads")
+
+    def grads(self):
+        """state_dict name -> gradient tensor (views of self.flat / self.small)"""
+        g = {"inc.conv.conv.weight": self.g_inc_w, "inc.conv.conv.bias": self.g_inc_b,
+             "outc.conv.weight": self.g_oc_w.reshape(1, 32, 1, 1), "outc.conv.bias": self.g_oc_b,
+             "gcn.pos_embed": self.g_pe.t().reshape(1, 256, 12, 12).contiguous()}
+        for i, nm in enumerate(self.names):
+            g[nm + ".weight"] = self.flat[self.w_off[i]:self.w_off[i + 1]].view(self.spec[nm + ".weight"][0])
+            g[nm + ".bias"] = self.gb[i]
+        return g
+
+    def finish(self, last_run):
+        """Unpack everything after the last uncl_gen_backward call of a pass (`last_run(ev)` makes that call).  With a
+        data-parallel reducer attached to the module the decoder half is unpacked and all-reduced on a side stream as soon as
+        its event fires, under the graph block's and the encoder's kernels; the rest follows on the caller's stream."""
+        red = getattr(self.module, "_grad_reducer", None)
+        if red is None or not red.active():
+            last_run(None)
+            self.unpack()
+            return self.grads()
+        ev = torch.cuda.Event()
+        ev.record()             # torch creates the hipEvent lazily: record once so that the raw handle exists, the library
+        last_run(ev)            # records it again where the decoder's gradients are final
+        cut = self.w_off[self.DEC0]
+        with torch.cuda.stream(red.stream(self.dev)):
+            red.stream(self.dev).wait_event(ev)
+            self.unpack(self.DEC0, len(self.names))
+            red.launch(self.flat[cut:], self)
+        self.unpack(0, self.DEC0)
+        g = self.grads()        # pos_embed's gradient is a transposed COPY of its slot in `small`, made before the reductions
+        red.launch(self.flat[:cut], self)
+        red.launch(self.small, self)
+        red.launch(g["gcn.pos_embed"], self)
+        red.keep(self, g)
+        return g
 
 
 class _GeneratorFn(torch.autograd.Function):
@@ -110,8 +153,7 @@ class _GeneratorFn(torch.autograd.Function):
         if g_upx is not None:
             gup = g_upx.permute(0, 2, 3, 1).to(_hip.torch_dtype(module._dtype_code())).contiguous()
         gs = _GradSet(module, xf.device)
-        gs.run(xf, out, up, ws, ds, g_out, gup)
-        grads = gs.unpack()
+        grads = gs.finish(lambda ev: gs.run(xf, out, up, ws, ds, g_out, gup, ev_half=ev))
         return (None, None) + tuple(grads.get(k) for k in ctx.pnames)
 
 
@@ -162,9 +204,11 @@ class _VideoGeneratorFn(torch.autograd.Function):
                                                          _hip.stream_ptr()), "uncl_gauss_stats_backward")
             carry_in = carries[(t + 1) % 2] if t < T - 1 else None      # written by frame t+1
             carry_out = carries[t % 2] if t > 0 else None               # read by frame t-1
-            gs.run(xf, out, up, ws, ds, go, gup, accumulate=(t != T - 1), prev_ws=frames[t - 1][3] if t > 0 else None,
-                   carry_in=carry_in, carry_out=carry_out)
-        grads = gs.unpack()
+            call = lambda ev, a_=(xf, out, up, ws, ds, go, gup), t_=t, ci=carry_in, co=carry_out: gs.run(
+                *a_, accumulate=(t_ != T - 1), prev_ws=frames[t_ - 1][3] if t_ > 0 else None, carry_in=ci, carry_out=co, ev_half=ev)
+            if t > 0:
+                call(None)
+        grads = gs.finish(call)         # frame 0: the last call of the pass
         # the saved activations stay with the graph node: the reference calls backward twice on it
         # (errG_d.backward(retain_graph=True), then the structural loss; GanTrainer.py:338,461)
         return (None, None) + tuple(grads.get(k) for k in ctx.pnames)

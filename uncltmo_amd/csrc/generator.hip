@@ -588,6 +588,11 @@ int backward_all(const BCtx& c) {
                                c.s));
     RUN(c.handoff(slot, c.G(q.x1), x1mask));
   }
+  // the decoder's parameter gradients are final from here on (biases: staged column sums are flushed first)
+  if (b->ev_decoder_done) {
+    RUN(c.flush_colsums());
+    if (hipEventRecord(reinterpret_cast<hipEvent_t>(b->ev_decoder_done), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
+  }
   // ---- graph block
   const float* drop0 = b->drop_scale;
   const float* drop1 = b->drop_scale ? b->drop_scale + c.n : nullptr;

@@ -45,17 +45,90 @@ def allreduce_gradients(params, bucket_bytes=32 << 20, group=None):
     flush()
 
 
+class GradReducer:
+    """In-place, overlapped gradient all-reduce for the HIP generator (uncltmo_amd/autograd.py:_GradSet.finish).
+
+    The generator's backward pass produces its parameter gradients as views of three flat fp32 buffers.  With a reducer attached
+    to the module, those buffers are all-reduced IN PLACE (no concatenation, no copy back): the decoder's weights on a side
+    stream from the moment their event fires -- while the graph block and the encoder are still running their backward kernels
+    on the caller's stream -- the encoder's weights and the small tensors right after the pass.  `finish` (called by
+    DistributedOptimizer.step) waits, divides by the world size and points every .grad at its reduced view.  xGMI rings are
+    per-link bound: three large messages per step, not 57 small ones."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._streams = {}
+        self._pending = []
+        self._grads = None
+        self._calls = 0
+
+    def active(self):
+        import os
+        if not td.is_available() or not td.is_initialized():
+            return False
+        return td.get_world_size(self.group) > 1 or os.environ.get("UNCL_FORCE_DIST") == "1"
+
+    def stream(self, dev):
+        if dev not in self._streams:
+            self._streams[dev] = torch.cuda.Stream(device=dev)
+        return self._streams[dev]
+
+    def launch(self, tensor, owner):
+        self._pending.append((td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.group, async_op=True), tensor, owner))
+
+    def keep(self, owner, grads):
+        self._grads = grads
+        self._calls += 1
+
+    def reset(self):
+        for work, _, _ in self._pending:
+            work.wait()
+        self._pending, self._grads, self._calls = [], None, 0
+
+    def finish(self, named_params):
+        """True if the gradients of this step were reduced here (exactly one backward pass since the last step: a second pass
+        accumulates into .grad outside these buffers, and the generic bucketed path takes over)."""
+        if self._calls != 1 or self._grads is None:
+            self.reset()
+            return False
+        world = td.get_world_size(self.group)
+        for work, t, _ in self._pending:
+            work.wait()                      # the current stream waits for the collective; the host does not block
+            if world > 1:
+                t.div_(world)
+        for k, p in named_params:
+            g = self._grads.get(k)
+            if g is not None and p.requires_grad:
+                p.grad = g
+        self._pending, self._grads, self._calls = [], None, 0
+        return True
+
+
 class DistributedOptimizer:
     """Wraps an optimizer so that step() first averages the gradients across ranks (what DistributedDataParallel's
-    reducer does for nn.DataParallel-free training); everything else is forwarded."""
+    reducer does for nn.DataParallel-free training); everything else is forwarded.  `module` = the HIP generator whose
+    parameters the optimizer updates: its backward pass then reduces its own flat gradient buffers in place, overlapped with
+    the backward tail (GradReducer); any other case (the discriminator's 12 373 gradients, a two-pass backward) goes through
+    allreduce_gradients."""
 
-    def __init__(self, optimizer, bucket_bytes=32 << 20):
+    def __init__(self, optimizer, bucket_bytes=32 << 20, module=None):
         self.optimizer = optimizer
         self.bucket_bytes = bucket_bytes
+        self.module = module
+        if module is not None and hasattr(module, "_packed_weights"):
+            module._grad_reducer = GradReducer()
 
     def step(self, *a, **k):
-        allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]], self.bucket_bytes)
+        red = getattr(self.module, "_grad_reducer", None) if self.module is not None else None
+        if red is None or not red.finish(list(self.module.named_parameters())):
+            allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]], self.bucket_bytes)
         return self.optimizer.step(*a, **k)
+
+    def zero_grad(self, *a, **k):
+        red = getattr(self.module, "_grad_reducer", None) if self.module is not None else None
+        if red is not None:
+            red.reset()
+        return self.optimizer.zero_grad(*a, **k)
 
     def __getattr__(self, name):
         return getattr(self.optimizer, name)
