@@ -467,6 +467,18 @@ int uncl_rgbe_to_planes(const uint8_t* rgbe, float* out, int H, int W, int scale
  * rgb min / max, luminance min / max. */
 int uncl_hdr_log_gray(const float* rgb, int H, int W, float f_factor, float* rgb_out, float* gray_log, float* stats, void* workspace,
                       void* stream);
+/* GPU-side data path of the trainers: the pixel arithmetic of npy_loader (utils/ProcessedDatasetFolderImg.py:43-206,
+ * utils/ProcessedDatasetFolder.py:43-236); the random choices stay on the host.
+ * uncl_loader_resize_crop: src (H, W, 3) fp32 -> the patch x patch window at (yy, xx) of cv2.resize(src, (rw, rh)) (INTER_LINEAR;
+ *   rh == H, rw == W: a copy) as color (3, patch, patch) and y_plane (patch, patch; NULL to skip) = y_scale * the Y row of
+ *   cv2.cvtColor(RGB2YUV), 0.299 R + 0.587 G + 0.114 B ("bugy_max_normalization": y_scale = 1/255, :18-19).
+ * uncl_loader_gray_outputs: gray_norm = Y / Y.max(), gray_shift = Y - Y.min() from the stats uncl_hdr_log_gray wrote (:137-144).
+ * uncl_loader_ldr_normalize: "max_normalization" (mode 0) / "stretch" (mode 1) of get_ldr_im (:15-24), in place. */
+int uncl_loader_resize_crop(const float* src_hwc, int H, int W, int rh, int rw, int yy, int xx, int patch, float y_scale,
+                            float* color_chw, float* y_plane, void* stream);
+int uncl_loader_gray_outputs(const float* color_chw, int H, int W, const float* stats, float* gray_norm, float* gray_shift,
+                             void* stream);
+int uncl_loader_ldr_normalize(float* x, long long n, int mode, float max_stretch, float min_stretch, void* workspace, void* stream);
 /* F.pad(x, (left, W1-W-left, top, H1-H-top), mode='replicate') on `planes` planes of H x W
  * (data_loader_util.add_frame_to_im / add_frame_to_im_batch / resize_im, utils/data_loader_util.py:135-185) */
 int uncl_replicate_pad(const float* x, float* y, int planes, int H, int W, int top, int left, int H1, int W1, void* stream);

@@ -339,6 +339,38 @@ def capture_generator_inorm(out):
         out["inorm.gradval." + k] = g[torch.from_numpy(pos_)].numpy()
 
 
+def loader_hdr_array():
+    """(256, 256, 3) linear radiance, heavy-tailed: already 256 high, so the reference's HDR branch neither resizes nor crops"""
+    u = synth.hash_uniform("loader_hdr", 256 * 256 * 3).astype(np.float64) ** 4
+    return (u * 4000.0 + 0.01).astype(np.float32).reshape(256, 256, 3)
+
+
+def capture_loader(out):
+    """npy_loader's HDR branch (utils/ProcessedDatasetFolderImg.py:103-160) run from the reference on a 256 x 256 array: the cv2
+    steps are skipped by the reference itself at that size (resize, crop) or unused in this branch (cvtColor's Y), so the
+    capture pins to_gray_tensor, the shift, the log10 compression and the normalisations without any cv2 stand-in."""
+    import tempfile
+    import cv2
+    from utils import ProcessedDatasetFolderImg as PD
+    cv2.cvtColor = lambda im, code: np.zeros_like(im)      # its result is overwritten in hdrMode (:131,143-145)
+    cv2.COLOR_RGB2YUV = 0
+    PD.preprocess = lambda raw: torch.from_numpy(raw.transpose((0, 3, 1, 2)))     # the reference's, minus .cuda()
+    d = tempfile.mkdtemp()
+    np.save(os.path.join(d, "sample.npy"), loader_hdr_array())
+    np.save(os.path.join(d, "lambdas.npy"), {"sample": np.float64(0.37)}, allow_pickle=True)
+    for add_frame in (0, 1):
+        inp, col, gnorm, gray, bf = PD.npy_loader(os.path.join(d, "sample.npy"), add_frame, True, False, "bugy_max_normalization", 0.0,
+                                                  1.0, 0.1, False, True, os.path.join(d, "lambdas.npy"), 16, False)
+        tag = "loader.hdr.frame%d" % add_frame
+        assert torch.equal(inp[0], inp[1])              # no random choice at this size: the two frames are the same
+        out.update(summarize(inp[0], tag + ".input", 4096))
+        out[tag + ".bf"] = np.float64(bf)
+        if not add_frame:
+            out.update(summarize(gnorm[0], tag + ".gray_norm", 4096))
+            out.update(summarize(gray[0], tag + ".gray", 4096))
+            out.update(summarize(col[0], tag + ".color", 1024))
+
+
 def capture_tiler(out):
     from utils import model_save_util
     torch.Tensor.cuda = lambda self, *a, **k: self          # the tiler hard-codes .cuda() (model_save_util.py:414)
@@ -440,12 +472,12 @@ def capture_tmqi(out):
 
 def main():
     which = sys.argv[1:] or ["generator", "generator_inorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
-                             "inference", "tmqi"]
+                             "inference", "tmqi", "loader"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
             "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "vid_c4": lambda o: capture_step_c4(o),
-            "generator_inorm": lambda o: capture_generator_inorm(o),
+            "generator_inorm": lambda o: capture_generator_inorm(o), "loader": lambda o: capture_loader(o),
             "tiler": lambda o: capture_tiler(o),
             "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o)}
     for name in which:

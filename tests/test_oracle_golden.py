@@ -205,3 +205,19 @@ def test_full_tmqi_matches_reference_class(golden):
         Q, S, N, sl = OT.tmqi(hdr, ldr)
         np.testing.assert_allclose([Q, S, N], g["tmqi.%s.QSN" % salt], rtol=1e-9)
         np.testing.assert_allclose(sl, g["tmqi.%s.s_local" % salt], rtol=1e-9)
+
+
+def test_loader_hdr_branch_oracle_vs_reference_golden(golden):
+    """oracle/data_loader.py's HDR branch against the reference's own npy_loader output (make_golden.py loader)"""
+    from oracle import data_loader as OD
+    from uncltmo_amd import synth
+    g = golden("loader")
+    u = synth.hash_uniform("loader_hdr", 256 * 256 * 3).astype(np.float64) ** 4
+    arr = (u * 4000.0 + 0.01).astype(np.float32).reshape(256, 256, 3)
+    bf = float(g["loader.hdr.frame0.bf"])
+    assert abs(bf - 0.37 * 255 * 0.1) < 1e-9          # get_f (ProcessedDatasetFolderImg.py:27-36)
+    out = OD.frame(arr, (256, 256, 0, 0), True, brightness_factor=bf)
+    check_summary(torch.from_numpy(out["input"]), g, "loader.hdr.frame0.input", rtol=2e-5, atol=2e-6)
+    check_summary(torch.from_numpy(out["gray_norm"]), g, "loader.hdr.frame0.gray_norm", rtol=2e-6, atol=1e-7)
+    check_summary(torch.from_numpy(out["gray"]), g, "loader.hdr.frame0.gray", rtol=2e-6, atol=1e-4)
+    check_summary(torch.from_numpy(out["color"]), g, "loader.hdr.frame0.color", rtol=0, atol=0)

@@ -152,6 +152,10 @@ SIGNATURES = {
                                   C.c_void_p]),
     "uncl_gen_layer_name": (C.c_char_p, [C.c_int]),
     "uncl_gen_set_streams": (C.c_int, [C.c_int]),
+    "uncl_loader_resize_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uncl_loader_gray_outputs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uncl_loader_ldr_normalize": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "uncl_percentile_lerp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "uncl_color_finish_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p]),
