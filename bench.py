@@ -296,15 +296,22 @@ def make_trainer(rk, video):
 
 
 def train_numbers(a, rk, video, steps, warmup):
+    import torch
     tr, step, n = make_trainer(rk, video)
-    dt, per_rank, _ = rk.timed(step, steps, warmup)
+    for _ in range(warmup):
+        step()
+    st0 = torch.cuda.memory_stats()
+    dt, per_rank, _ = rk.timed(step, steps, 0)
+    st1 = torch.cuda.memory_stats()
+    dev_allocs = st1.get("num_device_alloc", 0) - st0.get("num_device_alloc", 0)
+    dev_frees = st1.get("num_device_free", 0) - st0.get("num_device_free", 0)
     ms = dt / steps * 1e3
     # per frame: 2 generator forwards; backward = 2 x forward FLOPs per pass.  SURVEY §8(d) counts the reference's two
     # backward passes (109.7 GFLOP per frame); this build feeds the summed output gradient through ONE pass (73.1 GFLOP).
     tfl_1 = n * (2 * GFLOP_PER_TILE + 2 * GFLOP_PER_TILE) / ms
     tfl_2 = n * (2 * GFLOP_PER_TILE + 4 * GFLOP_PER_TILE) / ms
     return {"ms_per_step": ms, "frames_per_s": rk.world * n * steps / dt, "frames_per_step_per_gpu": n, "steps": steps,
-            "warmup": warmup, "dtype": "bf16",
+            "warmup": warmup, "dtype": "bf16", "device_mallocs_in_timed_steps": dev_allocs, "device_frees_in_timed_steps": dev_frees,
             "workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, Adam): 2 clips of "
                          "512x512 x T=5 per GPU cut into 4 crops of 256x256 each, epoch regime 0 (BASELINE configs[3])") if video
             else ("GanTrainerImg step (train_D + train_G, all losses, Adam): 32 frames of 256x256 per GPU, epoch regime 0 "
@@ -376,7 +383,7 @@ def infer_bench(a, rk):
 
     for _ in range(a.warmup):
         step()
-    lib.uncl_prof_enable(DOM_LAYER, 4096)
+    lib.uncl_prof_enable(DOM_LAYER, max(64, 2 * a.steps + 16))
     dt, per_rank, out = rk.timed(step, a.steps, 0)
     # per-launch durations of the dominant kernel, recorded by HIP events on the launch stream during the steps
     buf = (ctypes.c_float * 4096)()
@@ -404,7 +411,9 @@ def infer_bench(a, rk):
 
     train = {}
     if not a.no_train and a.dtype == "bf16":
-        del out
+        # the training legs are separate workloads: the inference model, its 6 GB workspace and the frames go first
+        del out, step, net, frames
+        torch.cuda.empty_cache()
         for key, video in (("train_step", False), ("train_video_step", True)):
             train[key], _ = train_numbers(a, rk, video, 10, 3)
             torch.cuda.empty_cache()

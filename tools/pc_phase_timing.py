@@ -30,8 +30,9 @@ def build():
     for s in srcs:
         o = os.path.join(out, os.path.basename(s) + ".pct.o")
         objs.append(o)
+        extra = os.environ.get("UNCL_PC_BUILD_FLAGS", "").split()
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-DUNCL_PC_TIMING",
-                                       "-c", s, "-o", o]))
+                                       *extra, "-c", s, "-o", o]))
     for p in procs:
         if p.wait() != 0:
             raise SystemExit("hipcc failed")
@@ -53,6 +54,8 @@ LAYERS = {
     "d2a": ("plain", 128, 128, 256, 28, 0, False),
     "d2b": ("plain", 256, 256, 256, 26, 0, True),
     "up0b": ("plain", 128, 128, 128, 26, 2, False),
+    "up3b": ("plain", 32, 32, 32, 254, 2, False),      # single chunk: UNCL_PC_NK1=1
+    "inc1": ("plain", 32, 32, 32, 254, 0, False),
 }
 
 
@@ -62,16 +65,19 @@ def main():
     ap.add_argument("--layers", default="up3f,up2a,up1a,up0a,d0b,d1b,d2b")
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--product", action="store_true", help="time the in-tree library (no phase stamps): for rocprofv3 --pmc runs")
+    ap.add_argument("--only-pc", type=int, default=-1, help="with --product: run only this kernel structure (0 / 2)")
     args = ap.parse_args()
-    lib_path = build()
+    lib_path = os.path.join(ROOT, "uncltmo_amd", "libuncltmo_hip.so") if args.product else build()
     if args.build_only:
         return
     import torch
     from uncltmo_amd import _hip
     _hip.LIB_PATH = lib_path
     lib = _hip.lib()
-    lib.uncl_pc_timing_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    lib.uncl_pc_timing_read.restype = C.c_int
+    if not args.product:
+        lib.uncl_pc_timing_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        lib.uncl_pc_timing_read.restype = C.c_int
     bf = torch.bfloat16
     n = args.n
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -112,24 +118,27 @@ def main():
                 _hip.check(lib.uncl_conv3x3_pipe(C.byref(d), plp, _hip.stream_ptr()), "pipe")
 
         res = {}
-        for pc in (0, 1, 0, 1):
+        t = [0] * 16
+        for pc in ((0, 2, 0, 2) if args.only_pc < 0 else (args.only_pc,)):
             lib.uncl_conv3x3_set_pc(pc)
             run(2)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             buf = (C.c_ulonglong * 16)()
-            lib.uncl_pc_timing_read(buf, 1)
+            if not args.product:
+                lib.uncl_pc_timing_read(buf, 1)
             e0.record()
             run(args.reps)
             e1.record()
             torch.cuda.synchronize()
             res.setdefault(pc, []).append(e0.elapsed_time(e1) / args.reps)
-            if pc == 1:
+            if pc == 2 and not args.product:
                 lib.uncl_pc_timing_read(buf, 1)
                 t = [int(buf[i]) for i in range(16)]
         lib.uncl_conv3x3_set_pc(1)
+        r0, r2 = res.get(0, [float("nan")]), res.get(2, [float("nan")])
         print("== %s: four-wave %s ms, producer/consumer %s ms (%.0f / %.0f TFLOP/s)" % (
-            name, ["%.3f" % v for v in res[0]], ["%.3f" % v for v in res[1]], gflop / min(res[0]), gflop / min(res[1])))
+            name, ["%.3f" % v for v in r0], ["%.3f" % v for v in r2], gflop / min(r0), gflop / min(r2)))
         for label, names, base, cnt in (("consumer wave 0", CONS, 0, t[8]), ("producer wave 4", PROD, 4, t[9])):
             tot = sum(t[base:base + 4])
             if tot == 0 or cnt == 0:

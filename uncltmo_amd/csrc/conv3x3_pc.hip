@@ -36,7 +36,9 @@ __device__ __forceinline__ unsigned long long pct_now() {
   return t;
 }
 #define PCT_DECL unsigned long long pct_acc[4] = {}; unsigned long long pct_last = pct_now();
-#define PCT(i) { const unsigned long long pct_t = pct_now(); pct_acc[i] += pct_t - pct_last; pct_last = pct_t; }
+// sched_barrier: register-only instructions (MFMAs) must not drift across the stamp (an asm memory clobber does not hold them)
+#define PCT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long pct_t = pct_now(); __builtin_amdgcn_sched_barrier(0); \
+                 pct_acc[i] += pct_t - pct_last; pct_last = pct_t; }
 #define PCT_FLUSH(base) if ((threadIdx.x & 255) == 0) { for (int i = 0; i < 4; ++i) atomicAdd(&g_pc_t[base + i], pct_acc[i]); atomicAdd(&g_pc_t[8 + base / 4], 1ull); }
 #else
 #define PCT_DECL
@@ -215,7 +217,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         return __builtin_bit_cast(vec, w);
       };
       const int ox = x0 + lr;
+#ifdef UNCL_PC_ONLY_RELU
+      constexpr bool plain = true;
+#else
       const bool plain = a.mask == nullptr && !a.accumulate;     // wave-uniform
+#endif
       if (!a.skip_main) {
 #pragma unroll
         for (int m = 0; m < MPW; ++m) {
@@ -227,6 +233,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {
               vec v = widen(act_pack(acc[m][nt], 2 * qp, bq[nt][2 * qp]), act_pack(acc[m][nt], 2 * qp + 1, bq[nt][2 * qp + 1]));
+#ifdef UNCL_PC_TIMING
+              if (a.pc_prio & 128) v = E::zero();       // experiment: no epilogue arithmetic (wrong results)
+#endif
               const size_t e = e0 + nt * 32 + 16 * qp;
               if (in) {
                 if (!plain) {
@@ -297,9 +306,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       mfma_phase(smem + (s & 1) * STAGE);
       PCT(0)
       if (cc.kc == a.nk - 1) {
+#ifdef UNCL_PC_ONLY_RELU      // experiment (code size): one epilogue variant
+        epilogue(cc, tpar, IntTag<0>{});
+#else
         if (a.slope == 0.f) epilogue(cc, tpar, IntTag<0>{});
         else if (a.slope == 1.f) epilogue(cc, tpar, IntTag<1>{});
         else epilogue(cc, tpar, IntTag<2>{});
+#endif
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
 #pragma unroll
@@ -660,7 +673,7 @@ extern "C" int uncl_pc_timing_read(unsigned long long* out16, int reset) {
 
 template <typename T>
 static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
-  if (a.nk < 2 || a.res != nullptr || a.out1_w != nullptr || a.flat_S != 0) return UNCL_ERR_ARG;
+  if (a.nk < 1 || a.res != nullptr || a.out1_w != nullptr || a.flat_S != 0) return UNCL_ERR_ARG;
   static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
   a.pc_prio = prio;
   static const int pw = [] { const char* e = getenv("UNCL_PC_PW"); return e ? atoi(e) : 8; }();

@@ -908,13 +908,14 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
                       : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? 4 : -1;
   // measured per layer at bench size (tools/pc_phase_timing.py): the concat layers (deep K, transforms in the staging waves)
   // gain 3 - 13 %, the plain 64-channel-tile layers (two to eight chunks per tile, pooled copy) lose 10 - 20 %
-  const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc == 2 ? 0 : 1) && a.nk >= 2 && d->res == nullptr && d->out1_w == nullptr &&
-                     !d->skip_main_store;
+  static const int pc_nk1 = [] { const char* e = getenv("UNCL_PC_NK1"); return e ? atoi(e) : 0; }();   // experiment: single-chunk layers
+  const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc == 2 ? 0 : 1) && a.nk >= (pc_nk1 ? 1 : 2) && d->res == nullptr &&
+                     d->out1_w == nullptr && !d->skip_main_store;
   if (d->Cout == 32) {
     // 8-row tiles at three workgroups per CU (50 KB LDS, 168 VGPRs) overlap the serial load / stage / store phases of the
     // single-chunk 32 -> 32 transposed layers better than 16-row tiles at two (measured: up_path.{2,3}.conv.conv1 -9 %);
     // the valid 32 -> 32 layer and the multi-chunk concat layers are faster (or read less) with the larger tile
-    if (d->pad == 2 && d->src_mode == UNCL_SRC_PLAIN && d->Cin == 32 && !prev) {
+    if (d->pad == 2 && d->src_mode == UNCL_SRC_PLAIN && d->Cin == 32 && !prev && !(pc_ok && pc_nk1 && g_use_pc == 2)) {
       a.n_ct = 1;
       a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + 7) / 8;
       a.total_tiles = d->N * a.tiles_x * a.tiles_y;
