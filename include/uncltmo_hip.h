@@ -375,11 +375,21 @@ int uncl_simple_d_backward(const float* x, const float* w0, const float* w2, con
  * InstanceNorm(eps 1e-5) -> LeakyReLU], [conv(4,1,1) -> InstanceNorm -> LeakyReLU], conv(4,1,1)+bias.  fp32.
  * x: (N,H,H) one-channel frames; w: HOST array of n_layers+2 device pointers to reference-layout weights (Cout,Cin,4,4);
  * b_first (ndf), b_last (1); out: (N,Ho,Ho) with Ho = uncl_patch_d_out_size(H, n_layers) (30 for 256 / 3 layers).
- * Forward-parity module: the reference's trainers never build it. */
+ * The reference's trainers never build it; it is kept usable as a drop-in `--d_model patchD`.
+ *
+ * Training form: uncl_patch_d_forward_train keeps a_0 and per normalised block {a, zhat, rstd} in `arena`
+ * (uncl_patch_d_train_bytes, which also covers the two gradient buffers of the backward).  uncl_patch_d_backward takes
+ * g_out (N,Ho,Ho) and OVERWRITES gw[i] (reference layout, one per convolution), gb_first (ndf), gb_last (1) and, when not
+ * NULL, g_x (N,H,H).  Every sum has one owner and a fixed order: results are run-to-run identical. */
 size_t uncl_patch_d_workspace_bytes(int N, int H, int ndf, int n_layers);
 int uncl_patch_d_out_size(int H, int n_layers);
 int uncl_patch_d_forward(const float* x, const float* const* w, const float* b_first, const float* b_last, float* out, int N, int H,
                          int ndf, int n_layers, void* workspace, void* stream);
+size_t uncl_patch_d_train_bytes(int N, int H, int ndf, int n_layers);
+int uncl_patch_d_forward_train(const float* x, const float* const* w, const float* b_first, const float* b_last, float* out, int N,
+                               int H, int ndf, int n_layers, void* arena, void* stream);
+int uncl_patch_d_backward(const float* x, const float* const* w, const float* g_out, float* const* gw, float* gb_first,
+                          float* gb_last, float* g_x, int N, int H, int ndf, int n_layers, void* arena, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Loss heads.  Each returns the weighted loss (written or accumulated into a device fp32 scalar) and, where

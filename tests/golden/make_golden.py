@@ -137,6 +137,24 @@ def capture_discriminator(out):
     out["patchd.output"] = po.numpy()
 
 
+def capture_patchd_grad(out):
+    """Gradients of the least-squares GAN loss through the reference PatchGAN (models/Discriminator.py:129-167)."""
+    from models import Discriminator
+    P = Discriminator.NLayerDiscriminator(1, ndf=16, n_layers=3, norm_layer="instance_norm", last_activation="none")
+    synth.fill_state_dict(P, "p0")
+    P.train()
+    x = torch.cat([synth.ldr_frames(1, salt="dA"), synth.smooth_hdr_frames(1, salt="dB")], 0).requires_grad_(True)
+    o = P(x)
+    loss = ((o - 1.0) ** 2).mean()
+    loss.backward()
+    out["loss"] = np.float64(loss.item())
+    out.update(summarize(x.grad, "g.input", 1024))
+    for k, p_ in P.named_parameters():
+        if p_.grad is not None:
+            out.update(summarize(p_.grad, "g." + k, 512))
+            out["gnorm." + k] = np.float64(p_.grad.double().norm().item())
+
+
 def make_trainer(video):
     """A trainer instance without its dataset-loading constructor (GanTrainerImg.py:59-137)."""
     import GanTrainer as GV
@@ -472,13 +490,13 @@ def capture_tmqi(out):
 
 def main():
     which = sys.argv[1:] or ["generator", "generator_inorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
-                             "inference", "tmqi", "loader"]
+                             "inference", "tmqi", "loader", "patchd_grad"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
             "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "vid_c4": lambda o: capture_step_c4(o),
             "generator_inorm": lambda o: capture_generator_inorm(o), "loader": lambda o: capture_loader(o),
-            "tiler": lambda o: capture_tiler(o),
+            "tiler": lambda o: capture_tiler(o), "patchd_grad": lambda o: capture_patchd_grad(o),
             "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o)}
     for name in which:
         out = {}

@@ -254,5 +254,65 @@ def test_patch_d_forward_matches_reference_golden(golden):
         o2 = p(x2)
     ref = OD.patch_d_forward({k: v.cpu() for k, v in p.state_dict().items()}, x2.cpu())
     assert o2.shape == ref.shape and rel_l2(o2.cpu(), ref) < 1e-4
-    with pytest.raises(NotImplementedError):
-        p(x)                                     # gradients enabled: no backward kernels for this module
+
+
+def _patch_d():
+    from uncltmo_amd import model_factory
+    p = model_factory.create_D_net(1, 16, torch.device("cuda"), False, "instance_norm", False, "patchD", 3, "none", 1, 0, 0, 0)
+    synth.fill_state_dict(p, "p0")
+    return p
+
+
+def test_patch_d_backward_matches_reference_golden(golden):
+    """Least-squares GAN loss through the PatchGAN: loss, every parameter gradient and the input gradient against vectors
+    captured from the reference's module under torch autograd (make_golden.py capture_patchd_grad)."""
+    g = golden("patchd_grad")
+    p = _patch_d()
+    x = torch.cat([synth.ldr_frames(1, salt="dA"), synth.smooth_hdr_frames(1, salt="dB")], 0).cuda().requires_grad_(True)
+    o = p(x)
+    loss = ((o - 1.0) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    named = dict(p.named_parameters())
+    for key, t in [("input", x.grad)] + [(k, v.grad) for k, v in named.items()]:
+        assert t is not None, key
+        flat = t.detach().reshape(-1).cpu()
+        pos, val = g["g.%s.pos" % key], g["g.%s.val" % key]
+        assert list(g["g.%s.shape" % key]) == list(t.shape)
+        got = flat[torch.from_numpy(pos)].numpy()
+        scale = np.abs(val).max() + 1e-30
+        assert np.abs(got - val).max() / scale < 2e-4, key
+        assert abs(flat.double().sum().item() - float(g["g.%s.sum" % key])) < 2e-4 * float(g["g.%s.abssum" % key]) + 1e-12, key
+
+
+def test_patch_d_backward_matches_oracle_other_shapes():
+    p = _patch_d()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in p.state_dict().items()}
+    for n, h, salt in [(1, 64, "pA"), (3, 144, "pB")]:
+        x = synth.smooth_hdr_frames(n, h, h, salt=salt)
+        xg = x.cuda().requires_grad_(True)
+        for q in p.parameters():
+            q.grad = None
+        o = p(xg)
+        w = torch.linspace(-0.5, 1, o.numel(), device="cuda").reshape(o.shape)
+        (o * w).sum().backward()
+        xc = x.clone().requires_grad_(True)
+        for v in sd.values():
+            v.grad = None
+        oc = OD.patch_d_forward(sd, xc)
+        (oc * w.cpu()).sum().backward()
+        assert rel_l2(o.detach().cpu(), oc.detach()) < 1e-4
+        assert rel_l2(xg.grad.cpu(), xc.grad) < 1e-3
+        for k, q in p.named_parameters():
+            assert rel_l2(q.grad.cpu(), sd[k].grad) < 1e-3, (k, n, h)
+    # deterministic: a second backward of the same input gives the same bits
+    a = [q.grad.clone() for q in p.parameters()]
+    for q in p.parameters():
+        q.grad = None
+    o = p(xg)
+    (o * w).sum().backward()
+    assert all(torch.equal(u, q.grad) for u, q in zip(a, p.parameters()))
+    # x without grad and frozen parameters: plain forward path
+    for q in p.parameters():
+        q.requires_grad_(False)
+    assert not p(x.cuda()).requires_grad

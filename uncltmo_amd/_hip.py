@@ -133,6 +133,11 @@ SIGNATURES = {
     "uncl_patch_d_out_size": (C.c_int, [C.c_int, C.c_int]),
     "uncl_patch_d_forward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_patch_d_train_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "uncl_patch_d_forward_train": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_patch_d_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uncl_gauss_stats_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p]),
     "uncl_gcn_maxrel_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),

@@ -89,10 +89,50 @@ class Conv2dBlock(nn.Module):
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, padding, bias=False)
 
 
+class _PatchDFn(torch.autograd.Function):
+    """PatchGAN forward keeping what its backward needs (uncl_patch_d_forward_train / uncl_patch_d_backward, fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, ndf, n_layers, b_first, b_last, *weights):
+        import ctypes as C
+        lib = _hip.lib()
+        n, h = x.shape[0], x.shape[2]
+        xf = x.detach().reshape(n, h, h).float().contiguous()
+        ws_ = [w.detach().float().contiguous() for w in weights]
+        b0, bl = b_first.detach().float().contiguous(), b_last.detach().float().contiguous()
+        wp = (C.c_void_p * len(ws_))(*[w.data_ptr() for w in ws_])
+        ho = lib.uncl_patch_d_out_size(h, n_layers)
+        out = torch.empty(n, 1, ho, ho, dtype=torch.float32, device=x.device)
+        arena = torch.empty(lib.uncl_patch_d_train_bytes(n, h, ndf, n_layers), dtype=torch.uint8, device=x.device)
+        _hip.check(lib.uncl_patch_d_forward_train(xf.data_ptr(), wp, b0.data_ptr(), bl.data_ptr(), out.data_ptr(), n, h, ndf,
+                                                  n_layers, arena.data_ptr(), _hip.stream_ptr()), "uncl_patch_d_forward_train")
+        ctx.save_for_backward(xf, arena, *ws_)
+        ctx.geom = (n, h, ndf, n_layers)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes as C
+        lib = _hip.lib()
+        xf, arena, *ws_ = ctx.saved_tensors
+        n, h, ndf, n_layers = ctx.geom
+        g = g_out.detach().float().contiguous()
+        gws = [torch.empty_like(w) for w in ws_]
+        gb0 = torch.empty(ndf, dtype=torch.float32, device=g.device)
+        gbl = torch.empty(1, dtype=torch.float32, device=g.device)
+        gx = torch.empty(n, h, h, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        wp = (C.c_void_p * len(ws_))(*[w.data_ptr() for w in ws_])
+        gp = (C.c_void_p * len(gws))(*[w.data_ptr() for w in gws])
+        _hip.check(lib.uncl_patch_d_backward(xf.data_ptr(), wp, g.data_ptr(), gp, gb0.data_ptr(), gbl.data_ptr(),
+                                             gx.data_ptr() if gx is not None else None, n, h, ndf, n_layers, arena.data_ptr(),
+                                             _hip.stream_ptr()), "uncl_patch_d_backward")
+        return (gx.reshape(n, 1, h, h) if gx is not None else None, None, None, gb0, gbl) + tuple(gws)
+
+
 class NLayerDiscriminator(nn.Module):
-    """PatchGAN discriminator, forward only (reference: models/Discriminator.py:129-167; same constructor, state_dict keys
-    and output shape (N,1,30,30) for 256x256 inputs).  The reference's trainers never construct it, so no backward kernels
-    are built: calling it with gradients enabled on its parameters raises."""
+    """PatchGAN discriminator (reference: models/Discriminator.py:129-167; same constructor, state_dict keys and output
+    shape (N,1,30,30) for 256x256 inputs).  Under torch.no_grad() the ping-pong forward runs; with gradients enabled the
+    training form keeps the activations and `backward()` fills every parameter's .grad and the input gradient."""
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer="batch_norm", last_activation="none"):
         super().__init__()
@@ -116,13 +156,12 @@ class NLayerDiscriminator(nn.Module):
             raise _hip.HipError("NLayerDiscriminator needs CUDA(HIP) tensors; there is no CPU path")
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != x.shape[3]:
             raise ValueError("NLayerDiscriminator expects square one-channel frames (N,1,H,H)")
+        convs = [self.model[0]] + [m.conv for m in self.model if isinstance(m, Conv2dBlock)] + [self.model[-1]]
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("uncltmo_amd: the PatchGAN is a forward-parity module (not reachable from the reference's "
-                                      "trainers); run it under torch.no_grad()")
+            return _PatchDFn.apply(x, self.ndf, self.n_layers, convs[0].bias, convs[-1].bias, *[c.weight for c in convs])
         lib = _hip.lib()
         n, h = x.shape[0], x.shape[2]
         xf = x.detach().reshape(n, h, h).float().contiguous()
-        convs = [self.model[0]] + [m.conv for m in self.model if isinstance(m, Conv2dBlock)] + [self.model[-1]]
         ws_ = [c.weight.detach().float().contiguous() for c in convs]
         b0, bl = convs[0].bias.detach().float().contiguous(), convs[-1].bias.detach().float().contiguous()
         wp = (C.c_void_p * len(ws_))(*[w.data_ptr() for w in ws_])
