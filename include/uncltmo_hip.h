@@ -116,11 +116,11 @@ int uncl_conv_igemm(const uncl_conv_desc* d, void* stream);
  * maxpool2x2(out) as NHWC (N, Hout/2, Wout/2, Cout) — the MaxPool2d of the next encoder stage
  * (unet_parts.py:212,233) fused into the producer. */
 int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
-/* Kernel structure used by uncl_conv3x3_pipe / uncl_conv3x3_dgrad for the multi-chunk layers (Cin >= 64): 0 = the four-wave
- * kernel for every layer; 1 (default) = producer / consumer workgroups (csrc/conv3x3_pc.hip: four multiplying and four or
- * eight staging waves, one workgroup per CU) for the concat-source layers, where they measured faster; 2 = for every layer
- * they build (plain sources too).  All give bit-identical results; the switch exists for same-process A/B timing and for the
- * tests that compare the structures.  Returns the previous setting. */
+/* Kernel structure used by uncl_conv3x3_pipe / uncl_conv3x3_dgrad: 0 = the four-wave kernel for every layer; 1 = producer /
+ * consumer workgroups (csrc/conv3x3_pc.hip: four multiplying and four or eight staging waves, one workgroup per CU, LDS
+ * planes, resident weights where they fit) for the concat-source layers only; 2 (default) = for every layer they build
+ * (plain sources and single-chunk layers too; measured faster on all of them).  All give bit-identical results; the switch
+ * exists for same-process A/B timing and for the tests that compare the structures.  Returns the previous setting. */
 int uncl_conv3x3_set_pc(int on);
 
 /* ConvTranspose2d(k2, s2) + bias, bf16, HBM-bound layout (whole output-row runs per store).

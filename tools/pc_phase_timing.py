@@ -135,7 +135,7 @@ def main():
             if pc == 2 and not args.product:
                 lib.uncl_pc_timing_read(buf, 1)
                 t = [int(buf[i]) for i in range(16)]
-        lib.uncl_conv3x3_set_pc(1)
+        lib.uncl_conv3x3_set_pc(2)
         r0, r2 = res.get(0, [float("nan")]), res.get(2, [float("nan")])
         print("== %s: four-wave %s ms, producer/consumer %s ms (%.0f / %.0f TFLOP/s)" % (
             name, ["%.3f" % v for v in r0], ["%.3f" % v for v in r2], gflop / min(r0), gflop / min(r2)))

@@ -12,12 +12,17 @@
 //              fragments), one chunk ahead of the multiplying waves in a two-stage LDS ring.
 //
 // One s_barrier per K-chunk hands a stage from the producers to the consumers and the previous one back; global loads stay
-// in flight across it (raw s_barrier + lgkmcnt only).  Same tiles, same LDS images (80-byte padded rows), same MFMA order per
-// accumulator as conv3x3_pipe -> bit-identical results; tests/test_gpu_conv.py compares the two kernels element for element.
+// in flight across it (raw s_barrier + lgkmcnt only).  Same tiles and the same MFMA order per accumulator as conv3x3_pipe
+// -> bit-identical results; tests/test_gpu_conv.py compares the two kernels element for element.
 //
-// LDS (one workgroup per CU): 2 stages x (halo tile + 9 taps of weights) + the biases of two tiles = 144 256 B (32-channel
-// tiles, 16 x 32 pixels) / 147 072 B (64-channel tiles, 8 x 32 pixels) of 163 840; the epilogue needs none (lane-widening
-// v_permlane32_swap instead of a transposition).
+// LDS images are stored as four PLANES, one per 16-byte K-slot: plane s holds channels 8s..8s+7 of every halo pixel (or
+// weight row) back to back, so the 16 lanes of a ds_read_b128 group read 256 contiguous bytes (conflict-free without the
+// 80-byte row padding of conv3x3_pipe, which cost 25 % of the LDS) and every fragment address is "lane base + immediate".
+// Plane lengths are = 4 (mod 16) slots, which spreads the four planes a staging quad writes over distinct banks.
+// With the padding gone, the whole weight tensor of a layer with Cout = one tile and <= 4 K-chunks of 32 output channels
+// (or 2 of 64) fits next to two activation stages and stays RESIDENT for the launch (RESW): the staging waves then load
+// activations only -- per-CU vector-memory throughput (L2 -> L1, tens of GB/s per CU), not HBM, is what these kernels queue on.
+// The epilogue needs no LDS (lane-widening v_permlane32_swap instead of a transposition).
 #include <cstdlib>
 
 #include "conv3x3_args.h"
@@ -45,6 +50,9 @@ __device__ __forceinline__ unsigned long long pct_now() {
 #define PCT(i)
 #define PCT_FLUSH(base)
 #endif
+
+// bytes of one LDS plane of `rows` 16-byte slots: the slot count is padded to 4 (mod 16)
+constexpr int pc_plane(int rows) { return (rows + ((4 - rows % 16) + 16) % 16) * 16; }
 
 struct TileCur { int tile, ct, tx, ty, n, kc; };
 
@@ -74,7 +82,7 @@ __device__ __forceinline__ bool cur_next(TileCur& c, const PipeArgs& a, int tile
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) computed by the
 //       producers (32 channels, same extent as the skip)
-template <typename T, int NT, int MPW, int MODE, int PW>
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
 __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_kernel(const PipeArgs a) {
   static_assert(PW == 4 || PW == 8, "four or eight staging waves");
   using E = Elem<T>;
@@ -85,13 +93,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   constexpr int NPIX = HH * HW;
   constexpr int CT = NT * 32;
   constexpr int WROWS = 9 * CT;
-  constexpr int SLOTS = CT / 8;
-  constexpr int RP = 80;                      // padded LDS row (64 bytes of channels), see conv3x3_pipe.hip
-  constexpr int XBYTES = NPIX * RP, WBYTES = WROWS * RP, STAGE = XBYTES + WBYTES;
+  constexpr int XPL = pc_plane(NPIX), WPL = pc_plane(WROWS);      // bytes per plane
+  constexpr int XBYTES = 4 * XPL, WBYTES = 4 * WPL;
+  // streamed weights: two stages of [activations | weights]; resident weights: [X stage 0 | X stage 1 | nk weight chunks]
+  constexpr int STAGE = RESW ? XBYTES : XBYTES + WBYTES;
   static_assert(MODE != 4 || (NT == 1 && MPW == 4), "fused up-conv: 16 x 32 tiles of 32 channels");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const sBias = reinterpret_cast<float*>(smem + 2 * STAGE);   // [2 tiles][CT]
+  char* const wres = smem + 2 * XBYTES;                               // RESW: chunk kc at wres + kc * WBYTES
+  float* const sBias = reinterpret_cast<float*>(smem + (RESW ? 2 * XBYTES + a.nk * WBYTES : 2 * STAGE));   // [2 tiles][CT]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -111,9 +121,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     f32x16 zero16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-    // fragment bases of this lane (stage 0): A = weights row lr, B = halo pixel (wave*MPW) * HW + lr, 16-byte half lh
-    const int aoff = XBYTES + lr * RP + (lh << 4);
-    const int boff = (wave * MPW * HW + lr) * RP + (lh << 4);
+    // fragment bases of this lane: A = weights row lr, B = halo pixel (wave*MPW) * HW + lr, K-slot plane lh (+ 2 ks)
+    const int aoff = lh * WPL + lr * 16;
+    const int boff = lh * XPL + (wave * MPW * HW + lr) * 16;
 
     // One staged K-chunk = six (ks, tx) tap columns of 12 MFMAs each.  The fragments of column i + 1 are read while the MFMAs
     // of column i issue (two register sets, one DS read per MFMA gap pinned with sched_group_barrier): a single wave per SIMD
@@ -121,8 +131,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     // The accumulators are zeroed after each tile's epilogue, so the phase has no branch and is one scheduling region.
     constexpr int NRD = 3 * NT + MPW + 2;      // DS reads per column
     constexpr int NMM = 3 * NT * MPW;          // MFMAs per column
-    auto mfma_phase = [&](const char* st) __attribute__((always_inline)) {
-      const char* pa = st + aoff;
+    auto mfma_phase = [&](const char* st, const char* wst) __attribute__((always_inline)) {
+      const char* pa = wst + aoff;
       const char* pb = st + boff;
       vec A[2][3][NT], B[2][MPW + 2];
       auto rd = [&](int set, int col) __attribute__((always_inline)) {
@@ -131,9 +141,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            A[set][ty][nt] = *reinterpret_cast<const vec*>(pa + ((ty * 3 + tx) * CT + nt * 32) * RP + (ks << 5));
+            A[set][ty][nt] = *reinterpret_cast<const vec*>(pa + 2 * ks * WPL + ((ty * 3 + tx) * CT + nt * 32) * 16);
 #pragma unroll
-        for (int r = 0; r < MPW + 2; ++r) B[set][r] = *reinterpret_cast<const vec*>(pb + (r * HW + tx) * RP + (ks << 5));
+        for (int r = 0; r < MPW + 2; ++r) B[set][r] = *reinterpret_cast<const vec*>(pb + 2 * ks * XPL + (r * HW + tx) * 16);
       };
       rd(0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);     // column 0's own fragments first
@@ -217,11 +227,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         return __builtin_bit_cast(vec, w);
       };
       const int ox = x0 + lr;
-#ifdef UNCL_PC_ONLY_RELU
-      constexpr bool plain = true;
-#else
       const bool plain = a.mask == nullptr && !a.accumulate;     // wave-uniform
-#endif
       if (!a.skip_main) {
 #pragma unroll
         for (int m = 0; m < MPW; ++m) {
@@ -292,9 +298,87 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       }
     };
 
+    // The forward epilogue (bias + ReLU, plain store, optional pooled copy) with nothing in it that is not arithmetic on
+    // packed registers: 32 v_pk_add_f32 + 32 v_cvt_pk + 16 v_permlane32_swap + 32 v_pk_max_i16 per 64 accumulators, stores
+    // as "scalar row base + 32-bit lane offset + immediate".  The generic form above costs 3-7x the instructions (64-bit
+    // per-lane addresses, per-element selects, float round trips in the pooled copy) and was half of a 64-channel tile's time.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto epilogue_relu = [&](const TileCur& c, int tpar) __attribute__((always_inline)) {
+      const float* sBt = sBias + tpar * CT;
+      const int y0 = c.ty * TH + wave * MPW, x0 = c.tx * TW, co = c.ct * CT;
+      const int ox = x0 + lr;
+      f32x4 bq[NT][4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[nt][q] = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 8 * q + 4 * lh);
+      auto pack4 = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
+        const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
+        const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
+        vec4 o;
+        o[0] = (T)s0[0]; o[1] = (T)s0[1]; o[2] = (T)s1[0]; o[3] = (T)s1[1];
+        return o;
+      };
+      auto widen_relu = [&](const vec4& o0, const vec4& o1) __attribute__((always_inline)) {
+        const u32x2 d0 = __builtin_bit_cast(u32x2, o0), d1 = __builtin_bit_cast(u32x2, o1);
+        const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
+        const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
+        s16x8 si = __builtin_bit_cast(s16x8, w);
+        si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values (sign-symmetric rounding)
+        return __builtin_bit_cast(vec, si);
+      };
+      const bool xin = ox < a.Wout;
+      unsigned loff = (unsigned)(ox * a.oC + 8 * lh) * 2u;
+      asm volatile("" : "+v"(loff));        // keep the 32-bit lane offset (global_store ... v_off, s[base] offset:imm)
+      vec wv[MPW][NT][2];
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) {
+        const int oy = y0 + m;                                   // wave-uniform
+        char* rowp = reinterpret_cast<char*>(a.out + ((size_t)c.n * a.Hout + oy) * a.Wout * a.oC + co);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            wv[m][nt][qp] = widen_relu(pack4(acc[m][nt], 2 * qp, bq[nt][2 * qp]), pack4(acc[m][nt], 2 * qp + 1, bq[nt][2 * qp + 1]));
+#ifdef UNCL_PC_TIMING
+            if (a.pc_prio & 64) { asm volatile("" ::"v"(wv[m][nt][qp])); continue; }     // experiment: no output stores (wrong results)
+#endif
+            if (oy < a.Hout && xin) *reinterpret_cast<vec*>(rowp + loff + (nt * 32 + 16 * qp) * 2) = wv[m][nt][qp];
+          }
+      }
+      if (NT == 2 && a.pool_out != nullptr) {
+        // MaxPool2d(2) of the wave's two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
+        // maximum orders them like their floats; vertical maximum between the rows, horizontal with the neighbouring pixel's
+        // lane (DPP quad_perm [1,0,3,2]); the even lanes store the 16 pooled pixels
+        static_assert(NT != 2 || MPW == 2, "one pooled row per wave");
+        const int gy = (c.ty * TH >> 1) + wave, gx = (x0 >> 1) + (lr >> 1);
+        const bool in = (lr & 1) == 0 && gy < a.pH && gx < a.pW;
+        char* rowp = reinterpret_cast<char*>(a.pool_out + ((size_t)c.n * a.pH + gy) * a.pW * a.oC + co);
+        unsigned poff = (unsigned)(gx * a.oC + 8 * lh) * 2u;
+        asm volatile("" : "+v"(poff));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            s16x8 v = __builtin_elementwise_max(__builtin_bit_cast(s16x8, wv[0][nt][qp]), __builtin_bit_cast(s16x8, wv[MPW - 1][nt][qp]));
+            u32x4 u = __builtin_bit_cast(u32x4, v), h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)u[i], 0xB1, 0xF, 0xF, true);
+            v = __builtin_elementwise_max(v, __builtin_bit_cast(s16x8, h));
+#ifdef UNCL_PC_TIMING
+            if (a.pc_prio & 64) { asm volatile("" ::"v"(v)); continue; }
+#endif
+            if (in) *reinterpret_cast<vec*>(rowp + poff + (nt * 32 + 16 * qp) * 2) = __builtin_bit_cast(vec, v);
+          }
+      }
+    };
+
     TileCur cc;
     cur_init(cc, tile0, a);
     int tpar = 0;
+    const bool fast_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && !a.skip_main && !(a.pc_prio & 256);   // wave-uniform
 #pragma unroll
     for (int m = 0; m < MPW; ++m)
 #pragma unroll
@@ -303,16 +387,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     pc_barrier();     // stage 0 is staged
     PCT(2)
     for (int s = 0;; ++s) {
-      mfma_phase(smem + (s & 1) * STAGE);
+      mfma_phase(smem + (s & 1) * STAGE, RESW ? wres + cc.kc * WBYTES : smem + (s & 1) * STAGE + XBYTES);
       PCT(0)
       if (cc.kc == a.nk - 1) {
-#ifdef UNCL_PC_ONLY_RELU      // experiment (code size): one epilogue variant
-        epilogue(cc, tpar, IntTag<0>{});
-#else
-        if (a.slope == 0.f) epilogue(cc, tpar, IntTag<0>{});
+        if (fast_relu) epilogue_relu(cc, tpar);
+        else if (a.slope == 0.f) epilogue(cc, tpar, IntTag<0>{});
         else if (a.slope == 1.f) epilogue(cc, tpar, IntTag<1>{});
         else epilogue(cc, tpar, IntTag<2>{});
-#endif
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
 #pragma unroll
@@ -357,22 +438,24 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   const int xoff_e = (ey * a.s0W + 32 + ec) * a.s0C + ch * 8;
   const int pix_r0 = hy0 * HW + hx;
   const int pix_e = ey * HW + 32 + ec;
-  const int lds_w0 = XBYTES + p0 * RP + (ch << 4);
+  const int lds_w0 = ch * WPL + p0 * 16;             // + XBYTES (streamed) / kc * WBYTES (resident)
   const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;
 
-  // Register sets.  A chunk is loaded THREE steps before the multiplying waves reach it and written to LDS one step before:
-  // two chunks are always in flight in registers, so the memory latency of a load is covered by a whole step of the
-  // workgroup instead of sitting in the staging waves' serial chain (load -> wait -> write -> barrier).
-  //   plain source:   xa / xb and wa / wb alternate with the step's parity
+  // Staging registers: ONE set.  At step s (the consumers multiply chunk s) chunk s + 1 goes from registers to LDS and the
+  // loads of chunk s + 2 are issued into the registers that just became free, so every load has a whole step of the workgroup
+  // to land and a staging step waits only for loads issued a step earlier.  (A second set with a third chunk in flight was
+  // slower: the vector-memory queue of the CU fills, and both the staging waves' next loads and the multiplying waves' output
+  // stores then stall at issue.)
   //   concat source:  steps of a 32-channel slice are [x1, x2, x2^2, sqrt(x2)] (phase = step & 3, nk is a multiple of 4):
   //                   xa holds the x1 chunk (MODE 4: the up-conv's source fragments), xb the x2 slice, which is staged three
-  //                   times (as is, squared, square-rooted) and so read from memory once; weights alternate as above
-  vec xa[XV], xb[XV];
-  vec wa[WVN], wb[WVN];
-  f32x4 bra = {0.f, 0.f, 0.f, 0.f}, brb = {0.f, 0.f, 0.f, 0.f};
+  //                   times (as is, squared, square-rooted) and so read from memory once
+  constexpr bool CAT = MODE == 1 || MODE == 4;
+  vec xa[XV], xb[XV];       // xb is dead (and costs no registers) for plain sources
+  vec wv[WVN];
+  f32x4 br = {0.f, 0.f, 0.f, 0.f};
   unsigned xvalid_a = 0, xvalid_b = 0;
-  int bpar_a = 0, bpar_b = 0;
-  bool bp_a = false, bp_b = false;
+  int bpar = 0;
+  bool bp = false;
   int u_iy0 = 0, u_ix0 = 0;
   int ppar = 0;                 // parity of the tile the producers are loading
 
@@ -395,25 +478,82 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     for (int i = 0; i < 16; ++i) cb[i] = a.up_b ? a.up_b[16 * lh + i] : 0.f;
   }
 
-  // loads of the chunk the cursor points at; P = step index & 3 (compile time): which register set, and for the concat
-  // sources which member of [x1, x2, x2^2, sqrt] the chunk is
+  // position of K-chunk kc in the weight's K layout: concat layers store [x2 | x1 | x2^2 | sqrt] and are walked slice by slice
+  auto weight_chunk = [&](int kc) __attribute__((always_inline)) {
+    if (!CAT) return kc;
+    const int ph = kc & 3, g = ph == 0 ? 1 : (ph == 1 ? 0 : ph);
+    return g * (a.s0C >> 5) + (kc >> 2);
+  };
+  auto load_weights = [&](int cout0, int kc) __attribute__((always_inline)) {
+    const bf16_t* wb_ = a.weight + (size_t)cout0 * a.Cin + weight_chunk(kc) * 32;
+    const int wstride = (WPP / CT) * a.Cout * a.Cin;  // taps per pass x one tap
+#pragma unroll
+    for (int j = 0; j < WVN; ++j) {
+      unsigned off = (unsigned)woff0;
+      if (W_RAGGED && j == WVN - 1) off = (p0 + WPP * j < WROWS) ? off : 0u;
+      wv[j] = ld16ov<vec>(wb_ + j * wstride, off * 2u);
+    }
+  };
+  auto write_weights = [&](char* wst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < WVN; ++j) {
+      if (W_RAGGED && j == WVN - 1 && p0 + WPP * j >= WROWS) continue;
+      *reinterpret_cast<vec*>(wst + lds_w0 + j * WPP * 16) = wv[j];
+    }
+  };
+
+  // one 32-channel chunk of a same-extent source: halo tile at (iy0, ix0) of sample n, channels cbase..; returns the slot
+  // validity mask.  Offsets first (branchy, VALU only), then the loads in straight-line code: loads inside the arms of a
+  // uniform branch make the compiler's waitcnt insertion assume the other arm's loads may be in flight into these registers.
+  auto load_x = [&](vec (&xr)[XV], const bf16_t* xsrc, int n, int iy0, int ix0, int cbase) __attribute__((always_inline)) {
+    unsigned valid = 0xffffffffu;
+    const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+    unsigned off[XV];
+    const int toff = (iy0 * a.s0W + ix0) * a.s0C;  // may be negative on the border; masked below
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < RSN; ++j)
+        off[j] = (unsigned)((j < RSN - 1 || r_last_on) ? toff + xoff_r + j * RSTEP * row_el : 0) * 2u;
+      off[RSN] = (unsigned)(e_on ? toff + xoff_e : 0) * 2u;
+    } else {
+      valid = 0;
+      const bool xok = (unsigned)(ix0 + hx) < (unsigned)a.W;
+#pragma unroll
+      for (int j = 0; j <= RSN; ++j) {
+        bool ok;
+        int eoff;
+        if (j < RSN) {
+          ok = xok && (unsigned)(iy0 + hy0 + RSTEP * j) < (unsigned)a.H && (j < RSN - 1 || r_last_on);
+          eoff = xoff_r + j * RSTEP * row_el;
+        } else {
+          ok = e_on && (unsigned)(iy0 + ey) < (unsigned)a.H && (unsigned)(ix0 + 32 + ec) < (unsigned)a.W;
+          eoff = xoff_e;
+        }
+        valid |= (ok ? 1u : 0u) << j;
+        off[j] = (ok ? (unsigned)(toff + eoff) : 0u) * 2u;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j <= RSN; ++j) xr[j] = ld16ov<vec>(base, off[j]);
+    return valid;
+  };
+
+  // loads of the chunk the cursor points at; P = chunk index & 3 (compile time): for the concat sources which member of
+  // [x1, x2, x2^2, sqrt] the chunk is
   auto load_step = [&](const TileCur& c, auto p_tag) __attribute__((always_inline)) {
     constexpr int P = decltype(p_tag)::value;
-    constexpr bool CAT = MODE == 1 || MODE == 4;
-    constexpr bool SET_A = CAT ? P == 0 : (P & 1) == 0;     // X registers this chunk loads into (if it loads any)
-    constexpr bool X_LOAD = !CAT || P < 2;
-    constexpr bool W_A = (P & 1) == 0;
+    constexpr bool SET_A = !CAT || P == 0;     // X registers this chunk loads into (if it loads any)
+    constexpr bool X_LOAD = !CAT || P == 0;    // concat: the x1 AND x2 chunks of a slice are requested at its first step
     vec (&xr)[XV] = SET_A ? xa : xb;
-    vec (&wr)[WVN] = W_A ? wa : wb;
     const int n = c.n, y0 = c.ty * TH, x0 = c.tx * TW, cout0 = c.ct * CT, kc = c.kc;
-    int g = 0, cbase = kc * 32, wk = kc;
+    int g = 0, cbase = kc * 32;
     if (CAT) {
       cbase = (kc >> 2) * 32;
       g = P == 0 ? 1 : (P == 1 ? 0 : P);
-      wk = g * (a.s0C >> 5) + (kc >> 2);     // the chunk's position in the weight's K layout [x2 | x1 | x2^2 | sqrt]
     }
-    const bool bp = kc == 0;
-    if (W_A) { bp_a = bp; bpar_a = ppar; } else { bp_b = bp; bpar_b = ppar; }
+    bp = kc == 0;
+    bpar = ppar;
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
     const bool same_ext = a.s1H == a.s0H && a.s1W == a.s0W;
     const bf16_t* xsrc = (MODE != 0 && g == 1) ? a.src1 : a.src0;
@@ -440,6 +580,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     } else if (MODE == 1 && P == 0 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
       const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
+      unsigned off[XV];
       const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
       valid = 0;
       const int ix = ix0 + hx;
@@ -451,76 +592,40 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         const bool ok = xok && (unsigned)iy < (unsigned)a.H && (j < RSN - 1 || r_last_on);
         const int sy = min(max(iy - dy, 0), a.s1H - 1);
         valid |= (ok ? 1u : 0u) << j;
-        xr[j] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
+        off[j] = (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u;
       }
       {
         const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
         const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
         valid |= (ok ? 1u : 0u) << RSN;
-        xr[RSN] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
+        off[RSN] = (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u;
       }
+#pragma unroll
+      for (int j = 0; j <= RSN; ++j) xr[j] = ld16ov<vec>(base, off[j]);
     } else {
-      const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;  // wave-uniform
-      if (interior) {
-        const bf16_t* base = xsrc + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
-#pragma unroll
-        for (int j = 0; j < RSN; ++j)
-          xr[j] = ld16ov<vec>(base + j * RSTEP * row_el, (unsigned)((j < RSN - 1 || r_last_on) ? xoff_r : 0) * 2u);
-        xr[RSN] = ld16ov<vec>(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
-      } else {
-        const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
-        const int toff = (iy0 * a.s0W + ix0) * a.s0C;  // may be negative on the border; masked below
-        valid = 0;
-        const bool xok = (unsigned)(ix0 + hx) < (unsigned)a.W;
-#pragma unroll
-        for (int j = 0; j <= RSN; ++j) {
-          bool ok;
-          int eoff;
-          if (j < RSN) {
-            ok = xok && (unsigned)(iy0 + hy0 + RSTEP * j) < (unsigned)a.H && (j < RSN - 1 || r_last_on);
-            eoff = xoff_r + j * RSTEP * row_el;
-          } else {
-            ok = e_on && (unsigned)(iy0 + ey) < (unsigned)a.H && (unsigned)(ix0 + 32 + ec) < (unsigned)a.W;
-            eoff = xoff_e;
-          }
-          valid |= (ok ? 1u : 0u) << j;
-          const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
-          xr[j] = ld16ov<vec>(base, off * 2u);
-        }
-      }
+      valid = load_x(xr, xsrc, n, iy0, ix0, cbase);
     }
-    if (X_LOAD) {
-      if (SET_A) xvalid_a = valid; else xvalid_b = valid;
+    if (CAT && P == 0) {
+      // the x2 slice of this group as well (its own step would be the one in which the multiplying waves store the previous
+      // tile: with no loads queued at that time their stores do not wait behind ours)
+      xvalid_b = load_x(xb, a.src0, n, iy0, ix0, cbase);
     }
-    {
-      const bf16_t* wb_ = a.weight + (size_t)cout0 * a.Cin + wk * 32;
-      const int wstride = (WPP / CT) * a.Cout * a.Cin;  // taps per pass x one tap
-#pragma unroll
-      for (int j = 0; j < WVN; ++j) {
-        unsigned off = (unsigned)woff0;
-        if (W_RAGGED && j == WVN - 1) off = (p0 + WPP * j < WROWS) ? off : 0u;
-        wr[j] = ld16ov<vec>(wb_ + j * wstride, off * 2u);
-      }
-    }
-    if (bp && ptid < CT / 4 && a.bias != nullptr) {
-      const f32x4 v = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
-      if (W_A) bra = v; else brb = v;
-    }
+    if (X_LOAD) xvalid_a = valid;
+    if (!RESW) load_weights(cout0, kc);
+    if (bp && ptid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
   };
 
   auto write_step = [&](char* st, auto p_tag) __attribute__((always_inline)) {
     constexpr int P = decltype(p_tag)::value;
-    constexpr bool CAT = MODE == 1 || MODE == 4;
-    constexpr bool SET_A = CAT ? P == 0 : (P & 1) == 0;
-    constexpr bool W_A = (P & 1) == 0;
+    constexpr bool SET_A = !CAT || P == 0;
     vec (&xr)[XV] = SET_A ? xa : xb;
-    vec (&wr)[WVN] = W_A ? wa : wb;
     const unsigned xvalid = SET_A ? xvalid_a : xvalid_b;
     const bool all_ok = xvalid == 0xffffffffu;
     if (MODE == 4 && P == 0) {
       // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: per 32 source pixels two MFMAs (K = 32 input channels),
-      // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image in the D layout they already have
+      // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image: a lane's D registers are 16
+      // consecutive output channels, i.e. K-slot planes 2 lh and 2 lh + 1 of its pixel
       const int iy0h = u_iy0 + (tap >> 1), ix0h = u_ix0 + (tap & 1);
 #pragma unroll
       for (int i = 0; i < MT_PER; ++i) {
@@ -532,7 +637,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           cu = mfma32x16(ua[0], xr[2 * i], cu);
           cu = mfma32x16(ua[1], xr[2 * i + 1], cu);
           const bool in_img = (unsigned)(iy0h + 2 * spy) < (unsigned)a.H && (unsigned)(ix0h + 2 * spx) < (unsigned)a.W;
-          char* dst = st + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * RP + (lh << 5);
+          char* dst = st + 2 * lh * XPL + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * 16;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             float f[8];
@@ -540,7 +645,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
             for (int e = 0; e < 8; ++e) f[e] = cu[8 * h + e];
             vec o = E::pack(f);
             if (!in_img) o = E::zero();
-            if (sp < UPN) *reinterpret_cast<vec*>(dst + (h << 4)) = o;
+            if (sp < UPN) *reinterpret_cast<vec*>(dst + h * XPL) = o;
           }
         }
       }
@@ -564,24 +669,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         }
         if (!all_ok && !((xvalid >> j) & 1u)) v = E::zero();
         const int pix = j < RSN ? pix_r0 + j * RSTEP * HW : pix_e;
-        *reinterpret_cast<vec*>(st + pix * RP + (ch << 4)) = v;
+        *reinterpret_cast<vec*>(st + ch * XPL + pix * 16) = v;
       }
     }
-#pragma unroll
-    for (int j = 0; j < WVN; ++j) {
-      if (W_RAGGED && j == WVN - 1 && p0 + WPP * j >= WROWS) continue;
-      *reinterpret_cast<vec*>(st + lds_w0 + j * WPP * RP) = wr[j];
-    }
-    if ((W_A ? bp_a : bp_b) && ptid < CT / 4)
-      *reinterpret_cast<f32x4*>(sBias + (W_A ? bpar_a : bpar_b) * CT + ptid * 4) = W_A ? bra : brb;
-    // name the registers this step read as consumed on every path (path-insensitive waitcnt insertion, see conv3x3_pipe.hip)
-    if (!CAT || P < 2 || P == 3) {
-#pragma unroll
-      for (int j = 0; j < XV; ++j) asm volatile("" ::"v"(xr[j]));
-    }
-#pragma unroll
-    for (int j = 0; j < WVN; ++j) asm volatile("" ::"v"(wr[j]));
-    asm volatile("" ::"v"(W_A ? bra : brb));
+    if (!RESW) write_weights(st + XBYTES);
+    if (bp && ptid < CT / 4) *reinterpret_cast<f32x4*>(sBias + bpar * CT + ptid * 4) = br;
   };
 
   TileCur pc;
@@ -596,15 +688,21 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       if (cur_next(pc, a, tile_end) && pc.tile != t_old) ppar ^= 1;
     }
   };
+  if (RESW) {
+    // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order
+    for (int kc = 0; kc < a.nk; ++kc) {
+      load_weights(0, kc);
+      write_weights(wres + kc * WBYTES);
+    }
+  }
   load_next(IntTag<0>{});
   write_step(smem, IntTag<0>{});
   load_next(IntTag<1>{});
-  load_next(IntTag<2>{});
   PCT_DECL
   pc_barrier();                         // stage 0 is staged
   PCT(3)
   // iteration s (the consumers multiply chunk s): chunk s + 1 goes from registers to the stage the consumers left at the
-  // last barrier, then the loads of chunk s + 3 are issued into the registers that just became free
+  // last barrier, then the loads of chunk s + 2 are issued into the same registers
   int s = 0;
   auto iter = [&](auto q_tag) __attribute__((always_inline)) {
     constexpr int Q = decltype(q_tag)::value;
@@ -614,7 +712,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     }
     write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
     PCT(1)
-    load_next(IntTag<(Q + 3) & 3>{});
+    load_next(IntTag<(Q + 2) & 3>{});
     PCT(2)
     pc_barrier();
     PCT(3)
@@ -630,17 +728,24 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   PCT_FLUSH(4)
 }
 
-template <typename T, int NT, int MPW, int MODE, int PW>
+template <int NT, int MPW>
+constexpr size_t pc_lds_bytes(bool resw, int nk) {
+  constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
+  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 2 * NT * 32 * 4;
+}
+
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
 int launch_pc(PipeArgs& a, hipStream_t s) {
-  constexpr int TH = MPW * 4, CT = NT * 32;
-  constexpr size_t lds = 2 * ((size_t)(TH + 2) * 34 * 80 + (size_t)9 * CT * 80) + 2 * CT * 4;
-  static_assert(lds <= 163840, "one workgroup's LDS");
-  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW>;
+  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk);
+  static_assert(pc_lds_bytes<NT, MPW>(false, 0) <= 163840, "one workgroup's LDS");
+  if (lds > 163840) return UNCL_ERR_ARG;
+  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW>;
   static bool attr_done = false;
   static int n_cu = 0;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
+    // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT) : lds)) != hipSuccess)
       return UNCL_ERR_LAUNCH;
     hipDeviceProp_t p;
     int dev = 0;
@@ -676,25 +781,32 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
   if (a.nk < 1 || a.res != nullptr || a.out1_w != nullptr || a.flat_S != 0) return UNCL_ERR_ARG;
   static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
   a.pc_prio = prio;
-  static const int pw = [] { const char* e = getenv("UNCL_PC_PW"); return e ? atoi(e) : 8; }();
+  static const int resw_on = [] { const char* e = getenv("UNCL_PC_RESW"); return e ? atoi(e) : 1; }();
+  // resident weights: one cout tile for the whole layer and its K-chunks fit next to two activation stages
+  const bool resw = resw_on && a.n_ct == 1 && a.nk * nt <= 4;
   if (nt == 1 && mpw == 4) {
     if (a.pool_out != nullptr) return UNCL_ERR_ARG;
-    if (pw == 4) {
-      if (mode == 0) return launch_pc<T, 1, 4, 0, 4>(a, s);
-      if (mode == 1) return launch_pc<T, 1, 4, 1, 4>(a, s);
-      if (mode == 4) return launch_pc<T, 1, 4, 4, 4>(a, s);
+    if (resw) {
+      if (mode == 0) return launch_pc<T, 1, 4, 0, 8, true>(a, s);
+      if (mode == 1) return launch_pc<T, 1, 4, 1, 8, true>(a, s);
+      if (mode == 4) return launch_pc<T, 1, 4, 4, 8, true>(a, s);
     } else {
-      if (mode == 0) return launch_pc<T, 1, 4, 0, 8>(a, s);
-      if (mode == 1) return launch_pc<T, 1, 4, 1, 8>(a, s);
-      if (mode == 4) return launch_pc<T, 1, 4, 4, 8>(a, s);
+      if (mode == 0) return launch_pc<T, 1, 4, 0, 8, false>(a, s);
+      if (mode == 1) return launch_pc<T, 1, 4, 1, 8, false>(a, s);
+      if (mode == 4) return launch_pc<T, 1, 4, 4, 8, false>(a, s);
     }
     return UNCL_ERR_ARG;
   }
   if (nt == 2 && mpw == 2) {
     // 64-channel tiles: the multiplying waves need 234 registers (two fragment sets of ten vectors), which leaves room for two
     // waves per SIMD, i.e. four staging waves
-    if (mode == 0) return launch_pc<T, 2, 2, 0, 4>(a, s);
-    if (mode == 1) return launch_pc<T, 2, 2, 1, 4>(a, s);
+    if (resw) {
+      if (mode == 0) return launch_pc<T, 2, 2, 0, 4, true>(a, s);
+      if (mode == 1) return launch_pc<T, 2, 2, 1, 4, true>(a, s);
+    } else {
+      if (mode == 0) return launch_pc<T, 2, 2, 0, 4, false>(a, s);
+      if (mode == 1) return launch_pc<T, 2, 2, 1, 4, false>(a, s);
+    }
     return UNCL_ERR_ARG;
   }
   return UNCL_ERR_ARG;

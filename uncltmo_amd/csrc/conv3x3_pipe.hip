@@ -833,8 +833,8 @@ int dispatch_type(PipeArgs& a, int dtype, int mode, bool prev, hipStream_t s) {
 
 }  // namespace
 
-// 1 (default): the layers where the producer / consumer structure measured faster (concat sources); 2: every layer it builds
-static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 1; }();
+// 2 (default): every layer the producer / consumer kernel builds; 1: the concat-source layers only; 0: the four-wave kernel
+static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 2; }();
 extern "C" int uncl_conv3x3_set_pc(int on) {
   const int old = g_use_pc;
   g_use_pc = on < 0 ? 0 : (on > 2 ? 2 : on);
@@ -906,16 +906,16 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   // multi-chunk layers: producer / consumer workgroups (conv3x3_pc.hip); everything it does not build falls through
   const int pc_mode = d->src_mode == UNCL_SRC_PLAIN ? (prev ? -1 : 0)
                       : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? 4 : -1;
-  // measured per layer at bench size (tools/pc_phase_timing.py): the concat layers (deep K, transforms in the staging waves)
-  // gain 3 - 13 %, the plain 64-channel-tile layers (two to eight chunks per tile, pooled copy) lose 10 - 20 %
-  static const int pc_nk1 = [] { const char* e = getenv("UNCL_PC_NK1"); return e ? atoi(e) : 0; }();   // experiment: single-chunk layers
-  const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc == 2 ? 0 : 1) && a.nk >= (pc_nk1 ? 1 : 2) && d->res == nullptr &&
-                     d->out1_w == nullptr && !d->skip_main_store;
+  // measured per layer at bench size (tools/pc_phase_timing.py --product): with one staging register set, unpadded LDS planes
+  // and resident weights the producer / consumer structure is faster on every layer it builds (3 - 30 %), single-chunk ones
+  // included; UNCL_PC=1 restricts it to the concat layers, 0 turns it off
+  const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc == 2 ? 0 : 1) && a.nk >= 1 && d->res == nullptr && d->out1_w == nullptr &&
+                     !d->skip_main_store;
   if (d->Cout == 32) {
     // 8-row tiles at three workgroups per CU (50 KB LDS, 168 VGPRs) overlap the serial load / stage / store phases of the
     // single-chunk 32 -> 32 transposed layers better than 16-row tiles at two (measured: up_path.{2,3}.conv.conv1 -9 %);
     // the valid 32 -> 32 layer and the multi-chunk concat layers are faster (or read less) with the larger tile
-    if (d->pad == 2 && d->src_mode == UNCL_SRC_PLAIN && d->Cin == 32 && !prev && !(pc_ok && pc_nk1 && g_use_pc == 2)) {
+    if (d->pad == 2 && d->src_mode == UNCL_SRC_PLAIN && d->Cin == 32 && !prev && !(pc_ok && pool_out == nullptr)) {
       a.n_ct = 1;
       a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + 7) / 8;
       a.total_tiles = d->N * a.tiles_x * a.tiles_y;
