@@ -441,6 +441,50 @@ def test_pc_plain_layers_bitwise(cin, cout, h, w, n, pad, pool, act):
     assert rel_l2(from_nhwc(go), ref) < TOL[BF]
 
 
+@pytest.mark.parametrize("h,w,n,pool", [(40, 70, 2, True), (256, 256, 2, True), (37, 51, 3, False)])
+def test_pc_first_layer_fused_bitwise(h, w, n, pool):
+    """UNCL_SRC_IMAGE1 under both kernel structures (producer / consumer: the staging waves rebuild the halo tile from image
+    patches parked in LDS one step earlier), with the pooled copy beside 32-channel tiles."""
+    x = rnd(n, 1, h, w, seed=231).abs().reshape(n, h, w).cuda().contiguous()
+    w0, b0 = rnd(32, 1, 3, 3, seed=232, scale=0.3).cuda().contiguous(), rnd(32, seed=233).cuda()
+    w1, b1 = pack_weight(q(rnd(32, 32, 3, 3, seed=234, scale=0.06), BF), BF), rnd(32, seed=235).cuda()
+    ho, wo = h - 4, w - 4
+
+    def run():
+        out = torch.zeros(n, ho, wo, 32, dtype=torch.bfloat16, device="cuda")
+        pl = torch.zeros(n, ho // 2, wo // 2, 32, dtype=torch.bfloat16, device="cuda") if pool else None
+        run_pipe(pool_out=pl, dtype=BF, ksize=3, pad=0, src_mode=_hip.SRC_IMAGE1, N=n, H=h - 2, W=w - 2, Cin=32, Cout=32, src0=x,
+                 src0_H=h, src0_W=w, src0_C=1, pre_w=w0, pre_b=b0, weight=w1, bias=b1, act=_hip.ACT_RELU, out=out, out_H=ho,
+                 out_W=wo, out_C=32)
+        return out, pl
+
+    (ro, rp), (go, gp) = _both_structures(run)
+    assert torch.equal(ro, go)
+    if pool:
+        assert torch.equal(rp, gp)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n,pad,pool", [(32, 32, 45, 70, 2, 0, True), (32, 32, 126, 126, 2, 2, False),
+                                                     (32, 64, 63, 63, 2, 0, False), (64, 32, 40, 44, 2, 0, True)])
+def test_pc_single_chunk_and_pooled_32_bitwise(cin, cout, h, w, n, pad, pool):
+    x, wt, b = q(rnd(n, cin, h, w, seed=241), BF), q(rnd(cout, cin, 3, 3, seed=242, scale=0.1), BF), rnd(cout, seed=243)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    xd, wd, bd = to_nhwc(x, BF), pack_weight(wt, BF), b.cuda()
+
+    def run():
+        out = torch.zeros(n, ho, wo, cout, dtype=torch.bfloat16, device="cuda")
+        pl = torch.zeros(n, ho // 2, wo // 2, cout, dtype=torch.bfloat16, device="cuda") if pool else None
+        run_pipe(pool_out=pl, dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=xd,
+                 src0_H=h, src0_W=w, src0_C=cin, weight=wd, bias=bd, act=_hip.ACT_RELU, out=out, out_H=ho, out_W=wo, out_C=cout)
+        return out, pl
+
+    (ro, rp), (go, gp) = _both_structures(run)
+    assert torch.equal(ro, go)
+    if pool:
+        assert torch.equal(rp, gp)
+    assert rel_l2(from_nhwc(go), F.relu(F.conv2d(F.pad(x, (pad,) * 4), wt, b))) < TOL[BF]
+
+
 @pytest.mark.parametrize("c,cout,h,w,n,short", [(32, 32, 37, 45, 2, 1), (64, 32, 124, 124, 2, 0), (128, 64, 57, 57, 2, 1),
                                                 (256, 128, 24, 24, 3, 0)])
 def test_pc_concat_ssr_bitwise(c, cout, h, w, n, short):

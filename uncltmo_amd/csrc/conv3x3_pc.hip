@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned long long pct_now() {
 // sched_barrier: register-only instructions (MFMAs) must not drift across the stamp (an asm memory clobber does not hold them)
 #define PCT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long pct_t = pct_now(); __builtin_amdgcn_sched_barrier(0); \
                  pct_acc[i] += pct_t - pct_last; pct_last = pct_t; }
-#define PCT_FLUSH(base) if ((threadIdx.x & 255) == 0) { for (int i = 0; i < 4; ++i) atomicAdd(&g_pc_t[base + i], pct_acc[i]); atomicAdd(&g_pc_t[8 + base / 4], 1ull); }
+#define PCT_FLUSH(base) if (threadIdx.x == 0 || threadIdx.x == NCW * 64) { for (int i = 0; i < 4; ++i) atomicAdd(&g_pc_t[base + i], pct_acc[i]); atomicAdd(&g_pc_t[8 + base / 4], 1ull); }
 #else
 #define PCT_DECL
 #define PCT(i)
@@ -81,9 +81,11 @@ __device__ __forceinline__ bool cur_next(TileCur& c, const PipeArgs& a, int tile
 }
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) computed by the
-//       producers (32 channels, same extent as the skip)
+//       producers (32 channels, same extent as the skip), 3 = the 32-channel source is act(conv3x3_valid(fp32 image)) rebuilt
+//       by the producers' matrix cores from the image patch under the halo tile (inc.conv.conv fused into inc.conv.conv1)
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
 __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_kernel(const PipeArgs a) {
+  constexpr int NCW = 4;                      // multiplying waves
   static_assert(PW == 4 || PW == 8, "four or eight staging waves");
   using E = Elem<T>;
   using vec = typename Elem<T>::vec;
@@ -98,10 +100,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   // streamed weights: two stages of [activations | weights]; resident weights: [X stage 0 | X stage 1 | nk weight chunks]
   constexpr int STAGE = RESW ? XBYTES : XBYTES + WBYTES;
   static_assert(MODE != 4 || (NT == 1 && MPW == 4), "fused up-conv: 16 x 32 tiles of 32 channels");
+  static_assert(MODE != 3 || (NT == 1 && RESW), "fused first layer: 32 -> 32 channels, one chunk, resident weights");
+  constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;            // MODE 3: fp32 image patch under the halo tile
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wres = smem + 2 * XBYTES;                               // RESW: chunk kc at wres + kc * WBYTES
   float* const sBias = reinterpret_cast<float*>(smem + (RESW ? 2 * XBYTES + a.nk * WBYTES : 2 * STAGE));   // [2 tiles][CT]
+  float* const sP = sBias + 2 * CT;                                   // MODE 3: [2][PN3] image patches
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -112,10 +117,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   const int tile_end = min(tile0 + a.tiles_per_wg, a.total_tiles);
   if (tile0 >= tile_end) return;
 
-  if (wave < 4) {
+  if (wave < NCW) {
     // =================================================================================================================
     // consumers
     // =================================================================================================================
+    const int cw = wave;                      // row block of the tile this wave owns
     if ((a.pc_prio & 3) == 1) __builtin_amdgcn_s_setprio(2);
     f32x16 acc[MPW][NT];
     f32x16 zero16;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
     // fragment bases of this lane: A = weights row lr, B = halo pixel (wave*MPW) * HW + lr, K-slot plane lh (+ 2 ks)
     const int aoff = lh * WPL + lr * 16;
-    const int boff = lh * XPL + (wave * MPW * HW + lr) * 16;
+    const int boff = lh * XPL + (cw * MPW * HW + lr) * 16;
 
     // One staged K-chunk = six (ks, tx) tap columns of 12 MFMAs each.  The fragments of column i + 1 are read while the MFMAs
     // of column i issue (two register sets, one DS read per MFMA gap pinned with sched_group_barrier): a single wave per SIMD
@@ -198,7 +204,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     auto epilogue = [&](const TileCur& c, int tpar, auto act_tag) __attribute__((always_inline)) {
       constexpr int ACT = decltype(act_tag)::value;
       const float* sBt = sBias + tpar * CT;
-      const int y0 = c.ty * TH + wave * MPW, x0 = c.tx * TW, co = c.ct * CT;
+      const int y0 = c.ty * TH + cw * MPW, x0 = c.tx * TW, co = c.ct * CT;
       f32x4 bq[NT][4];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -274,7 +280,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         // MaxPool2d(2) of the wave's two rows (unet_parts.py:212,233): vertical max in registers, horizontal max with the
         // neighbouring pixel's lane through DPP quad_perm [1,0,3,2]; the even lanes store the 16 pooled pixels
         static_assert(NT != 2 || MPW == 2, "one pooled row per wave");
-        const int gy = (c.ty * TH >> 1) + wave, gx = (x0 >> 1) + (lr >> 1);
+        const int gy = (c.ty * TH >> 1) + cw, gx = (x0 >> 1) + (lr >> 1);
         const bool in = (lr & 1) == 0 && gy < a.pH && gx < a.pW;
         const size_t e0 = (((size_t)c.n * a.pH + gy) * a.pW + gx) * a.oC + co + 8 * lh;
         auto pooled = [&](int nt, int q) __attribute__((always_inline)) {
@@ -304,15 +310,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     // per-lane addresses, per-element selects, float round trips in the pooled copy) and was half of a 64-channel tile's time.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
+    // Units (pr, nt, qp): rows 2 pr and 2 pr + 1 of the wave, channels 32 nt + 16 qp.. of them (two row stores) and the same
+    // channels of pooled row pr.
     auto epilogue_relu = [&](const TileCur& c, int tpar) __attribute__((always_inline)) {
       const float* sBt = sBias + tpar * CT;
-      const int y0 = c.ty * TH + wave * MPW, x0 = c.tx * TW, co = c.ct * CT;
+      const int y0 = c.ty * TH + cw * MPW, x0 = c.tx * TW, co = c.ct * CT;
       const int ox = x0 + lr;
-      f32x4 bq[NT][4];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[nt][q] = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 8 * q + 4 * lh);
       auto pack4 = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
         const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
         const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
@@ -332,47 +335,47 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       const bool xin = ox < a.Wout;
       unsigned loff = (unsigned)(ox * a.oC + 8 * lh) * 2u;
       asm volatile("" : "+v"(loff));        // keep the 32-bit lane offset (global_store ... v_off, s[base] offset:imm)
-      vec wv[MPW][NT][2];
+      const int gx = (x0 >> 1) + (lr >> 1);
+      unsigned poff = (unsigned)(gx * a.oC + 8 * lh) * 2u;
+      asm volatile("" : "+v"(poff));
+      static_assert(MPW % 2 == 0, "whole pooled rows per wave");
 #pragma unroll
-      for (int m = 0; m < MPW; ++m) {
-        const int oy = y0 + m;                                   // wave-uniform
-        char* rowp = reinterpret_cast<char*>(a.out + ((size_t)c.n * a.Hout + oy) * a.Wout * a.oC + co);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int qp = 0; qp < 2; ++qp) {
-            wv[m][nt][qp] = widen_relu(pack4(acc[m][nt], 2 * qp, bq[nt][2 * qp]), pack4(acc[m][nt], 2 * qp + 1, bq[nt][2 * qp + 1]));
-#ifdef UNCL_PC_TIMING
-            if (a.pc_prio & 64) { asm volatile("" ::"v"(wv[m][nt][qp])); continue; }     // experiment: no output stores (wrong results)
-#endif
-            if (oy < a.Hout && xin) *reinterpret_cast<vec*>(rowp + loff + (nt * 32 + 16 * qp) * 2) = wv[m][nt][qp];
-          }
-      }
-      if (NT == 2 && a.pool_out != nullptr) {
-        // MaxPool2d(2) of the wave's two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
-        // maximum orders them like their floats; vertical maximum between the rows, horizontal with the neighbouring pixel's
-        // lane (DPP quad_perm [1,0,3,2]); the even lanes store the 16 pooled pixels
-        static_assert(NT != 2 || MPW == 2, "one pooled row per wave");
-        const int gy = (c.ty * TH >> 1) + wave, gx = (x0 >> 1) + (lr >> 1);
-        const bool in = (lr & 1) == 0 && gy < a.pH && gx < a.pW;
-        char* rowp = reinterpret_cast<char*>(a.pool_out + ((size_t)c.n * a.pH + gy) * a.pW * a.oC + co);
-        unsigned poff = (unsigned)(gx * a.oC + 8 * lh) * 2u;
-        asm volatile("" : "+v"(poff));
+      for (int pr = 0; pr < MPW / 2; ++pr)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int qp = 0; qp < 2; ++qp) {
-            s16x8 v = __builtin_elementwise_max(__builtin_bit_cast(s16x8, wv[0][nt][qp]), __builtin_bit_cast(s16x8, wv[MPW - 1][nt][qp]));
-            u32x4 u = __builtin_bit_cast(u32x4, v), h;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 4 * lh);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 8 + 4 * lh);
+            vec wv[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)u[i], 0xB1, 0xF, 0xF, true);
-            v = __builtin_elementwise_max(v, __builtin_bit_cast(s16x8, h));
+            for (int r = 0; r < 2; ++r) {
+              const int m = 2 * pr + r, oy = y0 + m;                              // wave-uniform
+              char* rowp = reinterpret_cast<char*>(a.out + ((size_t)c.n * a.Hout + oy) * a.Wout * a.oC + co);
+              wv[r] = widen_relu(pack4(acc[m][nt], 2 * qp, b0), pack4(acc[m][nt], 2 * qp + 1, b1));
 #ifdef UNCL_PC_TIMING
-            if (a.pc_prio & 64) { asm volatile("" ::"v"(v)); continue; }
+              if (a.pc_prio & 64) { asm volatile("" ::"v"(wv[r])); continue; }     // experiment: no output stores (wrong results)
 #endif
-            if (in) *reinterpret_cast<vec*>(rowp + poff + (nt * 32 + 16 * qp) * 2) = __builtin_bit_cast(vec, v);
+              if (oy < a.Hout && xin) *reinterpret_cast<vec*>(rowp + loff + (nt * 32 + 16 * qp) * 2) = wv[r];
+            }
+            if (a.pool_out != nullptr) {
+              // MaxPool2d(2) of the two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
+              // maximum orders them like their floats; vertical maximum between the rows, horizontal with the neighbouring
+              // pixel's lane (DPP quad_perm [1,0,3,2]); the even lanes store the 16 pooled pixels
+              const int gy = (c.ty * TH >> 1) + cw * (MPW / 2) + pr;
+              const bool in = (lr & 1) == 0 && gy < a.pH && gx < a.pW;
+              char* rowp = reinterpret_cast<char*>(a.pool_out + ((size_t)c.n * a.pH + gy) * a.pW * a.oC + co);
+              s16x8 v = __builtin_elementwise_max(__builtin_bit_cast(s16x8, wv[0]), __builtin_bit_cast(s16x8, wv[1]));
+              u32x4 u = __builtin_bit_cast(u32x4, v), h;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) h[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)u[i], 0xB1, 0xF, 0xF, true);
+              v = __builtin_elementwise_max(v, __builtin_bit_cast(s16x8, h));
+#ifdef UNCL_PC_TIMING
+              if (a.pc_prio & 64) { asm volatile("" ::"v"(v)); continue; }
+#endif
+              if (in) *reinterpret_cast<vec*>(rowp + poff + (nt * 32 + 16 * qp) * 2) = __builtin_bit_cast(vec, v);
+            }
           }
-      }
     };
 
     TileCur cc;
@@ -383,21 +386,28 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     for (int m = 0; m < MPW; ++m)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = 0; m < MPW; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
+    };
+    auto run_epilogue = [&](const TileCur& c, int tp) __attribute__((always_inline)) {
+      if (fast_relu) epilogue_relu(c, tp);
+      else if (a.slope == 0.f) epilogue(c, tp, IntTag<0>{});
+      else if (a.slope == 1.f) epilogue(c, tp, IntTag<1>{});
+      else epilogue(c, tp, IntTag<2>{});
+      zero_acc();
+    };
     PCT_DECL
+    if (MODE == 3) pc_barrier();     // the staging waves' first image patch
     pc_barrier();     // stage 0 is staged
     PCT(2)
     for (int s = 0;; ++s) {
       mfma_phase(smem + (s & 1) * STAGE, RESW ? wres + cc.kc * WBYTES : smem + (s & 1) * STAGE + XBYTES);
       PCT(0)
       if (cc.kc == a.nk - 1) {
-        if (fast_relu) epilogue_relu(cc, tpar);
-        else if (a.slope == 0.f) epilogue(cc, tpar, IntTag<0>{});
-        else if (a.slope == 1.f) epilogue(cc, tpar, IntTag<1>{});
-        else epilogue(cc, tpar, IntTag<2>{});
-#pragma unroll
-        for (int m = 0; m < MPW; ++m)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
+        run_epilogue(cc, tpar);
         PCT(1)
       }
       pc_barrier();   // done with stage s & 1; stage (s + 1) & 1 is staged
@@ -414,8 +424,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   // producers
   // ===================================================================================================================
   if ((a.pc_prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
-  const int ptid = tid - 256;
-  const int pwave = wave - 4;
+  const int ptid = tid - NCW * 64;
+  const int pwave = wave - NCW;
   // per-thread constants of the staging pattern (identical for every step): regular slot j = halo pixel (hy0 + RSTEP*j, hx),
   // vector ch; extra slot = halo pixel (ey, 32 + ec), vector ch
   constexpr int NPROD = PW * 64;
@@ -458,6 +468,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   bool bp = false;
   int u_iy0 = 0, u_ix0 = 0;
   int ppar = 0;                 // parity of the tile the producers are loading
+  int p3par = 0;                // MODE 3: the patch buffer the next build reads
 
   // MODE 4: this wave is tap (dy, dx) of the 2x2 stride-2 transposed conv (and, with eight staging waves, one half of the
   // M-tiles).  Its weight fragment (A rows in the order cout(r) = 16*bit2(r) + 4*(r >> 3) + (r & 3), which makes a lane's D
@@ -476,6 +487,24 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     for (int ks = 0; ks < 2; ++ks) ua[ks] = ld16v<vec>(a.up_w + arow * 32 + (2 * ks + lh) * 8);
 #pragma unroll
     for (int i = 0; i < 16; ++i) cb[i] = a.up_b ? a.up_b[16 * lh + i] : 0.f;
+  }
+
+  // MODE 3: image-patch values in flight, the first layer's weight fragment (cout = lr, k = 8 lh + j -> tap) and the biases
+  // of this lane's channels 8q + 4 lh + r
+  constexpr int IRN = (PN3 + NPROD - 1) / NPROD;
+  float ir[IRN];
+  vec preA;
+  float preB[16];
+  if (MODE == 3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lh + j;
+      preA[j] = (T)(k < 9 ? a.pre_w[lr * 9 + k] : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) preB[i] = a.pre_b ? a.pre_b[8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f;
+#pragma unroll
+    for (int k = 0; k < IRN; ++k) ir[k] = 0.f;
   }
 
   // position of K-chunk kc in the weight's K layout: concat layers store [x2 | x1 | x2^2 | sqrt] and are walked slice by slice
@@ -558,7 +587,17 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     const bool same_ext = a.s1H == a.s0H && a.s1W == a.s0W;
     const bf16_t* xsrc = (MODE != 0 && g == 1) ? a.src1 : a.src0;
     unsigned valid = 0xffffffffu;
-    if (!X_LOAD) {
+    if (MODE == 3) {
+      // the image patch under the halo tile: first-layer pixel (y, x) reads image rows y..y+2, columns x..x+2.  Rows and
+      // columns past the image only feed outputs that are never stored (valid convolution), so they are clamped.
+      const float* ib = a.img + (size_t)n * a.imgH * a.imgW;
+#pragma unroll
+      for (int k = 0; k < IRN; ++k) {
+        const int idx = min(ptid + k * NPROD, PN3 - 1);
+        const int pr = idx / PW3, pcl = idx - pr * PW3;
+        ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pcl, a.imgW - 1)];
+      }
+    } else if (!X_LOAD) {
       // x2^2 / sqrt(x2): staged from the x2 registers
     } else if (MODE == 4 && P == 0) {
       // B fragments of the up-conv straight from global memory: source pixel sp = 32 mt + lr of the 9 x 17 patch under the
@@ -612,8 +651,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       xvalid_b = load_x(xb, a.src0, n, iy0, ix0, cbase);
     }
     if (X_LOAD) xvalid_a = valid;
-    if (!RESW) load_weights(cout0, kc);
-    if (bp && ptid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
+    if (!RESW) {
+      load_weights(cout0, kc);
+      if (bp && ptid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
+    }
   };
 
   auto write_step = [&](char* st, auto p_tag) __attribute__((always_inline)) {
@@ -622,7 +663,54 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     vec (&xr)[XV] = SET_A ? xa : xb;
     const unsigned xvalid = SET_A ? xvalid_a : xvalid_b;
     const bool all_ok = xvalid == 0xffffffffu;
-    if (MODE == 4 && P == 0) {
+    if (MODE == 3) {
+      // Build the 32-channel halo tile of THIS step's tile from the image patch staged one step ago (sP[par], published by
+      // the last barrier) with the matrix cores: per 32 halo pixels two MFMAs over the nine taps of the bf16 head and of the
+      // bf16 tail of the fp32 input (x = hi + lo to 2^-17); a lane's D quad q is channels 8q + 4 lh.. of its pixel, i.e. one
+      // half of K-slot plane q.  Then park the patch of the NEXT tile (in registers since the last step) in the other buffer.
+      const float* sPt = sP + p3par * PN3;
+      f32x16 z16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z16[i] = 0.f;
+      constexpr int MT3 = (NPIX + 31) / 32, IT3 = (MT3 + PW - 1) / PW;
+      static_assert(HW == 34 && NPIX < 2048, "the reciprocal multiply below divides by 34");
+#pragma unroll
+      for (int i = 0; i < IT3; ++i) {
+        const int mt = pwave + PW * i;           // wave-uniform
+        if (mt < MT3) {
+          const int pix = mt * 32 + lr;
+          const int pcl = min(pix, NPIX - 1);
+          const int py = (pcl * 241) >> 13, px = pcl - py * HW;   // / 34 for pcl < 2048 (HW == 34)
+          const float* pp = sPt + py * PW3 + px;
+          vec Bh, Bl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int o0 = (j / 3) * PW3 + j % 3;  // tap j (lower half-wave)
+            float v = pp[lh ? 2 * PW3 + 2 : o0];   // upper half-wave: tap 8 in slot 0
+            if (j > 0) v = lh ? 0.f : v;
+            const T hi = (T)v;
+            Bh[j] = hi;
+            Bl[j] = (T)(v - (float)hi);
+          }
+          f32x16 c3 = mfma32x16(preA, Bh, z16);
+          c3 = mfma32x16(preA, Bl, c3);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vec4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = c3[4 * q + e] + preB[4 * q + e];
+              o[e] = (T)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+            }
+            if (pix < NPIX) *reinterpret_cast<vec4*>(st + q * XPL + pix * 16 + (lh << 3)) = o;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < IRN; ++k)
+        if (ptid + k * NPROD < PN3) sP[(p3par ^ 1) * PN3 + ptid + k * NPROD] = ir[k];
+      p3par ^= 1;
+    } else if (MODE == 4 && P == 0) {
       // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: per 32 source pixels two MFMAs (K = 32 input channels),
       // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image: a lane's D registers are 16
       // consecutive output channels, i.e. K-slot planes 2 lh and 2 lh + 1 of its pixel
@@ -672,8 +760,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         *reinterpret_cast<vec*>(st + ch * XPL + pix * 16) = v;
       }
     }
-    if (!RESW) write_weights(st + XBYTES);
-    if (bp && ptid < CT / 4) *reinterpret_cast<f32x4*>(sBias + bpar * CT + ptid * 4) = br;
+    if (!RESW) {
+      write_weights(st + XBYTES);
+      if (bp && ptid < CT / 4) *reinterpret_cast<f32x4*>(sBias + bpar * CT + ptid * 4) = br;
+    }
   };
 
   TileCur pc;
@@ -689,13 +779,28 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     }
   };
   if (RESW) {
-    // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order
+    // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order, and so
+    // does its bias (both tile parities)
     for (int kc = 0; kc < a.nk; ++kc) {
       load_weights(0, kc);
       write_weights(wres + kc * WBYTES);
     }
+    if (ptid < CT / 4) {
+      const f32x4 b4 = a.bias != nullptr ? *reinterpret_cast<const f32x4*>(a.bias + ptid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(sBias + ptid * 4) = b4;
+      *reinterpret_cast<f32x4*>(sBias + CT + ptid * 4) = b4;
+    }
   }
   load_next(IntTag<0>{});
+  if (MODE == 3) {
+    // one tile further ahead: patch 0 is parked in LDS, patch 1 requested, and a barrier publishes the former to every
+    // staging wave before the first build
+#pragma unroll
+    for (int k = 0; k < IRN; ++k)
+      if (ptid + k * NPROD < PN3) sP[ptid + k * NPROD] = ir[k];
+    load_next(IntTag<1>{});
+    pc_barrier();
+  }
   write_step(smem, IntTag<0>{});
   load_next(IntTag<1>{});
   PCT_DECL
@@ -729,15 +834,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 }
 
 template <int NT, int MPW>
-constexpr size_t pc_lds_bytes(bool resw, int nk) {
+constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
-  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 2 * NT * 32 * 4;
+  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 2 * NT * 32 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0);
 }
 
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
 int launch_pc(PipeArgs& a, hipStream_t s) {
-  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk);
-  static_assert(pc_lds_bytes<NT, MPW>(false, 0) <= 163840, "one workgroup's LDS");
+  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3);
+  static_assert(pc_lds_bytes<NT, MPW>(false, 0, false) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
   auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW>;
   static bool attr_done = false;
@@ -745,7 +850,7 @@ int launch_pc(PipeArgs& a, hipStream_t s) {
   if (!attr_done) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT) : lds)) != hipSuccess)
+                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3) : lds)) != hipSuccess)
       return UNCL_ERR_LAUNCH;
     hipDeviceProp_t p;
     int dev = 0;
@@ -784,8 +889,25 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
   static const int resw_on = [] { const char* e = getenv("UNCL_PC_RESW"); return e ? atoi(e) : 1; }();
   // resident weights: one cout tile for the whole layer and its K-chunks fit next to two activation stages
   const bool resw = resw_on && a.n_ct == 1 && a.nk * nt <= 4;
+  // a pooled copy beside 32-channel tiles: only the forward epilogue (ReLU, plain store) builds it
+  const bool fwd_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && !a.skip_main;
   if (nt == 1 && mpw == 4) {
-    if (a.pool_out != nullptr) return UNCL_ERR_ARG;
+    if (a.pool_out != nullptr && !fwd_relu) return UNCL_ERR_ARG;
+    static const int pw = [] { const char* e = getenv("UNCL_PC_PW"); return e ? atoi(e) : 8; }();      // experiment: staging waves
+    if (pw == 4) {
+      if (mode == 3) return resw && a.nk == 1 ? launch_pc<T, 1, 4, 3, 4, true>(a, s) : UNCL_ERR_ARG;
+      if (resw) {
+        if (mode == 0) return launch_pc<T, 1, 4, 0, 4, true>(a, s);
+        if (mode == 1) return launch_pc<T, 1, 4, 1, 4, true>(a, s);
+        if (mode == 4) return launch_pc<T, 1, 4, 4, 4, true>(a, s);
+      } else {
+        if (mode == 0) return launch_pc<T, 1, 4, 0, 4, false>(a, s);
+        if (mode == 1) return launch_pc<T, 1, 4, 1, 4, false>(a, s);
+        if (mode == 4) return launch_pc<T, 1, 4, 4, 4, false>(a, s);
+      }
+      return UNCL_ERR_ARG;
+    }
+    if (mode == 3) return resw && a.nk == 1 ? launch_pc<T, 1, 4, 3, 8, true>(a, s) : UNCL_ERR_ARG;
     if (resw) {
       if (mode == 0) return launch_pc<T, 1, 4, 0, 8, true>(a, s);
       if (mode == 1) return launch_pc<T, 1, 4, 1, 8, true>(a, s);

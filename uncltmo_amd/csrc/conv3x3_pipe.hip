@@ -905,7 +905,8 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // multi-chunk layers: producer / consumer workgroups (conv3x3_pc.hip); everything it does not build falls through
   const int pc_mode = d->src_mode == UNCL_SRC_PLAIN ? (prev ? -1 : 0)
-                      : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? 4 : -1;
+                      : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? 4
+                      : d->src_mode == UNCL_SRC_IMAGE1 ? 3 : -1;
   // measured per layer at bench size (tools/pc_phase_timing.py --product): with one staging register set, unpadded LDS planes
   // and resident weights the producer / consumer structure is faster on every layer it builds (3 - 30 %), single-chunk ones
   // included; UNCL_PC=1 restricts it to the concat layers, 0 turns it off
@@ -925,7 +926,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     a.n_ct = 1;
     a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
     a.total_tiles = d->N * a.tiles_x * a.tiles_y;
-    if (pc_ok && pool_out == nullptr) {
+    if (pc_ok) {
       const int rc = uncl_conv3x3_pc_launch(a, d->dtype, 1, 4, pc_mode, s);
       if (rc != UNCL_ERR_ARG) return rc;
     }
