@@ -227,6 +227,15 @@ def test_save_model_round_trip_and_lmcl(tmp_path):
         assert torch.equal(v, v2), k
     st, st2 = tr.optimizerG.state_dict()["state"], tr2.optimizerG.state_dict()["state"]
     assert st.keys() == st2.keys() and all(torch.equal(st[i]["exp_avg"], st2[i]["exp_avg"]) for i in st)
+    # the trainer's own resume (GanTrainerImg.py:484-493): epoch counter, nets in train mode, and the next step continues
+    # identically to the trainer that was never interrupted
+    tr3, G3, D3 = make_trainer()
+    assert tr3.save_model("models", 3, 8, str(tmp_path)).endswith("net_epoch3_iter8.pth")
+    tr3.load_model(path)
+    assert tr3.epoch == 3 and G3.training and D3.training
+    tr.train_D(hdr, pos, neg, 0); tr.train_G(hdr, hdr.clone(), pos, neg, 0)
+    tr3.train_D(hdr, pos, neg, 0); tr3.train_G(hdr, hdr.clone(), pos, neg, 0)
+    assert float(tr.errD.detach()) == float(tr3.errD.detach()) and float(tr.errG_d.detach()) == float(tr3.errG_d.detach())
     # LMCL form of nce (GanTrainerImg.py:434-450) against the formula on the similarities
     g = torch.Generator().manual_seed(5)
     a_, p_, q_ = (torch.rand(4, 2, 1, 1, generator=g).cuda().requires_grad_(True) for _ in range(3))

@@ -55,6 +55,23 @@ class GanTrainer:
         self.epoch_step1, self.epoch_step2 = 6, 9          # GanTrainerImg.py:111-112
         self.data_loaders = data_loaders
 
+    # ---------------------------------------------------------------- checkpoints (GanTrainerImg.py:484-493; model_save_util.py:121-131)
+    def load_model(self, path=None):
+        """Resume from a checkpoint written by save_model (or by the reference): epoch counter, both state dicts, both
+        optimiser states; the nets go back to train mode.  `path` defaults to opt.models_save_path-style attribute
+        `checkpoint_path`; like the reference this is a no-op unless `isCheckpoint` is set (or a path is given)."""
+        from . import model_factory
+        path = path or getattr(self, "checkpoint_path", None)
+        if path is None or not (getattr(self, "isCheckpoint", False) or path):
+            return
+        self.epoch = model_factory.load_checkpoint(path, self.device, self.netG, self.optimizerG, self.netD, self.optimizerD)
+        self.netD.train()
+        self.netG.train()
+
+    def save_model(self, path, epoch, epoch_iter, output_dir):
+        from . import model_factory
+        return model_factory.save_model(path, epoch, epoch_iter, output_dir, self.netG, self.optimizerG, self.netD, self.optimizerD)
+
     # ---------------------------------------------------------------- loop (GanTrainerImg.py:141-198)
     def train(self):
         for epoch in range(self.epoch, self.num_epochs):
