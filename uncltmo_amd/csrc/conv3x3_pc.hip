@@ -725,6 +725,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           cu = mfma32x16(ua[0], xr[2 * i], cu);
           cu = mfma32x16(ua[1], xr[2 * i + 1], cu);
           const bool in_img = (unsigned)(iy0h + 2 * spy) < (unsigned)a.H && (unsigned)(ix0h + 2 * spx) < (unsigned)a.W;
+          const bool any_out = __builtin_amdgcn_ballot_w64(!in_img) != 0;      // wave-uniform: interior tiles skip the selects
           char* dst = st + 2 * lh * XPL + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * 16;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -732,17 +733,16 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = cu[8 * h + e];
             vec o = E::pack(f);
-            if (!in_img) o = E::zero();
+            if (any_out && !in_img) o = E::zero();
             if (sp < UPN) *reinterpret_cast<vec*>(dst + h * XPL) = o;
           }
         }
       }
     } else {
-#pragma unroll
-      for (int j = 0; j <= RSN; ++j) {
-        if (j == RSN && !e_on) continue;
-        if (R_RAGGED && j == RSN - 1 && !r_last_on) continue;
-        vec v = xr[j];
+      // x2^2 / sqrt(x2 + 1e-8) as scalar fp32 (the packed v_pk_mul_f32 / v_pk_add_f32 forms made the concat layers 10 % slower);
+      // the validity select only exists on the path of a wave that has an out-of-image slot at all (wave-uniform test):
+      // interior tiles stage their registers as loaded
+      auto transform = [&](vec v) __attribute__((always_inline)) {
         if (CAT && P >= 2) {
           float f[8];
           E::unpack(v, f);
@@ -755,9 +755,27 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           }
           v = E::pack(f);
         }
-        if (!all_ok && !((xvalid >> j) & 1u)) v = E::zero();
-        const int pix = j < RSN ? pix_r0 + j * RSTEP * HW : pix_e;
-        *reinterpret_cast<vec*>(st + ch * XPL + pix * 16) = v;
+        return v;
+      };
+      const bool wave_ok = __builtin_amdgcn_ballot_w64(!all_ok) == 0;
+      if (wave_ok) {
+#pragma unroll
+        for (int j = 0; j <= RSN; ++j) {
+          if (j == RSN && !e_on) continue;
+          if (R_RAGGED && j == RSN - 1 && !r_last_on) continue;
+          const int pix = j < RSN ? pix_r0 + j * RSTEP * HW : pix_e;
+          *reinterpret_cast<vec*>(st + ch * XPL + pix * 16) = transform(xr[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j <= RSN; ++j) {
+          if (j == RSN && !e_on) continue;
+          if (R_RAGGED && j == RSN - 1 && !r_last_on) continue;
+          vec v = transform(xr[j]);
+          if (!((xvalid >> j) & 1u)) v = E::zero();
+          const int pix = j < RSN ? pix_r0 + j * RSTEP * HW : pix_e;
+          *reinterpret_cast<vec*>(st + ch * XPL + pix * 16) = v;
+        }
       }
     }
     if (!RESW) {
