@@ -405,7 +405,7 @@ def infer_bench(a, rk):
         nx = lib.uncl_prof_read(buf, 4096)
         excl_ms = sum(buf[i] for i in range(nx)) / max(nx, 1)
         excl_tiles = FRAMES * TILES_PER_FRAME * 3 / max(nx, 1)
-        lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "4")))
+        lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "2")))
     lib.uncl_prof_enable(-1, 0)
     assert torch.isfinite(out).all()
 

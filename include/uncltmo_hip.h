@@ -332,8 +332,9 @@ int uncl_gen_forward(const uncl_gen_weights* wts, const uncl_gen_run* run, void*
 /* uncl_gen_forward runs an un-chunked inference batch of >= 64 tiles as n contiguous parts on n streams (the caller's plus
  * internal ones, forked and joined with events, so the call keeps stream semantics) up to the third decoder stage: one
  * part's launches fill the ramp-down of the other's persistent grids; the last decoder stage then runs once for the whole
- * batch on the caller's stream.  n = 1 .. 4, default 4 (200 tiles: 5.65 ms on one stream, 5.35 on two, 5.2 on four; parts are
- * never smaller than 32 tiles); 1 = the caller's stream only. */
+ * batch on the caller's stream.  n = 1 .. 4, default 2 (200 tiles, every convolution a one-workgroup-per-CU producer /
+ * consumer launch: 4.86 ms on one stream, 4.67 on two, 4.78 on four; parts are never smaller than 32 tiles); 1 = the caller's
+ * stream only. */
 int uncl_gen_set_streams(int n);
 
 /* ------------------------------------------------------------------------------------------------------

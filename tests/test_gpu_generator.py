@@ -109,7 +109,7 @@ def test_large_batch_on_several_streams_equals_one_stream(dtype):
             _hip.check(lib.uncl_gen_set_streams(3), "set_streams")
             y3, _ = net.infer(x, want_knn=True)
     finally:
-        lib.uncl_gen_set_streams(4)
+        lib.uncl_gen_set_streams(2)
     assert torch.equal(y1, y2) and torch.equal(k1, k2) and torch.equal(y1, y3)
     assert lib.uncl_gen_set_streams(0) != 0 and lib.uncl_gen_set_streams(5) != 0
 

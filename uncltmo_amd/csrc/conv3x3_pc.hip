@@ -276,10 +276,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
             }
         }
       }
-      if (NT == 2 && a.pool_out != nullptr) {
+      if (NT == 2 && MPW == 2 && a.pool_out != nullptr) {
         // MaxPool2d(2) of the wave's two rows (unet_parts.py:212,233): vertical max in registers, horizontal max with the
         // neighbouring pixel's lane through DPP quad_perm [1,0,3,2]; the even lanes store the 16 pooled pixels
-        static_assert(NT != 2 || MPW == 2, "one pooled row per wave");
+        // (16-row tiles of 64 channels: the launcher only takes a pooled copy with the forward epilogue below)
         const int gy = (c.ty * TH >> 1) + cw, gx = (x0 >> 1) + (lr >> 1);
         const bool in = (lr & 1) == 0 && gy < a.pH && gx < a.pW;
         const size_t e0 = (((size_t)c.n * a.pH + gy) * a.pW + gx) * a.oC + co + 8 * lh;
@@ -934,6 +934,18 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
       if (mode == 0) return launch_pc<T, 1, 4, 0, 8, false>(a, s);
       if (mode == 1) return launch_pc<T, 1, 4, 1, 8, false>(a, s);
       if (mode == 4) return launch_pc<T, 1, 4, 4, 8, false>(a, s);
+    }
+    return UNCL_ERR_ARG;
+  }
+  if (nt == 2 && mpw == 4) {
+    // 16 x 32 pixels x 64 channels: half the weight re-streaming per output of the 8-row tile; 128 accumulator registers
+    if (a.pool_out != nullptr && !fwd_relu) return UNCL_ERR_ARG;
+    if (resw) {
+      if (mode == 0) return launch_pc<T, 2, 4, 0, 4, true>(a, s);
+      if (mode == 1) return launch_pc<T, 2, 4, 1, 4, true>(a, s);
+    } else {
+      if (mode == 0) return launch_pc<T, 2, 4, 0, 4, false>(a, s);
+      if (mode == 1) return launch_pc<T, 2, 4, 1, 4, false>(a, s);
     }
     return UNCL_ERR_ARG;
   }

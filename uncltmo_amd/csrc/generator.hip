@@ -672,7 +672,7 @@ int backward_all(const BCtx& c) {
 }  // namespace
 
 // streams an un-chunked inference batch of >= 64 tiles is spread over (1 = the caller's stream only), see uncl_gen_forward
-static int g_streams = 4;
+static int g_streams = 2;     // measured (every conv a one-workgroup-per-CU producer/consumer launch): 1 / 2 / 4 streams = 4.86 / 4.67 / 4.78 ms
 extern "C" int uncl_gen_set_streams(int n) {
   if (n < 1 || n > 4) return UNCL_ERR_ARG;
   g_streams = n;
