@@ -321,7 +321,7 @@ def train_numbers(a, rk, video, steps, warmup):
                                "achieved_survey_convention": tfl_2, "frac_survey_convention": tfl_2 / PEAK_BF16_TFLOPS,
                                "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
                                        "2 bwd (109.7 GFLOP, what the reference runs); both over the whole step time"},
-            "errD": float(tr.errD), "errG_d": float(tr.errG_d), "errG_struct": float(tr.errG_struct)}, per_rank
+            "errD": float(tr.errD.detach()), "errG_d": float(tr.errG_d.detach()), "errG_struct": float(tr.errG_struct.detach())}, per_rank
 
 
 def train_bench(a, rk):
@@ -334,6 +334,7 @@ def train_bench(a, rk):
         line.update({"dtype": "bf16",
                      "config": {"workload": nums["workload"], "parallelism": "data-parallel x%d, gradient all-reduce" % rk.world},
                      "generator_mfma": nums["generator_mfma"],
+                     "device_mallocs_in_timed_steps": nums["device_mallocs_in_timed_steps"],
                      "errD": nums["errD"], "errG_d": nums["errG_d"], "errG_struct": nums["errG_struct"]})
         _flush_c_stdio()
         print(json.dumps(line), flush=True)

@@ -168,7 +168,9 @@ class _GeneratorFn(torch.autograd.Function):
         lease.take("train")
         ctx.lease = lease
         ctx.module = module
-        ctx.saved = (xf, out, up, ws, ds)
+        # `out` is returned: the node must not hold the returned OBJECT (its grad_fn is this node -- a reference cycle that only
+        # the cyclic garbage collector breaks, which kept ~1.2 GB per step alive for several steps); an alias of its storage does
+        ctx.saved = (xf, out.detach(), up, ws, ds)
         ctx.mark_non_differentiable()
         return out, up.permute(0, 3, 1, 2)
 
