@@ -137,3 +137,30 @@ def test_full_tmqi_large_frame_vs_oracle():
     np.testing.assert_allclose(sl, rsl, rtol=1e-6)
     with pytest.raises(Exception):
         TMQI()(h32[:100, :100].cuda(), l32[:100, :100].cuda())           # pyramid would not hold an 11x11 window
+
+
+def test_eval_on_video_clip_metrics():
+    """Tester.eval_on_video's tensor path: the clip goes through the recurrent video generator tile by tile; the scene score is
+    the mean of the per-frame TMQI of the 8-bit results; the warp-error formulas against numpy."""
+    from uncltmo_amd import model_factory, tester
+    from uncltmo_amd.tmqi import TMQI
+    G = model_factory.create_G_net("unet", torch.device("cuda"), False, 1, "sigmoid", 32, "square_and_square_root", 4, 0, "none",
+                                   "none", "relu", True, 1, 1, 0, "replicate", 2, 0)
+    synth.fill_state_dict(G, "g0")
+    G.eval()
+    g = torch.Generator().manual_seed(9)
+    frames = [(torch.rand(3, 300, 340, generator=g) ** 4 * 50).cuda() for _ in range(3)]
+    score, ldr = tester.eval_on_video(G, frames, 127.5 * 0.1, final_shape_addition=0, add_frame=False)
+    assert len(ldr) == 3 and all(t.shape == (300, 340, 3) and t.dtype == torch.uint8 for t in ldr)
+    per = [TMQI()(frames[i].permute(1, 2, 0).contiguous(), ldr[i].float())[0] for i in range(3)]
+    assert abs(score - sum(per) / 3) < 1e-12 and 0.0 < score < 1.0
+    # the recurrent hand-off is live: frame 1 evaluated alone differs from frame 1 inside the clip
+    _, solo = tester.eval_on_video(G, [frames[1]], 127.5 * 0.1)
+    assert not torch.equal(solo[0], ldr[1])
+    # warp errors (Tester.py:385-389) with a caller-side alignment (identity here)
+    s2, ldr2, mse, rel = tester.eval_on_video(G, frames, 127.5 * 0.1, align_fn=lambda f1, f0: f1)
+    a = ldr[1].cpu().numpy().astype(np.float32)[32:-32, 32:-32] / 255.0
+    b = ldr[0].cpu().numpy().astype(np.float32)[32:-32, 32:-32] / 255.0
+    np.testing.assert_allclose(mse, np.mean((a - b) ** 2), rtol=1e-5)
+    np.testing.assert_allclose(rel, np.mean(np.abs(a - b) / (1e-8 + a + b)), rtol=1e-5)
+    assert s2 == score and all(torch.equal(u, v) for u, v in zip(ldr, ldr2))
