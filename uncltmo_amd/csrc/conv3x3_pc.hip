@@ -181,12 +181,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
                 acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
         }
         if (col + 1 < 6) {
+          {
 #pragma unroll
-          for (int k = 0; k < NRD; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read of the next column ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... per MFMA of this one
+            for (int k = 0; k < NRD; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read of the next column ...
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... per MFMA of this one
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);   // (two reads per gap, all in the first half: no gain)
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
         }
