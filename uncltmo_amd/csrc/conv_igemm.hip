@@ -17,6 +17,8 @@
 // The loader synthesises the reference's input-side ops on the fly instead of materialising them in HBM:
 // MaxPool2d(2) (unet_parts.py:212,233), the skip concat [x2, x1, x2^2, sqrt(x2+1e-8)] with replicate padding
 // of x1 (unet_parts.py:292-298, 319-322), and the video generator's recurrent channel hand-off (Unet.py:244,270).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -374,25 +376,49 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(const C1Args a) {
   const int ct = blockIdx.y % a.n_ct, grp = blockIdx.y / a.n_ct;
   const int in_off = grp * CIN, out_off = grp * a.Cout + ct * CT;
   const bf16_t* wg = a.w + ((size_t)grp * a.Cout + ct * CT) * CIN;
-  for (int v = tid; v < CT * S; v += 256) {
+  // every load of the launch's latency chain is requested before the first wait: the weight slice (CT*S/256 16-byte loads per
+  // thread), the biases (as float4s) and the first tile's K fragments
+  constexpr int WIT = (CT * S + 255) / 256;
+  vec wtmp[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int v = min(tid + i * 256, CT * S - 1);
     const int row = v / S, slot = v - row * S;
-    *reinterpret_cast<vec*>(sW + row * (CIN * 2) + ((slot ^ (row & (S - 1))) << 4)) =
-        *reinterpret_cast<const vec*>(wg + (size_t)row * CIN + slot * 8);
+    wtmp[i] = *reinterpret_cast<const vec*>(wg + (size_t)row * CIN + slot * 8);
   }
   float bv[NT][16];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      bv[nt][i] = a.bias ? a.bias[out_off + nt * 32 + 8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + out_off + nt * 32 + 8 * q + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[nt][4 * q + r] = b4[r];
+    }
+  vec B[KSTEPS];
+  {
+    const int m0 = blockIdx.x * 128 + wave * 32 + lr;
+    const bf16_t* xp0 = a.x + (size_t)min(m0, a.M - 1) * a.ld_in + in_off + lh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) B[ks] = *reinterpret_cast<const vec*>(xp0 + ks * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int v = tid + i * 256;
+    if (v < CT * S) {
+      const int row = v / S, slot = v - row * S;
+      *reinterpret_cast<vec*>(sW + row * (CIN * 2) + ((slot ^ (row & (S - 1))) << 4)) = wtmp[i];
+    }
+  }
   __syncthreads();
   for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
     const int m = t * 128 + wave * 32 + lr;
     const bool valid = m < a.M;
-    const bf16_t* xp = a.x + (size_t)min(m, a.M - 1) * a.ld_in + in_off + lh * 8;
-    vec B[KSTEPS];
+    if (t != (int)blockIdx.x) {
+      const bf16_t* xp = a.x + (size_t)min(m, a.M - 1) * a.ld_in + in_off + lh * 8;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) B[ks] = *reinterpret_cast<const vec*>(xp + ks * 16);
+      for (int ks = 0; ks < KSTEPS; ++ks) B[ks] = *reinterpret_cast<const vec*>(xp + ks * 16);
+    }
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -468,7 +494,8 @@ int conv1x1_direct(const uncl_conv_desc* d, hipStream_t s) {
   // the latency regime only (training batches: a few dozen samples x 144 nodes): with hundreds of pixel tiles the generic
   // kernel's small weight chunks win over staging a weight slice per workgroup (measured at 100 / 200 tiles: 25-40 us vs
   // 40-70 us), here one memory latency per launch wins over eight (9 us vs 19 us)
-  if (tiles > 48) return C1_NOT_MINE;
+  static const int force = [] { const char* e = getenv("UNCL_C1_FORCE"); return e ? atoi(e) : 0; }();   // A/B: tools/c1_probe.py
+  if (tiles > 48 && !force) return C1_NOT_MINE;
   int nt = d->Cin == 512 ? 2 : 4;
   while (nt > 1 && tiles * (d->Cout / (nt * 32)) * groups < 256) nt /= 2;
   if (d->Cout % (nt * 32) != 0) return C1_NOT_MINE;
