@@ -131,7 +131,9 @@ def pmc_traffic(dtype):
     if dtype != "bf16":
         return None, None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
+    # the newest record by NAME (r<round><letter>_...): modification times do not survive a checkout
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")),
+                   key=lambda f: (len(os.path.basename(f).split("_")[0]), os.path.basename(f)))
     if not files:
         return None, None
     try:
