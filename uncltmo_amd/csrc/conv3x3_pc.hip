@@ -314,7 +314,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     // Units (pr, nt, qp): rows 2 pr and 2 pr + 1 of the wave, channels 32 nt + 16 qp.. of them (two row stores) and the same
     // channels of pooled row pr.
-    auto epilogue_relu = [&](const TileCur& c, int tpar) __attribute__((always_inline)) {
+    // GRAD = 0: forward (ReLU, optional pooled copy); GRAD = 1: gradient store (identity, ReLU mask of the producing layer and /
+    // or accumulation into the gradient already there), on the same packed registers
+    auto epilogue_fast = [&](const TileCur& c, int tpar, auto grad_tag) __attribute__((always_inline)) {
+      constexpr bool GRAD = decltype(grad_tag)::value != 0;
       const float* sBt = sBias + tpar * CT;
       const int y0 = c.ty * TH + cw * MPW, x0 = c.tx * TW, co = c.ct * CT;
       const int ox = x0 + lr;
@@ -331,8 +334,28 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
         const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
         s16x8 si = __builtin_bit_cast(s16x8, w);
-        si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values (sign-symmetric rounding)
+        if (!GRAD) si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values (sign-symmetric rounding)
         return __builtin_bit_cast(vec, si);
+      };
+      // gradient store: zero where the producing layer's ReLU output is not positive (a signed 16-bit compare orders bf16 / f16
+      // values of one sign like their floats: mask > 0 <=> int16(mask) > 0; 0 / 1 factor, 16-bit multiply), then add the gradient
+      // already in memory in fp32 and round again -- the operation order of the generic epilogue
+      auto grad_ops = [&](vec w, const char* mrow, const char* orow, unsigned off) __attribute__((always_inline)) {
+        if (a.mask != nullptr) {
+          const s16x8 mk = __builtin_bit_cast(s16x8, *reinterpret_cast<const vec*>(mrow + off));
+          const s16x8 one = {1, 1, 1, 1, 1, 1, 1, 1}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
+          const s16x8 keep = __builtin_elementwise_max(__builtin_elementwise_min(mk, one), zero);
+          w = __builtin_bit_cast(vec, (s16x8)(__builtin_bit_cast(s16x8, w) * keep));
+        }
+        if (a.accumulate) {
+          float f[8], o[8];
+          E::unpack(w, f);
+          E::unpack(*reinterpret_cast<const vec*>(orow + off), o);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] += o[i];
+          w = E::pack(f);
+        }
+        return w;
       };
       const bool xin = ox < a.Wout;
       unsigned loff = (unsigned)(ox * a.oC + 8 * lh) * 2u;
@@ -358,9 +381,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 #ifdef UNCL_PC_TIMING
               if (a.pc_prio & 64) { asm volatile("" ::"v"(wv[r])); continue; }     // experiment: no output stores (wrong results)
 #endif
-              if (oy < a.Hout && xin) *reinterpret_cast<vec*>(rowp + loff + (nt * 32 + 16 * qp) * 2) = wv[r];
+              if (oy < a.Hout && xin) {
+                if (GRAD) {
+                  const char* mrow = reinterpret_cast<const char*>(a.mask + ((size_t)c.n * a.Hout + oy) * a.Wout * a.oC + co);
+                  wv[r] = grad_ops(wv[r], mrow, rowp, loff + (nt * 32 + 16 * qp) * 2);
+                }
+                *reinterpret_cast<vec*>(rowp + loff + (nt * 32 + 16 * qp) * 2) = wv[r];
+              }
             }
-            if (a.pool_out != nullptr) {
+            if (!GRAD && a.pool_out != nullptr) {
               // MaxPool2d(2) of the two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
               // maximum orders them like their floats; vertical maximum between the rows, horizontal with the neighbouring
               // pixel's lane (DPP quad_perm [1,0,3,2]); the even lanes store the 16 pooled pixels
@@ -384,6 +413,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     cur_init(cc, tile0, a);
     int tpar = 0;
     const bool fast_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && !a.skip_main && !(a.pc_prio & 256);   // wave-uniform
+    // gradient stores of ReLU networks (mask slope 0), and plain identity stores
+    const bool fast_grad = a.slope == 1.f && a.mask_slope == 0.f && !a.skip_main && a.pool_out == nullptr && !(a.pc_prio & (256 | 1024));
 #pragma unroll
     for (int m = 0; m < MPW; ++m)
 #pragma unroll
@@ -395,7 +426,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
     };
     auto run_epilogue = [&](const TileCur& c, int tp) __attribute__((always_inline)) {
-      if (fast_relu) epilogue_relu(c, tp);
+      if (fast_relu) epilogue_fast(c, tp, IntTag<0>{});
+      else if (fast_grad) epilogue_fast(c, tp, IntTag<1>{});
       else if (a.slope == 0.f) epilogue(c, tp, IntTag<0>{});
       else if (a.slope == 1.f) epilogue(c, tp, IntTag<1>{});
       else epilogue(c, tp, IntTag<2>{});
