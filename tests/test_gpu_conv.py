@@ -441,6 +441,41 @@ def test_pc_plain_layers_bitwise(cin, cout, h, w, n, pad, pool, act):
     assert rel_l2(from_nhwc(go), ref) < TOL[BF]
 
 
+@pytest.mark.parametrize("kind,c,cout,h,n,pool", [("plain", 64, 64, 124, 24, True),      # 24 x 4 x 8 = 768 tiles of 16 x 32 x 64
+                                                   ("plain", 128, 128, 59, 48, True),    # 57 x 57 output, two cout tiles
+                                                   ("ssr", 128, 64, 57, 96, False)])     # concat source, 59 x 59 output
+def test_pc_tall_64_channel_tiles_bitwise(kind, c, cout, h, n, pool):
+    """Launches large enough for the 16-row 64-channel tiles (>= 768 of them) under both kernel structures."""
+    if kind == "plain":
+        x, wt, b = q(rnd(n, c, h, h, seed=251), BF), q(rnd(cout, c, 3, 3, seed=252, scale=0.1), BF), rnd(cout, seed=253)
+        ho = h - 2
+        xd, wd, bd = to_nhwc(x, BF), pack_weight(wt, BF), b.cuda()
+
+        def run():
+            out = torch.zeros(n, ho, ho, cout, dtype=torch.bfloat16, device="cuda")
+            pl = torch.zeros(n, ho // 2, ho // 2, cout, dtype=torch.bfloat16, device="cuda") if pool else None
+            run_pipe(pool_out=pl, dtype=BF, ksize=3, pad=0, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=h, Cin=c, Cout=cout, src0=xd,
+                     src0_H=h, src0_W=h, src0_C=c, weight=wd, bias=bd, act=_hip.ACT_RELU, out=out, out_H=ho, out_W=ho, out_C=cout)
+            return out, pl
+    else:
+        x2 = q(rnd(n, c, h, h, seed=254).abs(), BF)
+        x1 = q(rnd(n, c, h - 1, h - 1, seed=255), BF)
+        wt, b = q(rnd(4 * c, cout, 3, 3, seed=256, scale=0.05), BF), rnd(cout, seed=257)
+        x2d, x1d, wd, bd = to_nhwc(x2, BF), to_nhwc(x1, BF), pack_weight(wt, BF, transposed=True, flip=True), b.cuda()
+
+        def run():
+            out = torch.zeros(n, h + 2, h + 2, cout, dtype=torch.bfloat16, device="cuda")
+            run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR, N=n, H=h, W=h, Cin=4 * c, Cout=cout, src0=x2d, src0_H=h,
+                     src0_W=h, src0_C=c, src1=x1d, src1_H=h - 1, src1_W=h - 1, src1_C=c, weight=wd, bias=bd, act=_hip.ACT_RELU,
+                     out=out, out_H=h + 2, out_W=h + 2, out_C=cout)
+            return out, None
+
+    (ro, rp), (go, gp) = _both_structures(run)
+    assert torch.equal(ro, go)
+    if pool:
+        assert torch.equal(rp, gp)
+
+
 @pytest.mark.parametrize("h,w,n,pool", [(40, 70, 2, True), (256, 256, 2, True), (37, 51, 3, False)])
 def test_pc_first_layer_fused_bitwise(h, w, n, pool):
     """UNCL_SRC_IMAGE1 under both kernel structures (producer / consumer: the staging waves rebuild the halo tile from image
