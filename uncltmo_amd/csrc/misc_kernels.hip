@@ -1,5 +1,7 @@
 // Bandwidth-bound helpers of the generator forward: weight re-layout, the 1-channel first layer, the graph
 // block's kNN / max-relative gather, and the overlap-tile gather / cross-fade.  gfx950 only.
+#include <cstdlib>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -406,6 +408,182 @@ __global__ __launch_bounds__(1024) void gcn_knn_kernel(const T* __restrict__ x, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same graph for 16-bit features at inference size, on the matrix cores: the 144 x 144 Gram matrix of the RAW bf16 / f16
+// rows is five 32 x 32 row tiles x five column tiles of v_mfma_f32_32x32x16 (exact products, fp32 accumulation), scaled to
+// the normalised inner products by 1/|x_i| 1/|x_j| afterwards; the top-9 of a row is selected straight from the accumulator
+// registers (a row's 160 candidates are ONE register slot of the 32 lanes of a half-wave x 5 column tiles).  The VALU kernel
+// above spends 150 us per 200 samples on 7 M sequential fmaf per sample; this one 75 (multiplies 5, norms 3, nine arg-min
+// rounds 46: ten slots x 75 VALU instructions per round and wave).  Distances agree with it to fp32
+// rounding (different summation order), so an index can differ only where two candidates are within ~1e-6: the fp32 parity
+// path keeps the VALU kernel, whose indices are pinned bit for bit.
+// ------------------------------------------------------------------------------------------------------
+#define KNM_ROW 528            // bytes per staged row: 512 + 16 (consecutive rows shift one 16-byte slot)
+#define KNM_UNITS 80           // 5 row tiles x 16 accumulator slots, dealt to 8 waves (10 each)
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gcn_knn_mfma_kernel(const T* __restrict__ x, const float* __restrict__ rel,
+                                                             int32_t* __restrict__ idx, int n) {
+  using vec = typename Elem<T>::vec;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sF = smem;                                                    // [n][KNM_ROW]
+  float* sInv = reinterpret_cast<float*>(smem + (size_t)KNN_MAX_NODES * KNM_ROW);   // [160] 1/|x_i|
+  float* sXX = sInv + 160;                                            // [160] |xn_i|^2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const T* xs = x + (size_t)blockIdx.x * n * KNN_C;
+  // stage the sample: every load of a thread requested before its first LDS write (nine 16-byte vectors)
+  {
+    constexpr int VPT = (KNN_MAX_NODES * (KNN_C / 8) + 511) / 512;
+    vec tmp[VPT];
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const int v = min(tid + q * 512, n * (KNN_C / 8) - 1);
+      tmp[q] = *reinterpret_cast<const vec*>(xs + (size_t)(v >> 5) * KNN_C + (v & 31) * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const int v = tid + q * 512;
+      if (v < n * (KNN_C / 8)) *reinterpret_cast<vec*>(sF + (v >> 5) * KNM_ROW + (v & 31) * 16) = tmp[q];
+    }
+  }
+  __syncthreads();
+  // norms, one thread per row from the staged copy (rows are one 16-byte slot apart mod 256 bytes: conflict-free):
+  // F.normalize = x / max(|x|, 1e-12); |xn|^2 is the sum over the normalised values, as in the reference
+  if (tid < 160) {
+    float inv = 0.f, s2 = 0.f;
+    if (tid < n) {
+      const char* rp = sF + tid * KNM_ROW;
+      float ss = 0.f;
+      for (int sl = 0; sl < KNN_C / 8; ++sl) {
+        float f[8];
+        Elem<T>::unpack(*reinterpret_cast<const vec*>(rp + sl * 16), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+      }
+      inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+      for (int sl = 0; sl < KNN_C / 8; ++sl) {
+        float f[8];
+        Elem<T>::unpack(*reinterpret_cast<const vec*>(rp + sl * 16), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float t = f[e] * inv; s2 = fmaf(t, t, s2); }
+      }
+    }
+    sInv[tid] = inv;
+    sXX[tid] = s2;
+  }
+  __syncthreads();
+  const int u0 = wave * (KNM_UNITS / 8), u1 = u0 + KNM_UNITS / 8;      // this wave's (row tile, slot) units
+  for (int rt = u0 >> 4; rt <= (u1 - 1) >> 4; ++rt) {
+    // Gram tile row: D[i][j] = sum_k x_i[k] x_j[k], i = 32 rt + (8q + 4 lh + r), j = 32 ct + lr
+    f32x16 acc[5];
+#pragma unroll
+    for (int ct = 0; ct < 5; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+    // relative_pos of this wave's (slot, column tile) pairs: all requested before the multiplies
+    constexpr int TS = KNM_UNITS / 8;
+    const int s_lo = max(u0 - rt * 16, 0), cnt = min(u1 - rt * 16, 16) - s_lo;
+    float relv[TS][5];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      const int sl = min(s_lo + t, 15);
+      const int i = min(rt * 32 + 8 * (sl >> 2) + 4 * lh + (sl & 3), n - 1);
+#pragma unroll
+      for (int ct = 0; ct < 5; ++ct) relv[t][ct] = rel != nullptr ? rel[(size_t)i * n + min(ct * 32 + lr, n - 1)] : 0.f;
+    }
+    const char* pa = sF + min(rt * 32 + lr, n - 1) * KNM_ROW + lh * 16;
+    const char* pb[5];
+#pragma unroll
+    for (int ct = 0; ct < 5; ++ct) pb[ct] = sF + min(ct * 32 + lr, n - 1) * KNM_ROW + lh * 16;
+#pragma unroll 4
+    for (int ks = 0; ks < KNN_C / 16; ++ks) {
+      const vec A = *reinterpret_cast<const vec*>(pa + ks * 32);
+#pragma unroll
+      for (int ct = 0; ct < 5; ++ct) acc[ct] = mfma32x16(A, *reinterpret_cast<const vec*>(pb[ct] + ks * 32), acc[ct]);
+    }
+    // This wave's slots of the row tile, s_lo .. s_lo + cnt - 1, are copied out of the accumulators (uniform selects: no
+    // register indexing) and then selected IN LOCKSTEP: the cross-lane steps of the nine arg-min rounds are dependent
+    // ds_bpermute chains of ~1 000 cycles per round, and ten independent chains in flight hide each other's latency (one
+    // slot at a time the selection alone took 60 us per sample).
+    float d[TS][5];
+    int row_i[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      const int sl = min(s_lo + t, 15);                                   // wave-uniform
+      float raw[5];
+#pragma unroll
+      for (int ct = 0; ct < 5; ++ct) {
+        float val = acc[ct][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) val = sl == e ? acc[ct][e] : val;
+        raw[ct] = val;
+      }
+      const int i = rt * 32 + 8 * (sl >> 2) + 4 * lh + (sl & 3);        // this half-wave's row
+      const bool row_ok = i < n && t < cnt;
+      row_i[t] = row_ok ? i : -1;
+      const float inv_i = sInv[min(i, 159)], xx_i = sXX[min(i, 159)];
+#pragma unroll
+      for (int ct = 0; ct < 5; ++ct) {
+        const int j = ct * 32 + lr;
+        d[t][ct] = INFINITY;
+        if (row_ok && j < n) {
+          // same association as the reference: (|xi|^2 + (-2 xi.xj)) + |xj|^2, then + relative_pos
+          float dd = (xx_i + (-2.f * (raw[ct] * inv_i * sInv[j]))) + sXX[j];
+          if (rel != nullptr) dd += relv[t][ct];
+          d[t][ct] = dd;
+        }
+      }
+    }
+    // nine rounds of arg-min over each half-wave's 5 x 32 candidates; ties go to the lower node index
+    for (int r = 0; r < 9; ++r) {
+      float bv[TS];
+      int bj[TS];
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        bv[t] = d[t][0];
+        bj[t] = lr;
+#pragma unroll
+        for (int ct = 1; ct < 5; ++ct)
+          if (d[t][ct] < bv[t]) { bv[t] = d[t][ct]; bj[t] = ct * 32 + lr; }
+      }
+      // all-reduce inside each row of 16 lanes with DPP moves (VALU: quad swaps, then the two mirrors), across the two rows
+      // of the half-wave with one ds_bpermute pair -- five bpermute steps per round put the CU's LDS pipe at 6 400 cycles
+      // per round for the eight waves
+#define KNM_STEP(CTRL)                                                                                                     \
+      _Pragma("unroll") for (int t = 0; t < TS; ++t) {                                                                     \
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bv[t]), CTRL, 0xF, 0xF, true)); \
+        const int oj = __builtin_amdgcn_mov_dpp(bj[t], CTRL, 0xF, 0xF, true);                                              \
+        if (ov < bv[t] || (ov == bv[t] && oj < bj[t])) { bv[t] = ov; bj[t] = oj; }                                         \
+      }
+      KNM_STEP(0xB1)      // quad_perm [1,0,3,2]
+      KNM_STEP(0x4E)      // quad_perm [2,3,0,1]
+      KNM_STEP(0x141)     // row_half_mirror
+      KNM_STEP(0x140)     // row_mirror
+#undef KNM_STEP
+      {
+        float ov[TS];
+        int oj[TS];
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+          ov[t] = __shfl_xor(bv[t], 16, 64);
+          oj[t] = __shfl_xor(bj[t], 16, 64);
+        }
+#pragma unroll
+        for (int t = 0; t < TS; ++t)
+          if (ov[t] < bv[t] || (ov[t] == bv[t] && oj[t] < bj[t])) { bv[t] = ov[t]; bj[t] = oj[t]; }
+      }
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct)
+          if (ct * 32 + lr == bj[t]) d[t][ct] = INFINITY;
+        if (lr == 0 && row_i[t] >= 0) idx[((size_t)blockIdx.x * n + row_i[t]) * 9 + r] = bj[t];
+      }
+    }
+  }
+}
+
 extern "C" size_t uncl_gcn_knn_workspace_bytes(int N, int n, int C) {
   (void)N; (void)n; (void)C;
   return 0;  // the sample lives in LDS
@@ -417,6 +595,28 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
   if (!x || !idx || N <= 0 || n <= 0 || n > KNN_MAX_NODES || C != KNN_C || k <= 0 || k > n) return UNCL_ERR_ARG;
   const size_t lds = ((size_t)n * KNN_LD + n) * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // 16-bit features: the matrix-core kernel, one workgroup per sample whatever the batch (the choice must not depend on how a
+  // batch is cut into launches: the two kernels may order near-ties differently)
+  static const int use_mfma = [] { const char* e = getenv("UNCL_KNN_MFMA"); return e ? atoi(e) : 1; }();
+  if (use_mfma && uncl_is_h16(dtype) && dist_out == nullptr && k == 9 && n > 32) {
+    const size_t l2 = (size_t)KNN_MAX_NODES * KNM_ROW + 2 * 160 * sizeof(float);
+    static bool attr2[2] = {false, false};
+    if (dtype == UNCL_F16) {
+      if (!attr2[0]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_mfma_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        attr2[0] = true;
+      }
+      hipLaunchKernelGGL(gcn_knn_mfma_kernel<f16_t>, dim3(N), dim3(512), l2, s, (const f16_t*)x, relative_pos, idx, n);
+    } else {
+      if (!attr2[1]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_mfma_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        attr2[1] = true;
+      }
+      hipLaunchKernelGGL(gcn_knn_mfma_kernel<bf16_t>, dim3(N), dim3(512), l2, s, (const bf16_t*)x, relative_pos, idx, n);
+    }
+    UNCL_CHECK_LAUNCH();
+    return UNCL_OK;
+  }
   // one workgroup per CU (the sample fills the LDS): with a CU per sample to spare the rows are not split
   const int split = N * KNN_SPLIT <= 256 ? KNN_SPLIT : 1;
   static bool attr[3] = {false, false, false};
