@@ -336,6 +336,16 @@ int uncl_gen_forward(const uncl_gen_weights* wts, const uncl_gen_run* run, void*
  * consumer launch: 4.86 ms on one stream, 4.67 on two, 4.78 on four; parts are never smaller than 32 tiles); 1 = the caller's
  * stream only. */
 int uncl_gen_set_streams(int n);
+/* Inference (16-bit, no DropPath): uncl_gen_forward runs the tail of the graph block -- max-relative gather
+ * (torch_vertex.py:22-29), grouped 1x1 conv + GELU, fc2 + residual (Grapher_noBN, :181-227), FFN fc1 + GELU, fc2 + residual
+ * (Unet_singleFrame.py:20-41) -- as ONE launch with every intermediate in LDS (uncl_gcn_tail) instead of a gather kernel
+ * and four 1x1 convolutions; same rounding points.  uncl_gen_set_fused_graph(0) restores the separate kernels (A/B, tests);
+ * returns the previous setting.
+ * uncl_gcn_tail: F = fc1 output (N,144,256), idx = its kNN graph (N,144,9), X4 = the block's input; weights in the packed 1x1
+ * layout of uncl_pack_conv_weight ([group][Cout][Cin]); out (N,144,256). */
+int uncl_gen_set_fused_graph(int on);
+int uncl_gcn_tail(const void* F, const int32_t* idx, const void* X4, const void* wg, const float* bg, const void* w2, const float* b2,
+                  const void* w3, const float* b3, const void* w4, const float* b4, void* out, int dtype, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Window statistics.

@@ -293,3 +293,29 @@ def test_generator_other_last_layers(last_layer, activation):
     named = dict(netb.named_parameters())
     for k in ("outc.conv.weight", "outc.conv.bias", "up_path.3.conv.conv1.weight", "inc.conv.conv.weight"):
         assert rel_l2(named[k].grad.cpu(), sd[k].grad) < 6e-2, k
+
+
+def test_fused_graph_tail_matches_separate_kernels():
+    """uncl_gcn_tail (max-relative gather + grouped conv + fc2 + FFN in one launch, intermediates in LDS) against the
+    gather kernel and the four 1x1 convolutions it replaces: same rounding points, so the generator's output must agree
+    to 16-bit rounding noise, for bf16 and fp16 and for a batch that is not a multiple of anything."""
+    from uncltmo_amd import _hip
+    lib = _hip.lib()
+    for dt in ("bf16", "fp16"):
+        net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0,
+                   compute_dtype=dt)
+        synth.fill_state_dict(net, "g0")
+        net = net.cuda().eval()
+        x = synth.hdr_frames(7, 256, 256, salt="fused-gcn").cuda()
+        old = lib.uncl_gen_set_fused_graph(0)
+        try:
+            with torch.no_grad():
+                y0, k0 = net.infer(x, want_knn=True)
+                y0 = y0.clone()
+                lib.uncl_gen_set_fused_graph(1)
+                y1, k1 = net.infer(x, want_knn=True)
+        finally:
+            lib.uncl_gen_set_fused_graph(old)
+        assert torch.equal(k0, k1)
+        assert rel_l2(y1.float().cpu(), y0.float().cpu()) < 2e-3, dt
+        assert (y1.float() - y0.float()).abs().max().item() < 2e-2, dt

@@ -7,8 +7,13 @@
 #include <map>
 #include <mutex>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "bwd_internal.h"
+
+// 1 (default): inference runs the tail of the graph block as one launch (uncl_gcn_tail); 0: separate kernels
+static int g_fused_graph = [] { const char* e = getenv("UNCL_GCN_FUSED"); return e ? atoi(e) : 1; }();
 
 namespace {
 
@@ -333,6 +338,12 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   RUN(uncl_gcn_knn(c.ptr(B_GFC1), w->dtype, w->relative_pos, knn, nullptr, c.n, NODES, 256, 9, nullptr, c.s));
   if (knn_out && hipMemcpyAsync(knn_out, knn, (size_t)c.n * NODES * 9 * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
     return UNCL_ERR_LAUNCH;
+  if (g_fused_graph && uncl_is_h16(w->dtype) && !c.save_preact && drop0 == nullptr && drop1 == nullptr) {
+    // inference: the rest of the block (max-relative gather, grouped conv + GELU, fc2 + residual, FFN) is one launch with
+    // the intermediates in LDS (csrc/graph_block.hip)
+    RUN(uncl_gcn_tail(c.ptr(B_GFC1), knn, c.ptr(B_X4), w->w[W_GGC], w->b[W_GGC], w->w[W_GFC2], w->b[W_GFC2], w->w[W_FFC1],
+                      w->b[W_FFC1], w->w[W_FFC2], w->b[W_FFC2], c.ptr(B_GOUT), w->dtype, c.n, c.s));
+  } else {
   RUN(uncl_gcn_maxrel(c.ptr(B_GFC1), knn, c.ptr(B_GMR), w->dtype, c.n, NODES, 256, 9, c.s));
   if (c.save_preact) {
     RUN(conv1(c, W_GGC, B_GMR, B_GGCZ, 512, 512, UNCL_ACT_NONE, nullptr, 0, nullptr, 4));
@@ -348,6 +359,7 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
     RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
   }
   RUN(conv1(c, W_FFC2, B_FH, B_GOUT, 256, 256, UNCL_ACT_NONE, c.ptr(B_GX1), 0, drop1));
+  }
   // decoder
   RUN(up_stage(c, W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128, 8, nullptr, nullptr));
   RUN(up_stage(c, W_U1UP, B_U0, B_X2, B_U1UP, B_U1A, B_U1, 128, 64, 4, nullptr, nullptr));
@@ -670,6 +682,12 @@ int backward_all(const BCtx& c) {
 }
 
 }  // namespace
+
+extern "C" int uncl_gen_set_fused_graph(int on) {
+  const int old = g_fused_graph;
+  g_fused_graph = on ? 1 : 0;
+  return old;
+}
 
 // streams an un-chunked inference batch of >= 64 tiles is spread over (1 = the caller's stream only), see uncl_gen_forward
 static int g_streams = 2;     // measured (every conv a one-workgroup-per-CU producer/consumer launch): 1 / 2 / 4 streams = 4.86 / 4.67 / 4.78 ms
