@@ -339,13 +339,18 @@ int uncl_gen_set_streams(int n);
 /* Inference (16-bit, no DropPath): uncl_gen_forward runs the tail of the graph block -- max-relative gather
  * (torch_vertex.py:22-29), grouped 1x1 conv + GELU, fc2 + residual (Grapher_noBN, :181-227), FFN fc1 + GELU, fc2 + residual
  * (Unet_singleFrame.py:20-41) -- as ONE launch with every intermediate in LDS (uncl_gcn_tail) instead of a gather kernel
- * and four 1x1 convolutions; same rounding points.  uncl_gen_set_fused_graph(0) restores the separate kernels (A/B, tests);
- * returns the previous setting.
+ * and four 1x1 convolutions; same rounding points.  uncl_gen_set_fused_graph: 2 (default) fc1 and the kNN graph as their own
+ * launches + uncl_gcn_tail; 1 the whole block incl. fc1 and the kNN in one launch (uncl_gcn_block; measured no faster);
+ * 0 separate kernels (A/B, tests); returns the previous setting.
  * uncl_gcn_tail: F = fc1 output (N,144,256), idx = its kNN graph (N,144,9), X4 = the block's input; weights in the packed 1x1
  * layout of uncl_pack_conv_weight ([group][Cout][Cin]); out (N,144,256). */
 int uncl_gen_set_fused_graph(int on);
 int uncl_gcn_tail(const void* F, const int32_t* idx, const void* X4, const void* wg, const float* bg, const void* w2, const float* b2,
                   const void* w3, const float* b3, const void* w4, const float* b4, void* out, int dtype, int N, void* stream);
+/* the whole block: w1 / b1 = fc1, relative_pos (144,144) or NULL; idx_out (N,144,9) or NULL receives the kNN graph */
+int uncl_gcn_block(const void* X4, const void* w1, const float* b1, const float* relative_pos, const void* wg, const float* bg,
+                   const void* w2, const float* b2, const void* w3, const float* b3, const void* w4, const float* b4, int32_t* idx_out,
+                   void* out, int dtype, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Window statistics.

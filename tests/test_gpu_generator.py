@@ -311,11 +311,12 @@ def test_fused_graph_tail_matches_separate_kernels():
         try:
             with torch.no_grad():
                 y0, k0 = net.infer(x, want_knn=True)
-                y0 = y0.clone()
-                lib.uncl_gen_set_fused_graph(1)
-                y1, k1 = net.infer(x, want_knn=True)
+                y0, k0 = y0.clone(), k0.clone()
+                for mode in (2, 1):          # 2: fc1 and kNN as launches + fused tail; 1: the whole block in one launch
+                    lib.uncl_gen_set_fused_graph(mode)
+                    y1, k1 = net.infer(x, want_knn=True)
+                    assert torch.equal(k0, k1), (dt, mode)
+                    assert rel_l2(y1.float().cpu(), y0.float().cpu()) < 2e-3, (dt, mode)
+                    assert (y1.float() - y0.float()).abs().max().item() < 2e-2, (dt, mode)
         finally:
             lib.uncl_gen_set_fused_graph(old)
-        assert torch.equal(k0, k1)
-        assert rel_l2(y1.float().cpu(), y0.float().cpu()) < 2e-3, dt
-        assert (y1.float() - y0.float()).abs().max().item() < 2e-2, dt

@@ -12,8 +12,10 @@
 #include "common.h"
 #include "bwd_internal.h"
 
-// 1 (default): inference runs the tail of the graph block as one launch (uncl_gcn_tail); 0: separate kernels
-static int g_fused_graph = [] { const char* e = getenv("UNCL_GCN_FUSED"); return e ? atoi(e) : 1; }();
+// 2 (default): fc1 and the kNN graph as their own launches, the rest of the block fused (uncl_gcn_tail); 1: the whole block as
+// one launch (uncl_gcn_block: measured no faster -- 200 us against 36 + 85 + 84 -- the phases of one sample serialise inside
+// its workgroup either way); 0: separate kernels
+static int g_fused_graph = [] { const char* e = getenv("UNCL_GCN_FUSED"); return e ? atoi(e) : 2; }();
 
 namespace {
 
@@ -333,32 +335,41 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
     if (c.norm) RUN(c.post_norm(c.ptr(B_X4), B_X4, w->pos_embed, 1));
   }
   // graph block: Grapher (fc1 -> kNN -> max-relative -> grouped 1x1 + GELU -> fc2, residual) then FFN
-  RUN(conv1(c, W_GFC1, B_X4, B_GFC1, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
   int32_t* knn = reinterpret_cast<int32_t*>(c.ptr(B_KNN));
-  RUN(uncl_gcn_knn(c.ptr(B_GFC1), w->dtype, w->relative_pos, knn, nullptr, c.n, NODES, 256, 9, nullptr, c.s));
-  if (knn_out && hipMemcpyAsync(knn_out, knn, (size_t)c.n * NODES * 9 * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
-    return UNCL_ERR_LAUNCH;
-  if (g_fused_graph && uncl_is_h16(w->dtype) && !c.save_preact && drop0 == nullptr && drop1 == nullptr) {
-    // inference: the rest of the block (max-relative gather, grouped conv + GELU, fc2 + residual, FFN) is one launch with
-    // the intermediates in LDS (csrc/graph_block.hip)
-    RUN(uncl_gcn_tail(c.ptr(B_GFC1), knn, c.ptr(B_X4), w->w[W_GGC], w->b[W_GGC], w->w[W_GFC2], w->b[W_GFC2], w->w[W_FFC1],
-                      w->b[W_FFC1], w->w[W_FFC2], w->b[W_FFC2], c.ptr(B_GOUT), w->dtype, c.n, c.s));
+  const bool fused = g_fused_graph && uncl_is_h16(w->dtype) && !c.save_preact && drop0 == nullptr && drop1 == nullptr;
+  if (fused && g_fused_graph == 1) {
+    // inference: the whole block is one launch with the intermediates in LDS (csrc/graph_block.hip)
+    RUN(uncl_gcn_block(c.ptr(B_X4), w->w[W_GFC1], w->b[W_GFC1], w->relative_pos, w->w[W_GGC], w->b[W_GGC], w->w[W_GFC2],
+                       w->b[W_GFC2], w->w[W_FFC1], w->b[W_FFC1], w->w[W_FFC2], w->b[W_FFC2], knn, c.ptr(B_GOUT), w->dtype, c.n,
+                       c.s));
+    if (knn_out && hipMemcpyAsync(knn_out, knn, (size_t)c.n * NODES * 9 * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
   } else {
-  RUN(uncl_gcn_maxrel(c.ptr(B_GFC1), knn, c.ptr(B_GMR), w->dtype, c.n, NODES, 256, 9, c.s));
-  if (c.save_preact) {
-    RUN(conv1(c, W_GGC, B_GMR, B_GGCZ, 512, 512, UNCL_ACT_NONE, nullptr, 0, nullptr, 4));
-    RUN(bwd_gelu_forward(w->dtype, c.ptr(B_GGCZ), c.ptr(B_GGC), (long long)c.n * NODES * 512, c.s));
-  } else {
-    RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_GELU, nullptr, 0, nullptr, 4));
-  }
-  RUN(conv1(c, W_GFC2, B_GGC, B_GX1, 512, 256, UNCL_ACT_NONE, c.ptr(B_X4), 0, drop0));
-  if (c.save_preact) {
-    RUN(conv1(c, W_FFC1, B_GX1, B_FHZ, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
-    RUN(bwd_gelu_forward(w->dtype, c.ptr(B_FHZ), c.ptr(B_FH), (long long)c.n * NODES * 256, c.s));
-  } else {
-    RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
-  }
-  RUN(conv1(c, W_FFC2, B_FH, B_GOUT, 256, 256, UNCL_ACT_NONE, c.ptr(B_GX1), 0, drop1));
+    RUN(conv1(c, W_GFC1, B_X4, B_GFC1, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
+    RUN(uncl_gcn_knn(c.ptr(B_GFC1), w->dtype, w->relative_pos, knn, nullptr, c.n, NODES, 256, 9, nullptr, c.s));
+    if (knn_out && hipMemcpyAsync(knn_out, knn, (size_t)c.n * NODES * 9 * 4, hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    if (fused) {
+      // g_fused_graph == 2: fc1 and the kNN as their own launches, the rest of the block fused (A/B)
+      RUN(uncl_gcn_tail(c.ptr(B_GFC1), knn, c.ptr(B_X4), w->w[W_GGC], w->b[W_GGC], w->w[W_GFC2], w->b[W_GFC2], w->w[W_FFC1],
+                        w->b[W_FFC1], w->w[W_FFC2], w->b[W_FFC2], c.ptr(B_GOUT), w->dtype, c.n, c.s));
+    } else {
+      RUN(uncl_gcn_maxrel(c.ptr(B_GFC1), knn, c.ptr(B_GMR), w->dtype, c.n, NODES, 256, 9, c.s));
+      if (c.save_preact) {
+        RUN(conv1(c, W_GGC, B_GMR, B_GGCZ, 512, 512, UNCL_ACT_NONE, nullptr, 0, nullptr, 4));
+        RUN(bwd_gelu_forward(w->dtype, c.ptr(B_GGCZ), c.ptr(B_GGC), (long long)c.n * NODES * 512, c.s));
+      } else {
+        RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_GELU, nullptr, 0, nullptr, 4));
+      }
+      RUN(conv1(c, W_GFC2, B_GGC, B_GX1, 512, 256, UNCL_ACT_NONE, c.ptr(B_X4), 0, drop0));
+      if (c.save_preact) {
+        RUN(conv1(c, W_FFC1, B_GX1, B_FHZ, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
+        RUN(bwd_gelu_forward(w->dtype, c.ptr(B_FHZ), c.ptr(B_FH), (long long)c.n * NODES * 256, c.s));
+      } else {
+        RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
+      }
+      RUN(conv1(c, W_FFC2, B_FH, B_GOUT, 256, 256, UNCL_ACT_NONE, c.ptr(B_GX1), 0, drop1));
+    }
   }
   // decoder
   RUN(up_stage(c, W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128, 8, nullptr, nullptr));
@@ -685,7 +696,7 @@ int backward_all(const BCtx& c) {
 
 extern "C" int uncl_gen_set_fused_graph(int on) {
   const int old = g_fused_graph;
-  g_fused_graph = on ? 1 : 0;
+  g_fused_graph = on < 0 ? 0 : (on > 2 ? 2 : on);
   return old;
 }
 

@@ -25,9 +25,30 @@ struct GbArgs {
   const float *bg, *b2, *b3, *b4;    // [512], [256], [256], [256] or NULL
   void* out;             // (N,144,256)
   int N;
+  // FULL (the whole block in one launch): fc1 and the kNN graph are computed here too
+  const void* w1;        // packed [256][256]
+  const float* b1;       // [256] or NULL
+  const float* rel;      // relative_pos (144,144) or NULL
+  int32_t* idx_out;      // (N,144,9): the graph, also written to global memory (uncl_gen_forward's knn_idx output)
 };
 
-template <typename T>
+// GELU with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the 16-bit rounding of the value it feeds):
+// one reciprocal, one exponential and a five-term Horner chain instead of erff's ~40 instructions -- the block's 110 k GELUs
+// per sample were the largest VALU item of this kernel
+__device__ __forceinline__ float gelu_as(float x) {
+  const float z = x * 0.70710678118654752440f, az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-az * az * 1.44269504088896340736f);
+  const float er = copysignf(1.f - p * e, z);
+  return 0.5f * x * (1.f + er);
+}
+
+template <typename T, bool FULL>
 __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
   using E = Elem<T>;
   using vec = typename E::vec;
@@ -36,35 +57,14 @@ __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
   char* R1 = smem;                                   // F, later the Grapher's output X1   [144][GB_ROW]
   char* R0 = smem + GB_NODES * GB_ROW;               // max-relative / grouped-conv group, later the FFN's hidden layer
   int* sIdx = reinterpret_cast<int*>(smem + 2 * GB_NODES * GB_ROW);   // [144][9]
+  float* sInv = reinterpret_cast<float*>(sIdx + GB_NODES * GB_K);     // FULL: [160] 1/|x_i|, [160] |xn_i|^2
+  float* sXX = sInv + 160;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int n = blockIdx.x;
   const T* Fg = reinterpret_cast<const T*>(a.F) + (size_t)n * GB_NODES * GB_C;
   const T* Xg = reinterpret_cast<const T*>(a.X4) + (size_t)n * GB_NODES * GB_C;
   T* Og = reinterpret_cast<T*>(a.out) + (size_t)n * GB_NODES * GB_C;
-
-  // ---- stage F and the neighbour lists (all loads of a thread before its first LDS write)
-  {
-    constexpr int VPT = (GB_NODES * (GB_C / 8) + 511) / 512;     // 9
-    vec tmp[VPT];
-#pragma unroll
-    for (int q = 0; q < VPT; ++q) {
-      const int v = min(tid + q * 512, GB_NODES * (GB_C / 8) - 1);
-      tmp[q] = *reinterpret_cast<const vec*>(Fg + (size_t)(v >> 5) * GB_C + (v & 31) * 8);
-    }
-    int ti[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) ti[q] = a.idx[(size_t)n * GB_NODES * GB_K + min(tid + q * 512, GB_NODES * GB_K - 1)];
-#pragma unroll
-    for (int q = 0; q < VPT; ++q) {
-      const int v = tid + q * 512;
-      if (v < GB_NODES * (GB_C / 8)) *reinterpret_cast<vec*>(R1 + (v >> 5) * GB_ROW + (v & 31) * 16) = tmp[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (tid + q * 512 < GB_NODES * GB_K) sIdx[tid + q * 512] = ti[q];
-  }
-  __syncthreads();
 
   // B-fragment row pointers of this lane for the five node tiles (rows past the last node are clamped: their columns of the
   // accumulators are never stored)
@@ -74,6 +74,191 @@ __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
   auto bias4 = [&](const float* b, int c0) __attribute__((always_inline)) {
     return b ? *reinterpret_cast<const f32x4*>(b + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
   };
+  auto gemm256 = [&](const vec (&A)[16], const char* src, f32x16 (&acc)[5]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt)
+        acc[nt] = mfma32x16(A[ks], *reinterpret_cast<const vec*>(src + rowB[nt] * GB_ROW + (2 * ks + lh) * 16), acc[nt]);
+  };
+  // ---- stage a (144, 256) tensor of this sample (all loads of a thread before its first LDS write)
+  auto stage = [&](const T* src, char* dst) __attribute__((always_inline)) {
+    constexpr int VPT = (GB_NODES * (GB_C / 8) + 511) / 512;     // 9
+    vec tmp[VPT];
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const int v = min(tid + q * 512, GB_NODES * (GB_C / 8) - 1);
+      tmp[q] = *reinterpret_cast<const vec*>(src + (size_t)(v >> 5) * GB_C + (v & 31) * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const int v = tid + q * 512;
+      if (v < GB_NODES * (GB_C / 8)) *reinterpret_cast<vec*>(dst + (v >> 5) * GB_ROW + (v & 31) * 16) = tmp[q];
+    }
+  };
+  if (!FULL) {
+    int ti[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ti[q] = a.idx[(size_t)n * GB_NODES * GB_K + min(tid + q * 512, GB_NODES * GB_K - 1)];
+    stage(Fg, R1);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (tid + q * 512 < GB_NODES * GB_K) sIdx[tid + q * 512] = ti[q];
+    __syncthreads();
+  } else {
+    // ---- fc1: F = X4 W1^T + b1 (Grapher_noBN.fc1, torch_vertex.py:190), rounded to the 16-bit type like the stored tensor
+    vec A1[16];
+    {
+      const T* w1r = reinterpret_cast<const T*>(a.w1) + ((size_t)(wave * 32 + lr)) * GB_C + 8 * lh;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) A1[ks] = *reinterpret_cast<const vec*>(w1r + 16 * ks);
+    }
+    stage(Xg, R0);
+    __syncthreads();
+    {
+      f32x16 acc1[5];
+      gemm256(A1, R0, acc1);
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        const int node = nt * 32 + lr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = wave * 32 + 8 * q + 4 * lh;
+          const f32x4 b = bias4(a.b1, co);
+          vec4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (T)(acc1[nt][4 * q + r] + b[r]);
+          if (node < GB_NODES) *reinterpret_cast<vec4*>(R1 + node * GB_ROW + co * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the kNN graph of F (DenseDilatedKnnGraph, torch_edge.py:150-158): as gcn_knn_mfma_kernel (csrc/misc_kernels.hip),
+    //      on the copy of F that is already here
+    if (tid < 160) {
+      float inv = 0.f, s2 = 0.f;
+      if (tid < GB_NODES) {
+        const char* rp = R1 + tid * GB_ROW;
+        float ss = 0.f;
+        for (int sl = 0; sl < GB_C / 8; ++sl) {
+          float f[8];
+          E::unpack(*reinterpret_cast<const vec*>(rp + sl * 16), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+        }
+        inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        for (int sl = 0; sl < GB_C / 8; ++sl) {
+          float f[8];
+          E::unpack(*reinterpret_cast<const vec*>(rp + sl * 16), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float t = f[e] * inv; s2 = fmaf(t, t, s2); }
+        }
+      }
+      sInv[tid] = inv;
+      sXX[tid] = s2;
+    }
+    __syncthreads();
+    constexpr int TS = 10;                                  // 80 (row tile, accumulator slot) units over 8 waves
+    const int u0 = wave * TS, u1 = u0 + TS;
+    for (int rt = u0 >> 4; rt <= (u1 - 1) >> 4; ++rt) {
+      const int s_lo = max(u0 - rt * 16, 0), cnt = min(u1 - rt * 16, 16) - s_lo;
+      f32x16 gr[5];
+#pragma unroll
+      for (int ct = 0; ct < 5; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gr[ct][e] = 0.f;
+      const char* pa = R1 + min(rt * 32 + lr, GB_NODES - 1) * GB_ROW + lh * 16;
+#pragma unroll 4
+      for (int ks = 0; ks < GB_C / 16; ++ks) {
+        const vec A = *reinterpret_cast<const vec*>(pa + ks * 32);
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct)
+          gr[ct] = mfma32x16(A, *reinterpret_cast<const vec*>(R1 + rowB[ct] * GB_ROW + lh * 16 + ks * 32), gr[ct]);
+      }
+      float relv[TS][5];                       // relative_pos of this wave's (slot, column tile) pairs, requested together
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        const int sl = min(s_lo + t, 15);
+        const int i = min(rt * 32 + 8 * (sl >> 2) + 4 * lh + (sl & 3), GB_NODES - 1);
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct)
+          relv[t][ct] = a.rel != nullptr ? a.rel[(size_t)i * GB_NODES + min(ct * 32 + lr, GB_NODES - 1)] : 0.f;
+      }
+      float d[TS][5];
+      int row_i[TS];
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        const int sl = min(s_lo + t, 15);                                   // wave-uniform
+        float raw[5];
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct) {
+          float val = gr[ct][0];
+#pragma unroll
+          for (int e = 1; e < 16; ++e) val = sl == e ? gr[ct][e] : val;
+          raw[ct] = val;
+        }
+        const int i = rt * 32 + 8 * (sl >> 2) + 4 * lh + (sl & 3);
+        const bool row_ok = i < GB_NODES && t < cnt;
+        row_i[t] = row_ok ? i : -1;
+        const float inv_i = sInv[min(i, 159)], xx_i = sXX[min(i, 159)];
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct) {
+          const int j = ct * 32 + lr;
+          d[t][ct] = INFINITY;
+          if (row_ok && j < GB_NODES) {
+            float dd = (xx_i + (-2.f * (raw[ct] * inv_i * sInv[j]))) + sXX[j];
+            if (a.rel != nullptr) dd += relv[t][ct];
+            d[t][ct] = dd;
+          }
+        }
+      }
+      for (int r = 0; r < GB_K; ++r) {
+        float bv[TS];
+        int bj[TS];
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+          bv[t] = d[t][0];
+          bj[t] = lr;
+#pragma unroll
+          for (int ct = 1; ct < 5; ++ct)
+            if (d[t][ct] < bv[t]) { bv[t] = d[t][ct]; bj[t] = ct * 32 + lr; }
+        }
+#define GB_STEP(CTRL)                                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < TS; ++t) {                                                                    \
+          const float ov = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bv[t]), CTRL, 0xF, 0xF, true)); \
+          const int oj = __builtin_amdgcn_mov_dpp(bj[t], CTRL, 0xF, 0xF, true);                                             \
+          if (ov < bv[t] || (ov == bv[t] && oj < bj[t])) { bv[t] = ov; bj[t] = oj; }                                        \
+        }
+        GB_STEP(0xB1)
+        GB_STEP(0x4E)
+        GB_STEP(0x141)
+        GB_STEP(0x140)
+#undef GB_STEP
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+          const float ov = __shfl_xor(bv[t], 16, 64);
+          const int oj = __shfl_xor(bj[t], 16, 64);
+          if (ov < bv[t] || (ov == bv[t] && oj < bj[t])) { bv[t] = ov; bj[t] = oj; }
+        }
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+#pragma unroll
+          for (int ct = 0; ct < 5; ++ct)
+            if (ct * 32 + lr == bj[t]) d[t][ct] = INFINITY;
+          if (lr == 0 && row_i[t] >= 0) {
+            sIdx[row_i[t] * GB_K + r] = bj[t];
+            if (a.idx_out != nullptr) a.idx_out[((size_t)n * GB_NODES + row_i[t]) * GB_K + r] = bj[t];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
 
   // ---- Grapher: per group of the grouped conv (64 source channels -> 128 interleaved max-relative channels -> 128 outputs),
   //      fc2 accumulated over the groups in registers
@@ -153,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
         const f32x4 b = bias4(a.bg, g * 128 + co);
         vec4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (T)uncl_gelu(accg[i][4 * q + r] + b[r]);
+        for (int r = 0; r < 4; ++r) o[r] = (T)gelu_as(accg[i][4 * q + r] + b[r]);
         if (node < GB_NODES) *reinterpret_cast<vec4*>(R0 + node * GB_ROWG + co * 2) = o;
       }
     }
@@ -195,17 +380,6 @@ __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
   __syncthreads();
 
   // ---- (f) FFN fc1 + GELU -> LDS, (g) FFN fc2 + bias + X1 -> global
-  auto gemm256 = [&](const vec (&A)[16], const char* src, f32x16 (&acc)[5]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-      for (int nt = 0; nt < 5; ++nt)
-        acc[nt] = mfma32x16(A[ks], *reinterpret_cast<const vec*>(src + rowB[nt] * GB_ROW + (2 * ks + lh) * 16), acc[nt]);
-  };
   f32x16 acc[5];
   gemm256(A3, R1, acc);
   vec A4[16];
@@ -221,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
       const f32x4 b = bias4(a.b3, co);
       vec4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (T)uncl_gelu(acc[nt][4 * q + r] + b[r]);
+      for (int r = 0; r < 4; ++r) o[r] = (T)gelu_as(acc[nt][4 * q + r] + b[r]);
       if (node < GB_NODES) *reinterpret_cast<vec4*>(R0 + node * GB_ROW + co * 2) = o;
     }
   }
@@ -245,35 +419,48 @@ __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
 
 }  // namespace
 
+static int launch_graph(GbArgs& a, int dtype, bool full, hipStream_t s) {
+  const size_t lds = 2 * (size_t)GB_NODES * GB_ROW + (size_t)GB_NODES * GB_K * 4 + 2 * 160 * sizeof(float);
+  static bool attr[4] = {false, false, false, false};
+  const int which = (dtype == UNCL_F16 ? 0 : 1) + (full ? 2 : 0);
+  const void* kern = which == 0 ? reinterpret_cast<const void*>(graph_tail_kernel<f16_t, false>)
+                     : which == 1 ? reinterpret_cast<const void*>(graph_tail_kernel<bf16_t, false>)
+                     : which == 2 ? reinterpret_cast<const void*>(graph_tail_kernel<f16_t, true>)
+                                  : reinterpret_cast<const void*>(graph_tail_kernel<bf16_t, true>);
+  if (!attr[which]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UNCL_ERR_LAUNCH;
+    attr[which] = true;
+  }
+  switch (which) {
+    case 0: hipLaunchKernelGGL((graph_tail_kernel<f16_t, false>), dim3(a.N), dim3(512), lds, s, a); break;
+    case 1: hipLaunchKernelGGL((graph_tail_kernel<bf16_t, false>), dim3(a.N), dim3(512), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((graph_tail_kernel<f16_t, true>), dim3(a.N), dim3(512), lds, s, a); break;
+    default: hipLaunchKernelGGL((graph_tail_kernel<bf16_t, true>), dim3(a.N), dim3(512), lds, s, a); break;
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
 // F: fc1 output, idx: its kNN graph, X4: the block's input.  Weights in the packed 1x1 layout of uncl_pack_conv_weight
 // ([group][Cout][Cin], K contiguous).  16-bit types only; no DropPath scaling (inference).
 extern "C" int uncl_gcn_tail(const void* F, const int32_t* idx, const void* X4, const void* wg, const float* bg, const void* w2,
                              const float* b2, const void* w3, const float* b3, const void* w4, const float* b4, void* out,
                              int dtype, int N, void* stream) {
   if (!F || !idx || !X4 || !wg || !w2 || !w3 || !w4 || !out || N <= 0 || !uncl_is_h16(dtype)) return UNCL_ERR_ARG;
-  GbArgs a;
+  GbArgs a = {};
   a.F = F; a.idx = idx; a.X4 = X4; a.wg = wg; a.w2 = w2; a.w3 = w3; a.w4 = w4;
   a.bg = bg; a.b2 = b2; a.b3 = b3; a.b4 = b4; a.out = out; a.N = N;
-  const size_t lds = 2 * (size_t)GB_NODES * GB_ROW + (size_t)GB_NODES * GB_K * 4;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static bool attr[2] = {false, false};
-  if (dtype == UNCL_F16) {
-    if (!attr[0]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(graph_tail_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess)
-        return UNCL_ERR_LAUNCH;
-      attr[0] = true;
-    }
-    hipLaunchKernelGGL(graph_tail_kernel<f16_t>, dim3(N), dim3(512), lds, s, a);
-  } else {
-    if (!attr[1]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(graph_tail_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess)
-        return UNCL_ERR_LAUNCH;
-      attr[1] = true;
-    }
-    hipLaunchKernelGGL(graph_tail_kernel<bf16_t>, dim3(N), dim3(512), lds, s, a);
-  }
-  UNCL_CHECK_LAUNCH();
-  return UNCL_OK;
+  return launch_graph(a, dtype, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The whole block in one launch: fc1 and the kNN graph (relative_pos: (144,144) or NULL) are computed in the kernel as well;
+// idx_out (N,144,9), if not NULL, receives the graph.
+extern "C" int uncl_gcn_block(const void* X4, const void* w1, const float* b1, const float* relative_pos, const void* wg,
+                              const float* bg, const void* w2, const float* b2, const void* w3, const float* b3, const void* w4,
+                              const float* b4, int32_t* idx_out, void* out, int dtype, int N, void* stream) {
+  if (!X4 || !w1 || !wg || !w2 || !w3 || !w4 || !out || N <= 0 || !uncl_is_h16(dtype)) return UNCL_ERR_ARG;
+  GbArgs a = {};
+  a.X4 = X4; a.w1 = w1; a.b1 = b1; a.rel = relative_pos; a.idx_out = idx_out;
+  a.wg = wg; a.w2 = w2; a.w3 = w3; a.w4 = w4; a.bg = bg; a.b2 = b2; a.b3 = b3; a.b4 = b4; a.out = out; a.N = N;
+  return launch_graph(a, dtype, true, reinterpret_cast<hipStream_t>(stream));
 }
