@@ -957,9 +957,11 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     // 16-row tiles (16 x 32 pixels x 64 channels, 128 accumulator registers) halve the weight re-streaming per output of the
     // 8-row tile: same-box A/B -4 ... -14 % per layer wherever they cover the map without extra rows (24 x 24 maps: +7 %)
     static const int tall = [] { const char* e = getenv("UNCL_PC_TALL"); return e ? atoi(e) : 1; }();
-    // ... and leave every CU a few tiles (training batches: the halved tile count would idle CUs; measured +1 ... +4 % there)
+    // ... and give every CU a tile (the video step's 8-sample launches: the halved tile count would idle CUs, +4 % there;
+    // thresholds of 128 ... 384 tiles measured alike, 768 cost the two-part inference forward 2 %)
     const int tall_tiles = d->N * a.tiles_x * ((a.Hout + 15) / 16) * a.n_ct;
-    if (tall && ((a.Hout + 15) / 16) * 16 <= ((a.Hout + 7) / 8) * 8 && tall_tiles >= 768) {
+    static const int tall_min = [] { const char* e = getenv("UNCL_PC_TALL_MIN"); return e ? atoi(e) : 256; }();
+    if (tall && ((a.Hout + 15) / 16) * 16 <= ((a.Hout + 7) / 8) * 8 && tall_tiles >= tall_min) {
       PipeArgs b = a;
       b.tiles_y = (a.Hout + 15) / 16;
       b.total_tiles = tall_tiles;
