@@ -119,7 +119,8 @@ int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
 /* Kernel structure used by uncl_conv3x3_pipe / uncl_conv3x3_dgrad: 0 = the four-wave kernel for every layer; 1 = producer /
  * consumer workgroups (csrc/conv3x3_pc.hip: four multiplying and four or eight staging waves, one workgroup per CU, LDS
  * planes, resident weights where they fit) for the concat-source layers only; 2 (default) = for every layer they build
- * (plain sources and single-chunk layers too; measured faster on all of them).  All give bit-identical results; the switch
+ * (plain sources and single-chunk layers too; measured faster on all of them); 3 = also the layers with a fused 1x1 tail
+ * (measured slower there).  All give bit-identical results; the switch
  * exists for same-process A/B timing and for the tests that compare the structures.  Returns the previous setting. */
 int uncl_conv3x3_set_pc(int on);
 

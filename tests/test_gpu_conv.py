@@ -399,12 +399,12 @@ def test_pipe_transposed_plain_layers_zero_borders(cin, cout, h, w, n, act):
 
 # ---- producer / consumer kernel (csrc/conv3x3_pc.hip) against the four-wave kernel: same tiles, same MFMA order per
 # ---- accumulator, so every stored element must be IDENTICAL (the torch comparisons above already run through it by default)
-def _both_structures(fn):
+def _both_structures(fn, pc=2):
     lib = _hip.lib()
     old = lib.uncl_conv3x3_set_pc(0)
     try:
         ref = fn()
-        lib.uncl_conv3x3_set_pc(2)
+        lib.uncl_conv3x3_set_pc(pc)
         got = fn()
     finally:
         lib.uncl_conv3x3_set_pc(old)
@@ -439,6 +439,34 @@ def test_pc_plain_layers_bitwise(cin, cout, h, w, n, pad, pool, act):
     ref = F.conv2d(F.pad(x, (pad,) * 4), wt, b)
     ref = {_hip.ACT_RELU: F.relu, _hip.ACT_LRELU: lambda t: F.leaky_relu(t, 0.2), _hip.ACT_NONE: lambda t: t}[act](ref)
     assert rel_l2(from_nhwc(go), ref) < TOL[BF]
+
+
+@pytest.mark.parametrize("cin,h,w,n,skip,act1", [(32, 30, 45, 2, False, _hip.ACT_SIGMOID), (32, 126, 126, 2, True, _hip.ACT_SIGMOID),
+                                                 (64, 40, 70, 2, True, _hip.ACT_TANH), (32, 17, 33, 3, False, _hip.ACT_NONE)])
+def test_pc_fused_outc_tail_bitwise(cin, h, w, n, skip, act1):
+    """The fused 1x1 tail (outconv + last activation) under both kernel structures: the producer / consumer kernel chains the 32
+    rounded channels through the two half-waves in channel order, which must reproduce the four-wave kernel's sum exactly --
+    with the 32-channel map stored (training) and skipped (inference)."""
+    x, wt, b = q(rnd(n, cin, h, w, seed=261), BF), q(rnd(cin, 32, 3, 3, seed=262, scale=0.1), BF), rnd(32, seed=263)
+    w1, b1 = rnd(32, seed=264).cuda(), rnd(1, seed=265).cuda()
+    xd, wd, bd = to_nhwc(x, BF), pack_weight(wt, BF, transposed=True, flip=True), b.cuda()
+
+    def run():
+        out = None if skip else torch.zeros(n, h + 2, w + 2, 32, dtype=torch.bfloat16, device="cuda")
+        out1 = torch.zeros(n, h + 2, w + 2, dtype=torch.float32, device="cuda")
+        run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=32, src0=xd, src0_H=h, src0_W=w,
+                 src0_C=cin, weight=wd, bias=bd, act=_hip.ACT_RELU, out=out, out_H=h + 2, out_W=w + 2, out_C=32, out1_w=w1, out1_b=b1,
+                 out1_act=act1, out1=out1, skip_main_store=1 if skip else 0)
+        return out, out1
+
+    (ro, r1), (go, g1) = _both_structures(run, pc=3)       # 3: the producer / consumer kernel takes the fused tail as well
+    assert torch.equal(r1, g1)
+    if not skip:
+        assert torch.equal(ro, go)
+    up = F.relu(F.conv_transpose2d(x, wt, b))
+    ref1 = F.conv2d(q(up, BF), w1.cpu().reshape(1, 32, 1, 1), b1.cpu())
+    ref1 = {_hip.ACT_SIGMOID: torch.sigmoid, _hip.ACT_TANH: torch.tanh, _hip.ACT_NONE: lambda t: t}[act1](ref1)
+    assert rel_l2(g1.cpu().unsqueeze(1), ref1) < TOL[BF]
 
 
 @pytest.mark.parametrize("kind,c,cout,h,n,pool", [("plain", 64, 64, 124, 24, True),      # 24 x 4 x 8 = 768 tiles of 16 x 32 x 64

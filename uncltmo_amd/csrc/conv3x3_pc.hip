@@ -106,7 +106,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wres = smem + 2 * XBYTES;                               // RESW: chunk kc at wres + kc * WBYTES
   float* const sBias = reinterpret_cast<float*>(smem + (RESW ? 2 * XBYTES + a.nk * WBYTES : 2 * STAGE));   // [2 tiles][CT]
-  float* const sP = sBias + 2 * CT;                                   // MODE 3: [2][PN3] image patches
+  float* const sO1 = sBias + 2 * CT;                                  // fused 1x1 tail: 32 weights + its bias (+ pad)
+  float* const sP = sO1 + 64;                                         // MODE 3: [2][PN3] image patches
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -365,7 +366,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       asm volatile("" : "+v"(poff));
       static_assert(MPW % 2 == 0, "whole pooled rows per wave");
 #pragma unroll
-      for (int pr = 0; pr < MPW / 2; ++pr)
+      for (int pr = 0; pr < MPW / 2; ++pr) {
+        float o1sum[2] = {0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -378,6 +380,27 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
               const int m = 2 * pr + r, oy = y0 + m;                              // wave-uniform
               char* rowp = reinterpret_cast<char*>(a.out + ((size_t)c.n * a.Hout + oy) * a.Wout * a.oC + co);
               wv[r] = widen_relu(pack4(acc[m][nt], 2 * qp, b0), pack4(acc[m][nt], 2 * qp + 1, b1));
+              if (!GRAD && NT == 1 && a.out1_w != nullptr) {
+                // fused 1x1 tail (outconv + last activation, unet_parts.py:338-345): one sequential fmaf chain over the 32
+                // ROUNDED channels in channel order, as the four-wave kernel computes it from its LDS image.  After the
+                // widening the lower half-wave holds channels 16 qp + 0..7 of its pixel and the upper half 16 qp + 8..15: the
+                // running sum goes lower -> upper -> (next qp) lower -> upper, handed over by a half-wave exchange.
+                float f[8];
+                E::unpack(wv[r], f);
+                const float* w8 = sO1 + 16 * qp + 8 * lh;
+                float t = qp == 0 ? sO1[32] : o1sum[r];                          // lower half: the chain so far
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t = fmaf(f[i], w8[i], t);
+                float u = __shfl_xor(t, 32, 64);                                 // upper half: the lower half's sum so far
+#pragma unroll
+                for (int i = 0; i < 8; ++i) u = fmaf(f[i], w8[i], u);
+                o1sum[r] = __shfl_xor(u, 32, 64);                                // lower half: the upper half's sum
+                // (half-wave exchanges: only the receiving half of each hand-over holds the chain; the final sum is read in
+                // the LOWER half)
+                if (qp == 1 && lh == 0 && oy < a.Hout && xin)
+                  a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(o1sum[r], a.out1_act);
+              }
+              if (a.skip_main) continue;
 #ifdef UNCL_PC_TIMING
               if (a.pc_prio & 64) { asm volatile("" ::"v"(wv[r])); continue; }     // experiment: no output stores (wrong results)
 #endif
@@ -407,12 +430,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
               if (in) *reinterpret_cast<vec*>(rowp + poff + (nt * 32 + 16 * qp) * 2) = __builtin_bit_cast(vec, v);
             }
           }
+      }
     };
 
     TileCur cc;
     cur_init(cc, tile0, a);
     int tpar = 0;
-    const bool fast_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && !a.skip_main && !(a.pc_prio & 256);   // wave-uniform
+    const bool fast_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && (!a.skip_main || a.out1_w != nullptr) &&
+                           !(a.pc_prio & 256);   // wave-uniform
     // gradient stores of ReLU networks (mask slope 0), and plain identity stores
     const bool fast_grad = a.slope == 1.f && a.mask_slope == 0.f && !a.skip_main && a.pool_out == nullptr && !(a.pc_prio & (256 | 1024));
 #pragma unroll
@@ -830,6 +855,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       if (cur_next(pc, a, tile_end) && pc.tile != t_old) ppar ^= 1;
     }
   };
+  if (a.out1_w != nullptr && ptid < 33) sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0];     // fused 1x1 tail (CT == 32)
   if (RESW) {
     // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order, and so
     // does its bias (both tile parities)
@@ -888,7 +914,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 template <int NT, int MPW>
 constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
-  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 2 * NT * 32 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0);
+  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 2 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0);
 }
 
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
@@ -935,14 +961,17 @@ extern "C" int uncl_pc_timing_read(unsigned long long* out16, int reset) {
 
 template <typename T>
 static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
-  if (a.nk < 1 || a.res != nullptr || a.out1_w != nullptr || a.flat_S != 0) return UNCL_ERR_ARG;
+  if (a.nk < 1 || a.res != nullptr || a.flat_S != 0) return UNCL_ERR_ARG;
   static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
   a.pc_prio = prio;
   static const int resw_on = [] { const char* e = getenv("UNCL_PC_RESW"); return e ? atoi(e) : 1; }();
   // resident weights: one cout tile for the whole layer and its K-chunks fit next to two activation stages
   const bool resw = resw_on && a.n_ct == 1 && a.nk * nt <= 4;
   // a pooled copy beside 32-channel tiles: only the forward epilogue (ReLU, plain store) builds it
-  const bool fwd_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && !a.skip_main;
+  const bool fwd_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && (!a.skip_main || a.out1_w != nullptr);
+  // the fused 1x1 tail: 32-channel tiles, forward epilogue, no pooled copy
+  if (a.out1_w != nullptr && !(nt == 1 && fwd_relu && a.pool_out == nullptr && a.out1 != nullptr && a.out1_b != nullptr)) return UNCL_ERR_ARG;
+  if (a.skip_main && a.out1_w == nullptr) return UNCL_ERR_ARG;
   if (nt == 1 && mpw == 4) {
     if (a.pool_out != nullptr && !fwd_relu) return UNCL_ERR_ARG;
     static const int pw = [] { const char* e = getenv("UNCL_PC_PW"); return e ? atoi(e) : 8; }();      // experiment: staging waves

@@ -833,11 +833,12 @@ int dispatch_type(PipeArgs& a, int dtype, int mode, bool prev, hipStream_t s) {
 
 }  // namespace
 
-// 2 (default): every layer the producer / consumer kernel builds; 1: the concat-source layers only; 0: the four-wave kernel
+// 2 (default): every layer the producer / consumer kernel builds faster; 3: also the fused 1x1 tails (slower there); 1: the
+// concat-source layers only; 0: the four-wave kernel
 static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 2; }();
 extern "C" int uncl_conv3x3_set_pc(int on) {
   const int old = g_use_pc;
-  g_use_pc = on < 0 ? 0 : (on > 2 ? 2 : on);
+  g_use_pc = on < 0 ? 0 : (on > 3 ? 3 : on);
   return old;
 }
 
@@ -910,8 +911,11 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   // measured per layer at bench size (tools/pc_phase_timing.py --product): with one staging register set, unpadded LDS planes
   // and resident weights the producer / consumer structure is faster on every layer it builds (3 - 30 %), single-chunk ones
   // included; UNCL_PC=1 restricts it to the concat layers, 0 turns it off
-  const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc == 2 ? 0 : 1) && a.nk >= 1 && d->res == nullptr && d->out1_w == nullptr &&
-                     !d->skip_main_store;
+  // A fused 1x1 tail / skipped main store stays on the four-wave kernel: the producer / consumer epilogue builds it too
+  // (bit-identical, set_pc(3): A/B and tests) but its channel-order chain crosses the half-waves three times per row with
+  // nobody to hide the exchanges behind -- 0.43 against 0.32 ms on up_path.3.conv.conv1.
+  const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc >= 2 ? 0 : 1) && a.nk >= 1 && d->res == nullptr &&
+                     ((d->out1_w == nullptr && !d->skip_main_store) || (g_use_pc == 3 && d->Cout == 32 && d->out1_b != nullptr));
   if (d->Cout == 32) {
     // 8-row tiles at three workgroups per CU (50 KB LDS, 168 VGPRs) overlap the serial load / stage / store phases of the
     // single-chunk 32 -> 32 transposed layers better than 16-row tiles at two (measured: up_path.{2,3}.conv.conv1 -9 %);
