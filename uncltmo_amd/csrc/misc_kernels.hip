@@ -413,13 +413,11 @@ __global__ __launch_bounds__(1024) void gcn_knn_kernel(const T* __restrict__ x, 
 // rows is five 32 x 32 row tiles x five column tiles of v_mfma_f32_32x32x16 (exact products, fp32 accumulation), scaled to
 // the normalised inner products by 1/|x_i| 1/|x_j| afterwards; the top-9 of a row is selected straight from the accumulator
 // registers (a row's 160 candidates are ONE register slot of the 32 lanes of a half-wave x 5 column tiles).  The VALU kernel
-// above spends 150 us per 200 samples on 7 M sequential fmaf per sample; this one 75 (multiplies 5, norms 3, nine arg-min
-// rounds 46: ten slots x 75 VALU instructions per round and wave).  Distances agree with it to fp32
+// above spends 150 us per 200 samples on 7 M sequential fmaf per sample.  Distances agree with it to fp32
 // rounding (different summation order), so an index can differ only where two candidates are within ~1e-6: the fp32 parity
 // path keeps the VALU kernel, whose indices are pinned bit for bit.
 // ------------------------------------------------------------------------------------------------------
 #define KNM_ROW 528            // bytes per staged row: 512 + 16 (consecutive rows shift one 16-byte slot)
-#define KNM_UNITS 80           // 5 row tiles x 16 accumulator slots, dealt to 8 waves (10 each)
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void gcn_knn_mfma_kernel(const T* __restrict__ x, const float* __restrict__ rel,
@@ -473,113 +471,84 @@ __global__ __launch_bounds__(512, 2) void gcn_knn_mfma_kernel(const T* __restric
     sXX[tid] = s2;
   }
   __syncthreads();
-  const int u0 = wave * (KNM_UNITS / 8), u1 = u0 + KNM_UNITS / 8;      // this wave's (row tile, slot) units
-  for (int rt = u0 >> 4; rt <= (u1 - 1) >> 4; ++rt) {
-    // Gram tile row: D[i][j] = sum_k x_i[k] x_j[k], i = 32 rt + (8q + 4 lh + r), j = 32 ct + lr
-    f32x16 acc[5];
+  // The Gram matrix is symmetric, so the registers of a LANE are already a row's candidates: with the row tile as the A operand
+  // lane lr of column tile ct holds D[i][j] for its node j = 32 ct + lr and the 16 nodes i = 32 rt + 8q + 4 lh + r of every
+  // row tile -- half of row j's 160 candidates per half-wave.  Each lane keeps a sorted top-9 of its 80 candidates (they come
+  // in ascending i, so a strict compare keeps the lower index on ties), the two half-waves merge their lists.  One wave per
+  // column tile; nine rounds of wave-wide arg-min per row were 46 of this kernel's 75 us.
+  if (wave < 5) {
+    const int ct = wave, j = ct * 32 + lr;
+    const bool j_ok = j < n;
+    const int jc = min(j, n - 1);
+    vec Bf[KNN_C / 16];
+    {
+      const char* pb = sF + jc * KNM_ROW + lh * 16;
 #pragma unroll
-    for (int ct = 0; ct < 5; ++ct)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
-    // relative_pos of this wave's (slot, column tile) pairs: all requested before the multiplies
-    constexpr int TS = KNM_UNITS / 8;
-    const int s_lo = max(u0 - rt * 16, 0), cnt = min(u1 - rt * 16, 16) - s_lo;
-    float relv[TS][5];
-#pragma unroll
-    for (int t = 0; t < TS; ++t) {
-      const int sl = min(s_lo + t, 15);
-      const int i = min(rt * 32 + 8 * (sl >> 2) + 4 * lh + (sl & 3), n - 1);
-#pragma unroll
-      for (int ct = 0; ct < 5; ++ct) relv[t][ct] = rel != nullptr ? rel[(size_t)i * n + min(ct * 32 + lr, n - 1)] : 0.f;
+      for (int ks = 0; ks < KNN_C / 16; ++ks) Bf[ks] = *reinterpret_cast<const vec*>(pb + ks * 32);
     }
-    const char* pa = sF + min(rt * 32 + lr, n - 1) * KNM_ROW + lh * 16;
-    const char* pb[5];
+    const float inv_j = sInv[min(j, 159)], xx_j = sXX[min(j, 159)];
+    float tv[9];
+    int ti[9];
 #pragma unroll
-    for (int ct = 0; ct < 5; ++ct) pb[ct] = sF + min(ct * 32 + lr, n - 1) * KNM_ROW + lh * 16;
-#pragma unroll 4
-    for (int ks = 0; ks < KNN_C / 16; ++ks) {
-      const vec A = *reinterpret_cast<const vec*>(pa + ks * 32);
+    for (int p = 0; p < 9; ++p) { tv[p] = INFINITY; ti[p] = 0x7fffffff; }
+#pragma unroll 1
+    for (int rt = 0; rt < 5; ++rt) {
+      f32x16 acc;
 #pragma unroll
-      for (int ct = 0; ct < 5; ++ct) acc[ct] = mfma32x16(A, *reinterpret_cast<const vec*>(pb[ct] + ks * 32), acc[ct]);
-    }
-    // This wave's slots of the row tile, s_lo .. s_lo + cnt - 1, are copied out of the accumulators (uniform selects: no
-    // register indexing) and then selected IN LOCKSTEP: the cross-lane steps of the nine arg-min rounds are dependent
-    // ds_bpermute chains of ~1 000 cycles per round, and ten independent chains in flight hide each other's latency (one
-    // slot at a time the selection alone took 60 us per sample).
-    float d[TS][5];
-    int row_i[TS];
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      const char* pa = sF + min(rt * 32 + lr, n - 1) * KNM_ROW + lh * 16;
 #pragma unroll
-    for (int t = 0; t < TS; ++t) {
-      const int sl = min(s_lo + t, 15);                                   // wave-uniform
-      float raw[5];
+      for (int ks = 0; ks < KNN_C / 16; ++ks) acc = mfma32x16(*reinterpret_cast<const vec*>(pa + ks * 32), Bf[ks], acc);
+      float rl[16];
 #pragma unroll
-      for (int ct = 0; ct < 5; ++ct) {
-        float val = acc[ct][0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) val = sl == e ? acc[ct][e] : val;
-        raw[ct] = val;
+      for (int e = 0; e < 16; ++e) {
+        const int i = min(rt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3), n - 1);
+        rl[e] = rel != nullptr ? rel[(size_t)jc * n + i] : 0.f;
       }
-      const int i = rt * 32 + 8 * (sl >> 2) + 4 * lh + (sl & 3);        // this half-wave's row
-      const bool row_ok = i < n && t < cnt;
-      row_i[t] = row_ok ? i : -1;
-      const float inv_i = sInv[min(i, 159)], xx_i = sXX[min(i, 159)];
 #pragma unroll
-      for (int ct = 0; ct < 5; ++ct) {
-        const int j = ct * 32 + lr;
-        d[t][ct] = INFINITY;
-        if (row_ok && j < n) {
-          // same association as the reference: (|xi|^2 + (-2 xi.xj)) + |xj|^2, then + relative_pos
-          float dd = (xx_i + (-2.f * (raw[ct] * inv_i * sInv[j]))) + sXX[j];
-          if (rel != nullptr) dd += relv[t][ct];
-          d[t][ct] = dd;
+      for (int e = 0; e < 16; ++e) {
+        const int i = rt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
+        // same association as the reference: (|x_row|^2 + (-2 x_row.x_col)) + |x_col|^2, then + relative_pos[row][col]; row = j
+        float dd = (xx_j + (-2.f * (acc[e] * inv_j * sInv[min(i, 159)]))) + sXX[min(i, 159)];
+        dd += rl[e];
+        if (i >= n) dd = INFINITY;
+        // insert (dd, i) into the sorted list; strict compare: an equal earlier (lower-index) entry stays in front
+        bool c[9];
+#pragma unroll
+        for (int p = 0; p < 9; ++p) c[p] = dd < tv[p];
+#pragma unroll
+        for (int p = 8; p > 0; --p) {
+          tv[p] = c[p] ? (c[p - 1] ? tv[p - 1] : dd) : tv[p];
+          ti[p] = c[p] ? (c[p - 1] ? ti[p - 1] : i) : ti[p];
         }
+        tv[0] = c[0] ? dd : tv[0];
+        ti[0] = c[0] ? i : ti[0];
       }
     }
-    // nine rounds of arg-min over each half-wave's 5 x 32 candidates; ties go to the lower node index
-    for (int r = 0; r < 9; ++r) {
-      float bv[TS];
-      int bj[TS];
+    // merge the other half-wave's list (same node, the other half of the candidates): its entries are inserted with the full
+    // (value, index) order
+    float ov[9];
+    int oi[9];
 #pragma unroll
-      for (int t = 0; t < TS; ++t) {
-        bv[t] = d[t][0];
-        bj[t] = lr;
+    for (int p = 0; p < 9; ++p) { ov[p] = __shfl_xor(tv[p], 32, 64); oi[p] = __shfl_xor(ti[p], 32, 64); }
 #pragma unroll
-        for (int ct = 1; ct < 5; ++ct)
-          if (d[t][ct] < bv[t]) { bv[t] = d[t][ct]; bj[t] = ct * 32 + lr; }
+    for (int s2 = 0; s2 < 9; ++s2) {
+      const float dd = ov[s2];
+      const int i = oi[s2];
+      bool c[9];
+#pragma unroll
+      for (int p = 0; p < 9; ++p) c[p] = dd < tv[p] || (dd == tv[p] && i < ti[p]);
+#pragma unroll
+      for (int p = 8; p > 0; --p) {
+        tv[p] = c[p] ? (c[p - 1] ? tv[p - 1] : dd) : tv[p];
+        ti[p] = c[p] ? (c[p - 1] ? ti[p - 1] : i) : ti[p];
       }
-      // all-reduce inside each row of 16 lanes with DPP moves (VALU: quad swaps, then the two mirrors), across the two rows
-      // of the half-wave with one ds_bpermute pair -- five bpermute steps per round put the CU's LDS pipe at 6 400 cycles
-      // per round for the eight waves
-#define KNM_STEP(CTRL)                                                                                                     \
-      _Pragma("unroll") for (int t = 0; t < TS; ++t) {                                                                     \
-        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bv[t]), CTRL, 0xF, 0xF, true)); \
-        const int oj = __builtin_amdgcn_mov_dpp(bj[t], CTRL, 0xF, 0xF, true);                                              \
-        if (ov < bv[t] || (ov == bv[t] && oj < bj[t])) { bv[t] = ov; bj[t] = oj; }                                         \
-      }
-      KNM_STEP(0xB1)      // quad_perm [1,0,3,2]
-      KNM_STEP(0x4E)      // quad_perm [2,3,0,1]
-      KNM_STEP(0x141)     // row_half_mirror
-      KNM_STEP(0x140)     // row_mirror
-#undef KNM_STEP
-      {
-        float ov[TS];
-        int oj[TS];
+      tv[0] = c[0] ? dd : tv[0];
+      ti[0] = c[0] ? i : ti[0];
+    }
+    if (lh == 0 && j_ok) {
 #pragma unroll
-        for (int t = 0; t < TS; ++t) {
-          ov[t] = __shfl_xor(bv[t], 16, 64);
-          oj[t] = __shfl_xor(bj[t], 16, 64);
-        }
-#pragma unroll
-        for (int t = 0; t < TS; ++t)
-          if (ov[t] < bv[t] || (ov[t] == bv[t] && oj[t] < bj[t])) { bv[t] = ov[t]; bj[t] = oj[t]; }
-      }
-#pragma unroll
-      for (int t = 0; t < TS; ++t) {
-#pragma unroll
-        for (int ct = 0; ct < 5; ++ct)
-          if (ct * 32 + lr == bj[t]) d[t][ct] = INFINITY;
-        if (lr == 0 && row_i[t] >= 0) idx[((size_t)blockIdx.x * n + row_i[t]) * 9 + r] = bj[t];
-      }
+      for (int p = 0; p < 9; ++p) idx[((size_t)blockIdx.x * n + j) * 9 + p] = ti[p];
     }
   }
 }
