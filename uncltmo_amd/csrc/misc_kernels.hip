@@ -718,15 +718,24 @@ extern "C" int uncl_tile_count(int H, int W) {
 
 __global__ __launch_bounds__(256) void tile_gather_kernel(const float* __restrict__ frames, float* __restrict__ tiles,
                                                           int H, int W, AxisPlan py, AxisPlan px) {
-  // grid: (tile rows of 4 px-quads, tiles per frame, frames)
+  // grid: (tile rows of 4 px-quads, tiles per frame, frames); four pixels per thread, as one 16-byte access where the tile's
+  // column origin and the row pitch allow it
   const int t = blockIdx.y, f = blockIdx.z;
   const int ty = t / px.count, tx = t - ty * px.count;
   const int y0 = py.start[ty], x0 = px.start[tx];
   const float* src = frames + (size_t)f * H * W;
   float* dst = tiles + ((size_t)f * gridDim.y + t) * TILE * TILE;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < TILE * TILE; i += gridDim.x * blockDim.x) {
+  const bool al = ((x0 | W) & 3) == 0;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < TILE * TILE; i += gridDim.x * blockDim.x * 4) {
     const int y = i >> 8, x = i & 255;
-    dst[i] = src[(size_t)(y0 + y) * W + x0 + x];
+    const float* sp = src + (size_t)(y0 + y) * W + x0 + x;
+    f32x4 v;
+    if (al) {
+      v = *reinterpret_cast<const f32x4*>(sp);
+    } else {
+      v = f32x4{sp[0], sp[1], sp[2], sp[3]};
+    }
+    *reinterpret_cast<f32x4*>(dst + i) = v;
   }
 }
 
@@ -739,26 +748,45 @@ __device__ __forceinline__ float fold1(float acc, float piece, int i, int blend,
 
 __global__ __launch_bounds__(256) void tile_blend_kernel(const float* __restrict__ tiles, float* __restrict__ frames,
                                                          int H, int W, AxisPlan py, AxisPlan px) {
+  // four consecutive pixels of a row per thread (W % 4 == 0: the host falls back to QUAD = 1 otherwise); a tile's row is read
+  // as one 16-byte vector where the quad lies inside the tile and the tile's column origin is a multiple of four
   const int f = blockIdx.y;
   const int T = py.count * px.count;
   const float* tf = tiles + (size_t)f * T * TILE * TILE;
   float* dst = frames + (size_t)f * H * W;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+  const bool quad = (W & 3) == 0;
+  const int step = quad ? 4 : 1;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * step; i < H * W; i += gridDim.x * blockDim.x * step) {
     const int y = i / W, x = i - y * W;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int sy = 0; sy < py.count; ++sy) {
       const int ly = y - py.start[sy];
       if (ly < 0 || ly >= TILE) continue;
-      float strip = 0.f;
+      float strip[4] = {0.f, 0.f, 0.f, 0.f};
       for (int sx = 0; sx < px.count; ++sx) {
         const int lx = x - px.start[sx];
-        if (lx < 0 || lx >= TILE) continue;
-        const float piece = tf[((size_t)(sy * px.count + sx) * TILE + ly) * TILE + lx];
-        strip = fold1(strip, piece, lx, px.blend[sx], sx == 0);
+        if (lx + step - 1 < 0 || lx >= TILE) continue;
+        const float* tp = tf + ((size_t)(sy * px.count + sx) * TILE + ly) * TILE;
+        if (quad && lx >= 0 && lx + 3 < TILE && (px.start[sx] & 3) == 0) {
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(tp + lx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) strip[e] = fold1(strip[e], p4[e], lx + e, px.blend[sx], sx == 0);
+        } else {
+          for (int e = 0; e < step; ++e) {
+            const int le = lx + e;
+            if (le < 0 || le >= TILE) continue;
+            strip[e] = fold1(strip[e], tp[le], le, px.blend[sx], sx == 0);
+          }
+        }
       }
-      acc = fold1(acc, strip, ly, py.blend[sy], sy == 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fold1(acc[e], strip[e], ly, py.blend[sy], sy == 0);
     }
-    dst[i] = acc;
+    if (quad) {
+      *reinterpret_cast<f32x4*>(dst + i) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    } else {
+      dst[i] = acc[0];
+    }
   }
 }
 
@@ -776,7 +804,8 @@ extern "C" int uncl_tile_blend(const float* tiles, float* frames, int F, int H, 
   AxisPlan py, px;
   if (!frames || !tiles || F <= 0) return UNCL_ERR_ARG;
   if (make_axis_plan(H, &py) != UNCL_OK || make_axis_plan(W, &px) != UNCL_OK) return UNCL_ERR_ARG;
-  const int blocks = (H * W + 255) / 256 < 4096 ? (H * W + 255) / 256 : 4096;
+  const int work = (W & 3) == 0 ? H * W / 4 : H * W;
+  const int blocks = (work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096;
   hipLaunchKernelGGL(tile_blend_kernel, dim3(blocks, F), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tiles,
                      frames, H, W, py, px);
   UNCL_CHECK_LAUNCH();
