@@ -231,6 +231,10 @@ int uncl_conv_in_c1(const float* x, const float* w, const float* b, void* out, i
 size_t uncl_gcn_knn_workspace_bytes(int N, int n, int C);
 int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos, int32_t* idx, float* dist_out /*nullable*/,
                  int N, int n, int C, int k, void* workspace, void* stream);
+/* 16-bit features without dist_out (k = 9, n > 32) take the matrix-core kernel (Gram matrix of the raw rows by MFMA, scaled by
+ * 1/|x_i| 1/|x_j|, top-9 per lane); uncl_gcn_set_knn_mfma(0) selects the VALU kernel for them as well (A/B runs and the parity
+ * tests that compare the two; env UNCL_KNN_MFMA sets the initial value).  Returns the previous setting. */
+int uncl_gcn_set_knn_mfma(int on);
 /* out (N, n, 2C): out[.., 2c] = x_c, out[.., 2c+1] = max_k (x_c[idx] - x_c).  Replaces MRConv2d.forward
  * up to its 1x1 conv (torch_vertex.py:22-29). */
 int uncl_gcn_maxrel(const void* x, const int32_t* idx, void* out, int dtype, int N, int n, int C, int k,

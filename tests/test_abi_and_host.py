@@ -124,3 +124,97 @@ def test_gradient_allreduce_equals_mean_of_rank_gradients():
     for r in range(2):
         for g_, m in zip(got[r], mean):
             np.testing.assert_allclose(g_.numpy(), m.numpy(), rtol=1e-6, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GradReducer bookkeeping at world size 2 (gloo, CPU tensors): the decoder / encoder split of _GradSet.finish, one and two
+# backward passes per step, a skipped step, pre-existing .grad
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeG(torch.nn.Module):
+    """stands in for the HIP generator: parameters + the attribute DistributedOptimizer looks for"""
+
+    def __init__(self):
+        super().__init__()
+        self.dec = torch.nn.Parameter(torch.zeros(6, 4))
+        self.enc = torch.nn.Parameter(torch.zeros(5, 3))
+        self.bias = torch.nn.Parameter(torch.zeros(7))
+        self.pe = torch.nn.Parameter(torch.zeros(3, 2))
+        self._packed_weights = None
+
+
+class _FakePass:
+    """the buffers of one backward pass, laid out like autograd._GradSet: `flat` = [encoder | decoder] weights, `small`,
+    and a transposed COPY for pos_embed; launched in _GradSet.finish's order (decoder half first, from the side stream)"""
+
+    def __init__(self, rank, seed):
+        g = torch.Generator().manual_seed(1000 * seed + rank)
+        self.flat = torch.randn(15 + 24, generator=g)
+        self.small = torch.randn(7 + 6, generator=g)
+        self.cut = 15
+
+    def grads(self):
+        return {"enc": self.flat[:15].view(5, 3), "dec": self.flat[15:].view(6, 4), "bias": self.small[:7],
+                "pe": self.small[7:].view(2, 3).t().contiguous()}
+
+    def finish(self, red):
+        red.launch(self.flat[self.cut:], self)          # decoder half: launched while the encoder's kernels still run
+        g = self.grads()                                # pos_embed's transposed copy is made before the in-place reductions
+        red.launch(self.flat[:self.cut], self)
+        red.launch(self.small, self)
+        red.launch(g["pe"], self)
+        red.keep(self, g)
+        return g
+
+
+def _reducer_worker(rank, world, port, q):
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from uncltmo_amd.distributed import DistributedOptimizer
+    out = {}
+    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad"):
+        net = _FakeG()
+        opt = DistributedOptimizer(torch.optim.SGD(net.parameters(), lr=1.0), module=net)
+        red = net._grad_reducer
+        assert red.active()
+        if case == "skipped_step":
+            _FakePass(rank, 9).finish(red)
+            assert red.pending() == 1
+            opt.zero_grad()                             # drops the pass of the step that was never taken
+            assert red.pending() == 0
+        if case == "accumulate_into_grad":
+            for p in net.parameters():
+                p.grad = torch.ones_like(p)
+        passes = [_FakePass(rank, 1)] + ([_FakePass(rank, 2)] if case == "two_pass" else [])
+        for ps in passes:
+            local = {k: v.clone().numpy() for k, v in ps.grads().items()}
+            ps.finish(red)
+            assert all(p.grad is None for p in net.parameters()) or case == "accumulate_into_grad"
+            out.setdefault(case + ".local", []).append(local)
+        opt.step()
+        assert red.pending() == 0
+        out[case] = {k: p.detach().clone().numpy() for k, p in net.named_parameters()}     # numpy: pickled by value
+    q.put((rank, out))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_grad_reducer_world2_single_pass_two_pass_and_skipped_step():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad"):
+        n_pass = len(got[0][case + ".local"])
+        for k in ("enc", "dec", "bias", "pe"):
+            mean = sum(got[r][case + ".local"][i][k] for r in range(2) for i in range(n_pass)) / 2.0
+            if case == "accumulate_into_grad":
+                mean = mean + 1.0
+            for r in range(2):          # SGD, lr 1, from zero: parameter = -(mean gradient); identical on both ranks
+                np.testing.assert_allclose(got[r][case][k], -mean, rtol=1e-6, atol=1e-7, err_msg=case + "." + k)

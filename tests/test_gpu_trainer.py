@@ -346,8 +346,10 @@ def test_fp32_step_vs_reference_golden_and_oracle(golden, video, epoch):
 
 def test_overlapped_in_place_gradient_allreduce_matches_plain_step():
     """DistributedOptimizer(module=G): the generator's flat gradient buffers are all-reduced in place over RCCL (decoder half on
-    a side stream from its event on), .grad is re-pointed at the reduced views.  On one GPU (world size 1 with the forced
-    data-parallel path) the step must leave exactly the parameters of the plain step."""
+    a side stream from its event on); the backward pass hands autograd no parameter gradients and step() adds the reduced
+    buffers into .grad.  On one GPU (world size 1 with the forced data-parallel path) the step must leave exactly the parameters
+    of the plain step -- for the summed single backward pass AND for the reference's two passes with retain_graph
+    (two reduced buffer sets per step), and a skipped step followed by zero_grad() must not leak into the next one."""
     import os
     import torch.distributed as td
     from uncltmo_amd.distributed import DistributedOptimizer
@@ -355,21 +357,31 @@ def test_overlapped_in_place_gradient_allreduce_matches_plain_step():
     td.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29700 + os.getpid() % 200), rank=0, world_size=1,
                           device_id=torch.device("cuda", 0))
     try:
-        after = []
-        for wrap in (False, True):
-            tr, G, D = _fp32_trainer(False)             # fp32 mode: deterministic, so the two runs can be compared exactly
-            if wrap:
-                tr.optimizerG = DistributedOptimizer(tr.optimizerG, module=G)
-                tr.optimizerD = DistributedOptimizer(tr.optimizerD)
-                assert G._grad_reducer.active()
-            hdr, pos, neg = step_inputs()
-            for _ in range(2):
-                tr.train_D(hdr, pos, neg, 0)
-                tr.train_G(hdr, hdr.clone(), pos, neg, 0)
-            torch.cuda.synchronize()
-            after.append({k: v.clone() for k, v in G.state_dict().items()})
-        for k in after[0]:
-            assert torch.equal(after[0][k], after[1][k]), k
+        for two_pass in (0, 1):
+            after = []
+            for wrap in (False, True):
+                tr, G, D = _fp32_trainer(False)             # fp32 mode: deterministic, so the two runs can be compared exactly
+                tr.two_pass_backward = two_pass
+                if wrap:
+                    tr.optimizerG = DistributedOptimizer(tr.optimizerG, module=G)
+                    tr.optimizerD = DistributedOptimizer(tr.optimizerD)
+                    assert G._grad_reducer.active()
+                hdr, pos, neg = step_inputs()
+                if wrap:
+                    # a backward pass whose step is never taken: its buffers stay with the reducer until zero_grad drops them
+                    out, _ = G(hdr.reshape(-1, 1, 256, 256).float())
+                    out.sum().backward()
+                    assert G._grad_reducer.pending() == 1
+                    assert all(p.grad is None for p in G.parameters())      # nothing was handed to autograd
+                for _ in range(2):
+                    tr.train_D(hdr, pos, neg, 0)
+                    tr.train_G(hdr, hdr.clone(), pos, neg, 0)
+                    if wrap:
+                        assert G._grad_reducer.pending() == 0
+                torch.cuda.synchronize()
+                after.append({k: v.clone() for k, v in G.state_dict().items()})
+            for k in after[0]:
+                assert torch.equal(after[0][k], after[1][k]), (two_pass, k)
     finally:
         td.destroy_process_group()
         os.environ.pop("UNCL_FORCE_DIST", None)

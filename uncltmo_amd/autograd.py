@@ -112,10 +112,12 @@ class _GradSet:
         data-parallel reducer attached to the module the decoder half is unpacked and all-reduced on a side stream as soon as
         its event fires, under the graph block's and the encoder's kernels; the rest follows on the caller's stream."""
         red = getattr(self.module, "_grad_reducer", None)
+        self.reduced = False
         if red is None or not red.active():
             last_run(None)
             self.unpack()
             return self.grads()
+        self.reduced = True     # the buffers now belong to the reducer: the caller hands autograd NO parameter gradients
         ev = torch.cuda.Event()
         ev.record()             # torch creates the hipEvent lazily: record once so that the raw handle exists, the library
         last_run(ev)            # records it again where the decoder's gradients are final
@@ -185,6 +187,8 @@ class _GeneratorFn(torch.autograd.Function):
             gup = g_upx.permute(0, 2, 3, 1).to(_hip.torch_dtype(module._dtype_code())).contiguous()
         gs = _GradSet(module, xf.device)
         grads = gs.finish(lambda ev: gs.run(xf, out, up, ws, ds, g_out, gup, ev_half=ev))
+        if gs.reduced:      # data-parallel: .grad is assigned by GradReducer.finish after the collectives (distributed.py)
+            return (None, None) + (None,) * len(ctx.pnames)
         return (None, None) + tuple(grads.get(k) for k in ctx.pnames)
 
 
@@ -244,6 +248,8 @@ class _VideoGeneratorFn(torch.autograd.Function):
         grads = gs.finish(call)         # frame 0: the last call of the pass
         # the saved activations stay with the graph node: the reference calls backward twice on it
         # (errG_d.backward(retain_graph=True), then the structural loss; GanTrainer.py:338,461)
+        if gs.reduced:
+            return (None, None) + (None,) * len(ctx.pnames)
         return (None, None) + tuple(grads.get(k) for k in ctx.pnames)
 
 

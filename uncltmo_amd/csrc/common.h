@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/uncltmo_hip.h"
 
 typedef __bf16 bf16_t;
@@ -20,6 +22,33 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     hipError_t e__ = hipGetLastError();                       \
     if (e__ != hipSuccess) return UNCL_ERR_LAUNCH;            \
   } while (0)
+
+// Launch preparation that is a property of (kernel, DEVICE) -- hipFuncSetAttribute(MaxDynamicSharedMemorySize), the CU count --
+// is cached per device ordinal, not per process: one process may drive several GPUs (SideStreams in generator.hip does), and a
+// flag set while device 0 was current must not skip the attribute on device 1.  Two threads racing on a first call both set
+// the (idempotent) attribute.
+static inline int uncl_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d & 31;
+}
+struct UnclDevOnce {
+  std::atomic<unsigned> mask{0};
+  bool need() const { return !((mask.load(std::memory_order_acquire) >> uncl_device()) & 1u); }
+  void done() { mask.fetch_or(1u << uncl_device(), std::memory_order_release); }
+};
+static inline int uncl_cu_count() {
+  static std::atomic<int> cus[32];
+  const int d = uncl_device();
+  int c = cus[d].load(std::memory_order_relaxed);
+  if (c == 0) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) != hipSuccess) return 0;
+    c = p.multiProcessorCount;
+    cus[d].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
 
 // Element traits: a "vec" is always 16 bytes, the unit every loader / LDS access moves.
 template <typename T>

@@ -923,20 +923,16 @@ int launch_pc(PipeArgs& a, hipStream_t s) {
   static_assert(pc_lds_bytes<NT, MPW>(false, 0, false) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
   auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW>;
-  static bool attr_done = false;
-  static int n_cu = 0;
-  if (!attr_done) {
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3) : lds)) != hipSuccess)
       return UNCL_ERR_LAUNCH;
-    hipDeviceProp_t p;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return UNCL_ERR_LAUNCH;
-    n_cu = p.multiProcessorCount;
-    attr_done = true;
+    attr_done.done();
   }
+  const int n_cu = uncl_cu_count();
+  if (n_cu <= 0) return UNCL_ERR_LAUNCH;
   int grid = a.total_tiles < n_cu ? a.total_tiles : n_cu;
   a.tiles_per_wg = (a.total_tiles + grid - 1) / grid;
   grid = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;

@@ -783,9 +783,9 @@ int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr size_t lds = ximg + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
                          (MODE == 3 ? (size_t)((TH + 4) * 36 + 32) * 4 : 0);
   auto kern = conv3x3_pipe_kernel<T, NT, MPW, WAVES, MODE, PREV, FLAT>;
-  static bool attr_done = false;
-  static int max_blocks = 0;
-  if (!attr_done) {
+  static UnclDevOnce attr_done;
+  static std::atomic<int> per_cu_s{0};
+  if (attr_done.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
       return UNCL_ERR_LAUNCH;
@@ -794,13 +794,11 @@ int launch_pipe(PipeArgs& a, hipStream_t s) {
             hipSuccess || per_cu <= 0)
       per_cu = 1;
     if (per_cu > ((NT == 1 && MPW == 2) ? 3 : 2)) per_cu = (NT == 1 && MPW == 2) ? 3 : 2;
-    hipDeviceProp_t p;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return UNCL_ERR_LAUNCH;
-    max_blocks = per_cu * p.multiProcessorCount;
-    attr_done = true;
+    per_cu_s.store(per_cu, std::memory_order_relaxed);
+    attr_done.done();
   }
+  const int max_blocks = per_cu_s.load(std::memory_order_relaxed) * uncl_cu_count();
+  if (max_blocks <= 0) return UNCL_ERR_LAUNCH;
   int grid = a.total_tiles < max_blocks ? a.total_tiles : max_blocks;
   a.tiles_per_wg = (a.total_tiles + grid - 1) / grid;
   grid = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;

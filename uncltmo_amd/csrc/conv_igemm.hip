@@ -321,12 +321,12 @@ int launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
   constexpr int HH = MT_Y + KS - 1, HW = MT_X * 32 + KS - 1;
   constexpr size_t lds = (size_t)HH * HW * 64 + (size_t)KS * KS * NT * 32 * 64;
   auto kern = conv_igemm_kernel<T, KS, MT_Y, MT_X, NT>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
+  static UnclDevOnce attr_done;  // per instantiation and device
+  if (attr_done.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return UNCL_ERR_LAUNCH;
-    attr_done = true;
+    attr_done.done();
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   UNCL_CHECK_LAUNCH();
@@ -461,11 +461,11 @@ template <int CIN, int NT>
 int launch_c1(const C1Args& a, int groups, hipStream_t s) {
   constexpr size_t lds = (size_t)NT * 32 * CIN * 2;
   auto kern = conv1x1_direct_kernel<CIN, NT>;
-  static bool attr = false;
-  if (!attr) {
+  static UnclDevOnce attr;
+  if (attr.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return UNCL_ERR_LAUNCH;
-    attr = true;
+    attr.done();
   }
   // every workgroup stages up to 64 KB of weights: a strided share of the tiles per resident slot, not one workgroup per tile
   const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : ((int)(160 * 1024 / lds) > 4 ? 4 : (int)(160 * 1024 / lds));

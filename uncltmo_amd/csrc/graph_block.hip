@@ -421,15 +421,15 @@ __global__ __launch_bounds__(512, 2) void graph_tail_kernel(const GbArgs a) {
 
 static int launch_graph(GbArgs& a, int dtype, bool full, hipStream_t s) {
   const size_t lds = 2 * (size_t)GB_NODES * GB_ROW + (size_t)GB_NODES * GB_K * 4 + 2 * 160 * sizeof(float);
-  static bool attr[4] = {false, false, false, false};
+  static UnclDevOnce attr[4];
   const int which = (dtype == UNCL_F16 ? 0 : 1) + (full ? 2 : 0);
   const void* kern = which == 0 ? reinterpret_cast<const void*>(graph_tail_kernel<f16_t, false>)
                      : which == 1 ? reinterpret_cast<const void*>(graph_tail_kernel<bf16_t, false>)
                      : which == 2 ? reinterpret_cast<const void*>(graph_tail_kernel<f16_t, true>)
                                   : reinterpret_cast<const void*>(graph_tail_kernel<bf16_t, true>);
-  if (!attr[which]) {
+  if (attr[which].need()) {
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UNCL_ERR_LAUNCH;
-    attr[which] = true;
+    attr[which].done();
   }
   switch (which) {
     case 0: hipLaunchKernelGGL((graph_tail_kernel<f16_t, false>), dim3(a.N), dim3(512), lds, s, a); break;

@@ -875,12 +875,12 @@ extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == UNCL_BF16 && C == 32) {
     constexpr size_t lds = (size_t)32 * (HI * HI + 2) * 2 + (size_t)8 * (HI * HM + HM * HM) * 4 + (size_t)HT * HT * 32 * 2;
-    static bool attr = false;
-    if (!attr) {
+    static UnclDevOnce attr;
+    if (attr.need()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_stats_bwd32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds) != hipSuccess)
         return UNCL_ERR_LAUNCH;
-      attr = true;
+      attr.done();
     }
     const int tx16 = (W + HT - 1) / HT, ty16 = (H + HT - 1) / HT;
     hipLaunchKernelGGL(gauss_stats_bwd32_kernel, dim3(tx16 * ty16, N), dim3(512), lds, st, (const bf16_t*)x, g_stats, (bf16_t*)gx, H, W,

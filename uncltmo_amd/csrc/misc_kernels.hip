@@ -553,6 +553,10 @@ __global__ __launch_bounds__(512, 2) void gcn_knn_mfma_kernel(const T* __restric
   }
 }
 
+// 16-bit features: 1 (default) the matrix-core kernel, 0 the VALU kernel (A/B runs, and the parity tests that compare the two)
+static std::atomic<int> g_knn_mfma{[] { const char* e = getenv("UNCL_KNN_MFMA"); return e ? atoi(e) : 1; }()};
+extern "C" int uncl_gcn_set_knn_mfma(int on) { return g_knn_mfma.exchange(on ? 1 : 0); }
+
 extern "C" size_t uncl_gcn_knn_workspace_bytes(int N, int n, int C) {
   (void)N; (void)n; (void)C;
   return 0;  // the sample lives in LDS
@@ -566,20 +570,19 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // 16-bit features: the matrix-core kernel, one workgroup per sample whatever the batch (the choice must not depend on how a
   // batch is cut into launches: the two kernels may order near-ties differently)
-  static const int use_mfma = [] { const char* e = getenv("UNCL_KNN_MFMA"); return e ? atoi(e) : 1; }();
-  if (use_mfma && uncl_is_h16(dtype) && dist_out == nullptr && k == 9 && n > 32) {
+  if (g_knn_mfma.load(std::memory_order_relaxed) && uncl_is_h16(dtype) && dist_out == nullptr && k == 9 && n > 32) {
     const size_t l2 = (size_t)KNN_MAX_NODES * KNM_ROW + 2 * 160 * sizeof(float);
-    static bool attr2[2] = {false, false};
+    static UnclDevOnce attr2[2];
     if (dtype == UNCL_F16) {
-      if (!attr2[0]) {
+      if (attr2[0].need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_mfma_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-        attr2[0] = true;
+        attr2[0].done();
       }
       hipLaunchKernelGGL(gcn_knn_mfma_kernel<f16_t>, dim3(N), dim3(512), l2, s, (const f16_t*)x, relative_pos, idx, n);
     } else {
-      if (!attr2[1]) {
+      if (attr2[1].need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_mfma_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-        attr2[1] = true;
+        attr2[1].done();
       }
       hipLaunchKernelGGL(gcn_knn_mfma_kernel<bf16_t>, dim3(N), dim3(512), l2, s, (const bf16_t*)x, relative_pos, idx, n);
     }
@@ -588,28 +591,28 @@ extern "C" int uncl_gcn_knn(const void* x, int dtype, const float* relative_pos,
   }
   // one workgroup per CU (the sample fills the LDS): with a CU per sample to spare the rows are not split
   const int split = N * KNN_SPLIT <= 256 ? KNN_SPLIT : 1;
-  static bool attr[3] = {false, false, false};
+  static UnclDevOnce attr[3];
   if (dtype == UNCL_F16) {
-    if (!attr[2]) {
+    if (attr[2].need()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_kernel<f16_t>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
-      attr[2] = true;
+      attr[2].done();
     }
     hipLaunchKernelGGL(gcn_knn_kernel<f16_t>, dim3(N, split), dim3(1024), lds, s, (const f16_t*)x, relative_pos, idx, dist_out,
                        n, k);
   } else if (dtype == UNCL_BF16) {
-    if (!attr[1]) {
+    if (attr[1].need()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_kernel<bf16_t>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
-      attr[1] = true;
+      attr[1].done();
     }
     hipLaunchKernelGGL(gcn_knn_kernel<bf16_t>, dim3(N, split), dim3(1024), lds, s, (const bf16_t*)x, relative_pos, idx, dist_out,
                        n, k);
   } else if (dtype == UNCL_F32) {
-    if (!attr[0]) {
+    if (attr[0].need()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_knn_kernel<float>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)KNN_MAX_NODES * KNN_LD + KNN_MAX_NODES) * 4));
-      attr[0] = true;
+      attr[0].done();
     }
     hipLaunchKernelGGL(gcn_knn_kernel<float>, dim3(N, split), dim3(1024), lds, s, (const float*)x, relative_pos, idx, dist_out, n,
                        k);

@@ -147,13 +147,13 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
 template <typename T, int CIN>
 int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
   constexpr size_t lds = (size_t)128 * CIN * 2 + 128 * 256;
-  static bool attr_done[2] = {false, false};
+  static UnclDevOnce attr_done[2];
   auto k0 = upconv2x2_kernel<T, CIN, false>;
   auto k1 = upconv2x2_kernel<T, CIN, true>;
   const void* kp = prev ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0);
-  if (!attr_done[prev]) {
+  if (attr_done[prev].need()) {
     if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UNCL_ERR_LAUNCH;
-    attr_done[prev] = true;
+    attr_done[prev].done();
   }
   const int n_ct = 4 * a.Cout / 128;
   // every workgroup stages its 128-row weight slice (up to 64 KB) before its first tile: a grid of one (CIN >= 128) or two
@@ -314,11 +314,11 @@ template <int COUT>
 int launch_up_bwd(const UpBwdArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)128 * COUT * 2 + 128 * 256;
   auto kern = upconv2x2_dgrad_kernel<COUT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return UNCL_ERR_LAUNCH;
-    attr_done = true;
+    attr_done.done();
   }
   const int n_ct = (a.Cin + 127) / 128;
   const int gx = a.n_tiles < 2048 ? a.n_tiles : 2048;

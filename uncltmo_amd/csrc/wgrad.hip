@@ -380,11 +380,11 @@ template <int MODE>
 int launch_wg3(WgArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)18 * 34 * 64 + 512 * 64;
   auto kern = wgrad3_kernel<MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return UNCL_ERR_LAUNCH;
-    attr_done = true;
+    attr_done.done();
   }
   const int pairs = a.nci * (a.Cout / 32);
   int groups = 512 / pairs;      // one persistent workgroup per resident slot, see launch_wg
@@ -402,11 +402,11 @@ int launch_wg(WgArgs& a, hipStream_t s) {
   constexpr int XW = 32 + KS - 1;
   constexpr size_t lds = (size_t)16 * XW * 64 + 512 * 64;
   auto kern = wgrad_kernel<MODE, KS>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return UNCL_ERR_LAUNCH;
-    attr_done = true;
+    attr_done.done();
   }
   const int pairs = a.nci * (a.Cout / 32);
   // one persistent workgroup per resident slot (2 per CU x 256 CUs): every workgroup ends with a cross-wave reduction and

@@ -48,19 +48,26 @@ def allreduce_gradients(params, bucket_bytes=32 << 20, group=None):
 class GradReducer:
     """In-place, overlapped gradient all-reduce for the HIP generator (uncltmo_amd/autograd.py:_GradSet.finish).
 
-    The generator's backward pass produces its parameter gradients as views of three flat fp32 buffers.  With a reducer attached
-    to the module, those buffers are all-reduced IN PLACE (no concatenation, no copy back): the decoder's weights on a side
-    stream from the moment their event fires -- while the graph block and the encoder are still running their backward kernels
-    on the caller's stream -- the encoder's weights and the small tensors right after the pass.  `finish` (called by
-    DistributedOptimizer.step) waits, divides by the world size and points every .grad at its reduced view.  xGMI rings are
-    per-link bound: three large messages per step, not 57 small ones."""
+    The generator's backward pass produces its parameter gradients as views of flat fp32 buffers that belong to the pass
+    (`_GradSet`).  With a reducer attached to the module those buffers are all-reduced IN PLACE (no concatenation, no copy
+    back): the decoder's weights on a side stream from the moment their event fires -- while the graph block and the encoder
+    are still running their backward kernels on the caller's stream -- the encoder's weights and the small tensors right after
+    the pass.  xGMI rings are per-link bound: a few large messages per step, not 57 small ones.
+
+    Ownership rule (what keeps the collective away from autograd): while a reducer is active the backward pass returns NO
+    parameter gradients to autograd (None for every parameter), so nothing clones or accumulates a buffer that RCCL is still
+    writing.  The buffers of every pass since the last step stay with the reducer; `finish` (DistributedOptimizer.step /
+    .synchronize) waits for their collectives, divides by the world size and only then ADDS them into .grad -- one pass, the
+    reference's two passes with retain_graph (GanTrainerImg.py:338,460), or gradient accumulation over several batches all
+    give the mean over ranks of what a single process would have accumulated (the all-reduce is linear).  `.grad` of the
+    generator's parameters is therefore defined after step() / synchronize(), not between backward() and step().
+    `reset` (module.zero_grad / optimizer.zero_grad) drops the passes of a step that was never taken."""
 
     def __init__(self, group=None):
         self.group = group
         self._streams = {}
-        self._pending = []
-        self._grads = None
-        self._calls = 0
+        self._passes = []        # finished backward passes since the last step: {"work": [(handle, tensor)], "grads": {...}}
+        self._open = None        # the pass whose collectives are being launched
 
     def active(self):
         import os
@@ -74,33 +81,50 @@ class GradReducer:
         return self._streams[dev]
 
     def launch(self, tensor, owner):
-        self._pending.append((td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.group, async_op=True), tensor, owner))
+        if self._open is None or self._open["owner"] is not owner:
+            self._open = {"owner": owner, "work": [], "grads": None}
+        self._open["work"].append((td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.group, async_op=True), tensor))
 
     def keep(self, owner, grads):
-        self._grads = grads
-        self._calls += 1
+        """end of a pass: `grads` (state_dict name -> view of the buffers just launched) and the owner (which keeps the
+        buffers alive) stay here until finish()"""
+        ps = self._open if self._open is not None and self._open["owner"] is owner else {"owner": owner, "work": [], "grads": None}
+        ps["grads"] = grads
+        self._passes.append(ps)
+        self._open = None
+
+    def pending(self):
+        return len(self._passes)
 
     def reset(self):
-        for work, _, _ in self._pending:
-            work.wait()
-        self._pending, self._grads, self._calls = [], None, 0
+        for ps in self._passes + ([self._open] if self._open is not None else []):
+            for work, _ in ps["work"]:
+                work.wait()
+        self._passes, self._open = [], None
 
     def finish(self, named_params):
-        """True if the gradients of this step were reduced here (exactly one backward pass since the last step: a second pass
-        accumulates into .grad outside these buffers, and the generic bucketed path takes over)."""
-        if self._calls != 1 or self._grads is None:
-            self.reset()
+        """Wait for the collectives of every pass since the last step, average, and add the result into .grad.
+        True if there was anything to do (False: no generator backward ran through this reducer since the last step)."""
+        if not self._passes:
             return False
         world = td.get_world_size(self.group)
-        for work, t, _ in self._pending:
-            work.wait()                      # the current stream waits for the collective; the host does not block
-            if world > 1:
-                t.div_(world)
+        for ps in self._passes:
+            for work, t in ps["work"]:
+                work.wait()                  # the current stream waits for the collective; the host does not block
+                if world > 1:
+                    t.div_(world)
         for k, p in named_params:
-            g = self._grads.get(k)
-            if g is not None and p.requires_grad:
-                p.grad = g
-        self._pending, self._grads, self._calls = [], None, 0
+            if not p.requires_grad:
+                continue
+            total = None
+            for ps in self._passes:
+                g = ps["grads"].get(k)
+                if g is not None:
+                    total = g if total is None else total + g
+            if total is not None:
+                total = total.view_as(p) if total.shape != p.shape else total
+                p.grad = total if p.grad is None else p.grad + total
+        self._passes, self._open = [], None
         return True
 
 
@@ -108,8 +132,8 @@ class DistributedOptimizer:
     """Wraps an optimizer so that step() first averages the gradients across ranks (what DistributedDataParallel's
     reducer does for nn.DataParallel-free training); everything else is forwarded.  `module` = the HIP generator whose
     parameters the optimizer updates: its backward pass then reduces its own flat gradient buffers in place, overlapped with
-    the backward tail (GradReducer); any other case (the discriminator's 12 373 gradients, a two-pass backward) goes through
-    allreduce_gradients."""
+    the backward tail (GradReducer), and its .grad tensors appear in step() / synchronize(); any other parameter (the
+    discriminator's 12 373 gradients) goes through allreduce_gradients."""
 
     def __init__(self, optimizer, bucket_bytes=32 << 20, module=None):
         self.optimizer = optimizer
@@ -118,10 +142,14 @@ class DistributedOptimizer:
         if module is not None and hasattr(module, "_packed_weights"):
             module._grad_reducer = GradReducer()
 
-    def step(self, *a, **k):
+    def synchronize(self):
+        """Make .grad of every parameter the mean over ranks (call before reading or clipping gradients; step() does)."""
         red = getattr(self.module, "_grad_reducer", None) if self.module is not None else None
         if red is None or not red.finish(list(self.module.named_parameters())):
             allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]], self.bucket_bytes)
+
+    def step(self, *a, **k):
+        self.synchronize()
         return self.optimizer.step(*a, **k)
 
     def zero_grad(self, *a, **k):

@@ -108,6 +108,14 @@ class _GeneratorBase(nn.Module):
         self._packed = None
         self._ws = {}
 
+    def zero_grad(self, set_to_none=True):
+        """nn.Module.zero_grad + the data-parallel reducer's pending passes: gradients of a backward pass whose optimiser step
+        was never taken must not be added to the next step's (distributed.GradReducer keeps them until step())."""
+        red = self.__dict__.get("_grad_reducer")
+        if red is not None:
+            red.reset()
+        return super().zero_grad(set_to_none=set_to_none)
+
     # --- initialisation: what `create_G_net*` + `set_parallel_net(use_xaviar=True)` leave behind
     def reset_parameters(self):
         """Conv2d: xavier_normal(gain sqrt 2), zero bias (model_save_util.py:41-47); the class-name test there does
