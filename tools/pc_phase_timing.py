@@ -118,13 +118,13 @@ def main():
                 _hip.check(lib.uncl_conv3x3_pipe(C.byref(d), plp, _hip.stream_ptr()), "pipe")
 
         res = {}
-        t = [0] * 16
+        t = [0] * 32
         for pc in ((0, 2, 0, 2) if args.only_pc < 0 else (args.only_pc,)):
             lib.uncl_conv3x3_set_pc(pc)
             run(2)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            buf = (C.c_ulonglong * 16)()
+            buf = (C.c_ulonglong * 32)()
             if not args.product:
                 lib.uncl_pc_timing_read(buf, 1)
             e0.record()
@@ -134,7 +134,7 @@ def main():
             res.setdefault(pc, []).append(e0.elapsed_time(e1) / args.reps)
             if pc == 2 and not args.product:
                 lib.uncl_pc_timing_read(buf, 1)
-                t = [int(buf[i]) for i in range(16)]
+                t = [int(buf[i]) for i in range(32)]
         lib.uncl_conv3x3_set_pc(2)
         r0, r2 = res.get(0, [float("nan")]), res.get(2, [float("nan")])
         print("== %s: four-wave %s ms, producer/consumer %s ms (%.0f / %.0f TFLOP/s)" % (
@@ -146,6 +146,11 @@ def main():
                 continue
             print("   %s: %d cycles per workgroup-launch" % (label, tot // cnt) + "".join(
                 "; %s %.1f %%" % (nm, 100.0 * t[base + i] / tot) for i, nm in enumerate(names) if nm != "-"))
+        if t[8] and t[9]:
+            # per chunk kind (chunk index & 3; concat layers: the consumers multiply [x1, x2, x2^2, sqrt] = 0..3 while the producers
+            # of iteration Q stage chunk Q + 1 and request chunk Q + 2): cycles per workgroup-launch
+            print("   per chunk kind   consumer busy %s wait %s | producer (iteration Q) busy %s wait %s" % (
+                [v // t[8] for v in t[24:28]], [v // t[8] for v in t[28:32]], [v // t[9] for v in t[16:20]], [v // t[9] for v in t[20:24]]))
 
 
 if __name__ == "__main__":

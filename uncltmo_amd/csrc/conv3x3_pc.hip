@@ -34,20 +34,25 @@ __device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // Phase timing (measurement builds only, -DUNCL_PC_TIMING; tools/pc_phase_timing.py): wave 0 (consumer) and wave 4 (producer) of
 // every workgroup accumulate s_memtime deltas per loop phase into g_pc_t[]; the product library compiles all of this away.
 #ifdef UNCL_PC_TIMING
-__device__ unsigned long long g_pc_t[16];
+__device__ unsigned long long g_pc_t[32];    // [16..31]: per chunk kind (index & 3): producer busy / wait, consumer busy / wait
 __device__ __forceinline__ unsigned long long pct_now() {
   unsigned long long t;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
-#define PCT_DECL unsigned long long pct_acc[4] = {}; unsigned long long pct_last = pct_now();
+#define PCT_DECL unsigned long long pct_acc[4] = {}; unsigned long long pct_k[8] = {}; unsigned long long pct_last = pct_now();
 // sched_barrier: register-only instructions (MFMAs) must not drift across the stamp (an asm memory clobber does not hold them)
 #define PCT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long pct_t = pct_now(); __builtin_amdgcn_sched_barrier(0); \
                  pct_acc[i] += pct_t - pct_last; pct_last = pct_t; }
-#define PCT_FLUSH(base) if (threadIdx.x == 0 || threadIdx.x == NCW * 64) { for (int i = 0; i < 4; ++i) atomicAdd(&g_pc_t[base + i], pct_acc[i]); atomicAdd(&g_pc_t[8 + base / 4], 1ull); }
+#define PCT_FLUSH(base) if (threadIdx.x == 0 || threadIdx.x == NCW * 64) { for (int i = 0; i < 4; ++i) atomicAdd(&g_pc_t[base + i], pct_acc[i]); atomicAdd(&g_pc_t[8 + base / 4], 1ull); \
+                          for (int i = 0; i < 8; ++i) atomicAdd(&g_pc_t[(base ? 16 : 24) + i], pct_k[i]); }
+// per chunk kind: K(i, slot) adds the time since the last stamp to slot (busy: 0..3, wait: 4..7) + the chunk's index & 3
+#define PCT_K(i, slot) { __builtin_amdgcn_sched_barrier(0); const unsigned long long pct_t = pct_now(); __builtin_amdgcn_sched_barrier(0); \
+                         pct_acc[i] += pct_t - pct_last; pct_k[slot] += pct_t - pct_last; pct_last = pct_t; }
 #else
 #define PCT_DECL
 #define PCT(i)
+#define PCT_K(i, slot)
 #define PCT_FLUSH(base)
 #endif
 
@@ -464,13 +469,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     PCT(2)
     for (int s = 0;; ++s) {
       mfma_phase(smem + (s & 1) * STAGE, RESW ? wres + cc.kc * WBYTES : smem + (s & 1) * STAGE + XBYTES);
-      PCT(0)
+      PCT_K(0, cc.kc & 3)
       if (cc.kc == a.nk - 1) {
         run_epilogue(cc, tpar);
-        PCT(1)
+        PCT_K(1, cc.kc & 3)
       }
       pc_barrier();   // done with stage s & 1; stage (s + 1) & 1 is staged
-      PCT(2)
+      PCT_K(2, 4 + (cc.kc & 3))
       const int t_old = cc.tile;
       if (!cur_next(cc, a, tile_end)) break;
       if (cc.tile != t_old) tpar ^= 1;
@@ -629,10 +634,18 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 
   // loads of the chunk the cursor points at; P = chunk index & 3 (compile time): for the concat sources which member of
   // [x1, x2, x2^2, sqrt] the chunk is
-  auto load_step = [&](const TileCur& c, auto p_tag) __attribute__((always_inline)) {
+  // Concat sources spread the requests of a slice [x1, x2, x2^2, sqrt] over the iterations: the x2 registers (xb) are requested
+  // with the slice's first chunk (P = 0: the iteration that has just staged the previous slice's sqrt chunk from them), the x1
+  // registers (xa) TWO chunks earlier, from the iteration that loads the previous slice's x2^2 chunk (`xa_tag` = 1, cursor two
+  // chunks ahead).  Both in one iteration were one 12-load burst per thread every fourth iteration -- 98 KB per CU at once: the
+  // waves stall at issue until the CU's vector-memory queue drains, and that iteration (which also has the slice's only
+  // transcendental transform) took twice a multiplying step; the other three issued no loads at all.
+  auto load_step = [&](const TileCur& c, auto p_tag, auto xa_tag) __attribute__((always_inline)) {
     constexpr int P = decltype(p_tag)::value;
+    constexpr bool XA_ONLY = decltype(xa_tag)::value != 0;           // concat: only the x1 registers of the slice starting at c
+    static_assert(!XA_ONLY || (CAT && P == 0), "x1 requests are slice starts of concat sources");
     constexpr bool SET_A = !CAT || P == 0;     // X registers this chunk loads into (if it loads any)
-    constexpr bool X_LOAD = !CAT || P == 0;    // concat: the x1 AND x2 chunks of a slice are requested at its first step
+    constexpr bool X_LOAD = !CAT || XA_ONLY;   // this call requests the registers `xr`
     vec (&xr)[XV] = SET_A ? xa : xb;
     const int n = c.n, y0 = c.ty * TH, x0 = c.tx * TW, cout0 = c.ct * CT, kc = c.kc;
     int g = 0, cbase = kc * 32;
@@ -640,8 +653,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       cbase = (kc >> 2) * 32;
       g = P == 0 ? 1 : (P == 1 ? 0 : P);
     }
-    bp = kc == 0;
-    bpar = ppar;
+    if (!XA_ONLY) {
+      bp = kc == 0;
+      bpar = ppar;
+    }
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
     const bool same_ext = a.s1H == a.s0H && a.s1W == a.s0W;
     const bf16_t* xsrc = (MODE != 0 && g == 1) ? a.src1 : a.src0;
@@ -704,12 +719,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     } else {
       valid = load_x(xr, xsrc, n, iy0, ix0, cbase);
     }
-    if (CAT && P == 0) {
-      // the x2 slice of this group as well (its own step would be the one in which the multiplying waves store the previous
-      // tile: with no loads queued at that time their stores do not wait behind ours)
+    if (CAT && P == 0 && !XA_ONLY) {
+      // the x2 slice of this group (its own step would be the one in which the multiplying waves store the previous tile: with
+      // no loads queued at that time their stores do not wait behind ours)
       xvalid_b = load_x(xb, a.src0, n, iy0, ix0, cbase);
     }
     if (X_LOAD) xvalid_a = valid;
+    if (XA_ONLY) return;
     if (!RESW) {
       load_weights(cout0, kc);
       if (bp && ptid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
@@ -848,8 +864,16 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   const int total = (tile_end - tile0) * a.nk;     // chunks this workgroup walks
   int loaded = 0;                                  // chunks handed to load_step so far; the cursor points at chunk `loaded`
   auto load_next = [&](auto p_tag) __attribute__((always_inline)) {
+    constexpr int P = decltype(p_tag)::value;
     if (loaded < total) {
-      load_step(pc, p_tag);
+      load_step(pc, p_tag, IntTag<0>{});
+      if (CAT && P == 2 && loaded + 2 < total) {
+        // x1 of the NEXT slice (chunk loaded + 2): xa has been free since this slice's x1 chunk was staged
+        TileCur la = pc;
+        cur_next(la, a, tile_end);
+        cur_next(la, a, tile_end);
+        if (CAT) load_step(la, IntTag<0>{}, IntTag<CAT ? 1 : 0>{});
+      }
       ++loaded;
       const int t_old = pc.tile;
       if (cur_next(pc, a, tile_end) && pc.tile != t_old) ppar ^= 1;
@@ -869,6 +893,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       *reinterpret_cast<f32x4*>(sBias + CT + ptid * 4) = b4;
     }
   }
+  if (CAT) load_step(pc, IntTag<0>{}, IntTag<CAT ? 1 : 0>{});       // the first slice's x1
   load_next(IntTag<0>{});
   if (MODE == 3) {
     // one tile further ahead: patch 0 is parked in LDS, patch 1 requested, and a barrier publishes the former to every
@@ -894,11 +919,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       return true;
     }
     write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
-    PCT(1)
+    PCT_K(1, Q)
     load_next(IntTag<(Q + 2) & 3>{});
-    PCT(2)
+    PCT_K(2, Q)
     pc_barrier();
-    PCT(3)
+    PCT_K(3, 4 + Q)
     ++s;
     return false;
   };
@@ -945,10 +970,10 @@ int launch_pc(PipeArgs& a, hipStream_t s) {
 
 #ifdef UNCL_PC_TIMING
 // measurement builds only: copy (and optionally clear) the per-phase cycle counters
-extern "C" int uncl_pc_timing_read(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pc_t), sizeof(unsigned long long) * 16) != hipSuccess) return UNCL_ERR_LAUNCH;
+extern "C" int uncl_pc_timing_read(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_pc_t), sizeof(unsigned long long) * 32) != hipSuccess) return UNCL_ERR_LAUNCH;
   if (reset) {
-    unsigned long long z[16] = {};
+    unsigned long long z[32] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_pc_t), z, sizeof(z)) != hipSuccess) return UNCL_ERR_LAUNCH;
   }
   return UNCL_OK;
