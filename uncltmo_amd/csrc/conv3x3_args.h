@@ -62,6 +62,19 @@ __device__ __forceinline__ bf16x8 ld16o(const bf16_t* base, unsigned byte_off) {
 
 template <int V>
 struct IntTag { static constexpr int value = V; };
+
+// Concat-ssr sources (unet_parts.py:319-322, weight K layout [x2 | x1 | x2^2 | sqrt(x2 + 1e-8)]): every 32-channel slice of the
+// skip is walked as four K-chunks, phase ph = chunk index & 3 -> member g of that layout.  Order [x1, sqrt, x2^2, x2]: the x2
+// registers are loaded once (for ph 1) and staged three times; the staging with the transcendental comes first and the plain copy
+// last, because the iteration that stages the LAST of the three also has to request the next slice's x2 registers
+// (producer / consumer kernel: balances the staging iterations against the multiplying waves' steps).  Both 3x3 kernels use this
+// one mapping, so their accumulation order -- and every output bit -- is the same.
+#ifndef UNCL_SSR_ORDER
+#define UNCL_SSR_ORDER 1
+#endif
+__host__ __device__ constexpr int ssr_member(int ph) {
+  return UNCL_SSR_ORDER ? (ph == 0 ? 1 : (ph == 1 ? 3 : (ph == 2 ? 2 : 0))) : (ph == 0 ? 1 : (ph == 1 ? 0 : ph));
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off) {

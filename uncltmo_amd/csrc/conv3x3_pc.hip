@@ -27,6 +27,19 @@
 
 #include "conv3x3_args.h"
 
+// concat sources: the iteration (its load slot P = loaded chunk index & 3) from which the next slice's x1 registers are requested
+// (0: together with the x2 registers, at the slice's own first chunk), and whether in two halves (slots P and P + 1).
+// Same-box A/B (tools/ab_variants.sh, tools/ab_layers.sh; ms per 200 tiles, slot 0 = round 2): slot 1 -- the iteration that has
+// just staged x1 and otherwise only streams weights -- is best where few slices end in the multiplying waves' stores (up_path.0 /
+// 1 / 2.conv.conv 0.410 -> 0.370, 0.399 -> 0.358, 0.474 -> 0.434); the fused up-conv layer stores after EVERY slice in exactly
+// that iteration (0.817 -> 0.800 with slot 1) and takes slot 3 (0.758).  Halves from two slots pay the address generation twice.
+#ifndef UNCL_PC_XA_SLOT
+#define UNCL_PC_XA_SLOT (MODE == 4 ? 3 : 1)
+#endif
+#ifndef UNCL_PC_XA_SPLIT
+#define UNCL_PC_XA_SPLIT 0
+#endif
+
 namespace {
 
 __device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -520,7 +533,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   // to land and a staging step waits only for loads issued a step earlier.  (A second set with a third chunk in flight was
   // slower: the vector-memory queue of the CU fills, and both the staging waves' next loads and the multiplying waves' output
   // stores then stall at issue.)
-  //   concat source:  steps of a 32-channel slice are [x1, x2, x2^2, sqrt(x2)] (phase = step & 3, nk is a multiple of 4):
+  //   concat source:  steps of a 32-channel slice are [x1, sqrt(x2), x2^2, x2] (phase = step & 3 -> ssr_member, nk is a multiple of 4):
   //                   xa holds the x1 chunk (MODE 4: the up-conv's source fragments), xb the x2 slice, which is staged three
   //                   times (as is, squared, square-rooted) and so read from memory once
   constexpr bool CAT = MODE == 1 || MODE == 4;
@@ -574,8 +587,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   // position of K-chunk kc in the weight's K layout: concat layers store [x2 | x1 | x2^2 | sqrt] and are walked slice by slice
   auto weight_chunk = [&](int kc) __attribute__((always_inline)) {
     if (!CAT) return kc;
-    const int ph = kc & 3, g = ph == 0 ? 1 : (ph == 1 ? 0 : ph);
-    return g * (a.s0C >> 5) + (kc >> 2);
+    return ssr_member(kc & 3) * (a.s0C >> 5) + (kc >> 2);
   };
   auto load_weights = [&](int cout0, int kc) __attribute__((always_inline)) {
     const bf16_t* wb_ = a.weight + (size_t)cout0 * a.Cin + weight_chunk(kc) * 32;
@@ -598,7 +610,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   // one 32-channel chunk of a same-extent source: halo tile at (iy0, ix0) of sample n, channels cbase..; returns the slot
   // validity mask.  Offsets first (branchy, VALU only), then the loads in straight-line code: loads inside the arms of a
   // uniform branch make the compiler's waitcnt insertion assume the other arm's loads may be in flight into these registers.
-  auto load_x = [&](vec (&xr)[XV], const bf16_t* xsrc, int n, int iy0, int ix0, int cbase) __attribute__((always_inline)) {
+  // (registers J0 <= j < J1 only: concat sources request their x1 registers in two halves; bits outside the range come back 1)
+  auto load_x = [&](vec (&xr)[XV], const bf16_t* xsrc, int n, int iy0, int ix0, int cbase, auto j0_tag, auto j1_tag) __attribute__((always_inline)) {
+    constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
     unsigned valid = 0xffffffffu;
     const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
     unsigned off[XV];
@@ -610,10 +624,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         off[j] = (unsigned)((j < RSN - 1 || r_last_on) ? toff + xoff_r + j * RSTEP * row_el : 0) * 2u;
       off[RSN] = (unsigned)(e_on ? toff + xoff_e : 0) * 2u;
     } else {
-      valid = 0;
+      valid = ~(((1u << J1) - 1u) & ~((1u << J0) - 1u));
       const bool xok = (unsigned)(ix0 + hx) < (unsigned)a.W;
 #pragma unroll
-      for (int j = 0; j <= RSN; ++j) {
+      for (int j = J0; j < J1; ++j) {
         bool ok;
         int eoff;
         if (j < RSN) {
@@ -628,30 +642,33 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       }
     }
 #pragma unroll
-    for (int j = 0; j <= RSN; ++j) xr[j] = ld16ov<vec>(base, off[j]);
+    for (int j = J0; j < J1; ++j) xr[j] = ld16ov<vec>(base, off[j]);
     return valid;
   };
 
   // loads of the chunk the cursor points at; P = chunk index & 3 (compile time): for the concat sources which member of
-  // [x1, x2, x2^2, sqrt] the chunk is
-  // Concat sources spread the requests of a slice [x1, x2, x2^2, sqrt] over the iterations: the x2 registers (xb) are requested
-  // with the slice's first chunk (P = 0: the iteration that has just staged the previous slice's sqrt chunk from them), the x1
-  // registers (xa) TWO chunks earlier, from the iteration that loads the previous slice's x2^2 chunk (`xa_tag` = 1, cursor two
-  // chunks ahead).  Both in one iteration were one 12-load burst per thread every fourth iteration -- 98 KB per CU at once: the
+  // [x1, sqrt, x2^2, x2] (ssr_member) the chunk is.
+  // Concat sources spread the requests of a slice over the iterations: the x2 registers (xb) are requested
+  // with the slice's first chunk (P = 0: the iteration that has just staged the last of the previous slice's three chunks from them), the x1
+  // registers (xa) earlier, one half each from the two iterations before that one (`xa_tag` = 1 / 2, cursor two chunks / one
+  // chunk ahead).  Both in one iteration were one 12-load burst per thread every fourth iteration -- 98 KB per CU at once: the
   // waves stall at issue until the CU's vector-memory queue drains, and that iteration (which also has the slice's only
   // transcendental transform) took twice a multiplying step; the other three issued no loads at all.
   auto load_step = [&](const TileCur& c, auto p_tag, auto xa_tag) __attribute__((always_inline)) {
     constexpr int P = decltype(p_tag)::value;
-    constexpr bool XA_ONLY = decltype(xa_tag)::value != 0;           // concat: only the x1 registers of the slice starting at c
+    constexpr int XA_PART = decltype(xa_tag)::value;                 // concat: only the x1 registers of the slice starting at c:
+    constexpr bool XA_ONLY = XA_PART != 0;                           // 1 = their first half, 2 = the second, 3 = all of them
+    constexpr int XH = (XV + 1) / 2;
+    constexpr int XJ0 = XA_PART == 2 ? XH : 0, XJ1 = XA_PART == 1 ? XH : XV;   // register range of this call
     static_assert(!XA_ONLY || (CAT && P == 0), "x1 requests are slice starts of concat sources");
     constexpr bool SET_A = !CAT || P == 0;     // X registers this chunk loads into (if it loads any)
-    constexpr bool X_LOAD = !CAT || XA_ONLY;   // this call requests the registers `xr`
+    constexpr bool X_LOAD = !CAT || XA_ONLY || (P == 0 && UNCL_PC_XA_SLOT == 0);   // this call requests the registers `xr`
     vec (&xr)[XV] = SET_A ? xa : xb;
     const int n = c.n, y0 = c.ty * TH, x0 = c.tx * TW, cout0 = c.ct * CT, kc = c.kc;
     int g = 0, cbase = kc * 32;
     if (CAT) {
       cbase = (kc >> 2) * 32;
-      g = P == 0 ? 1 : (P == 1 ? 0 : P);
+      g = ssr_member(P);
     }
     if (!XA_ONLY) {
       bp = kc == 0;
@@ -680,8 +697,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       const int sy0 = iy0 >> 1, sx0 = ix0 >> 1;
       u_iy0 = iy0; u_ix0 = ix0;
       const bf16_t* ub = a.src1 + (size_t)n * a.s1H * a.s1W * 32;
+      constexpr int IH = (MT_PER + 1) / 2;
 #pragma unroll
-      for (int i = 0; i < MT_PER; ++i) {
+      for (int i = (XA_PART == 2 ? IH : 0); i < (XA_PART == 1 ? IH : MT_PER); ++i) {
         const int mt = mt0 + MT_STEP * i;
         const int spc = min(mt * 32 + lr, UPN - 1);
         const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;     // / 17 for spc < 1024
@@ -695,19 +713,19 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase + ch * 8;
       unsigned off[XV];
       const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
-      valid = 0;
+      valid = ~(((1u << XJ1) - 1u) & ~((1u << XJ0) - 1u));
       const int ix = ix0 + hx;
       const bool xok = (unsigned)ix < (unsigned)a.W;
       const int sx = min(max(ix - dx, 0), a.s1W - 1);
 #pragma unroll
-      for (int j = 0; j < RSN; ++j) {
+      for (int j = XJ0; j < (XJ1 < RSN ? XJ1 : RSN); ++j) {
         const int iy = iy0 + hy0 + RSTEP * j;
         const bool ok = xok && (unsigned)iy < (unsigned)a.H && (j < RSN - 1 || r_last_on);
         const int sy = min(max(iy - dy, 0), a.s1H - 1);
         valid |= (ok ? 1u : 0u) << j;
         off[j] = (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u;
       }
-      {
+      if (XJ1 == XV) {
         const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
         const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
@@ -715,16 +733,16 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         off[RSN] = (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u;
       }
 #pragma unroll
-      for (int j = 0; j <= RSN; ++j) xr[j] = ld16ov<vec>(base, off[j]);
+      for (int j = XJ0; j < XJ1; ++j) xr[j] = ld16ov<vec>(base, off[j]);
     } else {
-      valid = load_x(xr, xsrc, n, iy0, ix0, cbase);
+      valid = load_x(xr, xsrc, n, iy0, ix0, cbase, IntTag<XJ0>{}, IntTag<XJ1>{});
     }
     if (CAT && P == 0 && !XA_ONLY) {
       // the x2 slice of this group (its own step would be the one in which the multiplying waves store the previous tile: with
       // no loads queued at that time their stores do not wait behind ours)
-      xvalid_b = load_x(xb, a.src0, n, iy0, ix0, cbase);
+      xvalid_b = load_x(xb, a.src0, n, iy0, ix0, cbase, IntTag<0>{}, IntTag<XV>{});
     }
-    if (X_LOAD) xvalid_a = valid;
+    if (X_LOAD) xvalid_a = XA_PART == 2 ? (xvalid_a & valid) : valid;     // (a half's mask has ones outside its range)
     if (XA_ONLY) return;
     if (!RESW) {
       load_weights(cout0, kc);
@@ -818,10 +836,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       // the validity select only exists on the path of a wave that has an out-of-image slot at all (wave-uniform test):
       // interior tiles stage their registers as loaded
       auto transform = [&](vec v) __attribute__((always_inline)) {
-        if (CAT && P >= 2) {
+        if (CAT && ssr_member(P) >= 2) {
           float f[8];
           E::unpack(v, f);
-          if (P == 2) {
+          if (ssr_member(P) == 2) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
           } else {
@@ -867,12 +885,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     constexpr int P = decltype(p_tag)::value;
     if (loaded < total) {
       load_step(pc, p_tag, IntTag<0>{});
-      if (CAT && P == 2 && loaded + 2 < total) {
-        // x1 of the NEXT slice (chunk loaded + 2): xa has been free since this slice's x1 chunk was staged
+      // x1 of the NEXT slice (chunk loaded + 4 - P): xa has been free since this slice's x1 chunk was staged
+      constexpr int SLOT = UNCL_PC_XA_SLOT, SPLIT = UNCL_PC_XA_SPLIT;
+      constexpr int PART = !CAT || SLOT == 0 ? 0 : (!SPLIT ? (P == SLOT ? 3 : 0) : (P == SLOT ? 1 : (P == ((SLOT + 1) & 3) ? 2 : 0)));
+      static_assert(!SPLIT || SLOT == 2 || SLOT == 1, "the second half's slot must not be the slice's own first step");
+      if (PART != 0 && loaded + (4 - P) < total) {
         TileCur la = pc;
-        cur_next(la, a, tile_end);
-        cur_next(la, a, tile_end);
-        if (CAT) load_step(la, IntTag<0>{}, IntTag<CAT ? 1 : 0>{});
+#pragma unroll
+        for (int k = 0; k < 4 - P; ++k) cur_next(la, a, tile_end);
+        load_step(la, IntTag<0>{}, IntTag<PART>{});
       }
       ++loaded;
       const int t_old = pc.tile;
@@ -893,7 +914,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       *reinterpret_cast<f32x4*>(sBias + CT + ptid * 4) = b4;
     }
   }
-  if (CAT) load_step(pc, IntTag<0>{}, IntTag<CAT ? 1 : 0>{});       // the first slice's x1
+  if (CAT && UNCL_PC_XA_SLOT != 0) load_step(pc, IntTag<0>{}, IntTag<CAT ? 3 : 0>{});       // the first slice's x1
   load_next(IntTag<0>{});
   if (MODE == 3) {
     // one tile further ahead: patch 0 is parked in LDS, patch 1 requested, and a barrier publishes the former to every

@@ -181,8 +181,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   bool b_pending = false;
   int u_iy0 = 0, u_ix0 = 0;   // MODE 4: image coordinates of the halo tile whose up-conv patch is in flight
 
-  // K-chunk order.  MODE 1 walks each 32-channel slice of the skip as [x1, x2, x2^2, sqrt(x2)]: the x2 registers loaded
-  // for the second step are kept and re-staged (squared, then square-rooted) for the third and fourth, so the skip is
+  // K-chunk order.  MODE 1 walks each 32-channel slice of the skip as [x1, sqrt(x2), x2^2, x2] (ssr_member): the x2 registers
+  // loaded for the second step are kept and re-staged for the third and fourth, so the skip is
   // read from memory once instead of three times; `wk` is the chunk's position in the weight's K layout
   // [x2 | x1 | x2^2 | sqrt] (unet_parts.py:319-322).
   auto load_regs = [&](int n, int y0, int x0, int cout0, int kc, bool with_w) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     if (MODE == 1 || MODE == 4) {
       const int ph = kc & 3;
       cbase = (kc >> 2) * 32;
-      g = ph == 0 ? 1 : (ph == 1 ? 0 : ph);
+      g = ssr_member(ph);
       wk = g * (a.s0C >> 5) + (kc >> 2);
       reuse = ph >= 2;
     } else if (MODE == 2) {
