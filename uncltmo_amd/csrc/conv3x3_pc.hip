@@ -123,8 +123,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wres = smem + 2 * XBYTES;                               // RESW: chunk kc at wres + kc * WBYTES
-  float* const sBias = reinterpret_cast<float*>(smem + (RESW ? 2 * XBYTES + a.nk * WBYTES : 2 * STAGE));   // [2 tiles][CT]
-  float* const sO1 = sBias + 2 * CT;                                  // fused 1x1 tail: 32 weights + its bias (+ pad)
+  // bias ring of four tiles: the multiplying waves read a tile's slot in its epilogue, AFTER the barrier of its last chunk (the
+  // barrier sits before the last tap column), while the staging waves may already write the slot of the tile two further on
+  float* const sBias = reinterpret_cast<float*>(smem + (RESW ? 2 * XBYTES + a.nk * WBYTES : 2 * STAGE));   // [4 tiles][CT]
+  float* const sO1 = sBias + 4 * CT;                                  // fused 1x1 tail: 32 weights + its bias (+ pad)
   float* const sP = sO1 + 64;                                         // MODE 3: [2][PN3] image patches
 
   const int tid = threadIdx.x;
@@ -156,61 +158,61 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     // The accumulators are zeroed after each tile's epilogue, so the phase has no branch and is one scheduling region.
     constexpr int NRD = 3 * NT + MPW + 2;      // DS reads per column
     constexpr int NMM = 3 * NT * MPW;          // MFMAs per column
-    auto mfma_phase = [&](const char* st, const char* wst) __attribute__((always_inline)) {
+    // Fragment registers live across the chunk loop: column 0 of chunk s + 1 is requested while column 5 of chunk s multiplies.
+    vec A[2][3][NT], B[2][MPW + 2];
+    auto rd = [&](const char* st, const char* wst, int set, int col) __attribute__((always_inline)) {
       const char* pa = wst + aoff;
       const char* pb = st + boff;
-      vec A[2][3][NT], B[2][MPW + 2];
-      auto rd = [&](int set, int col) __attribute__((always_inline)) {
-        const int ks = col / 3, tx = col - 3 * ks;
+      const int ks = col / 3, tx = col - 3 * ks;
 #pragma unroll
-        for (int ty = 0; ty < 3; ++ty)
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          A[set][ty][nt] = *reinterpret_cast<const vec*>(pa + 2 * ks * WPL + ((ty * 3 + tx) * CT + nt * 32) * 16);
+#pragma unroll
+      for (int r = 0; r < MPW + 2; ++r) B[set][r] = *reinterpret_cast<const vec*>(pb + 2 * ks * XPL + (r * HW + tx) * 16);
+    };
+    auto mfma_col = [&](int col) __attribute__((always_inline)) {
+      const int set = col & 1;
+      if (col == 0) {
+        // same order as conv3x3_pipe's first column: tap row 0 of every output row, then rows 1 and 2
+#pragma unroll
+        for (int m = 0; m < MPW; ++m)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            A[set][ty][nt] = *reinterpret_cast<const vec*>(pa + 2 * ks * WPL + ((ty * 3 + tx) * CT + nt * 32) * 16);
+            acc[m][nt] = mfma32x16(A[set][0][nt], B[set][m], acc[m][nt]);
 #pragma unroll
-        for (int r = 0; r < MPW + 2; ++r) B[set][r] = *reinterpret_cast<const vec*>(pb + 2 * ks * XPL + (r * HW + tx) * 16);
-      };
-      rd(0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);     // column 0's own fragments first
+        for (int m = 0; m < MPW; ++m)
 #pragma unroll
-      for (int col = 0; col < 6; ++col) {
-        const int set = col & 1;
-        if (col + 1 < 6) rd(set ^ 1, col + 1);
-        if (col == 0) {
-          // same order as conv3x3_pipe's first column: tap row 0 of every output row, then rows 1 and 2
-#pragma unroll
-          for (int m = 0; m < MPW; ++m)
+          for (int ty = 1; ty < 3; ++ty)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[m][nt] = mfma32x16(A[set][0][nt], B[set][m], acc[m][nt]);
+              acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
+      } else {
 #pragma unroll
-          for (int m = 0; m < MPW; ++m)
+        for (int m = 0; m < MPW; ++m)
 #pragma unroll
-            for (int ty = 1; ty < 3; ++ty)
+          for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
-        } else {
+            for (int nt = 0; nt < NT; ++nt)
+              acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
+      }
+    };
+    auto sched_reads_under_mfmas = [&]() __attribute__((always_inline)) {
 #pragma unroll
-          for (int m = 0; m < MPW; ++m)
+      for (int k = 0; k < NRD; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read of the next column ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... per MFMA of this one
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);   // (two reads per gap, all in the first half: no gain)
+    };
+    // columns 0 .. 4 of the staged chunk (column 0's fragments are already in flight or landed); column 5's are requested
+    auto mfma_cols_0_4 = [&](const char* st, const char* wst) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
-        }
-        if (col + 1 < 6) {
-          {
-#pragma unroll
-            for (int k = 0; k < NRD; ++k) {
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read of the next column ...
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... per MFMA of this one
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);   // (two reads per gap, all in the first half: no gain)
-          }
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
-        }
+      for (int col = 0; col < 5; ++col) {
+        rd(st, wst, (col & 1) ^ 1, col + 1);
+        mfma_col(col);
+        sched_reads_under_mfmas();
       }
     };
 
@@ -480,18 +482,50 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     if (MODE == 3) pc_barrier();     // the staging waves' first image patch
     pc_barrier();     // stage 0 is staged
     PCT(2)
-    for (int s = 0;; ++s) {
-      mfma_phase(smem + (s & 1) * STAGE, RESW ? wres + cc.kc * WBYTES : smem + (s & 1) * STAGE + XBYTES);
-      PCT_K(0, cc.kc & 3)
-      if (cc.kc == a.nk - 1) {
-        run_epilogue(cc, tpar);
-        PCT_K(1, cc.kc & 3)
+    // The barrier of a chunk sits between its LAST fragment read and the MFMAs of its last tap column: "done with the stage" is
+    // true as soon as column 5's fragments have landed, and the twelve-plus MFMAs still to go then cover the LDS latency of the
+    // next chunk's first fragments (a wave alone on its SIMD has nobody else to hide it: the MFMA phase ran at 80 - 84 % of its
+    // issue rate with the bubble at every chunk start).  The staging waves get the stage back that much earlier, too.
+    rd(smem, RESW ? wres : smem + XBYTES, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+    // Chunk kinds are positions in straight-line code (inner loop: every chunk but a tile's last; then the last one), not
+    // branches inside one loop body: with branches between the barrier and the last column the register allocator spills the
+    // in-flight fragment set across them.
+    int s = 0;                            // chunks multiplied so far: chunk s sits in stage s & 1
+    auto stage_x = [&](int k) __attribute__((always_inline)) { return smem + (k & 1) * STAGE; };
+    auto stage_w = [&](int k, int kc) __attribute__((always_inline)) { return RESW ? wres + kc * WBYTES : smem + (k & 1) * STAGE + XBYTES; };
+    for (int t = tile0; t < tile_end; ++t) {
+      for (int kc = 0; kc < a.nk - 1; ++kc) {
+        mfma_cols_0_4(stage_x(s), stage_w(s, kc));
+        __builtin_amdgcn_sched_barrier(0);
+        pc_barrier();   // (waits for lgkmcnt(0): column 5's fragments) done with stage s & 1; stage (s + 1) & 1 is staged
+        __builtin_amdgcn_sched_barrier(0);
+        PCT_K(2, 4 + (kc & 3))
+        rd(stage_x(s + 1), stage_w(s + 1, kc + 1), 0, 0);
+        mfma_col(5);
+        sched_reads_under_mfmas();
+        PCT_K(0, kc & 3)
+        ++s;
       }
-      pc_barrier();   // done with stage s & 1; stage (s + 1) & 1 is staged
-      PCT_K(2, 4 + (cc.kc & 3))
-      const int t_old = cc.tile;
-      if (!cur_next(cc, a, tile_end)) break;
-      if (cc.tile != t_old) tpar ^= 1;
+      // a tile's last chunk keeps its barrier BEHIND the epilogue: released earlier, the staging waves' next loads would queue
+      // beside the epilogue's stores (same-box A/B: the one- and two-chunk layers 10 - 38 % slower), and the next tile's first
+      // fragments held across the epilogue would push every epilogue form over the register budget
+      mfma_cols_0_4(stage_x(s), stage_w(s, a.nk - 1));
+      mfma_col(5);
+      __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+      PCT_K(0, (a.nk - 1) & 3)
+      run_epilogue(cc, tpar);
+      PCT_K(1, (a.nk - 1) & 3)
+      pc_barrier();
+      PCT_K(2, 4 + ((a.nk - 1) & 3))
+      ++s;
+      if (t + 1 < tile_end) {
+        rd(stage_x(s), stage_w(s, 0), 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      }
+      tpar = (tpar + 1) & 3;
+      cc.kc = a.nk - 1;
+      cur_next(cc, a, tile_end);          // the next tile's coordinates (unused past the end of the range)
     }
     PCT_FLUSH(0)
     return;
@@ -544,7 +578,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
   int bpar = 0;
   bool bp = false;
   int u_iy0 = 0, u_ix0 = 0;
-  int ppar = 0;                 // parity of the tile the producers are loading
+  int ppar = 0;                 // bias slot (tile count & 3) of the tile the producers are loading
   int p3par = 0;                // MODE 3: the patch buffer the next build reads
 
   // MODE 4: this wave is tap (dy, dx) of the 2x2 stride-2 transposed conv (and, with eight staging waves, one half of the
@@ -897,21 +931,21 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       }
       ++loaded;
       const int t_old = pc.tile;
-      if (cur_next(pc, a, tile_end) && pc.tile != t_old) ppar ^= 1;
+      if (cur_next(pc, a, tile_end) && pc.tile != t_old) ppar = (ppar + 1) & 3;
     }
   };
   if (a.out1_w != nullptr && ptid < 33) sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0];     // fused 1x1 tail (CT == 32)
   if (RESW) {
     // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order, and so
-    // does its bias (both tile parities)
+    // does its bias (all four slots)
     for (int kc = 0; kc < a.nk; ++kc) {
       load_weights(0, kc);
       write_weights(wres + kc * WBYTES);
     }
     if (ptid < CT / 4) {
       const f32x4 b4 = a.bias != nullptr ? *reinterpret_cast<const f32x4*>(a.bias + ptid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(sBias + ptid * 4) = b4;
-      *reinterpret_cast<f32x4*>(sBias + CT + ptid * 4) = b4;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) *reinterpret_cast<f32x4*>(sBias + sl * CT + ptid * 4) = b4;
     }
   }
   if (CAT && UNCL_PC_XA_SLOT != 0) load_step(pc, IntTag<0>{}, IntTag<CAT ? 3 : 0>{});       // the first slice's x1
@@ -960,7 +994,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 template <int NT, int MPW>
 constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
-  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 2 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0);
+  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0);
 }
 
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
