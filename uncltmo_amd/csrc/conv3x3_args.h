@@ -34,6 +34,7 @@ struct PipeArgs {
   const bf16_t* up_w;   // MODE 4: packed [4 taps][32 cout][32 cin] weights of the 2x2 stride-2 transposed conv
   const float* up_b;    // MODE 4: its bias (32) or NULL
   int pc_prio;          // conv3x3_pc: 0 no priorities, 1 multiplying waves raised, 2 staging waves raised
+  int lean;             // conv3x3_pc: 1 = plain forward stores take the straight-line epilogue (buffer stores, no branches)
 };
 
 // conv3x3_pc.hip: the producer / consumer kernel for the multi-chunk layers; returns UNCL_ERR_ARG when (nt, mpw, mode) is not built

@@ -36,6 +36,9 @@
 #ifndef UNCL_PC_XA_SLOT
 #define UNCL_PC_XA_SLOT (MODE == 4 ? 3 : 1)
 #endif
+#ifndef UNCL_PC_LEAN_DEFAULT
+#define UNCL_PC_LEAN_DEFAULT 1
+#endif
 #ifndef UNCL_PC_XA_SPLIT
 #define UNCL_PC_XA_SPLIT 0
 #endif
@@ -470,8 +473,99 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
     };
+    // The plain forward store (bias + ReLU, optional pooled copy; no fused 1x1 tail) once more, as straight-line code.  A
+    // multiplying wave is alone on its SIMD and the matrix pipe idles while it runs its epilogue, so the epilogue costs its
+    // INSTRUCTION COUNT (4 - 5 cycles each; ablation in a timing build: without its stores it is still 44 % of the first
+    // layer's step): epilogue_fast spends ~650 instructions per 32-channel tile, most of them per-row 64-bit address arithmetic
+    // on the scalar unit and an exec-mask branch around every store.  Here one buffer descriptor per tile (base = the sample,
+    // num_records = its bytes) replaces both: a store's offset is "lane offset + row offset", where an out-of-image column or
+    // row contributes 2^30, i.e. lands beyond num_records and is dropped by the hardware (every sample is < 1 GiB: launcher).
+    typedef unsigned u32x4l __attribute__((ext_vector_type(4)));
+    auto epilogue_lean = [&](const TileCur& c, int tp, auto pool_tag) __attribute__((always_inline)) {
+      constexpr bool POOL = decltype(pool_tag)::value != 0;
+      constexpr unsigned BAD = 0x40000000u;
+      const float* sBt = sBias + tp * CT;
+      const int y0 = c.ty * TH + cw * MPW, x0 = c.tx * TW, co = c.ct * CT;
+      const int ox = x0 + lr;
+      const unsigned sample = (unsigned)(a.Hout * a.Wout * a.oC) * 2u;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (size_t)c.n * sample, (short)0,
+                                                                          (int)sample, 0x00020000);
+      // (both arms of the selects are constants: an arm with arithmetic in it is compiled as a branch)
+      const unsigned loff = ((unsigned)(ox * a.oC + co + 8 * lh) * 2u) | (ox < a.Wout ? 0u : BAD);
+      const unsigned rowb = (unsigned)(a.Wout * a.oC) * 2u;
+      __amdgpu_buffer_rsrc_t prs = rs;
+      unsigned ploff = BAD, prowb = 0;
+      if (POOL) {
+        const unsigned psample = (unsigned)(a.pH * a.pW * a.oC) * 2u;
+        const int gx = (x0 >> 1) + (lr >> 1);
+        prs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.pool_out) + (size_t)c.n * psample, (short)0, (int)psample, 0x00020000);
+        ploff = ((unsigned)(gx * a.oC + co + 8 * lh) * 2u) | (gx < a.pW ? 0u : BAD);
+        prowb = (unsigned)(a.pW * a.oC) * 2u;
+      }
+      auto pack4 = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
+        const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
+        const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
+        vec4 o;
+        o[0] = (T)s0[0]; o[1] = (T)s0[1]; o[2] = (T)s1[0]; o[3] = (T)s1[1];
+        return o;
+      };
+      auto widen_relu = [&](const vec4& o0, const vec4& o1) __attribute__((always_inline)) {
+        const u32x2 d0 = __builtin_bit_cast(u32x2, o0), d1 = __builtin_bit_cast(u32x2, o1);
+        const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
+        const u32x4l w = {sx[0], sy[0], sx[1], sy[1]};
+        s16x8 si = __builtin_bit_cast(s16x8, w);
+        si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values (sign-symmetric rounding)
+        return si;
+      };
+#pragma unroll
+      for (int pr = 0; pr < MPW / 2; ++pr) {
+        unsigned voff[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int oy = y0 + 2 * pr + r;                                    // wave-uniform
+          voff[r] = loff + (((unsigned)oy * rowb) | (oy < a.Hout ? 0u : BAD));
+        }
+        unsigned pvoff = BAD;
+        if (POOL) {
+          const int gy = (c.ty * TH >> 1) + cw * (MPW / 2) + pr;
+          pvoff = ploff + (((unsigned)gy * prowb) | (gy < a.pH ? 0u : BAD));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 4 * lh);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 8 + 4 * lh);
+            s16x8 wv[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const int m = 2 * pr + r;
+              wv[r] = widen_relu(pack4(acc[m][nt], 2 * qp, b0), pack4(acc[m][nt], 2 * qp + 1, b1));
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, 0);
+            }
+            if (POOL) {
+              // MaxPool2d(2) of the two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
+              // maximum orders them like their floats; vertical, then horizontal with the neighbouring pixel's lane
+              s16x8 v = __builtin_elementwise_max(wv[0], wv[1]);
+              u32x4l u = __builtin_bit_cast(u32x4l, v), h;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) h[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)u[i], 0xB1, 0xF, 0xF, true);
+              v = __builtin_elementwise_max(v, __builtin_bit_cast(s16x8, h));
+              // (the odd lanes hold the same maxima: masked off by EXEC rather than by offset, so that the memory pipeline
+              // sees a 32-lane store)
+              if ((lr & 1) == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, v), prs, pvoff + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, 0);
+            }
+          }
+      }
+    };
+    const bool lean = fast_relu && a.out1_w == nullptr && !a.skip_main && a.lean;      // wave-uniform
     auto run_epilogue = [&](const TileCur& c, int tp) __attribute__((always_inline)) {
-      if (fast_relu) epilogue_fast(c, tp, IntTag<0>{});
+      if (lean) {
+        if (a.pool_out != nullptr) epilogue_lean(c, tp, IntTag<1>{});
+        else epilogue_lean(c, tp, IntTag<0>{});
+      } else if (fast_relu) epilogue_fast(c, tp, IntTag<0>{});
       else if (fast_grad) epilogue_fast(c, tp, IntTag<1>{});
       else if (a.slope == 0.f) epilogue(c, tp, IntTag<0>{});
       else if (a.slope == 1.f) epilogue(c, tp, IntTag<1>{});
@@ -1048,6 +1142,9 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
   // the fused 1x1 tail: 32-channel tiles, forward epilogue, no pooled copy
   if (a.out1_w != nullptr && !(nt == 1 && fwd_relu && a.pool_out == nullptr && a.out1 != nullptr && a.out1_b != nullptr)) return UNCL_ERR_ARG;
   if (a.skip_main && a.out1_w == nullptr) return UNCL_ERR_ARG;
+  // the straight-line forward epilogue addresses a sample through one 32-bit buffer descriptor
+  static const int lean_on = [] { const char* e = getenv("UNCL_PC_LEAN"); return e ? atoi(e) : UNCL_PC_LEAN_DEFAULT; }();
+  a.lean = lean_on && (size_t)a.Hout * a.Wout * a.oC * 2 < (1u << 30) && (size_t)a.pH * a.pW * a.oC * 2 < (1u << 30);
   if (nt == 1 && mpw == 4) {
     if (a.pool_out != nullptr && !fwd_relu) return UNCL_ERR_ARG;
     static const int pw = [] { const char* e = getenv("UNCL_PC_PW"); return e ? atoi(e) : 8; }();      // experiment: staging waves
