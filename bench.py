@@ -44,7 +44,21 @@ DOM_GFLOP_PER_TILE = 4.6820 + 0.1300
 DOM_GFLOP_PER_TILE_F32 = 4.6820     # fp32 parity mode: separate up-conv launch
 PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_TFLOPS = 157.3
-FRAMES, H, W, TILES_PER_FRAME = 8, 1024, 1024, 25
+# workloads: frames per step per GPU, frame size, overlap tiles per frame (reference tiler loop, model_save_util.py:417-481)
+WORKLOADS = {
+    "1024": dict(frames=8, H=1024, W=1024, tiles=25,
+                 name="UNet generator forward, batch 8 x 1024x1024 synthetic HDR -> 200 overlap tiles of 256x256 per GPU, eval "
+                      "mode, random-init weights (BASELINE.json configs[1])"),
+    "4k": dict(frames=1, H=2160, W=3840, tiles=220,
+               name="4K HDR inference: whole 2160x3840 frames per GPU -> 220 overlap tiles of 256x256 each, tiled UNet forward, "
+                    "eval mode, random-init weights (BASELINE.json configs[4]; quote it with --dtype fp16)"),
+}
+# (Cin, Cout, output extent, taps) of the 26 packed-weight layers in uncl_gen_layer_name order: FLOP = 2 taps Cin Cout Hout^2
+LAYER_SHAPES = [(32, 32, 252, 9), (32, 64, 124, 9), (64, 64, 122, 9), (64, 128, 59, 9), (128, 128, 57, 9), (128, 256, 26, 9),
+                (256, 256, 24, 9), (256, 256, 10, 9), (256, 256, 12, 9), (256, 256, 12, 1), (128, 512, 12, 1), (512, 256, 12, 1),
+                (256, 256, 12, 1), (256, 256, 12, 1), (256, 256, 24, 1), (1024, 128, 26, 9), (128, 128, 28, 9), (128, 128, 56, 1),
+                (512, 64, 59, 9), (64, 64, 61, 9), (64, 64, 122, 1), (256, 32, 124, 9), (32, 32, 126, 9), (32, 32, 252, 1),
+                (128, 32, 254, 9), (32, 32, 256, 9)]
 
 
 def parse(argv=None):
@@ -53,6 +67,11 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--workload", default="1024", choices=sorted(WORKLOADS),
+                    help="infer mode: 1024 = BASELINE configs[1] (default, the headline metric); 4k = configs[4], whole "
+                         "2160x3840 frames per GPU (frame-parallel, no collective), normally with --dtype fp16")
+    ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default: the workload's)")
+    ap.add_argument("--no-layers", action="store_true", help="skip the untimed per-layer pass behind roofline.layers")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("UNCL_CHUNK", "0")))
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "train_video"],
                     help="infer: BASELINE configs[1] (default, the headline metric; its line also carries train_step / "
@@ -82,11 +101,35 @@ def _free_port():
     return port
 
 
+def visible_gpu_count():
+    """GPUs a child of this process may use, WITHOUT touching the HIP / HSA runtime (the launcher parent must not open the
+    device before it forks its ranks): KFD topology nodes with simd_count > 0 (CPU nodes have 0), cut down by the
+    *_VISIBLE_DEVICES lists the runtime itself would honour."""
+    import re
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for d in os.listdir(base):
+            try:
+                props = open(os.path.join(base, d, "properties")).read()
+            except OSError:
+                continue
+            m = re.search(r"^simd_count\s+(\d+)", props, re.M)
+            if m and int(m.group(1)) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch(a, argv):
     """Parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): start one child per GPU, pass rank 0's stdout through."""
     if not a.stub:
-        import torch    # device_count() enumerates without creating a HIP context in this process
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()      # sysfs: this process never initialises the GPU runtime
         if a.gpus > have:
             sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run fewer ranks "
                              "than asked for\n" % (a.gpus, have))
@@ -149,7 +192,7 @@ def pmc_traffic(dtype):
     return None, None
 
 
-def cpu_baseline(seconds):
+def cpu_baseline(seconds, tiles_per_frame=25, frame_name="1024x1024"):
     """Oracle generator forward on the host cores, fp32, bounded to ~`seconds` of work."""
     import torch
     from oracle.state import generator_state
@@ -168,9 +211,9 @@ def cpu_baseline(seconds):
             done += x.shape[0]
         dt = time.perf_counter() - t0
     tiles_per_s = done / dt
-    return {"value": tiles_per_s / TILES_PER_FRAME, "unit": "frames/s", "cores": torch.get_num_threads(),
+    return {"value": tiles_per_s / tiles_per_frame, "unit": "frames/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": "%d 256x256 tile forwards of the fp32 CPU oracle in %.1f s (%.2f tiles/s); "
-                                      "one 1024x1024 frame = 25 tiles" % (done, dt, tiles_per_s)}
+                                      "one %s frame = %d tiles" % (done, dt, tiles_per_s, frame_name, tiles_per_frame)}
 
 
 class Ranks:
@@ -222,6 +265,31 @@ class Ranks:
             self.td.all_gather(allt, t)
             per_rank = [float(x.item()) for x in allt]
         return max(per_rank), per_rank, out
+
+    def timed_steps(self, step, steps):
+        """EXACTLY `steps` steps between barrier + device sync on both sides, like timed(), plus what one mean cannot show: an
+        event pair around every step (device time of each step) and the host time each step took to enqueue.  Returns
+        (max-over-ranks seconds, per-rank seconds, per-step device ms, per-step host-enqueue ms)."""
+        torch = self.torch
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        host = []
+        self.sync()
+        t0 = time.perf_counter()
+        for e0, e1 in evs:
+            h0 = time.perf_counter()
+            e0.record()
+            step()
+            e1.record()
+            host.append((time.perf_counter() - h0) * 1e3)
+        self.sync()
+        dt = time.perf_counter() - t0
+        per_rank = [dt]
+        if self.dist:
+            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            allt = [torch.zeros_like(t) for _ in range(self.world)]
+            self.td.all_gather(allt, t)
+            per_rank = [float(x.item()) for x in allt]
+        return max(per_rank), per_rank, [e0.elapsed_time(e1) for e0, e1 in evs], host
 
     def ranks_seen(self):
         if not self.dist:
@@ -294,50 +362,100 @@ def make_trainer(rk, video):
         tr.train_D(hdr, pos, neg, 0)
         tr.train_G(hdr, hdr, pos, neg, 0)
 
+    tr._step_graph = None
+    tr._step_graph_error = None
+    if not rk.dist and os.environ.get("UNCL_TRAIN_GRAPH", "1") != "0":
+        # one hipGraph replay per optimisation step (uncltmo_amd/step_graph.py); eager launches if the capture fails
+        from uncltmo_amd.step_graph import StepGraph
+        try:
+            sg = StepGraph(tr, hdr, hdr, pos, neg, 0)
+            step = sg.replay
+        except Exception as e:          # noqa: BLE001 -- report and fall back: the eager step is the same arithmetic
+            tr._step_graph = None
+            tr._step_graph_error = "%s: %s" % (type(e).__name__, str(e)[:200])
+            torch.cuda.synchronize()
+
     return tr, step, B * T
 
 
+def _median(v):
+    v = sorted(v)
+    n = len(v)
+    return 0.0 if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
+
+
 def train_numbers(a, rk, video, steps, warmup):
+    """One optimisation step (train_D + train_G) timed `steps` times after `warmup` untimed ones.  `ms_per_step` is the MEDIAN
+    of the per-step device times; the mean over the bracketed region, min / max, the whole per-step list, the host
+    time to enqueue a step and the garbage collector's activity are reported beside it, so that a number that moves between boxes
+    (round 2: 8.4 ms here, 17.5 ms on the driver's box) can be told apart: a stall in one step, a host-bound step, or a slow GPU."""
+    import gc
     import torch
     tr, step, n = make_trainer(rk, video)
     for _ in range(warmup):
         step()
     st0 = torch.cuda.memory_stats()
-    dt, per_rank, _ = rk.timed(step, steps, 0)
+    gc0 = [g["collections"] for g in gc.get_stats()]
+    dt, per_rank, dev_ms, host_ms = rk.timed_steps(step, steps)
+    gc1 = [g["collections"] for g in gc.get_stats()]
     st1 = torch.cuda.memory_stats()
     dev_allocs = st1.get("num_device_alloc", 0) - st0.get("num_device_alloc", 0)
     dev_frees = st1.get("num_device_free", 0) - st0.get("num_device_free", 0)
-    ms = dt / steps * 1e3
+    ms_mean = dt / steps * 1e3
+    ms = _median(dev_ms)
     # per frame: 2 generator forwards; backward = 2 x forward FLOPs per pass.  SURVEY §8(d) counts the reference's two
     # backward passes (109.7 GFLOP per frame); this build feeds the summed output gradient through ONE pass (73.1 GFLOP).
     tfl_1 = n * (2 * GFLOP_PER_TILE + 2 * GFLOP_PER_TILE) / ms
     tfl_2 = n * (2 * GFLOP_PER_TILE + 4 * GFLOP_PER_TILE) / ms
-    return {"ms_per_step": ms, "frames_per_s": rk.world * n * steps / dt, "frames_per_step_per_gpu": n, "steps": steps,
-            "warmup": warmup, "dtype": "bf16", "device_mallocs_in_timed_steps": dev_allocs, "device_frees_in_timed_steps": dev_frees,
-            "workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, Adam): 2 clips of "
-                         "512x512 x T=5 per GPU cut into 4 crops of 256x256 each, epoch regime 0 (BASELINE configs[3])") if video
-            else ("GanTrainerImg step (train_D + train_G, all losses, Adam): 32 frames of 256x256 per GPU, epoch regime 0 "
-                  "(BASELINE configs[2])"),
-            "generator_mfma": {"peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "achieved_executed": tfl_1, "frac_executed": tfl_1 / PEAK_BF16_TFLOPS,
-                               "achieved_survey_convention": tfl_2, "frac_survey_convention": tfl_2 / PEAK_BF16_TFLOPS,
-                               "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
-                                       "2 bwd (109.7 GFLOP, what the reference runs); both over the whole step time"},
-            "errD": float(tr.errD.detach()), "errG_d": float(tr.errG_d.detach()), "errG_struct": float(tr.errG_struct.detach())}, per_rank
+    out = {"ms_per_step": ms, "ms_median": ms, "ms_mean_wall": ms_mean, "ms_min": min(dev_ms), "ms_max": max(dev_ms),
+           "ms_steps": [round(x, 3) for x in dev_ms],
+           "host_enqueue_ms_median": _median(host_ms), "host_enqueue_ms_max": max(host_ms),
+           "gc_collections_in_timed_steps": [b - c for b, c in zip(gc1, gc0)],
+           "graph_replay": bool(getattr(tr, "_step_graph", None) is not None),
+           "graph_capture_error": getattr(tr, "_step_graph_error", None),
+           "frames_per_s": rk.world * n / (ms * 1e-3), "frames_per_s_wall": rk.world * n * steps / dt,
+           "frames_per_step_per_gpu": n, "steps": steps,
+           "warmup": warmup, "dtype": "bf16", "device_mallocs_in_timed_steps": dev_allocs, "device_frees_in_timed_steps": dev_frees,
+           "workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, Adam): 2 clips of "
+                        "512x512 x T=5 per GPU cut into 4 crops of 256x256 each, epoch regime 0 (BASELINE configs[3])") if video
+           else ("GanTrainerImg step (train_D + train_G, all losses, Adam): 32 frames of 256x256 per GPU, epoch regime 0 "
+                 "(BASELINE configs[2])"),
+           "generator_mfma": {"peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                              "achieved_executed": tfl_1, "frac_executed": tfl_1 / PEAK_BF16_TFLOPS,
+                              "achieved_survey_convention": tfl_2, "frac_survey_convention": tfl_2 / PEAK_BF16_TFLOPS,
+                              "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
+                                      "2 bwd (109.7 GFLOP, what the reference runs); both over the median step time"},
+           "errD": float(tr.errD.detach()), "errG_d": float(tr.errG_d.detach()), "errG_struct": float(tr.errG_struct.detach())}
+    if rk.dist:
+        # gradient exchange: bytes per step and the time the compute stream spent waiting in DistributedOptimizer.synchronize()
+        # (collectives launched during the backward pass that had not finished when the optimiser asked for the gradients)
+        from uncltmo_amd.distributed import exposed_allreduce_ms
+        ex = exposed_allreduce_ms([tr.optimizerG, tr.optimizerD])[-steps:]
+        out["allreduce"] = {"bytes_per_step": int(sum(p.numel() for p in tr.netG.parameters() if p.requires_grad) * 4 +
+                                                   sum(p.numel() for p in tr.netD.parameters()) * 4),
+                            "ms_exposed_median": _median(ex) if ex else None, "ms_exposed_max": max(ex) if ex else None,
+                            "world": rk.world}
+    return out, per_rank, dt
 
 
 def train_bench(a, rk):
     video = a.mode == "train_video"
-    nums, per_rank = train_numbers(a, rk, video, a.steps, a.warmup)
+    nums, per_rank, dt = train_numbers(a, rk, video, a.steps, a.warmup)
     if rk.rank == 0:
         name = "GanTrainer (video, T=5)" if video else "GanTrainerImg"
-        line = {"metric": "HDR frames/sec (256x256 full %s step)" % name, "value": nums["frames_per_s"], "unit": "frames/s"}
-        line.update(common_fields(a, rk, nums["ms_per_step"] * a.steps / 1e3, per_rank))
+        # the line's value / ms_per_step follow the bench contract (K steps between two syncs, slowest rank); the per-step
+        # distribution sits beside them
+        line = {"metric": "HDR frames/sec (256x256 full %s step)" % name, "value": nums["frames_per_s_wall"], "unit": "frames/s"}
+        line.update(common_fields(a, rk, dt, per_rank))
         line.update({"dtype": "bf16",
                      "config": {"workload": nums["workload"], "parallelism": "data-parallel x%d, gradient all-reduce" % rk.world},
                      "generator_mfma": nums["generator_mfma"],
                      "device_mallocs_in_timed_steps": nums["device_mallocs_in_timed_steps"],
                      "errD": nums["errD"], "errG_d": nums["errG_d"], "errG_struct": nums["errG_struct"]})
+        for k in ("ms_median", "ms_mean_wall", "ms_min", "ms_max", "ms_steps", "host_enqueue_ms_median", "host_enqueue_ms_max",
+                  "gc_collections_in_timed_steps", "graph_replay", "graph_capture_error", "allreduce"):
+            if k in nums:
+                line[k] = nums[k]
         _flush_c_stdio()
         print(json.dumps(line), flush=True)
     elif rk.dist:
@@ -378,6 +496,8 @@ def infer_bench(a, rk):
                "replicate", 2, 0, compute_dtype=a.dtype, chunk=a.chunk)
     synth.fill_state_dict(net, "g0")
     net = net.cuda().eval()
+    wl = WORKLOADS[a.workload]
+    FRAMES, H, W, TILES_PER_FRAME = (a.frames or wl["frames"]), wl["H"], wl["W"], wl["tiles"]
     # synthetic frames (seeded, heavy-tailed log-compressed radiance), resident in HBM before timing starts
     frames = synth.hdr_frames(FRAMES, H, W, salt="bench%d" % rk.rank).cuda()
 
@@ -409,6 +529,27 @@ def infer_bench(a, rk):
         excl_ms = sum(buf[i] for i in range(nx)) / max(nx, 1)
         excl_tiles = FRAMES * TILES_PER_FRAME * 3 / max(nx, 1)
         lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "2")))
+    # per-layer table (untimed, one stream, one layer's launches timed at a time): which layer is furthest below its roofline
+    layers = None
+    if not a.no_layers and a.dtype != "fp32":
+        lib.uncl_gen_set_streams(1)
+        layers = []
+        peak_l = PEAK_BF16_TFLOPS
+        for i, (cin, cout, ho, taps) in enumerate(LAYER_SHAPES):
+            lib.uncl_prof_enable(i, 64)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            nl = lib.uncl_prof_read(buf, 4096)
+            gfl = 2.0 * taps * cin * cout * ho * ho * FRAMES * TILES_PER_FRAME / 1e9
+            ent = {"layer": lib.uncl_gen_layer_name(i).decode(), "gflop": round(gfl, 1)}
+            per_fwd = sum(buf[k] for k in range(nl)) / 2.0          # two forwards were timed
+            if nl > 0 and per_fwd > 0:
+                ent.update({"ms": round(per_fwd, 4), "tflops": round(gfl / per_fwd, 1), "frac": round(gfl / per_fwd / peak_l, 4)})
+            else:
+                ent.update({"ms": None, "note": "computed inside a neighbouring launch on this path"})
+            layers.append(ent)
+        lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "2")))
     lib.uncl_prof_enable(-1, 0)
     assert torch.isfinite(out).all()
 
@@ -418,7 +559,7 @@ def infer_bench(a, rk):
         del out, step, net, frames
         torch.cuda.empty_cache()
         for key, video in (("train_step", False), ("train_video_step", True)):
-            train[key], _ = train_numbers(a, rk, video, 10, 3)
+            train[key], _, _ = train_numbers(a, rk, video, 30, 5)
             torch.cuda.empty_cache()
 
     if rk.rank != 0:
@@ -432,19 +573,19 @@ def infer_bench(a, rk):
     dom_tflops = dom_gflop * tiles_per_launch / dom_ms if dom_ms > 0 else 0.0
     excl_tflops = dom_gflop * excl_tiles / excl_ms if excl_ms > 0 else 0.0
     fwd_tflops = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / ms          # per GPU
-    traffic, traffic_src = pmc_traffic(a.dtype)
+    traffic, traffic_src = pmc_traffic(a.dtype) if a.workload == "1024" else (None, None)
     mfma_name = {"bf16": "conv3x3 implicit-GEMM (bf16 MFMA)", "fp16": "conv3x3 implicit-GEMM (f16 MFMA)",
                  "fp32": "conv_igemm_kernel<float,3,8,1,1>"}[a.dtype]
-    line = {"metric": "HDR frames/sec (1024x1024 generator forward, tiled)", "value": fps, "unit": "frames/s"}
+    line = {"metric": "HDR frames/sec (%dx%d generator forward, tiled)" % (W, H) if a.workload != "1024" else
+            "HDR frames/sec (1024x1024 generator forward, tiled)", "value": fps, "unit": "frames/s"}
     line.update(common_fields(a, rk, dt, per_rank))
     line.update({
         "dtype": a.dtype,
-        "config": {"workload": "UNet generator forward, batch 8 x 1024x1024 synthetic HDR -> 200 overlap tiles "
-                               "of 256x256 per GPU, eval mode, random-init weights (BASELINE.json configs[1])",
+        "config": {"workload": wl["name"], "frame": "%dx%d" % (H, W),
                    "frames_per_step_per_gpu": FRAMES, "tiles_per_frame": TILES_PER_FRAME, "chunk": a.chunk,
                    "parallelism": "frame-parallel x%d, no collective" % rk.world},
         "roofline": {"bound": "mfma", "achieved": fwd_tflops, "peak": peak, "unit": "TFLOP/s", "frac": fwd_tflops / peak,
-                     "scope": "whole forward: 18.2858 GFLOP per tile x 200 tiles / ms_per_step (tiler included), per GPU",
+                     "scope": "whole forward: 18.2858 GFLOP per tile x %d tiles / ms_per_step (tiler included), per GPU" % (FRAMES * TILES_PER_FRAME),
                      "traffic": traffic, "traffic_unit": "bytes/launch of the dominant kernel",
                      "traffic_source": traffic_src,
                      "dominant_kernel": {
@@ -459,9 +600,11 @@ def infer_bench(a, rk):
                                        "tiles_per_launch": excl_tiles,
                                        "note": "same kernel, single stream, 3 untimed steps after the timed region"}}},
     })
+    if layers is not None:
+        line["roofline"]["layers"] = layers
     line.update(train)
     if rk.world == 1 and not a.no_cpu:
-        line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(a.cpu_seconds, TILES_PER_FRAME, "%dx%d" % (H, W))
     _flush_c_stdio()
     print(json.dumps(line), flush=True)
 

@@ -468,6 +468,11 @@ int uncl_tv_loss(const float* x, int N, int H, int W, float w, float* loss, floa
 /* torch.optim.Adam step over `count` tensors (HOST arrays of device pointers) */
 int uncl_adam_step(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int* numel,
                    int count, float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* the same update with the learning rate and the step count in DEVICE memory (hyper = float[2] {lr, step}, step already
+ * advanced on the stream): no kernel argument changes from step to step, so a captured optimisation step (hipGraph) replays
+ * with the right bias corrections.  torch.optim.Adam.step, main_train_image.py:29-32. */
+int uncl_adam_step_dev(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int* numel,
+                       int count, const float* hyper, float beta1, float beta2, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Overlap-tile inference (256^2 tiles, stride 192, linear cross-fade).

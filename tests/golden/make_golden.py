@@ -488,16 +488,94 @@ def capture_tmqi(out):
         print("captured tmqi", salt, Q, S, N, s_local, flush=True)
 
 
+def tester_inputs():
+    """Three synthetic linear-radiance frames (H,W,3) of one scene and the scene's brightness factor; shared with
+    tests/test_oracle_golden.py and tests/test_gpu_inference.py."""
+    base = synth.smooth_hdr_frames(1, 300, 340, salt="tst_base")[0, 0].numpy().astype(np.float32)
+    frames = []
+    for t in range(3):
+        tex = synth.hash_uniform("tst_f%d" % t, 300 * 340 * 3).reshape(300, 340, 3).astype(np.float32)
+        frames.append(((base[:, :, None] * (1.0 + 0.1 * t)) ** 3 * 40.0 * (0.7 + 0.3 * tex)).astype(np.float32))
+    return frames, 0.5          # lambda of the scene; f_factor = lambda * 255 * factor_coeff
+
+
+def tester_standin(p, apply_crop=True, diffY=0, diffX=0):
+    """(B,T,1,256,256) clip patch -> a tone curve of every frame mixed with its predecessor's: keeps the input's structure (the
+    scene's TMQI is finite) and depends on the frame order (the clip dimension is exercised)."""
+    c = p.clamp_min(0) ** 0.6
+    prev = torch.cat([c[:, :1], c[:, :-1]], 1)
+    return 0.05 + 0.75 * c + 0.15 * prev, None
+
+
+def capture_tester(out):
+    """`Tester.eval_on_video` (Tester.py:314-391) run through the reference's own class: load_inference, resize_im, its tiler
+    copy, the recurrent generator, post-processing, TMQI.  File reading (imageio), the lambda table and the optical flow (cv2
+    DeepFlow on another method's images) are stubbed at their call sites: frames come from tester_inputs(), the flow alignment
+    is the identity."""
+    import tempfile
+    import types
+    import Tester as ref_tester
+    import tranforms
+    from utils import hdr_image_util
+    frames, lam = tester_inputs()
+    tmp = tempfile.mkdtemp()
+    scene = os.path.join(tmp, "scene0")
+    os.makedirs(scene)
+    paths = [os.path.join(scene, "f%d.npy" % t) for t in range(len(frames))]
+    table = os.path.join(tmp, "lambdas.npy")
+    np.save(table, {"scene0": lam}, allow_pickle=True)
+    by_path = dict(zip(paths, frames))
+    hdr_image_util.read_hdr_image = lambda path: by_path[path].copy()
+    tranforms.hdr_im_transform = tranforms.ToTensor()          # the Compose([ToTensor()]) of tranforms.py:313-315
+    ref_tester.cv2.imread = lambda path: np.zeros((4, 4, 3), np.uint8)
+    ref_tester.compute_flow = lambda a, b: None
+    ref_tester.align_frames = lambda img, flow: img
+    G, _ = build_ref_models(video=True)
+    G.eval()
+    t = ref_tester.Tester.__new__(ref_tester.Tester)
+    t.args = types.SimpleNamespace(factor_coeff=0.1, add_frame=False)
+    t.device = DEV
+    ldrs = []
+    orig_t2n = t.tensor_to_numpy
+
+    def t2n(x):
+        r = orig_t2n(x)
+        ldrs.append(r)
+        return r
+
+    t.tensor_to_numpy = t2n
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the Tester's tiler copy hard-codes .cuda() (Tester.py:155)
+    out["tester.f_factor"] = np.array([lam * 255 * 0.1], dtype=np.float64)
+    try:
+        # "tone": a stand-in generator (a tone curve with a one-frame memory) whose output follows the input's structure, so
+        # the scene's TMQI is a finite number; "G": the recurrent generator with the synthetic weights -- its fine structure is
+        # unrelated to the input's, the reference's TMQI is NaN there (negative level-0 fidelity under a fractional power) and
+        # only the 8-bit frames and the warp errors are pinned
+        for tag, model in (("tone", tester_standin), ("G", G)):
+            del ldrs[:]
+            with torch.no_grad():
+                scene_q, w_mse, w_rel = t.eval_on_video(model, paths, DEV, ["f%d" % i for i in range(len(frames))], table, 0, 0, 0)
+            out["tester.%s.scores" % tag] = np.array([scene_q, w_mse, w_rel], dtype=np.float64)
+            for i, im in enumerate(ldrs):
+                out["tester.%s.ldr%d.shape" % (tag, i)] = np.array(im.shape, dtype=np.int64)
+                out["tester.%s.ldr%d.sum" % (tag, i)] = np.int64(im.astype(np.int64).sum())
+                pos = np.minimum((synth.hash_uniform("samp:tester%d" % i, 8192).astype(np.float64) * im.size).astype(np.int64), im.size - 1)
+                out["tester.%s.ldr%d.pos" % (tag, i)], out["tester.%s.ldr%d.val" % (tag, i)] = pos, im.reshape(-1)[pos]
+            print("captured tester", tag, scene_q, w_mse, w_rel, flush=True)
+    finally:
+        del torch.Tensor.cuda
+
+
 def main():
     which = sys.argv[1:] or ["generator", "generator_inorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
-                             "inference", "tmqi", "loader", "patchd_grad"]
+                             "inference", "tmqi", "loader", "patchd_grad", "tester"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
             "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "vid_c4": lambda o: capture_step_c4(o),
             "generator_inorm": lambda o: capture_generator_inorm(o), "loader": lambda o: capture_loader(o),
             "tiler": lambda o: capture_tiler(o), "patchd_grad": lambda o: capture_patchd_grad(o),
-            "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o)}
+            "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o), "tester": lambda o: capture_tester(o)}
     for name in which:
         out = {}
         jobs[name](out)

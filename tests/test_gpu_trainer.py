@@ -385,3 +385,41 @@ def test_overlapped_in_place_gradient_allreduce_matches_plain_step():
     finally:
         td.destroy_process_group()
         os.environ.pop("UNCL_FORCE_DIST", None)
+
+
+def test_step_graph_replay_equals_eager_steps():
+    """uncltmo_amd.step_graph.StepGraph: train_D + train_G captured once and replayed as one hipGraph launch.  In the
+    deterministic fp32 mode the parameters after warm-up + replays must be bit-identical to the same number of eager steps
+    (Adam's bias corrections come from the device-side step count, which every replay advances), the loss scalars of the last
+    step too, and the host-side bookkeeping (optimizer step counts, weight-pack epochs) must have followed the replays."""
+    from uncltmo_amd.step_graph import StepGraph
+    hdr, pos, neg = step_inputs()
+    tr_e, G_e, D_e = _fp32_trainer(False)
+    for _ in range(4):
+        tr_e.train_D(hdr, pos, neg, 0)
+        tr_e.train_G(hdr, hdr.clone(), pos, neg, 0)
+    tr_g, G_g, D_g = _fp32_trainer(False)
+    sg = StepGraph(tr_g, hdr, hdr.clone(), pos, neg, 0, warmup=2)
+    sg.replay()
+    sg.replay()
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(G_e.state_dict().items(), G_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    for (k, a), (_, b) in zip(D_e.state_dict().items(), D_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    for name in ("errD", "errG_d", "errG_struct"):
+        assert torch.equal(getattr(tr_e, name).detach(), getattr(tr_g, name).detach()), name
+    steps_e = sorted({int(st["step"]) for st in tr_e.optimizerG.state.values()})
+    steps_g = sorted({int(st["step"]) for st in tr_g.optimizerG.state.values()})
+    assert steps_e == steps_g == [4]
+    # a new batch through the static inputs, and an eager forward afterwards sees the replayed weights (pack epochs advanced)
+    hdr2 = hdr.flip(0).contiguous()
+    sg.load(hdr2, hdr2, pos, neg)
+    sg.replay()
+    tr_e.train_D(hdr2, pos, neg, 0)
+    tr_e.train_G(hdr2, hdr2.clone(), pos, neg, 0)
+    G_e.eval(); G_g.eval()
+    with torch.no_grad():
+        ye, _ = G_e(hdr2.reshape(-1, 1, 256, 256).float())
+        yg, _ = G_g(hdr2.reshape(-1, 1, 256, 256).float())
+    assert torch.equal(ye, yg)

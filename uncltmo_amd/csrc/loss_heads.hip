@@ -555,6 +555,30 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float lr, float 
   }
 }
 
+// The same update with lr and the step count read from DEVICE memory (hyper = [lr, step]: the caller advances `step` with a
+// device-side add before the launch): nothing of the launch depends on host state that changes from step to step, so a
+// captured optimisation step (hipGraph) replays with the right bias corrections.  bc1 / bc2s per thread: two powf, noise next
+// to the 28 bytes of memory traffic per element.
+__global__ __launch_bounds__(256) void adam_dev_kernel(AdamTable t, const float* __restrict__ hyper, float b1, float b2, float eps) {
+  const int ti = blockIdx.y;
+  if (ti >= t.count) return;
+  const float lr = hyper[0], step = hyper[1];
+  const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
+  float* p = t.p[ti];
+  const float* g = t.g[ti];
+  float* m = t.m[ti];
+  float* v = t.v[ti];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n[ti]; i += gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+
 }  // namespace
 
 extern "C" int uncl_cgan_loss(const float* real, const float* fake, int N, float w, float* loss, float* g_real, float* g_fake,
@@ -939,6 +963,28 @@ extern "C" int uncl_adam_step(void* const* params, void* const* grads, void* con
     }
     const int bx = (mx + 255) / 256 < 1024 ? (mx + 255) / 256 : 1024;
     hipLaunchKernelGGL(adam_kernel, dim3(bx, t.count), dim3(256), 0, st, t, lr, beta1, beta2, eps, bc1, bc2s);
+  }
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// hyper: DEVICE float[2] = {lr, step}; step >= 1 when the kernel runs (the caller adds 1 on the stream before this call)
+extern "C" int uncl_adam_step_dev(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                                  const int* numel, int count, const float* hyper, float beta1, float beta2, float eps, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !hyper || count <= 0) return UNCL_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < count; base += ADAM_MAX) {
+    AdamTable t;
+    t.count = count - base < ADAM_MAX ? count - base : ADAM_MAX;
+    int mx = 0;
+    for (int i = 0; i < t.count; ++i) {
+      t.p[i] = (float*)params[base + i]; t.g[i] = (const float*)grads[base + i];
+      t.m[i] = (float*)exp_avg[base + i]; t.v[i] = (float*)exp_avg_sq[base + i];
+      t.n[i] = numel[base + i];
+      if (t.n[i] > mx) mx = t.n[i];
+    }
+    const int bx = (mx + 255) / 256 < 1024 ? (mx + 255) / 256 : 1024;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(bx, t.count), dim3(256), 0, st, t, hyper, beta1, beta2, eps);
   }
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;

@@ -143,10 +143,21 @@ class DistributedOptimizer:
             module._grad_reducer = GradReducer()
 
     def synchronize(self):
-        """Make .grad of every parameter the mean over ranks (call before reading or clipping gradients; step() does)."""
+        """Make .grad of every parameter the mean over ranks (call before reading or clipping gradients; step() does).
+        An event pair brackets it on the compute stream: the time between them is what the step waited for the exchange --
+        collectives that the backward pass launched and that had not finished, plus the averaging (exposed_allreduce_ms)."""
+        ev = None
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        if params and params[0].is_cuda and td.is_available() and td.is_initialized():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         red = getattr(self.module, "_grad_reducer", None) if self.module is not None else None
         if red is None or not red.finish(list(self.module.named_parameters())):
-            allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]], self.bucket_bytes)
+            allreduce_gradients(params, self.bucket_bytes)
+        if ev is not None:
+            ev[1].record()
+            self.__dict__.setdefault("_sync_events", []).append(ev)
+            del self._sync_events[:-256]
 
     def step(self, *a, **k):
         self.synchronize()
@@ -160,3 +171,16 @@ class DistributedOptimizer:
 
     def __getattr__(self, name):
         return getattr(self.optimizer, name)
+
+
+def exposed_allreduce_ms(optimizers):
+    """Per step: milliseconds the compute stream spent inside DistributedOptimizer.synchronize() (summed over the given
+    optimizers, oldest step first).  Call after a device synchronisation; clears the record."""
+    per_opt = []
+    for o in optimizers:
+        evs = o.__dict__.get("_sync_events") or []
+        per_opt.append([a.elapsed_time(b) for a, b in evs])
+        if evs:
+            del evs[:]
+    n = min((len(v) for v in per_opt), default=0)
+    return [sum(v[len(v) - n + i] for v in per_opt) for i in range(n)]
