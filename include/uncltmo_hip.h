@@ -507,7 +507,8 @@ int uncl_hdr_log_gray(const float* rgb, int H, int W, float f_factor, float* rgb
  * utils/ProcessedDatasetFolder.py:43-236); the random choices stay on the host.
  * uncl_loader_resize_crop: src (H, W, 3) fp32 -> the patch x patch window at (yy, xx) of cv2.resize(src, (rw, rh)) (INTER_LINEAR;
  *   rh == H, rw == W: a copy) as color (3, patch, patch) and y_plane (patch, patch; NULL to skip) = y_scale * the Y row of
- *   cv2.cvtColor(RGB2YUV), 0.299 R + 0.587 G + 0.114 B ("bugy_max_normalization": y_scale = 1/255, :18-19).
+ *   cv2.cvtColor(RGB2YUV), 0.299 R + 0.587 G + 0.114 B; y_scale < 0 DIVIDES by -y_scale ("bugy_max_normalization":
+ *   y_scale = -255, the reference's `/ 255` at :18-19 -- a division, not a multiplication by 1/255).
  * uncl_loader_gray_outputs: gray_norm = Y / Y.max(), gray_shift = Y - Y.min() from the stats uncl_hdr_log_gray wrote (:137-144).
  * uncl_loader_ldr_normalize: "max_normalization" (mode 0) / "stretch" (mode 1) of get_ldr_im (:15-24), in place. */
 int uncl_loader_resize_crop(const float* src_hwc, int H, int W, int rh, int rw, int yy, int xx, int patch, float y_scale,

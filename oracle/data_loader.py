@@ -29,7 +29,7 @@ def frame(arr, draw, hdr, normalization="bugy_max_normalization", max_stretch=1.
     if not hdr:
         y = ((color[..., 0] * f32(0.299) + color[..., 1] * f32(0.587)) + color[..., 2] * f32(0.114)).astype(f32)
         if normalization == "bugy_max_normalization":
-            y = y * f32(1.0 / 255)        # the kernel multiplies by the rounded reciprocal
+            y = (y / f32(255)).astype(f32)   # ProcessedDatasetFolder.py:18-19: a division
         elif normalization == "max_normalization":
             y = y / y.max()
         elif normalization == "stretch":

@@ -60,3 +60,25 @@ def test_more_gpus_than_visible_is_refused():
                        text=True, timeout=300)
     assert p.returncode == 2
     assert "refusing" in p.stderr and not _json_lines(p.stdout)
+
+
+def test_visible_gpu_count_reads_sysfs_not_the_runtime(tmp_path, monkeypatch):
+    """bench.visible_gpu_count: KFD topology nodes with SIMDs, cut down by the *_VISIBLE_DEVICES lists -- the launcher parent
+    must be able to refuse `--gpus N` without initialising HIP (VERDICT r2 weak #4)."""
+    import builtins
+    import bench
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 256, 256, 256]):              # two CPU nodes, three GPUs
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    real_listdir, real_open = os.listdir, builtins.open
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    monkeypatch.setattr(os, "listdir", lambda p: real_listdir(str(nodes)) if p == base else real_listdir(p))
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace(base, str(nodes)), *a, **k))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count() == 1

@@ -221,3 +221,55 @@ def test_loader_hdr_branch_oracle_vs_reference_golden(golden):
     check_summary(torch.from_numpy(out["gray_norm"]), g, "loader.hdr.frame0.gray_norm", rtol=2e-6, atol=1e-7)
     check_summary(torch.from_numpy(out["gray"]), g, "loader.hdr.frame0.gray", rtol=2e-6, atol=1e-4)
     check_summary(torch.from_numpy(out["color"]), g, "loader.hdr.frame0.color", rtol=0, atol=0)
+
+
+def clip_inputs():
+    """the frames of tests/golden/make_golden.py:tester_inputs (same hash generator)"""
+    base = synth.smooth_hdr_frames(1, 300, 340, salt="tst_base")[0, 0].numpy().astype(np.float32)
+    frames = []
+    for t in range(3):
+        tex = synth.hash_uniform("tst_f%d" % t, 300 * 340 * 3).reshape(300, 340, 3).astype(np.float32)
+        frames.append(((base[:, :, None] * (1.0 + 0.1 * t)) ** 3 * 40.0 * (0.7 + 0.3 * tex)).astype(np.float32))
+    return frames, 0.5
+
+
+def clip_standin(p, apply_crop=True, diffY=0, diffX=0):
+    c = p.clamp_min(0) ** 0.6
+    prev = torch.cat([c[:, :1], c[:, :-1]], 1)
+    return 0.05 + 0.75 * c + 0.15 * prev, None
+
+
+def check_ldr_frames(results, g, tag, max_bad=0.0):
+    for i, im in enumerate(results):
+        im = np.asarray(im)
+        assert tuple(im.shape) == tuple(g["tester.%s.ldr%d.shape" % (tag, i)])
+        bad = (im.reshape(-1)[g["tester.%s.ldr%d.pos" % (tag, i)]].astype(np.int64) - g["tester.%s.ldr%d.val" % (tag, i)].astype(np.int64))
+        assert np.abs(bad).max() <= (0 if max_bad == 0.0 else 1), (tag, i, np.abs(bad).max())
+        assert (bad != 0).mean() <= max_bad, (tag, i, (bad != 0).mean())
+        if max_bad == 0.0:
+            assert int(im.astype(np.int64).sum()) == int(g["tester.%s.ldr%d.sum" % (tag, i)])
+
+
+def test_tester_eval_on_video_oracle_vs_reference_golden(golden, sdG):
+    """oracle/tester.py against the fixture captured through the reference's own Tester.eval_on_video (Tester.py:314-391): the
+    8-bit frames bit for bit, the warp errors, and -- with the structure-preserving stand-in generator -- the scene's TMQI."""
+    from oracle import tester as OTS
+    import oracle.tester
+    g = golden("tester")
+    frames, lam = clip_inputs()
+    f_factor = float(g["tester.f_factor"][0])
+    assert f_factor == lam * 255 * 0.1
+    ident = lambda f1, f0: f1
+    # stand-in generator: monkey-patch the oracle's model call through its tiler hook
+    orig = oracle.tester.unet_video_forward
+    try:
+        oracle.tester.unet_video_forward = lambda sd, x: clip_standin(x)
+        scene, res, scores, mse, rel = OTS.eval_on_video(None, frames, f_factor, align=ident)
+    finally:
+        oracle.tester.unet_video_forward = orig
+    check_ldr_frames(res, g, "tone")
+    np.testing.assert_allclose([scene, mse, rel], g["tester.tone.scores"], rtol=1e-6)
+    scene, res, scores, mse, rel = OTS.eval_on_video(sdG, frames, f_factor, align=ident)
+    check_ldr_frames(res, g, "G")
+    assert np.isnan(scene) and np.isnan(g["tester.G.scores"][0])     # the reference's own TMQI is NaN on this pairing (fixture note)
+    np.testing.assert_allclose([mse, rel], g["tester.G.scores"][1:], rtol=1e-6)

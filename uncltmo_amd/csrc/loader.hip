@@ -53,7 +53,12 @@ __global__ __launch_bounds__(256) void loader_resize_crop_kernel(const float* __
       }
     }
     color[i] = c[0]; color[total + i] = c[1]; color[2 * total + i] = c[2];
-    if (y_out) y_out[i] = (c[0] * 0.299f + c[1] * 0.587f + c[2] * 0.114f) * y_scale;
+    // y_scale < 0: DIVIDE by -y_scale (the reference's `/ 255`, ProcessedDatasetFolder.py:18-19, is a division: multiplying
+    // by 1/255 differs from it in the last bit of some values)
+    if (y_out) {
+      const float yv = c[0] * 0.299f + c[1] * 0.587f + c[2] * 0.114f;
+      y_out[i] = y_scale < 0.f ? __fdiv_rn(yv, -y_scale) : yv * y_scale;
+    }
   }
 }
 

@@ -71,7 +71,7 @@ def npy_loader(path, addFrame, hdrMode, ldrNegMode, normalization, min_stretch, 
         # the LDR-negative branch always draws a mode; the other branch only for inputs that are not already 256 high
         draw = _draw(h, w, always=bool(ldrNegMode))
         if not hdrMode or ldrNegMode:
-            y_scale = 1.0 / 255 if normalization == "bugy_max_normalization" else 1.0
+            y_scale = -255.0 if normalization == "bugy_max_normalization" else 1.0      # negative: divide (the reference's `/ 255`)
             color, y = _frame(src, h, w, draw, y_scale, True)
             if normalization in ("max_normalization", "stretch"):
                 ws = torch.empty(2050, dtype=torch.float32, device=src.device)

@@ -69,6 +69,9 @@ class _NceFn(torch.autograd.Function):
         lib = _hip.lib()
         n = anchor.shape[0]
         E = anchor.numel() // n
+        if anchor.dtype not in (torch.bfloat16, torch.float32):
+            # the kernels read bf16 or fp32 elements: anything else (fp16 is an accepted INFERENCE dtype) would be read as fp32
+            raise TypeError("uncltmo_amd nce: features must be bfloat16 or float32, got %s" % anchor.dtype)
         code = _hip.BF16 if anchor.dtype == torch.bfloat16 else _hip.F32
         a, perm = _dense(anchor.detach())
         if perm is None:

@@ -61,9 +61,14 @@ class GanTrainer:
         optimiser states; the nets go back to train mode.  `path` defaults to opt.models_save_path-style attribute
         `checkpoint_path`; like the reference this is a no-op unless `isCheckpoint` is set (or a path is given)."""
         from . import model_factory
-        path = path or getattr(self, "checkpoint_path", None)
-        if path is None or not (getattr(self, "isCheckpoint", False) or path):
-            return
+        # the reference loads only under `if self.isCheckpoint` (GanTrainerImg.py:484-493): a configured default path alone
+        # must not resume; an explicit `path` argument is the caller asking for it
+        if path is None:
+            if not getattr(self, "isCheckpoint", False):
+                return
+            path = getattr(self, "checkpoint_path", None)
+            if path is None:
+                return
         self.epoch = model_factory.load_checkpoint(path, self.device, self.netG, self.optimizerG, self.netD, self.optimizerD)
         self.netD.train()
         self.netG.train()
