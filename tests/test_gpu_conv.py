@@ -444,9 +444,11 @@ def test_pc_plain_layers_bitwise(cin, cout, h, w, n, pad, pool, act):
 @pytest.mark.parametrize("cin,h,w,n,skip,act1", [(32, 30, 45, 2, False, _hip.ACT_SIGMOID), (32, 126, 126, 2, True, _hip.ACT_SIGMOID),
                                                  (64, 40, 70, 2, True, _hip.ACT_TANH), (32, 17, 33, 3, False, _hip.ACT_NONE)])
 def test_pc_fused_outc_tail_bitwise(cin, h, w, n, skip, act1):
-    """The fused 1x1 tail (outconv + last activation) under both kernel structures: the producer / consumer kernel chains the 32
-    rounded channels through the two half-waves in channel order, which must reproduce the four-wave kernel's sum exactly --
-    with the 32-channel map stored (training) and skipped (inference)."""
+    """The fused 1x1 tail (outconv + last activation) under both kernel structures, with the 32-channel map stored (training) and
+    skipped (inference).  The 32-channel map is bit-identical; the 1-channel map is the same 32 products of the same ROUNDED
+    channels summed in a different order (four-wave kernel, the default for this layer: one channel-order chain; producer /
+    consumer kernel, set_pc(3): 16 products per lane, then the two half-waves; same-box A/B 0.325 vs 0.330 ms, so the default stays) -- equal to fp32 reassociation, 1e-6, and both within the stated bf16
+    tolerance of the torch reference."""
     x, wt, b = q(rnd(n, cin, h, w, seed=261), BF), q(rnd(cin, 32, 3, 3, seed=262, scale=0.1), BF), rnd(32, seed=263)
     w1, b1 = rnd(32, seed=264).cuda(), rnd(1, seed=265).cuda()
     xd, wd, bd = to_nhwc(x, BF), pack_weight(wt, BF, transposed=True, flip=True), b.cuda()
@@ -460,7 +462,7 @@ def test_pc_fused_outc_tail_bitwise(cin, h, w, n, skip, act1):
         return out, out1
 
     (ro, r1), (go, g1) = _both_structures(run, pc=3)       # 3: the producer / consumer kernel takes the fused tail as well
-    assert torch.equal(r1, g1)
+    assert (r1 - g1).abs().max().item() < 2e-6 * max(1.0, r1.abs().max().item())
     if not skip:
         assert torch.equal(ro, go)
     up = F.relu(F.conv_transpose2d(x, wt, b))

@@ -481,8 +481,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     // num_records = its bytes) replaces both: a store's offset is "lane offset + row offset", where an out-of-image column or
     // row contributes 2^30, i.e. lands beyond num_records and is dropped by the hardware (every sample is < 1 GiB: launcher).
     typedef unsigned u32x4l __attribute__((ext_vector_type(4)));
-    auto epilogue_lean = [&](const TileCur& c, int tp, auto pool_tag) __attribute__((always_inline)) {
+    // OUT1 (32-channel tiles): the fused 1x1 tail (outconv + last activation, unet_parts.py:338-345) on the ROUNDED, activated
+    // channels: after the widening a lane holds eight consecutive channels of its pixel, the other half-wave the other eight of
+    // the same sixteen; each lane accumulates its 16 products (8 per channel group qp) and the two half-waves are added once
+    // per row.  1: also store the 32-channel map; 2: only the 1-channel map (inference does not need up_x).
+    auto epilogue_lean = [&](const TileCur& c, int tp, auto pool_tag, auto out1_tag) __attribute__((always_inline)) {
       constexpr bool POOL = decltype(pool_tag)::value != 0;
+      constexpr int OUT1 = decltype(out1_tag)::value;
+      static_assert(OUT1 == 0 || !POOL, "the fused 1x1 tail has no pooled copy");
       constexpr unsigned BAD = 0x40000000u;
       const float* sBt = sBias + tp * CT;
       const int y0 = c.ty * TH + cw * MPW, x0 = c.tx * TW, co = c.ct * CT;
@@ -531,6 +537,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           const int gy = (c.ty * TH >> 1) + cw * (MPW / 2) + pr;
           pvoff = ploff + (((unsigned)gy * prowb) | (gy < a.pH ? 0u : BAD));
         }
+        float dot[2] = {0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -542,7 +549,18 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
             for (int r = 0; r < 2; ++r) {
               const int m = 2 * pr + r;
               wv[r] = widen_relu(pack4(acc[m][nt], 2 * qp, b0), pack4(acc[m][nt], 2 * qp + 1, b1));
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, 0);
+              if (OUT1 != 2)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, 0);
+              if (OUT1 != 0) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh + 4);
+                float f[8];
+                E::unpack(__builtin_bit_cast(vec, wv[r]), f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dot[r] = fmaf(f[i], w0[i], dot[r]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dot[r] = fmaf(f[4 + i], w1[i], dot[r]);
+              }
             }
             if (POOL) {
               // MaxPool2d(2) of the two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
@@ -558,13 +576,24 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, v), prs, pvoff + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, 0);
             }
           }
+        if (OUT1 != 0) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int oy = y0 + 2 * pr + r;
+            const float tot = dot[r] + __shfl_xor(dot[r], 32, 64) + sO1[32];
+            if (lh == 0 && oy < a.Hout && ox < a.Wout) a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act);
+          }
+        }
       }
     };
-    const bool lean = fast_relu && a.out1_w == nullptr && !a.skip_main && a.lean;      // wave-uniform
+    const bool lean = fast_relu && a.lean && (NT == 1 || a.out1_w == nullptr);      // wave-uniform
     auto run_epilogue = [&](const TileCur& c, int tp) __attribute__((always_inline)) {
       if (lean) {
-        if (a.pool_out != nullptr) epilogue_lean(c, tp, IntTag<1>{});
-        else epilogue_lean(c, tp, IntTag<0>{});
+        if (NT == 1 && a.out1_w != nullptr) {
+          if (a.skip_main) epilogue_lean(c, tp, IntTag<0>{}, IntTag<NT == 1 ? 2 : 0>{});
+          else epilogue_lean(c, tp, IntTag<0>{}, IntTag<NT == 1 ? 1 : 0>{});
+        } else if (a.pool_out != nullptr) epilogue_lean(c, tp, IntTag<1>{}, IntTag<0>{});
+        else epilogue_lean(c, tp, IntTag<0>{}, IntTag<0>{});
       } else if (fast_relu) epilogue_fast(c, tp, IntTag<0>{});
       else if (fast_grad) epilogue_fast(c, tp, IntTag<1>{});
       else if (a.slope == 0.f) epilogue(c, tp, IntTag<0>{});
