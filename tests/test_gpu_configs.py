@@ -98,15 +98,35 @@ def test_c3_image_step_n32_vs_oracle():
     tr.train_G(hdr.cuda(), hdr.cuda().clone(), pos.cuda(), neg.cuda(), 0)
     np.testing.assert_allclose(tr.errG_d.item(), errGd_o.item(), rtol=3e-2)
     np.testing.assert_allclose(tr.errG_struct.item(), errGs_o.item(), rtol=2e-2)
-    bad = {}
+    # bf16 activations and activation gradients end to end: the error grows with the depth of the backward path, so the gate
+    # is per LEVEL of the network (a regression in one decoder level cannot hide under the encoder's bound).  Bounds = 1.5 x
+    # the worst tensor of the level measured at round 3 (printed with -s), rounded up.
+    def level(k):
+        if k == "gcn.pos_embed":
+            return k
+        parts = k.split(".")
+        return ".".join(parts[:2]) if parts[0] in ("down_path", "up_path") else parts[0]
+
+    BOUND = C3_LEVEL_BOUNDS
+    worst = {}
     for k, p in G.named_parameters():
         if p.grad is None:              # the fixed relative_pos table
             continue
-        ref = want["grad_total"][k]
-        r = _rel(p.grad.cpu(), ref)
-        if r > (0.35 if k == "gcn.pos_embed" else 0.12):      # bf16 activations and activation gradients end to end
-            bad[k] = r
+        r = _rel(p.grad.cpu(), want["grad_total"][k])
+        lv = level(k)
+        if r > worst.get(lv, (0.0, ""))[0]:
+            worst[lv] = (r, k)
+    print("C3 bf16 gradient rel-L2, worst tensor per level:", {lv: round(v[0], 4) for lv, v in sorted(worst.items())})
+    bad = {lv: v for lv, v in worst.items() if v[0] > BOUND[lv]}
     assert not bad, bad
+    assert set(worst) == set(BOUND)
+
+
+# per-level gates of test_c3_*: 1.5 x the measured worst tensor of the level, rounded up
+C3_LEVEL_BOUNDS = {"inc": 0.055, "down_path.0": 0.075, "down_path.1": 0.12, "down_path.2": 0.13, "down_path.3": 0.05, "gcn": 0.05,
+                   "gcn.pos_embed": 0.2, "up_path.0": 0.05, "up_path.1": 0.07, "up_path.2": 0.065, "up_path.3": 0.05, "outc": 0.07}
+# measured (round 3, MI355X): inc 0.034, down_path.0 0.049, .1 0.080, .2 0.084, .3 0.032, gcn 0.031, gcn.pos_embed 0.134,
+# up_path.0 0.033, .1 0.046, .2 0.042, .3 0.031, outc 0.046
 
 
 def c4_inputs():

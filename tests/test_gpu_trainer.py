@@ -300,11 +300,11 @@ def test_fp32_step_vs_reference_golden_and_oracle(golden, video, epoch):
     # have condition numbers of 1e5 ... 1e6 (the sqrt(x2 + 1e-8) skip operator on ReLU outputs, arg-max selections).  That is
     # measured here, not assumed: the oracle is run a second time with every weight moved by at most ONE fp32 ulp
     # (w * (1 + 6e-8 u)); a tensor whose reference gradient moves by s under that perturbation cannot be pinned tighter than s
-    # by any fp32 implementation, so its gate is max(1e-3, 3 s) (s is a one-sample estimate of a random response).
+    # by any fp32 implementation, so its gate is max(floor, 3 s), s = the largest response over three perturbation seeds.
     def oracle_grads(perturb):
         sdG = synth_state(state_spec.generator_spec(), "g0")
         if perturb:
-            gen = torch.Generator().manual_seed(1)
+            gen = torch.Generator().manual_seed(perturb)
             sdG = {k: (v * (1 + 6e-8 * (2 * torch.rand(v.shape, generator=gen) - 1))).float()
                    if not k.endswith("relative_pos") else v for k, v in sdG.items()}
         st_ = OTR.StepState(sdG, synth_state(state_spec.simple_d_spec(), "d0"), video=video)
@@ -313,14 +313,16 @@ def test_fp32_step_vs_reference_golden_and_oracle(golden, video, epoch):
         OTR.train_g(st_, hdr.cpu(), pos.cpu(), neg.cpu(), epoch, training=False, want=want_)
         return st_, want_
 
-    st, want = oracle_grads(False)
-    _, want_p = oracle_grads(True)
+    st, want = oracle_grads(0)
+    # three independent one-ulp perturbations, the LARGEST response per tensor: one sample of a random response under-states it
+    # for some tensors and over-states it for others
+    perturbed = [oracle_grads(seed)[1] for seed in (1, 2, 3)]
     bad, tight = {}, 0
     for k, p in G.named_parameters():
         if p.grad is None:
             continue
         ref = want["grad_total"][k].double()
-        sens = ((want_p["grad_total"][k].double() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        sens = max(((wp["grad_total"][k].double() - ref).norm() / ref.norm().clamp_min(1e-30)).item() for wp in perturbed)
         r = ((p.grad.double().cpu() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
         tight += r <= 1e-3
         # floor 2e-3 (clips: 3e-3): the deepest encoder tensors sit at 1.1 - 1.4e-3 (s ~ 4e-4).  pos_embed's gradient is an

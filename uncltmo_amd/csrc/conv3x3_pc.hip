@@ -36,6 +36,10 @@
 #ifndef UNCL_PC_XA_SLOT
 #define UNCL_PC_XA_SLOT (MODE == 4 ? 3 : 1)
 #endif
+// cache-policy bits of the straight-line epilogue's buffer stores (0 default, 2 = nt: streaming)
+#ifndef UNCL_PC_STORE_AUX
+#define UNCL_PC_STORE_AUX 0
+#endif
 #ifndef UNCL_PC_LEAN_DEFAULT
 #define UNCL_PC_LEAN_DEFAULT 1
 #endif
@@ -550,7 +554,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
               const int m = 2 * pr + r;
               wv[r] = widen_relu(pack4(acc[m][nt], 2 * qp, b0), pack4(acc[m][nt], 2 * qp + 1, b1));
               if (OUT1 != 2)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, UNCL_PC_STORE_AUX);
               if (OUT1 != 0) {
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh);
                 const f32x4 w1 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh + 4);
@@ -573,7 +577,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
               // (the odd lanes hold the same maxima: masked off by EXEC rather than by offset, so that the memory pipeline
               // sees a 32-lane store)
               if ((lr & 1) == 0)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, v), prs, pvoff + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, v), prs, pvoff + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, UNCL_PC_STORE_AUX);
             }
           }
         if (OUT1 != 0) {
@@ -620,6 +624,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     for (int t = tile0; t < tile_end; ++t) {
       for (int kc = 0; kc < a.nk - 1; ++kc) {
         mfma_cols_0_4(stage_x(s), stage_w(s, kc));
+        PCT_K(0, kc & 3)
         __builtin_amdgcn_sched_barrier(0);
         pc_barrier();   // (waits for lgkmcnt(0): column 5's fragments) done with stage s & 1; stage (s + 1) & 1 is staged
         __builtin_amdgcn_sched_barrier(0);
