@@ -53,6 +53,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_row0_base, int pix0, i
   return out;
 }
 
+// The same fragment from a PLANE layout (plane s = channels 8s .. 8s+7 of every pixel, 16 bytes per pixel, planes padded to
+// 4 (mod 16) slots so that the four planes a 16-lane group touches sit in distinct bank ranges): the address is a per-lane base
+// (computed once per kernel) plus a compile-time pixel offset -- no per-read address arithmetic.  The swizzled layout above
+// costs ~8 vector instructions per transposed read (the XOR depends on the pixel), 8 per MFMA in the 3x3 kernel's inner loop,
+// on the issue port the MFMAs share.
+__device__ __forceinline__ bf16x8 tr_frag_plane(const char* lane_base, int pix_off_bytes) {
+  bf16x8 out;
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lane_base + pix_off_bytes + rd * 64));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[4 * rd + i] = __builtin_bit_cast(bf16_t, (short)v[i]);
+  }
+  return out;
+}
+constexpr int wg_plane(int rows) { return (rows + ((4 - rows % 16) + 16) % 16) * 16; }
+
 // MODE: 0 plain, 1 concat-ssr.  KS: 3 (three horizontal taps per workgroup) or 1
 template <int MODE, int KS>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
@@ -222,9 +239,10 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
   constexpr int TH = 16, TW = 32, XH = TH + 2, XW = TW + 2;
   constexpr int NX = XH * XW, NG = TH * TW, NT = 384, PP = NT / 4;   // PP pixels staged per pass
   constexpr int XV = (NX + PP - 1) / PP, GV = (NG + PP - 1) / PP;
+  constexpr int XPLB = wg_plane(NX), GPLB = wg_plane(NG);     // bytes per plane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
-  char* sG = smem + NX * 64;
+  char* sG = smem + 4 * XPLB;
   float* sR = reinterpret_cast<float*>(smem);  // [9][32][32] cross-wave reduction (after the loop)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -304,13 +322,13 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
         v = E::pack(f);
       }
       if (!((xvalid >> j) & 1u)) v = E::zero();
-      *reinterpret_cast<vec*>(sX + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = v;
+      *reinterpret_cast<vec*>(sX + ch * XPLB + pix * 16) = v;
     }
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
       const int pix = p0 + j * PP;
       if (pix >= NG) continue;
-      *reinterpret_cast<vec*>(sG + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = gr[j];
+      *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
     }
   };
 
@@ -322,6 +340,12 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
 
   const int grp = lane >> 4;
   const int c0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
+  // per-lane fragment bases (see tr_frag_plane): 16-lane group -> channels c0.., pixels kb..; lane li -> pixel li >> 2 of the
+  // 4-pixel block, 16-byte slot (li & 3) >> 1, its lower / upper 8 bytes
+  const int li = lane & 15;
+  const int frag_lane = (li >> 2) * 16 + ((li & 1) << 3);
+  const char* lbG = sG + ((c0 >> 3) + ((li & 3) >> 1)) * GPLB + (rh * 8 * TW + kb) * 16 + frag_lane;
+  const char* lbX = sX + ((c0 >> 3) + ((li & 3) >> 1)) * XPLB + ((rh * 8 + ty) * XW + kb) * 16 + frag_lane;
 
   load_tile(tile);
   write_lds();
@@ -329,15 +353,14 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
   while (true) {
     const bool more = tile + 1 < tile_end;
     if (more) load_tile(tile + 1);
-#pragma unroll 2
+#pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int row = rh * 8 + r;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const vec A = tr_frag(sG, row * TW + half * 16 + kb, c0, lane);
+        const vec A = tr_frag_plane(lbG, (r * TW + half * 16) * 16);
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
-          const vec B = tr_frag(sX, (row + ty) * XW + half * 16 + tx + kb, c0, lane);
+          const vec B = tr_frag_plane(lbX, (r * XW + half * 16 + tx) * 16);
           acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[tx], 0, 0, 0);
         }
       }
@@ -378,7 +401,7 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
 
 template <int MODE>
 int launch_wg3(WgArgs& a, hipStream_t s) {
-  constexpr size_t lds = (size_t)18 * 34 * 64 + 512 * 64;
+  constexpr size_t lds = 4 * (size_t)wg_plane(18 * 34) + 4 * (size_t)wg_plane(16 * 32);
   auto kern = wgrad3_kernel<MODE>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
