@@ -471,11 +471,18 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     for (int m = 0; m < MPW; ++m)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
+    // Accumulators are cleared by the matrix pipe itself: D = 0 x 0 + 0 (inline-zero C) is one instruction per accumulator,
+    // where sixteen v_mov each -- 64 / 128 per tile -- were 5 - 8 % of a short-K tile's time on a wave that is alone on its
+    // SIMD; the pipe idles during the epilogue anyway.  (The operand is made opaque so that the product is not folded back into
+    // moves; starting a tile's first MFMAs from an inline-zero C instead needs a second copy of every phase, and every
+    // formulation of that sent the register allocator into spills.)
     auto zero_acc = [&]() __attribute__((always_inline)) {
+      vec zv = E::zero();
+      asm volatile("" : "+v"(zv));
 #pragma unroll
       for (int m = 0; m < MPW; ++m)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma32x16(zv, zv, zero16);
     };
     // The plain forward store (bias + ReLU, optional pooled copy; no fused 1x1 tail) once more, as straight-line code.  A
     // multiplying wave is alone on its SIMD and the matrix pipe idles while it runs its epilogue, so the epilogue costs its
@@ -553,6 +560,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
             for (int r = 0; r < 2; ++r) {
               const int m = 2 * pr + r;
               wv[r] = widen_relu(pack4(acc[m][nt], 2 * qp, b0), pack4(acc[m][nt], 2 * qp + 1, b1));
+#if defined(UNCL_PC_TIMING) || defined(UNCL_PC_ABLATE)
+              // ablations (wrong results): 128 = no conversion arithmetic (the raw accumulator bits are stored), 64 = no stores
+              if (a.pc_prio & 128) wv[r] = __builtin_bit_cast(s16x8, f32x4{acc[m][nt][4 * qp], acc[m][nt][4 * qp + 1], acc[m][nt][4 * qp + 2], acc[m][nt][4 * qp + 3]});
+              if (a.pc_prio & 64) { asm volatile("" ::"v"(wv[r])); continue; }
+#endif
               if (OUT1 != 2)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, UNCL_PC_STORE_AUX);
               if (OUT1 != 0) {
