@@ -3,7 +3,9 @@
 //   dW[tap][co][ci] = sum over output pixels p of  gY[p][co] * X[p + tap][ci]
 //
 // The reduction runs over PIXELS, which is the strided dimension of both NHWC operands.  Both tiles are staged
-// into LDS in their natural [pixel][32 channels] (64-byte rows, XOR-swizzled 16-byte slots) and read back with
+// into LDS in their natural [pixel][32 channels] order -- the 1x1 / single-row forms as 64-byte rows with XOR-swizzled
+// 16-byte slots, the 3x3 form (wgrad3_kernel) as four PLANES of 16-byte slots (tr_frag_plane: one per-lane base, the tap /
+// row offsets are immediates, no swizzle arithmetic in the inner loop) -- and read back with
 // the transposing LDS read of CDNA4 (ds_read_b64_tr_b16): a 16-lane group fetches a 4-pixel x 16-channel block and
 // each lane receives 4 consecutive pixels of ONE channel — exactly the K-contiguous fragment the 32x32x16 MFMA
 // wants (A = gY^T: rows = co, k = pixel; B = X: k = pixel, cols = ci).  Lane mapping verified on hardware.
