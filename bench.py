@@ -20,8 +20,12 @@ Extra objects on the JSON line:
                FLOPs per launch / mean launch duration measured with HIP events on the launch stream inside the timed steps.
   cpu_baseline the CPU oracle (a port, not the reference's own code) timed on this box's host cores on a bounded
                sample of the same workload (generator forward over 256^2 tiles), reported in the same unit.
-  train_step / train_video_step   BASELINE configs[2] / configs[3] measured after the headline region (same ranks, gradient
-               all-reduce over RCCL at N > 1): ms per step, frames/s and the generator's MFMA fraction in both FLOP conventions.
+  train_step / train_video_step   BASELINE configs[2] / configs[3] (gradient all-reduce over RCCL at N > 1): ms per step,
+               frames/s and the generator's MFMA fraction in both FLOP conventions.
+  leg_failures (N = 1, default run) the default single-GPU line is produced by THREE children, one per workload, started
+               before this process makes a GPU call (run_legs): a child that dies is run once more and every failed attempt is
+               listed here with its exit code and last stderr lines.  Under a launcher (WORLD_SIZE set), with --no-train, in
+               --mode train / train_video and with UNCL_BENCH_INPROC=1 everything runs in the one process, as before.
 """
 import argparse
 import ctypes
@@ -84,6 +88,9 @@ def parse(argv=None):
     ap.add_argument("--no-exclusive", action="store_true",
                     help="skip the untimed single-stream pass that measures the dominant kernel alone (profiling runs: "
                          "keeps every launch of the trace in the product configuration)")
+    ap.add_argument("--leg", default=None, choices=["forward", "train_step", "train_video_step"],
+                    help="(set by bench.py itself) run ONE leg of the default single-GPU line in this process and print its JSON: "
+                         "the default run starts each leg as a child of its own, see run_legs()")
     ap.add_argument("--stub", action="store_true",
                     help="CPU self-test of the launcher and the JSON contract: gloo backend, the step is a small host matmul, "
                          "no GPU and no HIP library are touched (tests/test_bench_launcher.py)")
@@ -157,6 +164,62 @@ def launch(a, argv):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# default single-GPU run: one child process per leg
+# ---------------------------------------------------------------------------------------------------------------------
+def _leg_command(argv, leg):
+    return [sys.executable, os.path.abspath(__file__)] + list(argv) + ["--leg", leg]
+
+
+def _last_json(text):
+    for ln in reversed(text.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def run_legs(argv, legs=("train_step", "train_video_step", "forward"), attempts=2):
+    """The default line carries three workloads (forward = the headline, train_step, train_video_step).  Each runs in a child of
+    its own, started before this process has made any GPU call (like launch()): the three do not share an allocator history, and
+    a leg that dies (round 3 saw ONE GPU memory fault in ~50 whole-bench runs, in a training leg, never reproduced under the
+    uncached allocator, poisoned free memory or 40 repeats -- DESIGN.md) costs that leg one retry instead of the whole line.
+    Every failed attempt is reported in the line's `leg_failures`; nothing is hidden and nothing is measured twice."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    deadline = time.time() + float(os.environ.get("UNCL_BENCH_TIMEOUT", "1500"))
+    got, failures = {}, []
+    for leg in legs:
+        for attempt in range(1, attempts + 1):
+            try:
+                p = subprocess.run(_leg_command(argv, leg), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   timeout=max(1.0, deadline - time.time()))
+                rc, out, err = p.returncode, p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+            except subprocess.TimeoutExpired as e:
+                rc, out, err = 124, (e.stdout or b"").decode(errors="replace"), (e.stderr or b"").decode(errors="replace")
+            sys.stderr.write(err)
+            doc = _last_json(out)
+            if rc == 0 and doc is not None:
+                got[leg] = doc
+                break
+            failures.append({"leg": leg, "attempt": attempt, "rc": rc,
+                             "stderr_tail": [l for l in err.splitlines() if "amdgpu.ids" not in l][-3:]})
+    line = got.get("forward")
+    if line is None:
+        sys.stderr.write("bench.py: the forward leg produced no line\n")
+        return 1
+    for leg in legs:
+        if leg != "forward":
+            line[leg] = got.get(leg, {"error": "leg failed %d times, see leg_failures" % attempts})
+    line["leg_failures"] = failures
+    line["legs"] = "one process per leg (forward, train_step, train_video_step), started by bench.py before any GPU call"
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------------------------
 def _flush_c_stdio():
@@ -165,6 +228,12 @@ def _flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+
+
+def trace(msg):
+    """UNCL_BENCH_TRACE=1: leg markers on stderr (which leg a crash belongs to); stdout stays the one JSON line"""
+    if os.environ.get("UNCL_BENCH_TRACE"):
+        print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
 def pmc_traffic(dtype):
@@ -391,12 +460,20 @@ def train_numbers(a, rk, video, steps, warmup):
     (round 2: 8.4 ms here, 17.5 ms on the driver's box) can be told apart: a stall in one step, a host-bound step, or a slow GPU."""
     import gc
     import torch
+    if os.environ.get("UNCL_POISON_GB"):          # debug: unwritten workspace memory reads as 0x7F bytes, not as zeros
+        from uncltmo_amd.debug_poison import poison_free_memory
+        poison_free_memory()
+    trace("train leg (video=%s): building the trainer" % video)
     tr, step, n = make_trainer(rk, video)
+    trace("trainer ready, graph=%s; warm-up" % (getattr(tr, "_step_graph", None) is not None))
     for _ in range(warmup):
         step()
+    torch.cuda.synchronize()
+    trace("timed steps")
     st0 = torch.cuda.memory_stats()
     gc0 = [g["collections"] for g in gc.get_stats()]
     dt, per_rank, dev_ms, host_ms = rk.timed_steps(step, steps)
+    trace("timed steps done")
     gc1 = [g["collections"] for g in gc.get_stats()]
     st1 = torch.cuda.memory_stats()
     dev_allocs = st1.get("num_device_alloc", 0) - st0.get("num_device_alloc", 0)
@@ -508,6 +585,7 @@ def infer_bench(a, rk):
         step()
     lib.uncl_prof_enable(DOM_LAYER, max(64, 2 * a.steps + 16))
     dt, per_rank, out = rk.timed(step, a.steps, 0)
+    trace("forward timed")
     # per-launch durations of the dominant kernel, recorded by HIP events on the launch stream during the steps
     buf = (ctypes.c_float * 4096)()
     nrec = lib.uncl_prof_read(buf, 4096)
@@ -552,6 +630,7 @@ def infer_bench(a, rk):
         lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "2")))
     lib.uncl_prof_enable(-1, 0)
     assert torch.isfinite(out).all()
+    trace("exclusive / per-layer passes done")
 
     train = {}
     if not a.no_train and a.dtype == "bf16":
@@ -561,6 +640,7 @@ def infer_bench(a, rk):
         for key, video in (("train_step", False), ("train_video_step", True)):
             train[key], _, _ = train_numbers(a, rk, video, 30, 5)
             torch.cuda.empty_cache()
+            trace("%s done" % key)
 
     if rk.rank != 0:
         if rk.dist:
@@ -617,6 +697,9 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ:
         if a.gpus > 1:
             return launch(a, argv)
+        if (a.leg is None and not a.stub and a.mode == "infer" and not a.no_train and a.dtype == "bf16"
+                and os.environ.get("UNCL_BENCH_INPROC") != "1"):
+            return run_legs(argv)
     elif int(os.environ["WORLD_SIZE"]) != a.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; the launcher's world size is used\n"
                          % (a.gpus, os.environ["WORLD_SIZE"]))
@@ -628,9 +711,15 @@ def main(argv=None):
             from uncltmo_amd import _hip
             if os.environ.get("UNCL_STREAMS"):        # experiments: 1 = everything on the caller's stream
                 _hip.check(_hip.lib().uncl_gen_set_streams(int(os.environ["UNCL_STREAMS"])), "uncl_gen_set_streams")
-            if a.mode in ("train", "train_video"):
+            if a.leg in ("train_step", "train_video_step"):
+                nums, _, _ = train_numbers(a, rk, a.leg == "train_video_step", 30, 5)
+                _flush_c_stdio()
+                print(json.dumps(nums), flush=True)
+            elif a.mode in ("train", "train_video"):
                 train_bench(a, rk)
             else:
+                if a.leg == "forward":
+                    a.no_train = True
                 infer_bench(a, rk)
     finally:
         rk.close()

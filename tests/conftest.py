@@ -26,6 +26,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _poison_free_device_memory(request):
+    """UNCL_POISON_GB=8 python -m pytest tests -m gpu: every GPU test starts with the allocator's free memory full of 0x7F bytes
+    (uncltmo_amd/debug_poison.py), so that a read of unwritten workspace memory shows instead of seeing a fresh process's zeros"""
+    if os.environ.get("UNCL_POISON_GB") and "gpu" in request.keywords and torch.cuda.is_available():
+        from uncltmo_amd.debug_poison import poison_free_memory
+        poison_free_memory()
+    yield
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 

@@ -82,3 +82,43 @@ def test_visible_gpu_count_reads_sysfs_not_the_runtime(tmp_path, monkeypatch):
     assert bench.visible_gpu_count() == 2
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
     assert bench.visible_gpu_count() == 1
+
+
+def test_one_process_per_leg_retries_a_dead_leg_and_reports_it(tmp_path, monkeypatch, capsys):
+    """bench.run_legs: every leg of the default single-GPU line is a child of its own; a leg that dies is run once more and the
+    failed attempt is reported in `leg_failures`; a leg that dies twice leaves an error entry, the line is still printed."""
+    import json
+    import sys
+    import bench
+    marker = tmp_path / "first_attempt_done"
+    child = (
+        "import json, os, sys\n"
+        "leg = sys.argv[sys.argv.index('--leg') + 1]\n"
+        "if leg == 'train_step' and not os.path.exists(%r):\n"
+        "    open(%r, 'w').close(); sys.stderr.write('Memory access fault by GPU node-2\\n'); os._exit(134)\n"
+        "if leg == 'train_video_step':\n"
+        "    sys.exit(3)\n"
+        "print('banner line')\n"
+        "print(json.dumps({'metric': 'm', 'value': 1.0} if leg == 'forward' else {'ms_per_step': 8.0, 'leg': leg}))\n"
+    ) % (str(marker), str(marker))
+    monkeypatch.setattr(bench, "_leg_command", lambda argv, leg: [sys.executable, "-c", child] + list(argv) + ["--leg", leg])
+    assert bench.run_legs(["--steps", "2"]) == 0
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["metric"] == "m" and line["train_step"] == {"ms_per_step": 8.0, "leg": "train_step"}
+    assert "error" in line["train_video_step"]
+    fails = line["leg_failures"]
+    assert [(f["leg"], f["attempt"], f["rc"]) for f in fails] == [("train_step", 1, 134), ("train_video_step", 1, 3),
+                                                                   ("train_video_step", 2, 3)]
+    assert "Memory access fault" in fails[0]["stderr_tail"][-1]
+
+
+def test_leg_children_are_not_used_under_a_launcher_or_for_single_legs(monkeypatch):
+    import bench
+    called = []
+    monkeypatch.setattr(bench, "run_legs", lambda argv: called.append(argv) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main([]) == 0 and called == [[]]
+    # --no-train (profiling runs), a training mode of its own, another dtype and the CPU stub stay in this process
+    for argv in (["--stub"],):
+        called.clear()
+        assert bench.main(argv) == 0 and called == []

@@ -24,6 +24,13 @@ def main():
         for key, (val, n, us) in _demangled(read(os.path.join(base, "pmc_sq"), c)).items():
             e = per.setdefault(key, {"launches": n, "us": us})
             e[c] = val
+    # clock pass (its own run): GRBM_GUI_ACTIVE is summed over the 8 XCDs -> effective clock = count / 8 / launch time; reads
+    # high on launches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back)
+    if os.path.isdir(os.path.join(base, "pmc_clk")):
+        for key, (val, n, us) in _demangled(read(os.path.join(base, "pmc_clk"), "GRBM_GUI_ACTIVE")).items():
+            if key in per and us > 0:
+                per[key]["clk_ghz"] = val / 8.0 / (us * 1000.0)
+                per[key]["clk_us"] = us / max(n, 1)
     kernels = []
     for (name, grid), e in per.items():
         n = max(e["launches"], 1)
@@ -31,6 +38,9 @@ def main():
         for c in COUNTERS:
             if c in e:
                 k[c + "_per_launch"] = round(e[c] / n, 1)
+        if "clk_ghz" in e:
+            k["effective_clock_ghz"] = round(e["clk_ghz"], 3)
+            k["avg_us_in_clock_pass"] = round(e["clk_us"], 2)
         if e.get("SQ_INSTS_MFMA"):
             k["valu_per_mfma"] = round(e.get("SQ_INSTS_VALU", 0.0) / e["SQ_INSTS_MFMA"], 3)
             if e.get("SQ_BUSY_CYCLES"):
@@ -45,7 +55,8 @@ def main():
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path, len(kernels), "kernels")
     for k in kernels[:10]:
-        print("  %-90s %8.1f us  VALU/MFMA %s" % (k["kernel"][:90], k["avg_us"], k.get("valu_per_mfma")))
+        print("  %-90s %8.1f us  VALU/MFMA %s  clock %s GHz" % (k["kernel"][:90], k["avg_us"], k.get("valu_per_mfma"),
+                                                                k.get("effective_clock_ghz")))
 
 
 if __name__ == "__main__":

@@ -108,6 +108,44 @@ __device__ __forceinline__ bool cur_next(TileCur& c, const PipeArgs& a, int tile
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) computed by the
 //       producers (32 channels, same extent as the skip), 3 = the 32-channel source is act(conv3x3_valid(fp32 image)) rebuilt
 //       by the producers' matrix cores from the image patch under the halo tile (inc.conv.conv fused into inc.conv.conv1)
+#if defined(UNCL_PC_MFMA16_PROXY)
+// TIMING PROXY ONLY (tools/ab_variants.sh, never the product build): the same operand registers through two
+// v_mfma_f32_16x16x32 per 32x32x16 -- equal FLOP, equal LDS fragment reads, WRONG results -- to see what clock the chip holds on
+// the other shape before the fragment layouts are rebuilt for it (MI355X_MICROARCH.md, DVFS give-back item 7)
+__device__ __forceinline__ f32x4 mfma16x32_proxy(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16x32_proxy(const f16x8& a, const f16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+struct PcAcc {
+  f32x4 q[4];
+  __device__ __forceinline__ float operator[](int i) const { return q[i >> 2][i & 3]; }
+  __device__ __forceinline__ PcAcc& operator=(const f32x16& v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    return *this;
+  }
+};
+template <typename V>
+__device__ __forceinline__ PcAcc pc_mm(const V& a, const V& b, PcAcc c, int ty) {
+  const int j = 2 * (ty & 1);
+  c.q[j] = mfma16x32_proxy(a, b, c.q[j]);
+  c.q[j + 1] = mfma16x32_proxy(a, b, c.q[j + 1]);
+  return c;
+}
+template <typename V>
+__device__ __forceinline__ PcAcc pc_mm_zero(const V& z) {
+  PcAcc c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c.q[i] = mfma16x32_proxy(z, z, f32x4{0.f, 0.f, 0.f, 0.f});
+  return c;
+}
+#else
+typedef f32x16 PcAcc;
+template <typename V>
+__device__ __forceinline__ PcAcc pc_mm(const V& a, const V& b, const PcAcc& c, int) { return mfma32x16(a, b, c); }
+#endif
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
 __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_kernel(const PipeArgs a) {
   constexpr int NCW = 4;                      // multiplying waves
@@ -151,7 +189,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
     // =================================================================================================================
     const int cw = wave;                      // row block of the tile this wave owns
     if ((a.pc_prio & 3) == 1) __builtin_amdgcn_s_setprio(2);
-    f32x16 acc[MPW][NT];
+    PcAcc acc[MPW][NT];
     f32x16 zero16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
@@ -187,14 +225,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         for (int m = 0; m < MPW; ++m)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[m][nt] = mfma32x16(A[set][0][nt], B[set][m], acc[m][nt]);
+            acc[m][nt] = pc_mm(A[set][0][nt], B[set][m], acc[m][nt], 0);
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
 #pragma unroll
           for (int ty = 1; ty < 3; ++ty)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
+              acc[m][nt] = pc_mm(A[set][ty][nt], B[set][m + ty], acc[m][nt], ty);
       } else {
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
@@ -202,7 +240,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
           for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[m][nt] = mfma32x16(A[set][ty][nt], B[set][m + ty], acc[m][nt]);
+              acc[m][nt] = pc_mm(A[set][ty][nt], B[set][m + ty], acc[m][nt], ty);
       }
     };
     auto sched_reads_under_mfmas = [&]() __attribute__((always_inline)) {
@@ -240,7 +278,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[nt][q] = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 8 * q + 4 * lh);
-      auto act_pack = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
+      auto act_pack = [&](const PcAcc& v, int q, const f32x4& b) __attribute__((always_inline)) {
         vec4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -349,7 +387,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       const float* sBt = sBias + tpar * CT;
       const int y0 = c.ty * TH + cw * MPW, x0 = c.tx * TW, co = c.ct * CT;
       const int ox = x0 + lr;
-      auto pack4 = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
+      auto pack4 = [&](const PcAcc& v, int q, const f32x4& b) __attribute__((always_inline)) {
         const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
         const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
         vec4 o;
@@ -482,7 +520,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
 #pragma unroll
       for (int m = 0; m < MPW; ++m)
 #pragma unroll
+#if defined(UNCL_PC_MFMA16_PROXY)
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = pc_mm_zero(zv);
+#else
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma32x16(zv, zv, zero16);
+#endif
     };
     // The plain forward store (bias + ReLU, optional pooled copy; no fused 1x1 tail) once more, as straight-line code.  A
     // multiplying wave is alone on its SIMD and the matrix pipe idles while it runs its epilogue, so the epilogue costs its
@@ -519,7 +561,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
         ploff = ((unsigned)(gx * a.oC + co + 8 * lh) * 2u) | (gx < a.pW ? 0u : BAD);
         prowb = (unsigned)(a.pW * a.oC) * 2u;
       }
-      auto pack4 = [&](const f32x16& v, int q, const f32x4& b) __attribute__((always_inline)) {
+      auto pack4 = [&](const PcAcc& v, int q, const f32x4& b) __attribute__((always_inline)) {
         const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
         const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
         vec4 o;
