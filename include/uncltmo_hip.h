@@ -139,6 +139,11 @@ int uncl_upconv2x2_dt(const void* x, const void* prev, int prev_ch, const void* 
  * N, H, W, Cin, Cout, src0/src1 (+dims); gy: (N,Hout,Wout,Cout) bf16.  dw_packed is accumulated with float atomics:
  * zero it first.  Backward of the layers of uncl_conv3x3_pipe / the graph block's 1x1 convs. */
 int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* dw_packed, void* stream);
+/* 3x3 layers whose Cin and Cout are multiples of 64 can run a kernel that owns 64 x 64 channel blocks (whole 128-byte lines per
+ * pixel, half the bytes per MFMA, but four times the atomic traffic per pixel-range group): mode 1 (default) = the skip-concat
+ * layers, where it measured faster; 2 = every eligible layer; 0 = none (A/B runs and the tests that compare the two kernels).
+ * Returns the previous setting; env UNCL_WG_WIDE sets the initial one. */
+int uncl_wgrad_set_wide(int on);
 /* packed fp32 gradient -> reference layout (inverse of uncl_pack_conv_weight), written or accumulated */
 int uncl_unpack_conv_wgrad(const float* packed, float* dst, int Cout, int Cin, int k, int transposed, int flip,
                            int accumulate, void* stream);

@@ -482,3 +482,58 @@ def test_fp32_backward_is_deterministic():
         (y.sum() + 1e-3 * up.sum()).backward()
         runs.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
     assert all(torch.equal(runs[0][k], runs[1][k]) for k in runs[0])
+
+
+# ---- 64 x 64 channel-block weight gradient (wgrad3w_kernel): vs autograd, and vs the 32 x 32 kernel on the same inputs ----------
+@pytest.mark.parametrize("cin,cout,h,w,n,pad", [(64, 64, 61, 61, 3, 0), (128, 128, 30, 28, 5, 2), (256, 256, 12, 12, 9, 0),
+                                                (64, 128, 59, 61, 2, 0), (256, 64, 9, 70, 2, 2), (128, 256, 26, 26, 32, 0)])
+def test_wgrad3x3_wide_blocks(cin, cout, h, w, n, pad):
+    """8-row tiles (ragged last tile row, halo rows outside the image), many tiles per workgroup (n = 32), both paddings"""
+    lib = _hip.lib()
+    x = q(rnd(n, cin, h, w, seed=101))
+    if pad == 0:
+        wt = rnd(cout, cin, 3, 3, seed=102, scale=0.1).requires_grad_(True)
+        gy = q(rnd(n, cout, h - 2, w - 2, seed=103))
+        F.conv2d(x, wt).backward(gy)
+    else:
+        wt = rnd(cin, cout, 3, 3, seed=102, scale=0.1).requires_grad_(True)
+        gy = q(rnd(n, cout, h + 2, w + 2, seed=103))
+        F.conv_transpose2d(x, wt).backward(gy)
+    kw = dict(dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=to_nhwc(x, BF),
+              src0_H=h, src0_W=w, src0_C=cin)
+    got = {}
+    old = lib.uncl_wgrad_set_wide(2)
+    try:
+        for wide in (2, 0):       # 2: every eligible layer (plain sources are not on the wide kernel by default)
+            lib.uncl_wgrad_set_wide(wide)
+            got[wide] = unpack(wgrad(to_nhwc(gy, BF), (9, cout, cin), **kw), cout, cin, 3, pad == 2, pad == 2)
+    finally:
+        lib.uncl_wgrad_set_wide(old)
+    assert rel_l2(got[2], wt.grad) < 2e-3, rel_l2(got[2], wt.grad)
+    # same products, fp32 sums in another order
+    assert rel_l2(got[2], got[0]) < 2e-5, rel_l2(got[2], got[0])
+
+
+@pytest.mark.parametrize("c,cout,h,w,dy,dx", [(64, 64, 59, 59, 1, 1), (128, 128, 26, 26, 2, 2), (256, 128, 12, 13, 0, 1)])
+def test_wgrad3x3_wide_blocks_concat_ssr(c, cout, h, w, dy, dx):
+    """skip concat [x2, x1, x2^2, sqrt(x2+1e-8)] with a 64-channel chunk inside one member; the up-sampled operand smaller"""
+    lib = _hip.lib()
+    n = 3
+    x2, x1 = q(rnd(n, c, h, w, seed=111).abs()), q(rnd(n, c, h - dy, w - dx, seed=112))
+    x1p = F.pad(x1, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2), mode="replicate")
+    cat = torch.cat([x2, x1p, q(x2 ** 2), q((x2 + 1e-8) ** 0.5)], 1)
+    wt = rnd(4 * c, cout, 3, 3, seed=113, scale=0.05).requires_grad_(True)
+    gy = q(rnd(n, cout, h + 2, w + 2, seed=114))
+    F.conv_transpose2d(cat, wt).backward(gy)
+    kw = dict(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR, N=n, H=h, W=w, Cin=4 * c, Cout=cout,
+              src0=to_nhwc(x2, BF), src0_H=h, src0_W=w, src0_C=c, src1=to_nhwc(x1, BF), src1_H=h - dy, src1_W=w - dx, src1_C=c)
+    got = {}
+    old = lib.uncl_wgrad_set_wide(1)
+    try:
+        for wide in (1, 0):
+            lib.uncl_wgrad_set_wide(wide)
+            got[wide] = unpack(wgrad(to_nhwc(gy, BF), (9, cout, 4 * c), **kw), cout, 4 * c, 3, True, True)
+    finally:
+        lib.uncl_wgrad_set_wide(old)
+    assert rel_l2(got[1], wt.grad) < 3e-3, rel_l2(got[1], wt.grad)
+    assert rel_l2(got[1], got[0]) < 2e-5, rel_l2(got[1], got[0])

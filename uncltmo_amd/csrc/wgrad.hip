@@ -395,10 +395,203 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
       }
   }
   __syncthreads();
+#if defined(UNCL_WG_ABLATE_ATOMICS)      // timing ablation only (wrong gradients): what the atomic tail costs
+  if (a.dw == nullptr)
+#endif
   for (int i = tid; i < 9 * 1024; i += NT) {
     const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
     atomicAdd(a.dw + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
   }
+}
+
+// 3x3 form for layers with Cin and Cout multiples of 64: ONE workgroup covers a 64 (ci) x 64 (co) block of all nine taps over
+// 8 x 32 pixel tiles.  Why: a 32-channel chunk is 64 bytes of a pixel, so the 32 x 32 kernel above pulls HALF of every 128-byte
+// line it touches through L2 -> L1 (the other half goes to another workgroup), and moves 71 KB per 288 MFMAs; its launches sit
+// at 8 - 20 % of the matrix peak with a 35 - 45 us floor on the small maps.  Here a staging thread group reads whole lines
+// (8 x 16 bytes = 64 channels of a pixel) and a tile pass moves 75 KB (X: 10 x 34 halo pixels, gY: 8 x 32) for 576 MFMAs.
+// Six waves = (vertical tap ty) x (ci half); each holds the 2 (co halves) x 3 (tx) accumulators of its taps for the WHOLE pixel
+// range of the workgroup, so there is no cross-wave reduction: the sums go from the registers to the packed gradient with one
+// float atomic per element.  Two workgroups per CU overlap each other's staging.
+template <int MODE>
+__global__ __launch_bounds__(384, 3) void wgrad3w_kernel(const WgArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int TH = 8, TW = 32, XH = TH + 2, XW = TW + 2;
+  constexpr int NX = XH * XW, NG = TH * TW, NT = 384, PP = NT / 8;   // PP pixels (x 8 slots of 16 bytes) staged per pass
+  constexpr int XV = (NX + PP - 1) / PP, GV = (NG + PP - 1) / PP;
+  constexpr int XPLB = wg_plane(NX), GPLB = wg_plane(NG);     // bytes per plane (8 planes per tile: 64 channels)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;
+  char* sG = smem + 8 * XPLB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ty = wave >> 1, cih = wave & 1;
+  const int nci = a.Cin >> 6;
+  const int kc = blockIdx.z % nci, cc = blockIdx.z / nci;
+  int tile = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile + a.tiles_per_wg, a.total_tiles);
+  if (tile >= tile_end) return;
+
+  int g = 0, cbase = kc * 64;
+  if (MODE != 0) { g = cbase / a.s0C; cbase -= g * a.s0C; }
+  vec xr[XV], gr[GV];
+  unsigned xvalid = 0;
+
+  auto load_tile = [&](int t) {
+    int r = t;
+    const int tx_ = r % a.tiles_x; r /= a.tiles_x;
+    const int ty_ = r % a.tiles_y; r /= a.tiles_y;
+    const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    int t8 = tid;
+    asm volatile("" : "+v"(t8));
+    const int p0 = t8 >> 3, ch = t8 & 7;
+    unsigned valid = 0;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = min(p0 + j * PP, NX - 1);
+      const int hy = pix / XW, hx = pix - hy * XW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      valid |= (ok ? 1u : 0u) << j;
+      if (MODE != 0 && g == 1) {
+        const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
+        const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
+        const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
+        xr[j] = *reinterpret_cast<const vec*>(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
+      } else {
+        const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+        const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
+        xr[j] = *reinterpret_cast<const vec*>(base + off);
+      }
+    }
+    xvalid = valid;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = min(p0 + j * PP, NG - 1);
+      const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
+      const bool ok = gy_ < a.Hout && gx_ < a.Wout;
+      const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 64;
+      const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
+      vec v = *reinterpret_cast<const vec*>(base + off);
+      if (!ok) v = E::zero();
+      gr[j] = v;
+    }
+  };
+  auto write_lds = [&]() {
+    int t8 = tid;
+    asm volatile("" : "+v"(t8));
+    const int p0 = t8 >> 3, ch = t8 & 7;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = p0 + j * PP;
+      if (pix >= NX) continue;
+      vec v = xr[j];
+      if (MODE == 1 && g >= 2) {
+        float f[8];
+        E::unpack(v, f);
+        if (g == 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f);
+        }
+        v = E::pack(f);
+      }
+      if (!((xvalid >> j) & 1u)) v = E::zero();
+      *reinterpret_cast<vec*>(sX + ch * XPLB + pix * 16) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = p0 + j * PP;
+      if (pix >= NG) continue;
+      *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
+    }
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[h][t][i] = 0.f;
+
+  // per-lane fragment bases, as in wgrad3_kernel (tr_frag_plane); the X base carries this wave's ci half and vertical tap
+  const int grp = lane >> 4;
+  const int c0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
+  const int li = lane & 15;
+  const int frag_lane = (li >> 2) * 16 + ((li & 1) << 3);
+  const char* lbG = sG + ((c0 >> 3) + ((li & 3) >> 1)) * GPLB + kb * 16 + frag_lane;
+  const char* lbX = sX + (4 * cih + (c0 >> 3) + ((li & 3) >> 1)) * XPLB + (ty * XW + kb) * 16 + frag_lane;
+
+  // No register prefetch of the next tile: 14 more vectors per thread on top of the 96 accumulator registers do not fit three
+  // waves per SIMD without spilling; the CU's other workgroup multiplies while this one waits for its loads.
+  for (; tile < tile_end; ++tile) {
+    load_tile(tile);
+    write_lds();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        vec B[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) B[tx] = tr_frag_plane(lbX, (r * XW + half * 16 + tx) * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const vec A = tr_frag_plane(lbG + 4 * h * GPLB, (r * TW + half * 16) * 16);
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) acc[h][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[tx], acc[h][tx], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // accumulator (h, tx): rows = co (cc*64 + 32 h + ...), columns = ci (kc*64 + 32 cih + lane & 31): 128 contiguous bytes per row
+  const int lr = lane & 31, lh = lane >> 5;
+#if defined(UNCL_WG_ABLATE_ATOMICS)
+  if (a.dw == nullptr)
+#endif
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cc * 64 + 32 * h + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        atomicAdd(a.dw + ((size_t)(ty * 3 + tx) * a.Cout + co) * a.Cin + kc * 64 + 32 * cih + lr, acc[h][tx][i]);
+      }
+}
+
+template <int MODE>
+int launch_wg3w(WgArgs& a, hipStream_t s) {
+  constexpr size_t lds = 8 * (size_t)wg_plane(10 * 34) + 8 * (size_t)wg_plane(8 * 32);
+  auto kern = wgrad3w_kernel<MODE>;
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done.done();
+  }
+  // 8-row tiles (the caller's tile counts are for 16 rows)
+  a.tiles_y = (a.Hout + 7) / 8;
+  a.total_tiles = (a.total_tiles / ((a.Hout + 15) / 16)) * a.tiles_y;
+  const int pairs = (a.Cin / 64) * (a.Cout / 64);
+  // Pixel-range groups per block: every group ends with Cin x Cout x 9 float atomics into the same gradient, so the groups
+  // multiply that traffic.  Measured per layer (N = 32 step, us, 32 x 32 kernel -> this one at 512 / 256 / 128 workgroups):
+  // up_path.0.conv.conv 158 -> 157 / 125 / 219, up_path.1.conv.conv 153 -> 155 / 127 / 220, down_path.2 conv1 75 -> 84 / 63 /
+  // 78, 64 -> 64 at 122^2 94 -> 120 / 89 / 103, every other eligible layer slower at any count (46 -> 52 ... 141).
+  static const int slots = [] { const char* e = getenv("UNCL_WG_WIDE_SLOTS"); return e ? atoi(e) : 256; }();
+  int groups = slots / pairs;
+  if (groups < 1) groups = 1;
+  if (groups > a.total_tiles) groups = a.total_tiles;
+  a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
+  groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  hipLaunchKernelGGL(kern, dim3(groups, 1, pairs), dim3(384), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
 }
 
 template <int MODE>
@@ -577,6 +770,11 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBat
 
 }  // namespace
 
+static std::atomic<int> g_wg_wide{[] { const char* e = getenv("UNCL_WG_WIDE"); return e ? atoi(e) : 1; }()};
+// 3x3 layers with Cin and Cout multiples of 64 can use the 64 x 64 channel-block kernel: 1 (default) the skip-concat layers, 2 every
+// eligible layer, 0 none (A/B timing, and the parity tests that compare the two kernels).  Returns the previous setting.
+extern "C" int uncl_wgrad_set_wide(int on) { return g_wg_wide.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
+
 // dw_packed must be zeroed by the caller (it is accumulated with atomics).  Descriptor fields used: ksize (3 or 1),
 // pad, src_mode (PLAIN / CONCAT_SSR), N, H, W, Cin, Cout, src0/src1 (+dims); `gy` is (N, Hout, Wout, Cout) bf16.
 extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* dw_packed, void* stream) {
@@ -610,7 +808,22 @@ extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* d
   a.groups = (d->ksize == 1 && d->z_mode == UNCL_Z_GROUPS && d->groups > 1) ? d->groups : 1;
   a.gy_ld = d->out_C > 0 ? d->out_C : d->Cout;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->ksize == 3) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3<0>(a, s) : launch_wg3<1>(a, s);
+  if (d->ksize == 3) {
+    // 64 x 64 channel blocks where the layer has them (concat sources: a 64-channel chunk must lie inside one member)
+    // mode 1 (default): the skip-concat layers only -- the layers it was measured faster on (launch_wg3w); 2: every eligible layer
+    const int wmode = g_wg_wide.load(std::memory_order_relaxed);
+    bool wide = wmode != 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 && a.gy_ld % 8 == 0 &&
+                (d->src_mode == UNCL_SRC_PLAIN ? wmode == 2 : d->src0_C % 64 == 0);
+    if (wide && wmode == 1) {
+      // ... and only with enough tiles per workgroup to amortise its bigger atomic tail: the N = 32 image step gains 0.075 ms
+      // (16 tiles per workgroup on both layers), the video step's N = 8 passes (4 tiles) lose 0.07 ms
+      const int pairs64 = (d->Cin / 64) * (d->Cout / 64);
+      const int groups = 256 / pairs64 > 0 ? 256 / pairs64 : 1;
+      wide = d->N * a.tiles_x * ((a.Hout + 7) / 8) >= 8 * groups;
+    }
+    if (wide) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3w<0>(a, s) : launch_wg3w<1>(a, s);
+    return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3<0>(a, s) : launch_wg3<1>(a, s);
+  }
   return launch_wg<0, 1>(a, s);
 }
 
