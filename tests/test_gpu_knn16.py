@@ -186,3 +186,24 @@ def test_knn16_on_the_generators_own_fc1_output(dt):
         lib.uncl_gcn_set_knn_mfma(oldk)
         lib.uncl_gen_set_fused_graph(old)
     assert (kv.cpu().long() == graphs[0]).float().mean().item() >= 0.999
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_knn16_non_finite_rows_still_give_indices_inside_the_graph(dt, mfma):
+    """NaN / Inf features (a diverged training step) leave a row without nine comparable candidates; the consumers gather and
+    scatter by these indices, so every index must still be a node of the graph -- and the finite rows keep their neighbours
+    among the finite rows."""
+    nodes = 144
+    x = features("random", 6, nodes, 31)
+    x[0, 5] = float("nan")                  # one NaN row: its distance to everyone, and everyone's distance to it, is NaN
+    x[1] = float("nan")                     # a whole NaN sample
+    x[2, 7, 3] = float("inf")
+    x[3, :, 0] = float("nan")               # every row of the sample has one NaN channel
+    x16 = x.to(dt).cuda()
+    for rel in (None, rel_pos(nodes).cuda()):
+        idx = run_knn(x16, rel, mfma)
+        assert idx.min().item() >= 0 and idx.max().item() < nodes, (dt, mfma, idx.min().item(), idx.max().item())
+        # the untouched samples are unaffected
+        ref = ref_dist64(x16[4:], rel)
+        check_against_fp64(idx[4:], ref, ("finite samples", dt, mfma))

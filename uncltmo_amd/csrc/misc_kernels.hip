@@ -546,9 +546,12 @@ __global__ __launch_bounds__(512, 2) void gcn_knn_mfma_kernel(const T* __restric
       tv[0] = c[0] ? dd : tv[0];
       ti[0] = c[0] ? i : ti[0];
     }
+    // A row with NaN / Inf features has fewer than nine candidates that compare below +inf, and its unfilled slots still hold
+    // the sentinel: the consumers gather rows by these indices, so a slot that is not a node becomes node p (any valid node;
+    // torch.topk gives no meaningful neighbours for such a row either, but it never hands out an index outside the graph)
     if (lh == 0 && j_ok) {
 #pragma unroll
-      for (int p = 0; p < 9; ++p) idx[((size_t)blockIdx.x * n + j) * 9 + p] = ti[p];
+      for (int p = 0; p < 9; ++p) idx[((size_t)blockIdx.x * n + j) * 9 + p] = (unsigned)ti[p] < (unsigned)n ? ti[p] : min(p, n - 1);
     }
   }
 }
