@@ -24,8 +24,11 @@ Extra objects on the JSON line:
                frames/s and the generator's MFMA fraction in both FLOP conventions.
   leg_failures (N = 1, default run) the default single-GPU line is produced by THREE children, one per workload, started
                before this process makes a GPU call (run_legs): a child that dies is run once more and every failed attempt is
-               listed here with its exit code and last stderr lines.  Under a launcher (WORLD_SIZE set), with --no-train, in
-               --mode train / train_video and with UNCL_BENCH_INPROC=1 everything runs in the one process, as before.
+               listed here with its exit code and last stderr lines.  Under a launcher (WORLD_SIZE set) every rank starts one
+               child per TRAINING leg before it touches its GPU (run_rank_training_legs: the children of a leg form their own
+               process group on a shifted MASTER_PORT), then measures the headline region itself: a training leg that crashes
+               or hangs costs its timeout and an entry here, not the line.  With --no-train, in --mode train / train_video and
+               with UNCL_BENCH_INPROC=1 everything runs in the one process.
 """
 import argparse
 import ctypes
@@ -181,6 +184,24 @@ def _last_json(text):
     return None
 
 
+def _run_leg_child(argv, leg, env, attempts, deadline, failures):
+    """one leg in a child of its own: its last JSON line, or None after `attempts` failures (each appended to `failures`)"""
+    for attempt in range(1, attempts + 1):
+        try:
+            p = subprocess.run(_leg_command(argv, leg), env=env(attempt) if callable(env) else env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=max(1.0, deadline() - time.time()))
+            rc, out, err = p.returncode, p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+        except subprocess.TimeoutExpired as e:
+            rc, out, err = 124, (e.stdout or b"").decode(errors="replace"), (e.stderr or b"").decode(errors="replace")
+        sys.stderr.write(err)
+        doc = _last_json(out)
+        if rc == 0 and (doc is not None or int(os.environ.get("RANK", "0")) != 0):
+            return doc if doc is not None else {}
+        failures.append({"leg": leg, "attempt": attempt, "rc": rc,
+                         "stderr_tail": [l for l in err.splitlines() if "amdgpu.ids" not in l][-3:]})
+    return None
+
+
 def run_legs(argv, legs=("train_step", "train_video_step", "forward"), attempts=2):
     """The default line carries three workloads (forward = the headline, train_step, train_video_step).  Each runs in a child of
     its own, started before this process has made any GPU call (like launch()): the three do not share an allocator history, and
@@ -189,23 +210,12 @@ def run_legs(argv, legs=("train_step", "train_video_step", "forward"), attempts=
     Every failed attempt is reported in the line's `leg_failures`; nothing is hidden and nothing is measured twice."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    deadline = time.time() + float(os.environ.get("UNCL_BENCH_TIMEOUT", "1500"))
+    end = time.time() + float(os.environ.get("UNCL_BENCH_TIMEOUT", "1500"))
     got, failures = {}, []
     for leg in legs:
-        for attempt in range(1, attempts + 1):
-            try:
-                p = subprocess.run(_leg_command(argv, leg), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                   timeout=max(1.0, deadline - time.time()))
-                rc, out, err = p.returncode, p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
-            except subprocess.TimeoutExpired as e:
-                rc, out, err = 124, (e.stdout or b"").decode(errors="replace"), (e.stderr or b"").decode(errors="replace")
-            sys.stderr.write(err)
-            doc = _last_json(out)
-            if rc == 0 and doc is not None:
-                got[leg] = doc
-                break
-            failures.append({"leg": leg, "attempt": attempt, "rc": rc,
-                             "stderr_tail": [l for l in err.splitlines() if "amdgpu.ids" not in l][-3:]})
+        doc = _run_leg_child(argv, leg, env, attempts, lambda: end, failures)
+        if doc is not None:
+            got[leg] = doc
     line = got.get("forward")
     if line is None:
         sys.stderr.write("bench.py: the forward leg produced no line\n")
@@ -217,6 +227,25 @@ def run_legs(argv, legs=("train_step", "train_video_step", "forward"), attempts=
     line["legs"] = "one process per leg (forward, train_step, train_video_step), started by bench.py before any GPU call"
     print(json.dumps(line), flush=True)
     return 0
+
+
+def run_rank_training_legs(argv, legs=("train_step", "train_video_step")):
+    """Ranks of a launcher (WORLD_SIZE set): BEFORE this rank process touches its GPU, every rank starts the same child per
+    training leg; the children of one leg form a process group of their own (same RANK / LOCAL_RANK / WORLD_SIZE, MASTER_PORT
+    shifted per leg) and rank 0's child prints the leg's numbers.  A training leg that crashes or hangs (the RCCL gradient
+    exchange has only ever run here at world size 1) then costs its own timeout and an entry in `leg_failures`, not the headline
+    line, which this process measures afterwards in the launcher's own process group.  One attempt per leg: a retry would need
+    the ranks to agree that the first one failed."""
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    per_leg = float(os.environ.get("UNCL_BENCH_LEG_TIMEOUT", "240"))
+    got, failures = {}, []
+    for k, leg in enumerate(legs):
+        env = dict(os.environ, MASTER_PORT=str(base + 17 + 3 * k))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        end = time.time() + per_leg
+        doc = _run_leg_child(argv, leg, env, 1, lambda: end, failures)
+        got[leg] = {"error": "leg failed, see leg_failures"} if doc is None else doc
+    return got, failures
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -683,6 +712,10 @@ def infer_bench(a, rk):
     if layers is not None:
         line["roofline"]["layers"] = layers
     line.update(train)
+    if getattr(a, "rank_legs", None) is not None:
+        line.update(a.rank_legs[0])
+        line["leg_failures"] = a.rank_legs[1]
+        line["legs"] = "training legs: one child per rank and leg with a process group of their own, before the headline region"
     if rk.world == 1 and not a.no_cpu:
         line["cpu_baseline"] = cpu_baseline(a.cpu_seconds, TILES_PER_FRAME, "%dx%d" % (H, W))
     _flush_c_stdio()
@@ -700,9 +733,14 @@ def main(argv=None):
         if (a.leg is None and not a.stub and a.mode == "infer" and not a.no_train and a.dtype == "bf16"
                 and os.environ.get("UNCL_BENCH_INPROC") != "1"):
             return run_legs(argv)
-    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
-        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; the launcher's world size is used\n"
-                         % (a.gpus, os.environ["WORLD_SIZE"]))
+    else:
+        if int(os.environ["WORLD_SIZE"]) != a.gpus:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; the launcher's world size is used\n"
+                             % (a.gpus, os.environ["WORLD_SIZE"]))
+        if (a.leg is None and not a.stub and a.mode == "infer" and not a.no_train and a.dtype == "bf16"
+                and os.environ.get("UNCL_BENCH_INPROC") != "1"):
+            a.rank_legs = run_rank_training_legs(argv)      # children first: this process has not touched its GPU yet
+            a.no_train = True
     rk = Ranks(a)
     try:
         if a.stub:

@@ -122,3 +122,32 @@ def test_leg_children_are_not_used_under_a_launcher_or_for_single_legs(monkeypat
     for argv in (["--stub"],):
         called.clear()
         assert bench.main(argv) == 0 and called == []
+
+
+def test_rank_processes_run_the_training_legs_in_children_first(monkeypatch):
+    """under a launcher every rank starts one child per training leg (shifted MASTER_PORT) before its own headline region; a leg
+    that fails leaves an error entry and a leg_failures record, the other leg's numbers are kept"""
+    import sys
+    import bench
+    seen = []
+    child = (
+        "import json, os, sys\n"
+        "leg = sys.argv[sys.argv.index('--leg') + 1]\n"
+        "sys.stderr.write('port %s\\n' % os.environ['MASTER_PORT'])\n"
+        "if leg == 'train_video_step':\n"
+        "    sys.exit(7)\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    print(json.dumps({'ms_per_step': 8.0, 'port': os.environ['MASTER_PORT']}))\n"
+    )
+    monkeypatch.setattr(bench, "_leg_command", lambda argv, leg: seen.append(leg) or [sys.executable, "-c", child, "--leg", leg])
+    monkeypatch.setenv("MASTER_PORT", "29000")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    got, fails = bench.run_rank_training_legs([])
+    assert seen == ["train_step", "train_video_step"]
+    assert got["train_step"] == {"ms_per_step": 8.0, "port": "29017"} and "error" in got["train_video_step"]
+    assert [(f["leg"], f["rc"]) for f in fails] == [("train_video_step", 7)] and fails[0]["stderr_tail"] == ["port 29020"]
+    # a rank other than 0 prints nothing: an empty result is not a failure there
+    monkeypatch.setenv("RANK", "1")
+    got, fails = bench.run_rank_training_legs([], legs=("train_step",))
+    assert got == {"train_step": {}} and fails == []
