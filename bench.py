@@ -335,7 +335,12 @@ class Ranks:
             if self.stub:
                 td.init_process_group("gloo")
             else:
-                td.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                # RCCL's own stream at high priority: it then never shares the compute stream's hardware queue
+                try:
+                    opts = td.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                    td.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), pg_options=opts)
+                except (AttributeError, TypeError):
+                    td.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
         self.dev = torch.device("cpu") if self.stub else torch.device("cuda", self.local_rank)
 
     def sync(self):

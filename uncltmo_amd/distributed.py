@@ -77,7 +77,9 @@ class GradReducer:
 
     def stream(self, dev):
         if dev not in self._streams:
-            self._streams[dev] = torch.cuda.Stream(device=dev)
+            # high priority = another hardware-queue pool than the compute stream's: a normal-priority stream shares the
+            # compute stream's queue whenever the runtime's round-robin says so, and the exchange then cannot overlap it
+            self._streams[dev] = torch.cuda.Stream(device=dev, priority=-1)
         return self._streams[dev]
 
     def launch(self, tensor, owner):
