@@ -240,7 +240,9 @@ def run_rank_training_legs(argv, legs=("train_step", "train_video_step")):
     per_leg = float(os.environ.get("UNCL_BENCH_LEG_TIMEOUT", "240"))
     got, failures = {}, []
     for k, leg in enumerate(legs):
-        env = dict(os.environ, MASTER_PORT=str(base + 17 + 3 * k))
+        # torchrun's workers are told to use the AGENT's store on MASTER_PORT as clients; the children rendezvous on a port of
+        # their own, so rank 0's child must host that store itself
+        env = dict(os.environ, MASTER_PORT=str(base + 17 + 3 * k), TORCHELASTIC_USE_AGENT_STORE="False")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         end = time.time() + per_leg
         doc = _run_leg_child(argv, leg, env, 1, lambda: end, failures)

@@ -151,3 +151,41 @@ def test_rank_processes_run_the_training_legs_in_children_first(monkeypatch):
     monkeypatch.setenv("RANK", "1")
     got, fails = bench.run_rank_training_legs([], legs=("train_step",))
     assert got == {"train_step": {}} and fails == []
+
+
+def test_leg_children_of_torchrun_ranks_form_their_own_group(tmp_path):
+    """two ranks under `python -m torch.distributed.run` (whose workers are clients of the agent's store) each start the leg
+    children; the children must rendezvous among themselves on the shifted port (gloo here) and rank 0's child reports"""
+    import subprocess
+    import sys
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import json, os, sys\n"
+        "import torch, torch.distributed as td\n"
+        "td.init_process_group('gloo')\n"
+        "t = torch.tensor([float(td.get_rank() + 1)])\n"
+        "td.all_reduce(t)\n"
+        "if td.get_rank() == 0:\n"
+        "    print(json.dumps({'sum': t.item(), 'port': os.environ['MASTER_PORT'], 'leg': sys.argv[sys.argv.index('--leg') + 1]}))\n"
+        "td.destroy_process_group()\n")
+    parent = tmp_path / "parent.py"
+    parent.write_text(
+        "import json, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "bench._leg_command = lambda argv, leg: [sys.executable, %r, '--leg', leg]\n"
+        "got, fails = bench.run_rank_training_legs([])\n"
+        "open(os.path.join(%r, 'rank%%s.json' %% os.environ['RANK']), 'w').write(json.dumps([got, fails]))\n"
+        % (ROOT, str(child), str(tmp_path)))
+    port = 29000 + (os.getpid() % 500)
+    env = dict(os.environ, UNCL_BENCH_LEG_TIMEOUT="60")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(parent)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=240)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    import json
+    got0, fails0 = json.loads((tmp_path / "rank0.json").read_text())
+    got1, fails1 = json.loads((tmp_path / "rank1.json").read_text())
+    assert fails0 == [] and fails1 == [], (fails0, fails1)
+    assert got0["train_step"] == {"sum": 3.0, "port": str(port + 17), "leg": "train_step"}
+    assert got0["train_video_step"]["port"] == str(port + 20) and got1 == {"train_step": {}, "train_video_step": {}}
