@@ -13,6 +13,13 @@
 //     8-byte pieces scattered at a 2-pixel stride.
 #include "common.h"
 
+#ifndef UNCL_UP_PREFETCH
+#define UNCL_UP_PREFETCH 1
+#endif
+#ifndef UNCL_UP_PREFETCH_MAXC
+#define UNCL_UP_PREFETCH_MAXC 256
+#endif
+
 namespace {
 
 struct UpArgs {
@@ -53,39 +60,40 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
     const vec wv = *reinterpret_cast<const vec*>(a.w + ((size_t)(ct * CT + row)) * CIN + slot * 8);
     *reinterpret_cast<vec*>(sW + row * (CIN * 2) + (wswz(row, slot) << 4)) = wv;
   }
-  // bias of this lane's channels: virtual channel c' = ct*128 + nt*32 + 8q + 4lh + r  ->  co = c' % Cout
-  float bv[4][16];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = (ct * CT + nt * 32 + 8 * q + 4 * lh) % a.Cout;
-      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[nt][4 * q + r] = b[r];
-    }
+  // bias of the slice's 128 virtual channels (c' = ct*128 + i -> co = c' % Cout) in LDS: sixty-four registers of per-lane
+  // copies kept the kernel at two workgroups per CU
+  float* sB = reinterpret_cast<float*>(sO + 128 * 256);
+  if (tid < CT) sB[tid] = a.bias ? a.bias[(ct * CT + tid) % a.Cout] : 0.f;
   __syncthreads();
 
   f32x16 zero16;
 #pragma unroll
   for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
 
-  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-    const int m0 = t * 128;
-    // ---- B fragments: pixel m0 + wave*32 + lr, channels 16*ks + 8*lh .. +7
-    const int mp = min(m0 + wave * 32 + lr, a.M - 1);
-    vec B[KS];
+  // B fragments of a tile: pixel m0 + wave*32 + lr, channels 16*ks + 8*lh .. +7.  The next tile's are requested right after
+  // this tile's MFMAs, so that their latency runs under the transpose and the stores instead of in front of the next tile's
+  // first MFMA (same box, us per 200 tiles, C = 64 / 128 / 256 levels: 146 / 72 / 59 -> 116 / 68 / 59 together with the bias
+  // moved from 64 registers per lane into LDS, which took the kernel from two to three workgroups per CU).
+  constexpr bool PRE = CIN <= UNCL_UP_PREFETCH_MAXC && UNCL_UP_PREFETCH;
+  auto loadB = [&](int t, vec* Bv) __attribute__((always_inline)) {
+    const int mp = min(t * 128 + wave * 32 + lr, a.M - 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const size_t off = (size_t)mp * CIN + ks * 16 + lh * 8;
-      B[ks] = *reinterpret_cast<const vec*>(a.x + off);
+      Bv[ks] = *reinterpret_cast<const vec*>(a.x + off);
       if (PREV && ks * 16 + lh * 8 < a.prev_ch) {
         const vec p = *reinterpret_cast<const vec*>(a.prev + off);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (ks * 16 + lh * 8 + i < a.prev_ch) B[ks][i] = p[i];
+          if (ks * 16 + lh * 8 + i < a.prev_ch) Bv[ks][i] = p[i];
       }
     }
+  };
+  vec B[KS], Bn[PRE ? KS : 1];
+  if (PRE && (int)blockIdx.x < a.n_tiles) loadB(blockIdx.x, B);
+  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const int m0 = t * 128;
+    if (!PRE) loadB(t, B);
     f32x16 acc[4];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -96,6 +104,10 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
         acc[nt] = mfma32x16(A, B[ks], ks == 0 ? zero16 : acc[nt]);
       }
     }
+    if (PRE) {
+      const int tn = t + (int)gridDim.x;
+      if (tn < a.n_tiles) loadB(tn, Bn);
+    }
     // ---- transpose through LDS: image [pixel (128)][virtual channel (128)], 16-byte slots XOR pixel
     __syncthreads();  // previous tile's readers are done with sO
     const int pl = wave * 32 + lr;
@@ -104,8 +116,9 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         vec4 o;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + nt * 32 + 8 * q + 4 * lh);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (T)(acc[nt][4 * q + r] + bv[nt][4 * q + r]);
+        for (int r = 0; r < 4; ++r) o[r] = (T)(acc[nt][4 * q + r] + b4[r]);
         *reinterpret_cast<vec4*>(sO + pl * 256 + (((nt * 4 + q) ^ (pl & 15)) << 4) + (lh << 3)) = o;
       }
     __syncthreads();
@@ -141,12 +154,16 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
       const vec val = *reinterpret_cast<const vec*>(sO + p * 256 + ((slot ^ (p & 15)) << 4));
       *reinterpret_cast<vec*>(a.out + opix * a.Cout + co) = val;
     }
+    if (PRE) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) B[ks] = Bn[ks];
+    }
   }
 }
 
 template <typename T, int CIN>
 int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
-  constexpr size_t lds = (size_t)128 * CIN * 2 + 128 * 256;
+  constexpr size_t lds = (size_t)128 * CIN * 2 + 128 * 256 + 128 * 4;
   static UnclDevOnce attr_done[2];
   auto k0 = upconv2x2_kernel<T, CIN, false>;
   auto k1 = upconv2x2_kernel<T, CIN, true>;
