@@ -212,8 +212,15 @@ def run_legs(argv, legs=("train_step", "train_video_step", "forward"), attempts=
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     end = time.time() + float(os.environ.get("UNCL_BENCH_TIMEOUT", "1500"))
     got, failures = {}, []
+    per_leg = float(os.environ.get("UNCL_BENCH_LEG_TIMEOUT", "420"))      # a hung leg must not eat the whole budget
     for leg in legs:
-        doc = _run_leg_child(argv, leg, env, attempts, lambda: end, failures)
+        leg_end = [0.0]
+
+        def deadline():
+            if leg_end[0] == 0.0 or leg_end[0] < time.time():       # (re)armed at the start of every attempt
+                leg_end[0] = min(end, time.time() + per_leg)
+            return leg_end[0]
+        doc = _run_leg_child(argv, leg, env, attempts, deadline, failures)
         if doc is not None:
             got[leg] = doc
     line = got.get("forward")
