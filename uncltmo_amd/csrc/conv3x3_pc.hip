@@ -978,9 +978,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
       // bf16 tail of the fp32 input (x = hi + lo to 2^-17); a lane's D quad q is channels 8q + 4 lh.. of its pixel, i.e. one
       // half of K-slot plane q.  Then park the patch of the NEXT tile (in registers since the last step) in the other buffer.
       const float* sPt = sP + p3par * PN3;
-      f32x16 z16;
+      f32x16 preBv;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) z16[i] = 0.f;
+      for (int i = 0; i < 16; ++i) preBv[i] = preB[i];
       constexpr int MT3 = (NPIX + 31) / 32, IT3 = (MT3 + PW - 1) / PW;
       static_assert(HW == 34 && NPIX < 2048, "the reciprocal multiply below divides by 34");
 #pragma unroll
@@ -1001,17 +1001,32 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_ker
             Bh[j] = hi;
             Bl[j] = (T)(v - (float)hi);
           }
-          f32x16 c3 = mfma32x16(preA, Bh, z16);
+          // the bias is the first MFMA's C operand (sixteen adds per lane and 32 pixels otherwise: the staging waves of this
+          // layer issue ~8 vector instructions per MFMA of the whole kernel)
+          f32x16 c3 = mfma32x16(preA, Bh, preBv);
           c3 = mfma32x16(preA, Bl, c3);
+          if (a.slope == 0.f) {
+            // ReLU on the rounded pair (rounding is sign-symmetric), like the multiplying waves' epilogue
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            vec4 o;
+            for (int q = 0; q < 4; ++q) {
+              vec4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float t = c3[4 * q + e] + preB[4 * q + e];
-              o[e] = (T)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+              for (int e = 0; e < 4; ++e) o[e] = (T)c3[4 * q + e];
+              s16x4 si = __builtin_bit_cast(s16x4, o);
+              si = __builtin_elementwise_max(si, s16x4{0, 0, 0, 0});
+              if (pix < NPIX) *reinterpret_cast<s16x4*>(st + q * XPL + pix * 16 + (lh << 3)) = si;
             }
-            if (pix < NPIX) *reinterpret_cast<vec4*>(st + q * XPL + pix * 16 + (lh << 3)) = o;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              vec4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float t = c3[4 * q + e];
+                o[e] = (T)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
+              }
+              if (pix < NPIX) *reinterpret_cast<vec4*>(st + q * XPL + pix * 16 + (lh << 3)) = o;
+            }
           }
         }
       }

@@ -353,9 +353,9 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       for (int k = 0; k < IRN; ++k)
         if (tid + k * NTHR < PN3) sP[tid + k * NTHR] = ir[k];
       __syncthreads();
-      f32x16 z16;
+      f32x16 preBv;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) z16[i] = 0.f;
+      for (int i = 0; i < 16; ++i) preBv[i] = preB[i];
       constexpr int MT3 = (NPIX + 31) / 32, IT3 = (MT3 + WAVES - 1) / WAVES;
       static_assert(HW == 34 && NPIX < 2048, "the reciprocal multiply below divides by 34");
       // every lane issues its eight tap reads unconditionally (the upper half-wave only owns tap 8: its other slots read
@@ -379,14 +379,15 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
             Bh[j] = hi;
             Bl[j] = (T)(v - (float)hi);
           }
-          f32x16 c3 = mfma32x16(preA, Bh, z16);
+          // the bias is the first MFMA's C operand, as in conv3x3_pc_kernel (the two structures are bit-identical)
+          f32x16 c3 = mfma32x16(preA, Bh, preBv);
           c3 = mfma32x16(preA, Bl, c3);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             vec4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float t = c3[4 * q + e] + preB[4 * q + e];
+              const float t = c3[4 * q + e];
               o[e] = (T)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
             }
             if (p < NPIX) *reinterpret_cast<vec4*>(sX + p * RP + (q << 4) + (lh << 3)) = o;
