@@ -487,6 +487,8 @@ def make_trainer(rk, video):
             tr._step_graph_error = "%s: %s" % (type(e).__name__, str(e)[:200])
             torch.cuda.synchronize()
 
+    tr._eager_step = None if step is not None and getattr(tr, "_step_graph", None) is None else (
+        lambda: (tr.train_D(hdr, pos, neg, 0), tr.train_G(hdr, hdr, pos, neg, 0)))
     return tr, step, B * T
 
 
@@ -546,6 +548,15 @@ def train_numbers(a, rk, video, steps, warmup):
                               "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
                                       "2 bwd (109.7 GFLOP, what the reference runs); both over the median step time"},
            "errD": float(tr.errD.detach()), "errG_d": float(tr.errG_d.detach()), "errG_struct": float(tr.errG_struct.detach())}
+    if getattr(tr, "_eager_step", None) is not None and not rk.dist:
+        # beside the replayed step: the same step launched eagerly (no hipGraph).  On an idle host it is the faster of the two on
+        # the image step -- the generator's backward then runs its weight gradients on a second stream, which a replayed graph
+        # cannot afford on this runtime -- on a slow host it is the host-bound one; `ms_per_step` stays the replay
+        for _ in range(3):
+            tr._eager_step()
+        _, _, eager_ms, eager_host = rk.timed_steps(tr._eager_step, 10)
+        out["eager"] = {"ms_median": _median(eager_ms), "ms_min": min(eager_ms), "host_enqueue_ms_median": _median(eager_host),
+                        "steps": 10}
     if rk.dist:
         # gradient exchange: bytes per step and the time the compute stream spent waiting in DistributedOptimizer.synchronize()
         # (collectives launched during the backward pass that had not finished when the optimiser asked for the gradients)
@@ -573,7 +584,7 @@ def train_bench(a, rk):
                      "device_mallocs_in_timed_steps": nums["device_mallocs_in_timed_steps"],
                      "errD": nums["errD"], "errG_d": nums["errG_d"], "errG_struct": nums["errG_struct"]})
         for k in ("ms_median", "ms_mean_wall", "ms_min", "ms_max", "ms_steps", "host_enqueue_ms_median", "host_enqueue_ms_max",
-                  "gc_collections_in_timed_steps", "graph_replay", "graph_capture_error", "allreduce"):
+                  "gc_collections_in_timed_steps", "graph_replay", "graph_capture_error", "allreduce", "eager"):
             if k in nums:
                 line[k] = nums[k]
         _flush_c_stdio()

@@ -435,6 +435,31 @@ size_t bwd_scratch_bytes(int N, size_t es = 2) {
   return b + 4096;
 }
 
+#ifndef UNCL_BWD_WSTREAM_DEFAULT
+#define UNCL_BWD_WSTREAM_DEFAULT 1
+#endif
+// one weight-gradient stream (+ its fork / join events) per device, created under a lock on first use; at the other priority
+// level, like the forward's side streams: its hardware queue is then never the caller's
+struct WgradStream { hipStream_t s = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+static std::mutex g_wgs_mu;
+static std::map<int, WgradStream> g_wgs;
+static WgradStream* wgrad_stream_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_wgs_mu);
+  auto it = g_wgs.find(dev);
+  if (it != g_wgs.end()) return &it->second;
+  WgradStream w;
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  const hipError_t e = greatest != least ? hipStreamCreateWithPriority(&w.s, hipStreamNonBlocking, greatest)
+                                         : hipStreamCreateWithFlags(&w.s, hipStreamNonBlocking);
+  if (e != hipSuccess || hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming) != hipSuccess)
+    return nullptr;
+  return &(g_wgs[dev] = w);
+}
+
 struct BCtx {
   const uncl_gen_weights* w;
   const uncl_gen_bwd* b;
@@ -448,6 +473,21 @@ struct BCtx {
   size_t es;
   float slope;
   hipStream_t s;
+  // weight-gradient stream (image passes in bf16, UNCL_BWD_WSTREAM): the weight / bias gradients of a layer depend on nothing
+  // later in the pass and nothing depends on them before the pass ends, so they run beside the data-gradient chain and fill
+  // the ramp-down of its launches.  wfork(): everything issued on `s` so far is ordered before what follows on `ws`.
+  hipStream_t ws = nullptr;
+  hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
+  hipStream_t wfork() const {
+    if (!ws) return s;
+    if (hipEventRecord(ev_wfork, s) != hipSuccess || hipStreamWaitEvent(ws, ev_wfork, 0) != hipSuccess) return s;
+    return ws;
+  }
+  int wjoin() const {
+    if (!ws) return UNCL_OK;
+    if (hipEventRecord(ev_wjoin, ws) != hipSuccess || hipStreamWaitEvent(s, ev_wjoin, 0) != hipSuccess) return UNCL_ERR_LAUNCH;
+    return UNCL_OK;
+  }
   ColsumQueue* q;
   void* F(int buf) const { return fws + L.off[buf]; }
   void* G(int buf) const { return gws + L.off[buf]; }
@@ -465,6 +505,7 @@ struct BCtx {
     return UNCL_OK;
   }
   int flush_colsums() const {
+    if (wjoin() != UNCL_OK) return UNCL_ERR_LAUNCH;      // the staged sums (and the weight gradients) come from the side stream
     const int rc = uncl_colsum_finish(q->it, q->n, s);
     q->n = 0; q->channels = 0;
     return rc;
@@ -516,9 +557,11 @@ int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const voi
            const void* src = nullptr) {
   uncl_conv_desc d = bdesc(c, 3, pad, kDims[xin].h, kDims[xin].w, cin, cout);
   d.src0 = src ? src : c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
-  int rc = conv_wgrad(c, d, gy, c.b->gw[wi]);
+  BCtx cw = c;
+  cw.s = c.wfork();
+  int rc = conv_wgrad(cw, d, gy, c.b->gw[wi]);
   if (rc != UNCL_OK) return rc;
-  return c.colsum(gy, (long long)c.n * oh * ow, cout, c.b->gb[wi]);
+  return cw.colsum(gy, (long long)c.n * oh * ow, cout, c.b->gb[wi]);
 }
 
 // data gradient of a 3x3 layer: gy (N,gh,gw,gc) -> out buffer (cout_d channels), pad_d = 2 - pad_fwd
@@ -587,8 +630,10 @@ int backward_all(const BCtx& c) {
       d.src_mode = UNCL_SRC_CONCAT_SSR;
       d.src0 = c.F(q.skip); d.src0_H = sh; d.src0_W = sw; d.src0_C = q.ch;
       d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
-      RUN(conv_wgrad(c, d, c.G(q.a), b->gw[q.wi + 1]));
-      RUN(c.colsum(c.G(q.a), (long long)c.n * ah * aw, q.cout, b->gb[q.wi + 1]));
+      BCtx cw = c;
+      cw.s = c.wfork();
+      RUN(conv_wgrad(cw, d, c.G(q.a), b->gw[q.wi + 1]));
+      RUN(cw.colsum(c.G(q.a), (long long)c.n * ah * aw, q.cout, b->gb[q.wi + 1]));
     }
     RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
     RUN(bwd_ssr_backward(c.dt, c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
@@ -597,9 +642,13 @@ int backward_all(const BCtx& c) {
     const int slot = 4 + i;  // hand-off slot of this stage's input (video): GOUT, U0, U1, U2
     const void* x1m = c.mixed(slot);
     if (!x1m) return UNCL_ERR_LAUNCH;
-    if (c.dt == UNCL_F32) RUN(bwd_upconv2x2_wgrad_f32(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
-    else RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
-    RUN(c.colsum(c.G(q.up), (long long)c.n * uh * uw, q.ch, b->gb[q.wi]));
+    {
+      BCtx cw = c;
+      cw.s = c.wfork();
+      if (c.dt == UNCL_F32) RUN(bwd_upconv2x2_wgrad_f32(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, cw.s));
+      else RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, cw.s));
+      RUN(cw.colsum(c.G(q.up), (long long)c.n * uh * uw, q.ch, b->gb[q.wi]));
+    }
     // the ReLU derivative of the layer that produced x1 is applied by the dgrad kernel (single frames) or, for clips,
     // by the hand-off kernel after the head channels have been exchanged between frames
     const void* x1mask = i == 0 ? nullptr : c.F(q.x1);
@@ -913,7 +962,19 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   c.sc.cs = reinterpret_cast<float*>(p);
   ColsumQueue q;
   c.q = &q;
+  // weight gradients beside the data-gradient chain: single-frame bf16 passes (a clip's passes share scratch between frames:
+  // `mix`, the carries), see BCtx::wfork
+  static const int wstream_on = [] { const char* e = getenv("UNCL_BWD_WSTREAM"); return e ? atoi(e) : UNCL_BWD_WSTREAM_DEFAULT; }();
+  // ... and not while the caller's stream is being captured: a replayed hipGraph pays ~0.2 ms per cross-stream edge on this
+  // runtime (the N = 32 step: 7.9 ms on one stream, 17 ms with the ~45 forks of this pass captured; eager: 7.83 -> 7.60 ms)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(c.s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+  if (wstream_on && cap == hipStreamCaptureStatusNone && c.dt == UNCL_BF16 && !c.video() && c.pws == nullptr) {
+    WgradStream* wsd = wgrad_stream_for_current_device();
+    if (!wsd) return UNCL_ERR_LAUNCH;
+    c.ws = wsd->s; c.ev_wfork = wsd->ev_fork; c.ev_wjoin = wsd->ev_join;
+  }
   const int rc = backward_all(c);
-  const int rc2 = c.flush_colsums();
+  const int rc2 = c.flush_colsums();          // joins the weight-gradient stream
   return rc != UNCL_OK ? rc : rc2;
 }
