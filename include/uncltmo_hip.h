@@ -139,6 +139,9 @@ int uncl_upconv2x2_dt(const void* x, const void* prev, int prev_ch, const void* 
  * N, H, W, Cin, Cout, src0/src1 (+dims); gy: (N,Hout,Wout,Cout) bf16.  dw_packed is accumulated with float atomics:
  * zero it first.  Backward of the layers of uncl_conv3x3_pipe / the graph block's 1x1 convs. */
 int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* dw_packed, void* stream);
+/* ... with the bias gradient of a 3x3 layer from the same pass over gy: gb[co] += sum over pixels of gy[..][co] (float atomics:
+ * zero it first; NULL = weights only).  Autograd of nn.Conv2d / nn.ConvTranspose2d bias (unet_parts.py:56-64). */
+int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, float* dw_packed, float* gb, void* stream);
 /* 3x3 layers whose Cin and Cout are multiples of 64 can run a kernel that owns 64 x 64 channel blocks (whole 128-byte lines per
  * pixel, half the bytes per MFMA, but four times the atomic traffic per pixel-range group): mode 1 (default) = the skip-concat
  * layers, where it measured faster; 2 = every eligible layer; 0 = none (A/B runs and the tests that compare the two kernels).

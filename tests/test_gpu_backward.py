@@ -537,3 +537,35 @@ def test_wgrad3x3_wide_blocks_concat_ssr(c, cout, h, w, dy, dx):
         lib.uncl_wgrad_set_wide(old)
     assert rel_l2(got[1], wt.grad) < 3e-3, rel_l2(got[1], wt.grad)
     assert rel_l2(got[1], got[0]) < 2e-5, rel_l2(got[1], got[0])
+
+
+# ---- bias gradient out of the weight-gradient kernel's own pass over gy (uncl_conv_wgrad_bias) --------------------------------
+@pytest.mark.parametrize("cin,cout,h,w,n,pad", [(32, 32, 70, 45, 3, 0), (64, 128, 33, 40, 2, 2), (128, 64, 20, 37, 5, 0),
+                                                (32, 64, 254, 254, 2, 2)])
+def test_wgrad3x3_with_bias_gradient(cin, cout, h, w, n, pad):
+    """weights as in uncl_conv_wgrad, bias = column sums of gy (ragged tiles: the rows / columns outside the map add nothing);
+    a second call ADDS (the atomics' contract: the caller zeroes)"""
+    x = q(rnd(n, cin, h, w, seed=121))
+    if pad == 0:
+        wt, bt = rnd(cout, cin, 3, 3, seed=122, scale=0.1).requires_grad_(True), rnd(cout, seed=124).requires_grad_(True)
+        gy = q(rnd(n, cout, h - 2, w - 2, seed=123))
+        F.conv2d(x, wt, bt).backward(gy)
+    else:
+        wt, bt = rnd(cin, cout, 3, 3, seed=122, scale=0.1).requires_grad_(True), rnd(cout, seed=124).requires_grad_(True)
+        gy = q(rnd(n, cout, h + 2, w + 2, seed=123))
+        F.conv_transpose2d(x, wt, bt).backward(gy)
+    d = _hip.ConvDesc()
+    xs, gys = to_nhwc(x, BF), to_nhwc(gy, BF)
+    for k, v in dict(dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=xs.data_ptr(),
+                     src0_H=h, src0_W=w, src0_C=cin).items():
+        setattr(d, k, v)
+    dw = torch.zeros(9, cout, cin, dtype=torch.float32, device="cuda")
+    gb = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    lib = _hip.lib()
+    _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gys.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad_bias")
+    torch.cuda.synchronize()
+    assert rel_l2(unpack(dw, cout, cin, 3, pad == 2, pad == 2), wt.grad) < 2e-3
+    assert rel_l2(gb.cpu(), bt.grad) < 1e-5, rel_l2(gb.cpu(), bt.grad)
+    _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gys.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad_bias")
+    torch.cuda.synchronize()
+    assert rel_l2(gb.cpu(), 2 * bt.grad) < 1e-5

@@ -472,6 +472,7 @@ struct BCtx {
   int dt;        // UNCL_BF16 (training) or UNCL_F32 (parity mode: deterministic plain-fp32 kernels, bwd_f32.hip)
   size_t es;
   float slope;
+  bool fused_bias = false;   // bf16: 3x3 layers' bias gradients come out of the weight-gradient kernel (atomics into gb)
   hipStream_t s;
   // weight-gradient stream (image passes in bf16, UNCL_BWD_WSTREAM): the weight / bias gradients of a layer depend on nothing
   // later in the pass and nothing depends on them before the pass ends, so they run beside the data-gradient chain and fill
@@ -551,6 +552,15 @@ int conv_wgrad(const BCtx& c, const uncl_conv_desc& d, const void* gy, float* gw
   if (c.dt == UNCL_F32) return bwd_wgrad_f32(&d, gy, gw, c.s);
   return uncl_conv_wgrad(&d, gy, gw, c.s);
 }
+// weight AND bias gradient of a 3x3 layer (output gradient gy of oh x ow x cout): bf16 passes take the bias sums from the
+// weight-gradient kernel's own pass over gy (atomics into gb: zeroed at the start of a non-accumulating pass, see
+// uncl_gen_backward); fp32 passes keep the deterministic column-sum kernels
+int conv_wgrad_bias(const BCtx& c, const uncl_conv_desc& d, const void* gy, float* gw, float* gb, int oh, int ow, int cout) {
+  if (c.dt == UNCL_BF16 && c.fused_bias) return uncl_conv_wgrad_bias(&d, gy, gw, gb, c.s);
+  const int rc = conv_wgrad(c, d, gy, gw);
+  if (rc != UNCL_OK) return rc;
+  return c.colsum(gy, (long long)c.n * oh * ow, cout, gb);
+}
 
 // weight + bias gradient of a 3x3 layer whose input is buffer `xin` (plain) and whose output gradient is gy
 int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const void* gy, int oh, int ow,
@@ -559,9 +569,7 @@ int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const voi
   d.src0 = src ? src : c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
   BCtx cw = c;
   cw.s = c.wfork();
-  int rc = conv_wgrad(cw, d, gy, c.b->gw[wi]);
-  if (rc != UNCL_OK) return rc;
-  return cw.colsum(gy, (long long)c.n * oh * ow, cout, c.b->gb[wi]);
+  return conv_wgrad_bias(cw, d, gy, c.b->gw[wi], c.b->gb[wi], oh, ow, cout);
 }
 
 // data gradient of a 3x3 layer: gy (N,gh,gw,gc) -> out buffer (cout_d channels), pad_d = 2 - pad_fwd
@@ -632,8 +640,14 @@ int backward_all(const BCtx& c) {
       d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
       BCtx cw = c;
       cw.s = c.wfork();
-      RUN(conv_wgrad(cw, d, c.G(q.a), b->gw[q.wi + 1]));
-      RUN(cw.colsum(c.G(q.a), (long long)c.n * ah * aw, q.cout, b->gb[q.wi + 1]));
+      // the two stages whose weight gradient may run in 64 x 64 channel blocks keep the column-sum kernel for their bias: that
+      // kernel has no registers left for the sums (its slot was cleared with the others: the column sums then ADD or overwrite)
+      if (q.ch % 64 == 0 && q.cout % 64 == 0) {
+        RUN(conv_wgrad(cw, d, c.G(q.a), b->gw[q.wi + 1]));
+        RUN(cw.colsum(c.G(q.a), (long long)c.n * ah * aw, q.cout, b->gb[q.wi + 1]));
+      } else {
+        RUN(conv_wgrad_bias(cw, d, c.G(q.a), b->gw[q.wi + 1], b->gb[q.wi + 1], ah, aw, q.cout));
+      }
     }
     RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
     RUN(bwd_ssr_backward(c.dt, c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
@@ -973,6 +987,27 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
     WgradStream* wsd = wgrad_stream_for_current_device();
     if (!wsd) return UNCL_ERR_LAUNCH;
     c.ws = wsd->s; c.ev_wfork = wsd->ev_fork; c.ev_wjoin = wsd->ev_join;
+  }
+  // bias gradients of the 3x3 layers out of the weight-gradient kernels (bf16): they ADD into gb, so a pass that does not
+  // accumulate clears those slots first -- one memset when the caller's slots are one array (uncltmo_amd/autograd.py), one per
+  // layer otherwise.  UNCL_BWD_FUSED_BIAS=0: separate column-sum kernels as before.
+  static const int fused_bias_on = [] { const char* e = getenv("UNCL_BWD_FUSED_BIAS"); return e ? atoi(e) : 1; }();
+  c.fused_bias = fused_bias_on && c.dt == UNCL_BF16;
+  if (c.fused_bias && !b->accumulate) {
+    static const struct { int wi, cout; } k3[] = {{W_INC1, 32}, {W_D0A, 64}, {W_D0B, 64}, {W_D1A, 128}, {W_D1B, 128}, {W_D2A, 256},
+                                                  {W_D2B, 256}, {W_D3A, 256}, {W_D3B, 256}, {W_U0A, 128}, {W_U0B, 128}, {W_U1A, 64},
+                                                  {W_U1B, 64}, {W_U2A, 32}, {W_U2B, 32}, {W_U3A, 32}, {W_U3B, 32}};
+    float* lo = b->gb[W_INC1];
+    float* hi = b->gb[W_U3B] + 32;
+    // contiguous in weight order (the graph block's and the up-convs' slots in between are overwritten later in the pass)?
+    bool contiguous = hi > lo && (size_t)(hi - lo) <= 8192;
+    for (int i = 0; contiguous && i + 1 < UNCL_G_NUM_WEIGHTS; ++i) contiguous = b->gb[i + 1] > b->gb[i] && b->gb[i + 1] - b->gb[i] <= 512;
+    if (contiguous) {
+      if (hipMemsetAsync(lo, 0, (size_t)(hi - lo) * sizeof(float), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
+    } else {
+      for (const auto& e : k3)
+        if (hipMemsetAsync(b->gb[e.wi], 0, (size_t)e.cout * sizeof(float), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
+    }
   }
   const int rc = backward_all(c);
   const int rc2 = c.flush_colsums();          // joins the weight-gradient stream

@@ -26,6 +26,7 @@ struct WgArgs {
   const bf16_t* src1;   // upsampled x1 in concat mode
   const bf16_t* gy;     // (N, Hout, Wout, Cout) gradient w.r.t. the conv output (already through the activation)
   float* dw;            // packed [taps][Cout][Cin] fp32, accumulated with atomics
+  float* gb;            // 3x3 forms: bias gradient [Cout] (+= column sums of gy, float atomics) or NULL
   int H, W, Cin, Cout, pad, ks;  // ks = 3 or 1
   int s0H, s0W, s0C, s1H, s1W, s1C;
   int Hout, Wout;
@@ -258,6 +259,12 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
   if (MODE != 0) { g = cbase / a.s0C; cbase -= g * a.s0C; }
   vec xr[XV], gr[GV];
   unsigned xvalid = 0;
+  // bias gradient = column sums of gy: the workgroups of the first ci chunk add up the gy vectors they stage anyway (the
+  // vector pipe is idle beside the MFMAs of the other waves); summed over the staging threads and added with 32 / 64 atomics
+  const bool do_bias = a.gb != nullptr && kc == 0;      // workgroup-uniform
+  float bs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bs[i] = 0.f;
 
   auto load_tile = [&](int t) {
     int r = t;
@@ -331,6 +338,12 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
       const int pix = p0 + j * PP;
       if (pix >= NG) continue;
       *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
+      if (do_bias) {
+        float f[8];
+        E::unpack(gr[j], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bs[i] += f[i];
+      }
     }
   };
 
@@ -372,6 +385,20 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
     write_lds();
     __syncthreads();
     ++tile;
+  }
+  if (do_bias) {
+    // (the tile loop ended with a barrier: the staging area is free) [thread][8] partial sums -> 32 channels
+    float* sBs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sBs[tid * 8 + i] = bs[i];
+    __syncthreads();
+    if (tid < 32) {
+      const int sl = tid >> 3, e = tid & 7;
+      float t = 0.f;
+      for (int p = 0; p < NT / 4; ++p) t += sBs[(p * 4 + sl) * 8 + e];
+      atomicAdd(a.gb + cc * 32 + tid, t);
+    }
+    __syncthreads();
   }
   // ---- the two row halves of every tap are summed through LDS (fixed order), then one atomic per element
   const int lr = lane & 31, lh = lane >> 5;
@@ -778,13 +805,20 @@ extern "C" int uncl_wgrad_set_wide(int on) { return g_wg_wide.exchange(on < 0 ? 
 // dw_packed must be zeroed by the caller (it is accumulated with atomics).  Descriptor fields used: ksize (3 or 1),
 // pad, src_mode (PLAIN / CONCAT_SSR), N, H, W, Cin, Cout, src0/src1 (+dims); `gy` is (N, Hout, Wout, Cout) bf16.
 extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* dw_packed, void* stream) {
+  return uncl_conv_wgrad_bias(d, gy, dw_packed, nullptr, stream);
+}
+
+// The same with the bias gradient: gb[co] += sum over pixels of gy[..][co] (3x3 layers only; float atomics like dw_packed: zero
+// it first).  The kernel stages every gy tile anyway, so the sums replace a separate column-sum pass over gy.
+extern "C" int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, float* dw_packed, float* gb, void* stream) {
   if (!d || !gy || !dw_packed || d->dtype != UNCL_BF16) return UNCL_ERR_ARG;
+  if (gb != nullptr && d->ksize != 3) return UNCL_ERR_ARG;
   if (d->ksize != 3 && d->ksize != 1) return UNCL_ERR_ARG;
   if (d->src_mode != UNCL_SRC_PLAIN && d->src_mode != UNCL_SRC_CONCAT_SSR) return UNCL_ERR_ARG;
   if (d->Cin % 32 != 0 || d->Cout % 32 != 0 || d->src0 == nullptr) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_CONCAT_SSR && (d->src1 == nullptr || d->Cin != 4 * d->src0_C)) return UNCL_ERR_ARG;
   WgArgs a;
-  a.src0 = (const bf16_t*)d->src0; a.src1 = (const bf16_t*)d->src1; a.gy = (const bf16_t*)gy; a.dw = dw_packed;
+  a.src0 = (const bf16_t*)d->src0; a.src1 = (const bf16_t*)d->src1; a.gy = (const bf16_t*)gy; a.dw = dw_packed; a.gb = gb;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.pad = d->ksize == 3 ? d->pad : 0; a.ks = d->ksize;
   a.s0H = d->src0_H; a.s0W = d->src0_W; a.s0C = d->src0_C; a.s1H = d->src1_H; a.s1W = d->src1_W; a.s1C = d->src1_C;
   if (d->ksize == 1) {
@@ -812,7 +846,8 @@ extern "C" int uncl_conv_wgrad(const uncl_conv_desc* d, const void* gy, float* d
     // 64 x 64 channel blocks where the layer has them (concat sources: a 64-channel chunk must lie inside one member)
     // mode 1 (default): the skip-concat layers only -- the layers it was measured faster on (launch_wg3w); 2: every eligible layer
     const int wmode = g_wg_wide.load(std::memory_order_relaxed);
-    bool wide = wmode != 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 && a.gy_ld % 8 == 0 &&
+    // (the wide kernel has no registers left for the bias sums: a call that asks for them takes the 32 x 32 kernel)
+    bool wide = wmode != 0 && gb == nullptr && d->Cin % 64 == 0 && d->Cout % 64 == 0 && a.gy_ld % 8 == 0 &&
                 (d->src_mode == UNCL_SRC_PLAIN ? wmode == 2 : d->src0_C % 64 == 0);
     if (wide && wmode == 1) {
       // ... and only with enough tiles per workgroup to amortise its bigger atomic tail: the N = 32 image step gains 0.075 ms
@@ -836,7 +871,7 @@ extern "C" int uncl_upconv2x2_wgrad(const void* x, const void* gy, float* dw_pac
   if (M > 0x7fffffffLL) return UNCL_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   WgArgs a;     // one launch: grid.y enumerates the four taps, each adding into its own [Cout][C] slice of dw_packed
-  a.src0 = (const bf16_t*)x; a.src1 = nullptr; a.gy = (const bf16_t*)gy; a.dw = dw_packed;
+  a.src0 = (const bf16_t*)x; a.src1 = nullptr; a.gy = (const bf16_t*)gy; a.dw = dw_packed; a.gb = nullptr;
   a.Cin = C; a.Cout = Cout; a.pad = 0; a.ks = 1;
   a.s0C = C; a.s1H = a.s1W = a.s1C = 0;
   const int rows = (int)((M + 31) / 32);
