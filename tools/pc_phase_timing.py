@@ -56,6 +56,7 @@ LAYERS = {
     "up0b": ("plain", 128, 128, 128, 26, 2, False),
     "up3b": ("plain", 32, 32, 32, 254, 2, False),      # single chunk: UNCL_PC_NK1=1
     "inc1": ("plain", 32, 32, 32, 254, 0, False),
+    "incf": ("image1", 1, 32, 32, 256, 0, True),        # the product's first layer: inc.conv.conv rebuilt by the staging waves
 }
 
 
@@ -90,7 +91,13 @@ def main():
         keep = []
         d = _hip.ConvDesc()
         x0 = rnd(n, h, h, c); keep.append(x0)
-        if mode == "up":
+        if mode == "image1":
+            # fp32 image (n, 256, 256); the conv sees the 254 x 254 x 32 map of inc.conv.conv
+            x0 = torch.rand(n, h, h, device="cuda", generator=g); pw = torch.rand(32, 1, 3, 3, device="cuda", generator=g) * 0.3
+            pb = torch.zeros(32, device="cuda"); keep += [x0, pw, pb]
+            d.pre_w, d.pre_b = pw.data_ptr(), pb.data_ptr()
+            d.src_mode = _hip.SRC_IMAGE1
+        elif mode == "up":
             x1 = rnd(n, h // 2, h // 2, c); uw = rnd(4, 32, 32, scale=0.1); ub = torch.zeros(32, device="cuda"); keep += [x1, uw, ub]
             d.src1, d.src1_H, d.src1_W, d.src1_C = x1.data_ptr(), h // 2, h // 2, c
             d.up_w, d.up_b = uw.data_ptr(), ub.data_ptr()
@@ -102,11 +109,12 @@ def main():
             d.src_mode = _hip.SRC_CONCAT_SSR
         else:
             d.src_mode = _hip.SRC_PLAIN
-        ho = h + 2 * pad - 2
+        hc = h - 2 if mode == "image1" else h            # the extent the 3x3 layer itself sees
+        ho = hc + 2 * pad - 2
         w = rnd(9, cout, cin, scale=0.05); b = torch.zeros(cout, device="cuda"); out = torch.empty(n, ho, ho, cout, dtype=bf, device="cuda")
         pl = torch.empty(n, ho // 2, ho // 2, cout, dtype=bf, device="cuda") if pool else None
         keep += [w, b, out, pl]
-        d.dtype, d.ksize, d.pad, d.N, d.H, d.W, d.Cin, d.Cout = _hip.BF16, 3, pad, n, h, h, cin, cout
+        d.dtype, d.ksize, d.pad, d.N, d.H, d.W, d.Cin, d.Cout = _hip.BF16, 3, pad, n, hc, hc, cin, cout
         d.src0, d.src0_H, d.src0_W, d.src0_C = x0.data_ptr(), h, h, c
         d.weight, d.bias, d.act = w.data_ptr(), b.data_ptr(), _hip.ACT_RELU
         d.out, d.out_H, d.out_W, d.out_C = out.data_ptr(), ho, ho, cout

@@ -147,7 +147,10 @@ template <typename V>
 __device__ __forceinline__ PcAcc pc_mm(const V& a, const V& b, const PcAcc& c, int) { return mfma32x16(a, b, c); }
 #endif
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
-__global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_pc_kernel(const PipeArgs a) {
+// (NT == 1 && MPW == 2 with four staging waves: 8-row tiles, 64 KB of LDS and <= 128 registers, TWO workgroups per CU, so that
+// one workgroup's epilogue runs under the other's MFMAs -- the single-chunk 32-channel layers spend 52 - 61 % of a multiplying
+// wave's time in the epilogue)
+__global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ? 4 : 2)) void conv3x3_pc_kernel(const PipeArgs a) {
   constexpr int NCW = 4;                      // multiplying waves
   static_assert(PW == 4 || PW == 8, "four or eight staging waves");
   using E = Elem<T>;
@@ -1210,7 +1213,8 @@ int launch_pc(PipeArgs& a, hipStream_t s) {
   }
   const int n_cu = uncl_cu_count();
   if (n_cu <= 0) return UNCL_ERR_LAUNCH;
-  int grid = a.total_tiles < n_cu ? a.total_tiles : n_cu;
+  const int slots = (NT == 1 && MPW == 2) ? 2 * n_cu : n_cu;      // resident workgroups
+  int grid = a.total_tiles < slots ? a.total_tiles : slots;
   a.tiles_per_wg = (a.total_tiles + grid - 1) / grid;
   grid = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
   hipLaunchKernelGGL(kern, dim3(grid), dim3((4 + PW) * 64), lds, s, a);
@@ -1274,6 +1278,14 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
       if (mode == 1) return launch_pc<T, 1, 4, 1, 8, false>(a, s);
       if (mode == 4) return launch_pc<T, 1, 4, 4, 8, false>(a, s);
     }
+    return UNCL_ERR_ARG;
+  }
+  if (nt == 1 && mpw == 2) {
+    // two workgroups per CU: single-chunk 32-channel layers with resident weights only
+    if (a.pool_out != nullptr && !fwd_relu) return UNCL_ERR_ARG;
+    if (!resw || a.nk != 1) return UNCL_ERR_ARG;
+    if (mode == 0) return launch_pc<T, 1, 2, 0, 4, true>(a, s);
+    if (mode == 3) return launch_pc<T, 1, 2, 3, 4, true>(a, s);
     return UNCL_ERR_ARG;
   }
   if (nt == 2 && mpw == 4) {

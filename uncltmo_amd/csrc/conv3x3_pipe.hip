@@ -834,6 +834,9 @@ int dispatch_type(PipeArgs& a, int dtype, int mode, bool prev, hipStream_t s) {
 
 // 2 (default): every layer the producer / consumer kernel builds faster; 3: also the fused 1x1 tails (slower there); 1: the
 // concat-source layers only; 0: the four-wave kernel
+#ifndef UNCL_PC_TWO_DEFAULT
+#define UNCL_PC_TWO_DEFAULT 0
+#endif
 static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 2; }();
 extern "C" int uncl_conv3x3_set_pc(int on) {
   const int old = g_use_pc;
@@ -930,6 +933,15 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + TH - 1) / TH;
     a.total_tiles = d->N * a.tiles_x * a.tiles_y;
     if (pc_ok) {
+      // single-chunk layers (Cin = 32, plain or rebuilt-from-the-image source): 8-row tiles at two workgroups per CU
+      static const int two = [] { const char* e = getenv("UNCL_PC_TWO"); return e ? atoi(e) : UNCL_PC_TWO_DEFAULT; }();
+      if (two && a.nk == 1 && (pc_mode == 0 || pc_mode == 3) && d->out1_w == nullptr && !d->skip_main_store) {
+        PipeArgs b = a;
+        b.tiles_y = (a.Hout + 7) / 8;
+        b.total_tiles = d->N * b.tiles_x * b.tiles_y;
+        const int rc = uncl_conv3x3_pc_launch(b, d->dtype, 1, 2, pc_mode, s);
+        if (rc != UNCL_ERR_ARG) return rc;
+      }
       const int rc = uncl_conv3x3_pc_launch(a, d->dtype, 1, 4, pc_mode, s);
       if (rc != UNCL_ERR_ARG) return rc;
     }
