@@ -569,3 +569,35 @@ def test_wgrad3x3_with_bias_gradient(cin, cout, h, w, n, pad):
     _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gys.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad_bias")
     torch.cuda.synchronize()
     assert rel_l2(gb.cpu(), 2 * bt.grad) < 1e-5
+
+
+def test_generator_backward_bias_slots_need_not_be_one_array(monkeypatch):
+    """uncl_gen_backward clears the bias slots its weight-gradient kernels ADD into: with one memset when the caller's slots are one
+    array (the package's own layout), per layer otherwise -- here every slot is a tensor of its own, pre-filled with garbage."""
+    from uncltmo_amd import autograd as AG
+
+    def grads(scatter):
+        net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+                   "replicate", 2, 0, compute_dtype="bf16")
+        synth.fill_state_dict(net, "g0")
+        net = net.cuda().eval()
+        x = synth.smooth_hdr_frames(2, salt="bw")
+        wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
+        orig = AG._GradSet.__init__
+
+        def init(self, module, dev):
+            orig(self, module, dev)
+            if scatter:
+                self.gb = [torch.full((g.numel(),), 7.0, dtype=torch.float32, device=dev) for g in self.gb]
+
+        monkeypatch.setattr(AG._GradSet, "__init__", init)
+        y, up = net(x.cuda())
+        (y * wy.cuda()).sum().backward()
+        monkeypatch.setattr(AG._GradSet, "__init__", orig)
+        return {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if k.endswith(".bias") and p.grad is not None}
+
+    a, b = grads(False), grads(True)
+    assert a.keys() == b.keys() and len(a) > 20
+    for k in a:
+        # same kernels, float atomics in another order
+        assert rel_l2(b[k], a[k]) < 1e-4, (k, rel_l2(b[k], a[k]))
