@@ -107,6 +107,13 @@ typedef struct uncl_conv_desc {
   const float* pre_b;   /* UNCL_SRC_IMAGE1: first-layer bias (32) fp32 or NULL                    */
   const void* up_w;     /* UNCL_SRC_CONCAT_SSR_UP: packed k2 s2 transposed-conv weights [4 taps][32][32] bf16 */
   const float* up_b;    /* UNCL_SRC_CONCAT_SSR_UP: its bias (32) fp32 or NULL                      */
+  /* uncl_conv3x3_pipe only, with UNCL_SRC_CONCAT_SSR_UP, act RELU, out1_* set and skip_main_store = 1: the whole last decoder
+   * stage as ONE launch (inference; unet_parts.py:149-162 double_conv_traspose, :338-345 outconv, Unet_singleFrame.py:207-209).
+   * tail_w = the SECOND ConvTranspose2d(32, 32, 3) packed [9 taps][32][32] like `weight` (flipped: a pad-2 correlation), applied to
+   * relu(this layer's output), which stays in LDS; out1 then has extent (H + 4) x (W + 4):
+   *   out1 = out1_act(outc(relu(convT3x3(relu(convT3x3(cat-ssr(src0, up(src1))))))))                                       */
+  const void* tail_w;
+  const float* tail_b;  /* bias of the second layer (32) fp32 or NULL */
 } uncl_conv_desc;
 
 int uncl_conv_igemm(const uncl_conv_desc* d, void* stream);
@@ -123,6 +130,11 @@ int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
  * (measured slower there).  All give bit-identical results; the switch
  * exists for same-process A/B timing and for the tests that compare the structures.  Returns the previous setting. */
 int uncl_conv3x3_set_pc(int on);
+/* Inference, last decoder stage (up_path.3; Unet_singleFrame.py:200-209): 1 (default) = concat + fused up-conv -> ConvT3x3 -> ConvT3x3
+ * -> outconv + last activation as ONE launch (uncl_conv_desc.tail_w), the two 32-channel maps stay in LDS; 0 = two launches with the
+ * 254 x 254 x 32 map in HBM between them.  Same rounding points either way (the fused form equals uncl_conv3x3_set_pc(3) bit for
+ * bit).  Returns the previous setting; env UNCL_FUSE_TAIL sets the initial one. */
+int uncl_gen_set_fused_tail(int on);
 
 /* ConvTranspose2d(k2, s2) + bias, bf16, HBM-bound layout (whole output-row runs per store).
  * Replaces `self.up(x1)` in up.forward (unet_parts.py:269,288).  x: NHWC (N,H,W,C); w: packed [4][Cout][C]

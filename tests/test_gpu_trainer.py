@@ -391,17 +391,29 @@ def test_overlapped_in_place_gradient_allreduce_matches_plain_step():
 
 def test_step_graph_replay_equals_eager_steps():
     """uncltmo_amd.step_graph.StepGraph: train_D + train_G captured once and replayed as one hipGraph launch.  In the
-    deterministic fp32 mode the parameters after warm-up + replays must be bit-identical to the same number of eager steps
-    (Adam's bias corrections come from the device-side step count, which every replay advances), the loss scalars of the last
-    step too, and the host-side bookkeeping (optimizer step counts, weight-pack epochs) must have followed the replays."""
+    deterministic fp32 mode N replays must leave bit-identical parameters to N eager steps -- the warm-up steps of the constructor
+    are undone (parameters, Adam moments, step counts), Adam's bias corrections come from the device-side step count, which every
+    replay advances -- the loss scalars of the last step too, and the host-side bookkeeping (optimizer step counts, weight-pack
+    epochs) must have followed the replays.  An eager forward right after construction (before any replay) must see valid weight
+    packs (the capture only RECORDED the pack kernels), and a learning rate changed by a scheduler must reach the replayed Adam."""
     from uncltmo_amd.step_graph import StepGraph
     hdr, pos, neg = step_inputs()
     tr_e, G_e, D_e = _fp32_trainer(False)
-    for _ in range(4):
-        tr_e.train_D(hdr, pos, neg, 0)
-        tr_e.train_G(hdr, hdr.clone(), pos, neg, 0)
     tr_g, G_g, D_g = _fp32_trainer(False)
     sg = StepGraph(tr_g, hdr, hdr.clone(), pos, neg, 0, warmup=2)
+    # nothing was trained by building the graph, and an eager forward works before the first replay
+    for (k, a), (_, b) in zip(G_e.state_dict().items(), G_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert len(tr_g.D_losses) == 0
+    G_e.eval(); G_g.eval()
+    with torch.no_grad():
+        ye, _ = G_e(hdr.reshape(-1, 1, 256, 256).float())
+        yg, _ = G_g(hdr.reshape(-1, 1, 256, 256).float())
+    assert torch.equal(ye, yg)
+    G_e.train(); G_g.train()
+    for _ in range(2):
+        tr_e.train_D(hdr, pos, neg, 0)
+        tr_e.train_G(hdr, hdr.clone(), pos, neg, 0)
     sg.replay()
     sg.replay()
     torch.cuda.synchronize()
@@ -413,13 +425,23 @@ def test_step_graph_replay_equals_eager_steps():
         assert torch.equal(getattr(tr_e, name).detach(), getattr(tr_g, name).detach()), name
     steps_e = sorted({int(st["step"]) for st in tr_e.optimizerG.state.values()})
     steps_g = sorted({int(st["step"]) for st in tr_g.optimizerG.state.values()})
-    assert steps_e == steps_g == [4]
+    assert steps_e == steps_g == [2]
+    assert len(tr_g.D_losses) == len(tr_e.D_losses) == 2
+    # lr_scheduler.step() between steps (the reference steps StepLR every epoch, GanTrainerImg.py:160-161): the replay must train
+    # at the new rate
+    for tr in (tr_e, tr_g):
+        for opt in (tr.optimizerG, tr.optimizerD):
+            for g in opt.param_groups:
+                g["lr"] = g["lr"] * 0.5
     # a new batch through the static inputs, and an eager forward afterwards sees the replayed weights (pack epochs advanced)
     hdr2 = hdr.flip(0).contiguous()
     sg.load(hdr2, hdr2, pos, neg)
     sg.replay()
     tr_e.train_D(hdr2, pos, neg, 0)
     tr_e.train_G(hdr2, hdr2.clone(), pos, neg, 0)
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(G_e.state_dict().items(), G_g.state_dict().items()):
+        assert torch.equal(a, b), ("after the lr change", k)
     G_e.eval(); G_g.eval()
     with torch.no_grad():
         ye, _ = G_e(hdr2.reshape(-1, 1, 256, 256).float())

@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("out1_w", C.c_void_p), ("out1_b", C.c_void_p), ("out1_act", C.c_int), ("out1", C.c_void_p),
         ("skip_main_store", C.c_int),
         ("pre_w", C.c_void_p), ("pre_b", C.c_void_p), ("up_w", C.c_void_p), ("up_b", C.c_void_p),
+        ("tail_w", C.c_void_p), ("tail_b", C.c_void_p),
     ]
 
 
@@ -98,6 +99,7 @@ SIGNATURES = {
     "uncl_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "uncl_conv3x3_pipe": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p]),
     "uncl_conv3x3_set_pc": (C.c_int, [C.c_int]),
+    "uncl_gen_set_fused_tail": (C.c_int, [C.c_int]),
     "uncl_upconv2x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_upconv2x2_dt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -35,10 +35,18 @@ struct PipeArgs {
   const float* up_b;    // MODE 4: its bias (32) or NULL
   int pc_prio;          // conv3x3_pc: 0 no priorities, 1 multiplying waves raised, 2 staging waves raised
   int lean;             // conv3x3_pc: 1 = plain forward stores take the straight-line epilogue (buffer stores, no branches)
+  // conv3x3_pc TAIL (fused last decoder stage, inference): this layer's 32-channel output (Hout x Wout) never leaves the CU --
+  // a second transposed 3x3 (32 -> 32, pad-2 correlation over tail_w) and the 1x1 outconv run from an LDS image of it
+  const bf16_t* tail_w; // packed [9 taps][32 cout][32 cin] of the second layer
+  const float* tail_b;  // its bias (32) or NULL
+  int oH, oW;           // extent of the final one-channel map: Hout + 2, Wout + 2
 };
 
 // conv3x3_pc.hip: the producer / consumer kernel for the multi-chunk layers; returns UNCL_ERR_ARG when (nt, mpw, mode) is not built
 int uncl_conv3x3_pc_launch(PipeArgs& a, int dtype, int nt, int mpw, int mode, hipStream_t s);
+// conv3x3_pc.hip, TAIL form: concat-ssr + fused up-conv source (mode 4) -> transposed 3x3 -> transposed 3x3 -> 1x1 + last
+// activation as ONE launch; a.Hout / a.Wout = extent of the intermediate map, a.oH / a.oW = extent of the result a.out1
+int uncl_conv3x3_tail_launch(PipeArgs& a, int dtype, hipStream_t s);
 
 namespace {
 

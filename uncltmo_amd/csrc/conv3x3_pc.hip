@@ -81,20 +81,37 @@ constexpr int pc_plane(int rows) { return (rows + ((4 - rows % 16) + 16) % 16) *
 
 struct TileCur { int tile, ct, tx, ty, n, kc; };
 
+// STRIP (fused last decoder stage): a workgroup walks DOWN a strip of tiles (ty fastest, one cout tile), because the second
+// layer needs the last two rows of the previous tile's intermediate map
+template <bool STRIP = false>
 __device__ __forceinline__ void cur_init(TileCur& c, int tile, const PipeArgs& a) {
   int r = tile;
   c.tile = tile;
-  c.ct = r % a.n_ct; r /= a.n_ct;
-  c.tx = r % a.tiles_x; r /= a.tiles_x;
-  c.ty = r % a.tiles_y; r /= a.tiles_y;
+  if (STRIP) {
+    c.ct = 0;
+    c.ty = r % a.tiles_y; r /= a.tiles_y;
+    c.tx = r % a.tiles_x; r /= a.tiles_x;
+  } else {
+    c.ct = r % a.n_ct; r /= a.n_ct;
+    c.tx = r % a.tiles_x; r /= a.tiles_x;
+    c.ty = r % a.tiles_y; r /= a.tiles_y;
+  }
   c.n = r;
   c.kc = 0;
 }
 // one K-chunk further; false past the end of this workgroup's tile range
+template <bool STRIP = false>
 __device__ __forceinline__ bool cur_next(TileCur& c, const PipeArgs& a, int tile_end) {
   if (++c.kc < a.nk) return true;
   c.kc = 0;
   if (++c.tile >= tile_end) return false;
+  if (STRIP) {
+    if (++c.ty == a.tiles_y) {
+      c.ty = 0;
+      if (++c.tx == a.tiles_x) { c.tx = 0; ++c.n; }
+    }
+    return true;
+  }
   if (++c.ct == a.n_ct) {
     c.ct = 0;
     if (++c.tx == a.tiles_x) {
@@ -146,7 +163,7 @@ typedef f32x16 PcAcc;
 template <typename V>
 __device__ __forceinline__ PcAcc pc_mm(const V& a, const V& b, const PcAcc& c, int) { return mfma32x16(a, b, c); }
 #endif
-template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool TAIL = false>
 // (NT == 1 && MPW == 2 with four staging waves: 8-row tiles, 64 KB of LDS and <= 128 registers, TWO workgroups per CU, so that
 // one workgroup's epilogue runs under the other's MFMAs -- the single-chunk 32-channel layers spend 52 - 61 % of a multiplying
 // wave's time in the epilogue)
@@ -167,7 +184,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   constexpr int STAGE = RESW ? XBYTES : XBYTES + WBYTES;
   static_assert(MODE != 4 || (NT == 1 && MPW == 4), "fused up-conv: 16 x 32 tiles of 32 channels");
   static_assert(MODE != 3 || (NT == 1 && RESW), "fused first layer: 32 -> 32 channels, one chunk, resident weights");
+  static_assert(!TAIL || (NT == 1 && MPW == 4 && RESW && PW == 4 && (MODE == 4 || MODE == 1)), "fused last stage: 16 x 32 x 32 tiles, resident weights");
   constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;            // MODE 3: fp32 image patch under the halo tile
+  // TAIL: a tile of the intermediate map is TW columns wide but only XSTEP = TW - 2 columns further than its left neighbour
+  // (the second layer's output columns [XSTEP tx, XSTEP tx + XSTEP) need intermediate columns XSTEP tx - 2 ..); its first
+  // column is XSTEP tx + XOFF
+  constexpr int XSTEP = TAIL ? TW - 2 : TW, XOFF = TAIL ? -2 : 0;
+  constexpr int CPL = pc_plane(2 * HW);                        // TAIL: one plane of the two carried rows
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wres = smem + 2 * XBYTES;                               // RESW: chunk kc at wres + kc * WBYTES
@@ -176,14 +199,25 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   float* const sBias = reinterpret_cast<float*>(smem + (RESW ? 2 * XBYTES + a.nk * WBYTES : 2 * STAGE));   // [4 tiles][CT]
   float* const sO1 = sBias + 4 * CT;                                  // fused 1x1 tail: 32 weights + its bias (+ pad)
   float* const sP = sO1 + 64;                                         // MODE 3: [2][PN3] image patches
+  float* const sB1 = sO1 + 64;                                        // TAIL: bias of the second layer (32)
+  char* const sCarry = reinterpret_cast<char*>(sB1 + 32);             // TAIL: [2][4 planes][2 rows x HW] last two intermediate rows
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
 
-  const int tile0 = (int)blockIdx.x * a.tiles_per_wg;
-  const int tile_end = min(tile0 + a.tiles_per_wg, a.total_tiles);
+  int tile0 = (int)blockIdx.x * a.tiles_per_wg;
+  int tile_end = min(tile0 + a.tiles_per_wg, a.total_tiles);
+  bool warm = false;
+  if (TAIL) {
+    // an even share of the (strip, row tile) steps; a share that starts inside a strip first runs the tile above it for the
+    // two intermediate rows it hands down (that tile's results are not stored: its owner stores them)
+    const int own0 = (int)((long long)blockIdx.x * a.total_tiles / gridDim.x);
+    tile_end = (int)((long long)(blockIdx.x + 1) * a.total_tiles / gridDim.x);
+    warm = own0 % a.tiles_y != 0;
+    tile0 = own0 - (warm ? 1 : 0);
+  }
   if (tile0 >= tile_end) return;
 
   if (wave < NCW) {
@@ -502,7 +536,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     };
 
     TileCur cc;
-    cur_init(cc, tile0, a);
+    cur_init<TAIL>(cc, tile0, a);
     int tpar = 0;
     const bool fast_relu = a.slope == 0.f && a.mask == nullptr && !a.accumulate && (!a.skip_main || a.out1_w != nullptr) &&
                            !(a.pc_prio & 256);   // wave-uniform
@@ -662,6 +696,187 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       else epilogue(c, tp, IntTag<2>{});
       zero_acc();
     };
+    if constexpr (TAIL) {
+      // ===============================================================================================================
+      // Fused last decoder stage (inference; unet_parts.py:149-162, 338-345; Unet_singleFrame.py:207-209):
+      //   tile t of a strip:  chunks 0..3 (concat-ssr K = 128) -> 16 x 32 x 32-channel tile of the intermediate map
+      //                       -> bias + ReLU + rounding, written to an LDS image (rows 2..17 of stage 1; image rows 0 / 1 are
+      //                          the last two rows of the previous tile of the strip, kept in a small double buffer)
+      //                       -> second transposed 3x3 (K = 32 x 9, weights in registers) from that image: 16 rows x 30 columns
+      //                       -> bias + ReLU + rounding + 1x1 outconv + last activation -> one fp32 channel to memory.
+      // The 32-channel maps of both layers never reach HBM (826 MB written and 1.05 GB read back per 200 tiles otherwise).
+      // Barriers per tile: four chunk barriers (before each chunk's last tap column, as in the loop below), one after the
+      // image is written, one before the second layer's last tap column; the staging waves take the two extra ones idle.
+      // ===============================================================================================================
+      vec A1[2][3][3];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx)
+            A1[ks][ty][tx] = ld16v<vec>(a.tail_w + ((ty * 3 + tx) * 32 + lr) * 32 + (2 * ks + lh) * 8);
+      char* const img = smem + STAGE;                   // stage 1: every tile's last chunk (3) sits there
+      if (cw == 3)                                      // a strip's first tile sees zero rows above it
+        for (int i = lane; i < 2 * 4 * CPL / 16; i += 64) *reinterpret_cast<vec*>(sCarry + i * 16) = E::zero();
+      auto t_pack4 = [&](const PcAcc& v, int q, const f32x4& b) __attribute__((always_inline)) {
+        const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
+        const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
+        vec4 o;
+        o[0] = (T)s0[0]; o[1] = (T)s0[1]; o[2] = (T)s1[0]; o[3] = (T)s1[1];
+        return o;
+      };
+      auto t_widen_relu = [&](const vec4& o0, const vec4& o1) __attribute__((always_inline)) {
+        const u32x2 d0 = __builtin_bit_cast(u32x2, o0), d1 = __builtin_bit_cast(u32x2, o1);
+        const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
+        const u32x4l w = {sx[0], sy[0], sx[1], sy[1]};
+        s16x8 si = __builtin_bit_cast(s16x8, w);
+        si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values
+        return si;
+      };
+      // the tile of the intermediate map -> LDS image (the same bits epilogue_lean would have stored); pixels outside the map
+      // are the second layer's zero padding
+      auto mid_epilogue = [&](const TileCur& c, int par) __attribute__((always_inline)) {
+        const int my0 = c.ty * TH + cw * MPW, mx = c.tx * XSTEP + XOFF + lr;
+        const bool colok = (unsigned)mx < (unsigned)a.Wout;
+        char* const cnext = sCarry + (par ^ 1) * 4 * CPL;
+        const bool last_of_strip = c.ty == a.tiles_y - 1;
+#pragma unroll
+        for (int m = 0; m < MPW; ++m)
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBias + 16 * qp + 4 * lh);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBias + 16 * qp + 8 + 4 * lh);
+            s16x8 wv = t_widen_relu(t_pack4(acc[m][0], 2 * qp, b0), t_pack4(acc[m][0], 2 * qp + 1, b1));
+            if (!(colok && my0 + m < a.Hout)) wv = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<s16x8*>(img + (2 * qp + lh) * XPL + ((2 + cw * MPW + m) * HW + lr) * 16) = wv;
+            if (m >= MPW - 2 && cw == NCW - 1) {
+              if (last_of_strip) wv = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+              *reinterpret_cast<s16x8*>(cnext + (2 * qp + lh) * CPL + ((m - (MPW - 2)) * HW + lr) * 16) = wv;
+            }
+          }
+      };
+      // second layer's accumulators -> bias + ReLU + rounding -> 1x1 outconv (each lane its 16 products, the two half-waves
+      // added once per row: the arithmetic of epilogue_lean's OUT1 form) -> last activation -> fp32 store
+      auto out_epilogue = [&](const TileCur& c, bool store) __attribute__((always_inline)) {
+        const int oy0 = c.ty * TH + cw * MPW, ox = c.tx * XSTEP + lr;
+        const bool xin = store && lr < XSTEP && ox < a.oW && lh == 0;
+        float* const orow = a.out1 + ((size_t)c.n * a.oH + oy0) * a.oW + ox;
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+          float dot = 0.f;
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + 16 * qp + 4 * lh);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + 16 * qp + 8 + 4 * lh);
+            const s16x8 wv = t_widen_relu(t_pack4(acc[m][0], 2 * qp, b0), t_pack4(acc[m][0], 2 * qp + 1, b1));
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh + 4);
+            float f[8];
+            E::unpack(__builtin_bit_cast(vec, wv), f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dot = fmaf(f[i], w0[i], dot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dot = fmaf(f[4 + i], w1[i], dot);
+          }
+          const float tot = dot + __shfl_xor(dot, 32, 64) + sO1[32];
+          if (xin && oy0 + m < a.oH) orow[(size_t)m * a.oW] = uncl_act(tot, a.out1_act);
+        }
+      };
+      // B fragments of the image for tap column (ks, tx): rows 0 / 1 of the wave's six come from `p01` (wave 0: the carried
+      // rows; the others: the rows the wave above wrote), rows 2..5 are the wave's own
+      auto rd1 = [&](const char* p01k0, const char* p01k1, int set, int col) __attribute__((always_inline)) {
+        const int ks = col / 3, tx = col - 3 * ks;
+        const char* p01 = ks ? p01k1 : p01k0;
+        const char* pb = img + boff + 2 * ks * XPL;
+#pragma unroll
+        for (int r = 0; r < MPW + 2; ++r)
+          B[set][r] = *reinterpret_cast<const vec*>((r < 2 ? p01 : pb) + (r * HW + tx) * 16);
+      };
+      auto mfma_col1 = [&](int col) __attribute__((always_inline)) {
+        const int set = col & 1, ks = col / 3, tx = col - 3 * ks;
+        if (col == 0) {
+#pragma unroll
+          for (int m = 0; m < MPW; ++m) acc[m][0] = pc_mm(A1[0][0][0], B[set][m], acc[m][0], 0);
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 1; ty < 3; ++ty) acc[m][0] = pc_mm(A1[0][ty][0], B[set][m + ty], acc[m][0], ty);
+        } else {
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) acc[m][0] = pc_mm(A1[ks][ty][tx], B[set][m + ty], acc[m][0], ty);
+        }
+      };
+      auto sched1 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < MPW + 2; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM - (MPW + 2), 0);
+      };
+      TileCur tc;
+      cur_init<TAIL>(tc, tile0, a);
+      int par = 0;
+      bool store = !warm;
+      pc_barrier();                         // stage 0 is staged (and the carry buffers are cleared)
+      rd(smem, wres, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      int s = 0;
+      for (int t = tile0; t < tile_end; ++t) {
+        // chunks 0..2: as in the loop below
+        for (int kc = 0; kc < 3; ++kc) {
+          mfma_cols_0_4(smem + (s & 1) * STAGE, wres + kc * WBYTES);
+          __builtin_amdgcn_sched_barrier(0);
+          pc_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          rd(smem + ((s + 1) & 1) * STAGE, wres + (kc + 1) * WBYTES, 0, 0);
+          mfma_col(5);
+          sched_reads_under_mfmas();
+          ++s;
+        }
+        // chunk 3 (stage 1): after its barrier nobody reads stage 1 any more -> the image goes there
+        mfma_cols_0_4(img, wres + 3 * WBYTES);
+        __builtin_amdgcn_sched_barrier(0);
+        pc_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_col(5);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+        ++s;
+        mid_epilogue(tc, par);
+        zero_acc();
+        __builtin_amdgcn_sched_barrier(0);
+        pc_barrier();                       // the image (and the carried rows of the NEXT tile) are written
+        __builtin_amdgcn_sched_barrier(0);
+        const char* const ccur = sCarry + par * 4 * CPL;
+        const char* const p01k0 = cw == 0 ? ccur + lh * CPL + lr * 16 : img + boff;
+        const char* const p01k1 = cw == 0 ? ccur + (2 + lh) * CPL + lr * 16 : img + boff + 2 * XPL;
+        rd1(p01k0, p01k1, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MPW + 2, 0);
+#pragma unroll
+        for (int col = 0; col < 5; ++col) {
+          rd1(p01k0, p01k1, (col & 1) ^ 1, col + 1);
+          mfma_col1(col);
+          sched1();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pc_barrier();                       // done with the image: the staging waves may overwrite stage 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < tile_end) rd(smem, wres, 0, 0);
+        mfma_col1(5);
+        if (t + 1 < tile_end) sched_reads_under_mfmas();
+        out_epilogue(tc, store);
+        zero_acc();
+        store = true;
+        par ^= 1;
+        tc.kc = a.nk - 1;
+        cur_next<TAIL>(tc, a, tile_end);
+      }
+      return;
+    }
     PCT_DECL
     if (MODE == 3) pc_barrier();     // the staging waves' first image patch
     pc_barrier();     // stage 0 is staged
@@ -710,7 +925,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
       tpar = (tpar + 1) & 3;
       cc.kc = a.nk - 1;
-      cur_next(cc, a, tile_end);          // the next tile's coordinates (unused past the end of the range)
+      cur_next<TAIL>(cc, a, tile_end);          // the next tile's coordinates (unused past the end of the range)
     }
     PCT_FLUSH(0)
     return;
@@ -883,7 +1098,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     constexpr bool SET_A = !CAT || P == 0;     // X registers this chunk loads into (if it loads any)
     constexpr bool X_LOAD = !CAT || XA_ONLY || (P == 0 && UNCL_PC_XA_SLOT == 0);   // this call requests the registers `xr`
     vec (&xr)[XV] = SET_A ? xa : xb;
-    const int n = c.n, y0 = c.ty * TH, x0 = c.tx * TW, cout0 = c.ct * CT, kc = c.kc;
+    const int n = c.n, y0 = c.ty * TH, x0 = c.tx * XSTEP + XOFF, cout0 = c.ct * CT, kc = c.kc;
     int g = 0, cbase = kc * 32;
     if (CAT) {
       cbase = (kc >> 2) * 32;
@@ -1112,7 +1327,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   };
 
   TileCur pc;
-  cur_init(pc, tile0, a);
+  cur_init<TAIL>(pc, tile0, a);
   const int total = (tile_end - tile0) * a.nk;     // chunks this workgroup walks
   int loaded = 0;                                  // chunks handed to load_step so far; the cursor points at chunk `loaded`
   auto load_next = [&](auto p_tag) __attribute__((always_inline)) {
@@ -1126,15 +1341,16 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       if (PART != 0 && loaded + (4 - P) < total) {
         TileCur la = pc;
 #pragma unroll
-        for (int k = 0; k < 4 - P; ++k) cur_next(la, a, tile_end);
+        for (int k = 0; k < 4 - P; ++k) cur_next<TAIL>(la, a, tile_end);
         load_step(la, IntTag<0>{}, IntTag<PART>{});
       }
       ++loaded;
       const int t_old = pc.tile;
-      if (cur_next(pc, a, tile_end) && pc.tile != t_old) ppar = (ppar + 1) & 3;
+      if (cur_next<TAIL>(pc, a, tile_end) && pc.tile != t_old) ppar = (ppar + 1) & 3;
     }
   };
   if (a.out1_w != nullptr && ptid < 33) sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0];     // fused 1x1 tail (CT == 32)
+  if (TAIL && ptid < 32) sB1[ptid] = a.tail_b != nullptr ? a.tail_b[ptid] : 0.f;
   if (RESW) {
     // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order, and so
     // does its bias (all four slots)
@@ -1186,7 +1402,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     if (iter(IntTag<0>{})) break;
     if (iter(IntTag<1>{})) break;
     if (iter(IntTag<2>{})) break;
-    if (iter(IntTag<3>{})) break;
+    const bool done = iter(IntTag<3>{});
+    if (TAIL) {
+      // the multiplying waves write the intermediate image into stage 1, publish it, and run the second layer from it: nothing
+      // may be staged there before the second of these barriers (the next tile's chunk 0 already sits in stage 0)
+      pc_barrier();
+      pc_barrier();
+    }
+    if (done) break;
   }
   PCT_FLUSH(4)
 }
@@ -1195,6 +1418,27 @@ template <int NT, int MPW>
 constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
   return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0);
+}
+
+// fused last decoder stage: one workgroup per CU walks an even share of the (strip, row tile) steps
+template <typename T, int MODE>
+int launch_tail(PipeArgs& a, hipStream_t s) {
+  constexpr size_t lds = pc_lds_bytes<1, 4>(true, 4, false) + 32 * 4 + 2 * 4 * (size_t)pc_plane(2 * 34);
+  static_assert(lds <= 163840, "one workgroup's LDS");
+  auto kern = conv3x3_pc_kernel<T, 1, 4, MODE, 4, true, true>;
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done.done();
+  }
+  const int n_cu = uncl_cu_count();
+  if (n_cu <= 0) return UNCL_ERR_LAUNCH;
+  const int grid = a.total_tiles < n_cu ? a.total_tiles : n_cu;
+  a.tiles_per_wg = (a.total_tiles + grid - 1) / grid;     // (unused by this form: shares are computed from the grid size)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
 }
 
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
@@ -1313,6 +1557,23 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
     return UNCL_ERR_ARG;
   }
   return UNCL_ERR_ARG;
+}
+
+int uncl_conv3x3_tail_launch(PipeArgs& a, int dtype, hipStream_t s) {
+  // concat-ssr source with the 2x2 up-conv recomputed in the loader, 128 -> 32 channels, ReLU, then 32 -> 32, ReLU, 1x1
+  if (a.nk != 4 || a.Cout != 32 || a.res != nullptr || a.flat_S != 0 || a.slope != 0.f || a.mask != nullptr || a.accumulate ||
+      a.tail_w == nullptr || a.out1_w == nullptr || a.out1_b == nullptr || a.out1 == nullptr || a.up_w == nullptr || a.pad != 2)
+    return UNCL_ERR_ARG;
+  static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
+  a.pc_prio = prio;
+  a.lean = 1;
+  a.n_ct = 1;
+  a.oH = a.Hout + 2; a.oW = a.Wout + 2;
+  a.tiles_x = (a.oW + 29) / 30;               // strips of 30 result columns (32 intermediate columns each)
+  a.tiles_y = (a.oH + 15) / 16;               // 16 result rows per step
+  a.total_tiles = a.flat_N * a.tiles_x * a.tiles_y;
+  if (dtype == UNCL_F16) return launch_tail<f16_t, 4>(a, s);
+  return launch_tail<bf16_t, 4>(a, s);
 }
 
 int uncl_conv3x3_pc_launch(PipeArgs& a, int dtype, int nt, int mpw, int mode, hipStream_t s) {

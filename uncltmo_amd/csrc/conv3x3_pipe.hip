@@ -904,6 +904,14 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   a.up_w = (const bf16_t*)d->up_w; a.up_b = d->up_b;
   a.flat_S = 0; a.flat_hw = 0; a.flat_N = d->N;
   a.nk = d->Cin / 32;
+  a.tail_w = (const bf16_t*)d->tail_w; a.tail_b = d->tail_b; a.oH = a.oW = 0;
+  if (d->tail_w != nullptr) {
+    // fused last decoder stage: this layer's output and the next layer's never leave the CU; only out1 is written
+    if (d->src_mode != UNCL_SRC_CONCAT_SSR_UP || d->act != UNCL_ACT_RELU || !d->skip_main_store || d->out1_w == nullptr ||
+        d->out1_b == nullptr || d->out1 == nullptr || pool_out != nullptr || mask != nullptr || accumulate || d->res != nullptr)
+      return UNCL_ERR_ARG;
+    return uncl_conv3x3_tail_launch(a, d->dtype, reinterpret_cast<hipStream_t>(stream));
+  }
   const bool prev = d->prev0 != nullptr && d->prev_ch > 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // multi-chunk layers: producer / consumer workgroups (conv3x3_pc.hip); everything it does not build falls through

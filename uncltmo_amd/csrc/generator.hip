@@ -17,6 +17,15 @@
 // its workgroup either way); 0: separate kernels
 static int g_fused_graph = [] { const char* e = getenv("UNCL_GCN_FUSED"); return e ? atoi(e) : 2; }();
 
+// 1 (default): inference runs the last decoder stage (up_path.3: concat + fused up-conv -> ConvT3x3 -> ConvT3x3 -> outconv) as ONE
+// launch whose 32-channel maps stay in LDS (conv3x3_pc.hip, TAIL); 0: two launches with the 254 x 254 x 32 map in HBM between them
+static int g_fuse_tail = [] { const char* e = getenv("UNCL_FUSE_TAIL"); return e ? atoi(e) : 1; }();
+extern "C" int uncl_gen_set_fused_tail(int on) {
+  const int old = g_fuse_tail;
+  g_fuse_tail = on ? 1 : 0;
+  return old;
+}
+
 namespace {
 
 // spatial size of every stage for a 256x256 input
@@ -228,6 +237,15 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
     d.up_w = c.w->w[wi_up]; d.up_b = c.w->b[wi_up];
     d.H = kDims[skip].h; d.W = kDims[skip].w;
     set_out(d, c.ptr(abuf), abuf);
+    if (g_fuse_tail && tail != nullptr && tail->skip_main_store && !c.norm && c.w->act == UNCL_ACT_RELU) {
+      // the whole stage in one launch: neither this layer's map nor the next one's is written (only the 1-channel result)
+      d.tail_w = c.w->w[wi_up + 2]; d.tail_b = c.w->b[wi_up + 2];
+      d.out1_w = tail->out1_w; d.out1_b = tail->out1_b; d.out1 = tail->out1; d.out1_act = tail->out1_act;
+      d.skip_main_store = 1;
+      rc = run3(c, wi_up + 1, d, nullptr);
+      if (rc != UNCL_ERR_ARG) return rc;
+      d.tail_w = nullptr; d.tail_b = nullptr; d.out1_w = nullptr; d.out1_b = nullptr; d.out1 = nullptr; d.skip_main_store = 0;
+    }
     if ((rc = run3(c, wi_up + 1, d, nullptr)) != UNCL_OK) return rc;
   } else if (use_pipe(c)) {
     ProfScope ps(wi_up, c.s);

@@ -142,7 +142,18 @@ class DistributedOptimizer:
         self.bucket_bytes = bucket_bytes
         self.module = module
         if module is not None and hasattr(module, "_packed_weights"):
+            # `module` must be the network THIS optimizer updates: a second wrapper (say, the discriminator's optimizer given
+            # module=netG) would replace the generator's reducer, its zero_grad() would drop the generator's pending passes and
+            # its step() would take the generator's gradients for its own -- ranks then diverge without an error
+            own = {id(p) for g in optimizer.param_groups for p in g["params"]}
+            if not any(id(p) in own for p in module.parameters()):
+                raise ValueError("DistributedOptimizer(module=...): the optimizer updates none of the module's parameters; "
+                                 "pass module= only to the optimizer of that module (the generator's)")
+            prev = module.__dict__.get("_grad_reducer")
+            if prev is not None and getattr(prev, "owner_optimizer", None) is not optimizer and prev.pending():
+                raise RuntimeError("the module already has a GradReducer with pending passes from another optimizer")
             module._grad_reducer = GradReducer()
+            module._grad_reducer.owner_optimizer = optimizer
 
     def synchronize(self):
         """Make .grad of every parameter the mean over ranks (call before reading or clipping gradients; step() does).
@@ -154,8 +165,12 @@ class DistributedOptimizer:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         red = getattr(self.module, "_grad_reducer", None) if self.module is not None else None
-        if red is None or not red.finish(list(self.module.named_parameters())):
-            allreduce_gradients(params, self.bucket_bytes)
+        if red is not None and red.finish(list(self.module.named_parameters())):
+            # the module's gradients came reduced out of its backward pass; parameters of this optimizer that do NOT belong to
+            # the module still take the bucketed path
+            mine = {id(p) for p in self.module.parameters()}
+            params = [p for p in params if id(p) not in mine]
+        allreduce_gradients(params, self.bucket_bytes)
         if ev is not None:
             ev[1].record()
             self.__dict__.setdefault("_sync_events", []).append(ev)

@@ -74,6 +74,16 @@ class Adam(torch.optim.Optimizer):
         return loss
 
 
+    def sync_device_hyper(self):
+        """Push a learning rate that changed on the host (lr_scheduler.step() edits param_groups[...]['lr']) into the device-side
+        hyper-parameter buffer, in stream order.  step() does this itself; a REPLAYED hipGraph of step() never runs that Python,
+        so step_graph.StepGraph.replay() calls this before every launch (one comparison per group when nothing changed)."""
+        for group in self.param_groups:
+            host = group.get("_uncl_hyper_host")
+            if host is not None and host[0] != float(group["lr"]):
+                group["_uncl_hyper"][0:1].fill_(float(group["lr"]))
+                host[0] = float(group["lr"])
+
     def advance_host_steps(self, n=1):
         """A replayed hipGraph of step() advanced the device-side step count n times without running this Python: bring the
         host bookkeeping (state[p]['step'], what state_dict() saves) in line."""

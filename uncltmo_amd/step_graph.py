@@ -13,22 +13,76 @@ into them.  Data-parallel runs (RCCL inside the step) stay eager.
 import torch
 
 
+class _Snapshot:
+    """Parameters and optimiser state of a trainer before StepGraph's warm-up steps: the warm-up is there to bring the library,
+    the allocator and the weight packs into their steady state, not to train -- restore() puts every value back IN PLACE (the
+    addresses the capture records stay the ones the warm-up used)."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.opts = [o for o in (trainer.optimizerD, trainer.optimizerG)]
+        self.params, self.state = [], []
+        with torch.no_grad():
+            for opt in self.opts:
+                inner = getattr(opt, "optimizer", opt)               # DistributedOptimizer wraps one
+                for group in inner.param_groups:
+                    for p in group["params"]:
+                        self.params.append((p, p.detach().clone()))
+                        st = inner.state.get(p)
+                        self.state.append((inner, group, p, None if not st else
+                                           (int(st["step"]), st["exp_avg"].clone(), st["exp_avg_sq"].clone())))
+        self.lists = [(lst, len(lst)) for lst in (trainer.D_losses, trainer.G_loss_d, trainer.G_loss_struct)]
+
+    def restore(self):
+        with torch.no_grad():
+            for p, saved in self.params:
+                p.copy_(saved)                                       # bumps ._version: the weight packs are rebuilt
+                p.grad = None
+            for inner, group, p, saved in self.state:
+                st = inner.state.get(p)
+                if not st:
+                    continue
+                if saved is None:
+                    st["step"] = 0
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+                else:
+                    st["step"] = saved[0]
+                    st["exp_avg"].copy_(saved[1])
+                    st["exp_avg_sq"].copy_(saved[2])
+                host = group.get("_uncl_hyper_host")
+                if host is not None:                                 # device-side step count of optim.Adam
+                    host[1] = st["step"]
+                    group["_uncl_hyper"][1:2].fill_(float(st["step"]))
+        for lst, n in self.lists:
+            del lst[n:]
+
+
 class StepGraph:
-    def __init__(self, trainer, hdr_input, hdr_original_gray_norm, real_ldr_pos, real_ldr_neg, epoch, warmup=3):
+    def __init__(self, trainer, hdr_input, hdr_original_gray_norm, real_ldr_pos, real_ldr_neg, epoch, warmup=3,
+                 keep_warmup_updates=False):
+        """`warmup` eager steps run first (lazy initialisation inside the library, the allocator's pools, the weight packs);
+        unless `keep_warmup_updates`, parameters and optimiser state are put back afterwards, so that building a StepGraph
+        trains nothing: N replays == N eager steps."""
         self.tr, self.epoch = trainer, epoch
         self.inputs = [t.clone() for t in (hdr_input, hdr_original_gray_norm, real_ldr_pos, real_ldr_neg)]
         self.replays = 0
-        # eager steps on a side stream first (the documented capture recipe): lazy initialisation inside the library, the
-        # allocator's pools and the weight packs reach their steady state before anything is recorded
-        side = torch.cuda.Stream()
+        snap = None if keep_warmup_updates else _Snapshot(trainer)
+        # Warm-up AND capture on ONE side stream.  torch.cuda.graph() without `stream=` captures on a stream of its own: the
+        # autograd nodes (AccumulateGrad) and allocator blocks the warm-up created on `side` then belong to another stream than
+        # the capture -- autograd warns ("AccumulateGrad node's stream does not match"), inserts cross-stream edges into the
+        # graph, and a block freed on one stream and reused on the other without record_stream is a use-after-free candidate.
+        side = self.stream = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._eager()
+            if snap is not None:
+                snap.restore()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self._eager()
         # the capture pass ran the Python of one step (optimizer step counts went up) but none of its kernels
         for opt in (trainer.optimizerD, trainer.optimizerG):
@@ -38,6 +92,12 @@ class StepGraph:
         for lst in (trainer.D_losses, trainer.G_loss_d, trainer.G_loss_struct):
             if lst:
                 lst.pop()
+        # The capture pass stored pack keys for weight packs whose kernels were only RECORDED (their buffers live in the graph's
+        # pool and hold nothing until the first replay): an eager forward before that replay must re-pack, not trust the key.
+        for net in (getattr(trainer, "netG", None), getattr(trainer, "netD", None)):
+            if net is not None and hasattr(net, "_pack_key"):
+                net._pack_key = None
+                net._packed = None
         trainer._step_graph = self
 
     def _eager(self):
@@ -51,6 +111,12 @@ class StepGraph:
 
     def replay(self):
         """one optimisation step on the batch last given to load(); trainer.errD / errG_d / errG_struct are updated in place"""
+        # a learning rate changed since the last step (lr_scheduler.step() edits param_groups): Adam reads it from device memory,
+        # and the only code that writes it there is the Python step() a replay never runs -- push it eagerly, in stream order
+        for opt in (self.tr.optimizerD, self.tr.optimizerG):
+            sync = getattr(opt, "sync_device_hyper", None)
+            if sync is not None:
+                sync()
         self.graph.replay()
         self.replays += 1
         for opt in (self.tr.optimizerD, self.tr.optimizerG):
