@@ -559,6 +559,11 @@ int uncl_percentile_lerp(const float* pairs, const double* gamma, const int* f64
 int uncl_color_finish_dev(const float* rgb, const float* fake, float* out, int H1, int W1, int top, int left, int H, int W,
                           const float* lohi, void* stream);
 int uncl_to_uint8_dev(const float* x, unsigned char* out, int C, int H, int W, const float* lohi, void* stream);
+/* warp_flow (GanTrainer.py:584-595; used by Tester.eval_on_video's warp error, Tester.py:379-389): out = cv2.remap(img, flow + pixel
+ * grid, None, cv2.INTER_LINEAR).  img: (H,W,C) uint8, flow: (Hf,Wf,2) fp32 displacements (x, y) -- NOT modified (the reference adds
+ * the grid into its argument in place), out: (Hf,Wf,C) uint8.  OpenCV's fixed-point bilinear remap for 8-bit images restated
+ * (1/32-pixel coordinates, 15-bit weights, constant-0 border); cv2 is absent here: parity with cv2 unpinned, hand-computed vectors. */
+int uncl_warp_flow(const unsigned char* img, const float* flow, unsigned char* out, int H, int W, int C, int Hf, int Wf, void* stream);
 
 #ifdef __cplusplus
 }

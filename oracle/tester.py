@@ -28,6 +28,34 @@ def warp_errors(img0_target_u8, img1_aligned_u8, border=32):
     return float(np.mean(np.power(a - b, 2))), float(np.mean(np.abs(a - b) / (1e-8 + a + b)))
 
 
+def warp_flow(img_u8, flow):
+    """GanTrainer.warp_flow (GanTrainer.py:584-595): cv2.remap(img, flow + pixel grid, None, cv2.INTER_LINEAR).  cv2 is a
+    third-party dependency that is absent from the reference tree and from this image (README.md lists `opencv-python`, no version):
+    **parity with cv2 unpinned**.  Restated from OpenCV's published algorithm for CV_8U / INTER_LINEAR / BORDER_CONSTANT(0)
+    (imgproc/src/imgwarp.cpp, remap + remapBilinear, 4.x): map coordinates rounded to 1/32 pixel with cvRound (half to even),
+    integer weights (32-fy)(32-fx)*32 ... of 2^15, result (sum + 2^14) >> 15, taps outside the image contribute the border value 0.
+    Pinned by hand-computed vectors in tests/test_warp_flow.py.  img_u8 (H,W,C) uint8, flow (Hf,Wf,2) float32 -> (Hf,Wf,C) uint8;
+    `flow` is not modified (the reference adds the grid in place)."""
+    img = np.asarray(img_u8)
+    assert img.dtype == np.uint8 and img.ndim == 3 and flow.ndim == 3 and flow.shape[-1] == 2
+    H, W, C = img.shape
+    hf, wf = flow.shape[:2]
+    mx = (flow[:, :, 0].astype(np.float32) + np.arange(wf, dtype=np.float32)).astype(np.float32)
+    my = (flow[:, :, 1].astype(np.float32) + np.arange(hf, dtype=np.float32)[:, None]).astype(np.float32)
+    sxq = np.rint(np.nan_to_num(mx * np.float32(32.0), nan=0.0).clip(-2147483000.0, 2147483000.0)).astype(np.int64)
+    syq = np.rint(np.nan_to_num(my * np.float32(32.0), nan=0.0).clip(-2147483000.0, 2147483000.0)).astype(np.int64)
+    ax, ay = sxq & 31, syq & 31
+    sx, sy = np.clip(sxq >> 5, -32768, 32767), np.clip(syq >> 5, -32768, 32767)
+    w = [(32 - ay) * (32 - ax) * 32, (32 - ay) * ax * 32, ay * (32 - ax) * 32, ay * ax * 32]
+    out = np.zeros((hf, wf, C), np.int64)
+    for k, (dy, dx) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        yy, xx = sy + dy, sx + dx
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        pix = img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.int64) * ok[..., None]
+        out += pix * w[k][..., None]
+    return ((out + (1 << 14)) >> 15).astype(np.uint8)
+
+
 def eval_on_video(sd, rgb_frames_hwc, f_factor, align=None):
     """sd: video generator state dict; rgb_frames_hwc: list of (H,W,3) float32 numpy frames of one scene.
     Returns (tmqi_scene, [uint8 (H,W,3)], per-frame TMQI[, warp_mse, warp_rel])."""

@@ -55,3 +55,21 @@ def run_pipe(pool_out=None, **kw):
 def rel_l2(a, b):
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def assert_elementwise(out, ref, dtype="bf16", what=""):
+    """Element-wise gate for a 16-bit kernel output against an fp32 / fp64 evaluation of the SAME rounded operands:
+    |out - ref| <= 2^-7 |ref| + 2^-7 rms(ref) for bf16 (2^-10 for fp16) -- four times the relative spacing of the format plus a floor
+    tied to the tensor's own scale (cancellation near zero, one-ulp differences of the rounded concat members).  A rel-L2 gate of
+    1.5e-2 passes with 2e-4 of the elements entirely wrong; this one fails on a single wrong, missing (NaN) or shifted element."""
+    out, ref = out.double().cpu(), ref.double().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all(), "%s: %d non-finite (unwritten?) elements" % (what, int((~torch.isfinite(out)).sum()))
+    eps = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+    tol = eps * ref.abs() + eps * ref.pow(2).mean().sqrt()
+    bad = (out - ref).abs() > tol
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError("%s: %d of %d elements outside the element-wise gate; first at %s: got %.6g want %.6g (tol %.3g)"
+                             % (what, int(bad.sum()), bad.numel(), idx, out[tuple(idx)].item(), ref[tuple(idx)].item(),
+                                tol[tuple(idx)].item()))

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from hip_util import pack_weight, rel_l2, run_pipe
+from hip_util import assert_elementwise, pack_weight, rel_l2, run_pipe
 from uncltmo_amd import _hip, synth
 from uncltmo_amd.generator import UNet
 
@@ -89,11 +89,8 @@ def test_fused_stage_matches_reference_and_two_launches(dtype, n, h, w):
     assert torch.isfinite(two).all() and torch.isfinite(mid.float()).all()
     assert torch.equal(fused, two), "fused stage != two launches: max |d| %.3e" % (fused - two).abs().max().item()
     ref, mid_ref = _reference(dt, *ins)
-    # the intermediate map of the two-launch path, element-wise: one rounding to 2^-8 (bf16) / 2^-11 (fp16) relative, plus fp32
-    # accumulation-order noise
-    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
-    m = mid.float().cpu().permute(0, 3, 1, 2)
-    assert ((m - mid_ref).abs() <= 1.01 * ulp * mid_ref.abs() + 2e-5).all()
+    # the intermediate map of the two-launch path, element by element
+    assert_elementwise(mid.float().cpu().permute(0, 3, 1, 2), mid_ref, dtype, "intermediate map")
     # the result: a few flipped roundings of the two intermediate maps (fp32 vs fp64 accumulation) move the logit by ~1e-3
     err = (fused.cpu().unsqueeze(1) - ref).abs()
     assert err.max().item() < (6e-3 if dtype == "bf16" else 1e-3), err.max().item()
@@ -126,5 +123,6 @@ def test_generator_inference_fused_tail_is_bitwise_the_two_launch_path(dtype, n)
         lib.uncl_conv3x3_set_pc(old_p)
     assert torch.isfinite(y_f).all()
     assert torch.equal(y_f, y_2), (y_f - y_2).abs().max().item()
-    # against the four-wave kernel only the order of the 32-term fp32 dot product of the outconv differs
-    assert (y_f - y_4).abs().max().item() < 2e-6
+    # against the four-wave kernel only the outconv's 32-term dot product differs: an fp32 fma chain there, four MFMAs over the
+    # 16-bit head and tail of the fp32 weights here (w = hi + lo to 2^-17 |w|: ~1e-5 on the logit, a quarter of that behind the sigmoid)
+    assert (y_f - y_4).abs().max().item() < 3e-5

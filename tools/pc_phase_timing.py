@@ -56,6 +56,7 @@ LAYERS = {
     "up0b": ("plain", 128, 128, 128, 26, 2, False),
     "up3b": ("plain", 32, 32, 32, 254, 2, False),      # single chunk: UNCL_PC_NK1=1
     "inc1": ("plain", 32, 32, 32, 254, 0, False),
+    "tail": ("tail", 32, 128, 32, 252, 2, False),       # the fused last decoder stage (up3f + second 3x3 + outconv in one launch)
     "incf": ("image1", 1, 32, 32, 256, 0, True),        # the product's first layer: inc.conv.conv rebuilt by the staging waves
 }
 
@@ -97,7 +98,7 @@ def main():
             pb = torch.zeros(32, device="cuda"); keep += [x0, pw, pb]
             d.pre_w, d.pre_b = pw.data_ptr(), pb.data_ptr()
             d.src_mode = _hip.SRC_IMAGE1
-        elif mode == "up":
+        elif mode in ("up", "tail"):
             x1 = rnd(n, h // 2, h // 2, c); uw = rnd(4, 32, 32, scale=0.1); ub = torch.zeros(32, device="cuda"); keep += [x1, uw, ub]
             d.src1, d.src1_H, d.src1_W, d.src1_C = x1.data_ptr(), h // 2, h // 2, c
             d.up_w, d.up_b = uw.data_ptr(), ub.data_ptr()
@@ -119,6 +120,11 @@ def main():
         d.weight, d.bias, d.act = w.data_ptr(), b.data_ptr(), _hip.ACT_RELU
         d.out, d.out_H, d.out_W, d.out_C = out.data_ptr(), ho, ho, cout
         plp = pl.data_ptr() if pool else None
+        if mode == "tail":
+            w1 = rnd(9, 32, 32, scale=0.05); b1 = torch.zeros(32, device="cuda"); ow = torch.rand(32, device="cuda", generator=g) - 0.5
+            ob = torch.zeros(1, device="cuda"); o1 = torch.empty(n, ho + 2, ho + 2, device="cuda"); keep += [w1, b1, ow, ob, o1]
+            d.tail_w, d.tail_b, d.out1_w, d.out1_b, d.out1, d.out1_act = w1.data_ptr(), b1.data_ptr(), ow.data_ptr(), ob.data_ptr(), o1.data_ptr(), _hip.ACT_SIGMOID
+            d.skip_main_store = 1
         gflop = 2.0 * 9 * cin * cout * ho * ho * n / 1e9
 
         def run(k):
@@ -147,7 +153,9 @@ def main():
         r0, r2 = res.get(0, [float("nan")]), res.get(2, [float("nan")])
         print("== %s: four-wave %s ms, producer/consumer %s ms (%.0f / %.0f TFLOP/s)" % (
             name, ["%.3f" % v for v in r0], ["%.3f" % v for v in r2], gflop / min(r0), gflop / min(r2)))
-        for label, names, base, cnt in (("consumer wave 0", CONS, 0, t[8]), ("producer wave 4", PROD, 4, t[9])):
+        cons_names = ["MFMA of the four chunks", "image + result epilogues", "barrier wait", "second layer's MFMA"] if name == "tail" else CONS
+        prod_names = ["the two idle barriers per tile"] + PROD[1:] if name == "tail" else PROD
+        for label, names, base, cnt in (("consumer wave 0", cons_names, 0, t[8]), ("producer wave 4", prod_names, 4, t[9])):
             tot = sum(t[base:base + 4])
             if tot == 0 or cnt == 0:
                 print("   %s: no samples (layer did not take the producer/consumer path)" % label)

@@ -173,6 +173,7 @@ SIGNATURES = {
     "uncl_color_finish_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p]),
     "uncl_to_uint8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_warp_flow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_rgbe_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     "uncl_rgbe_to_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_prof_enable": (C.c_int, [C.c_int, C.c_int]),

@@ -572,9 +572,50 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     // row contributes 2^30, i.e. lands beyond num_records and is dropped by the hardware (every sample is < 1 GiB: launcher).
     typedef unsigned u32x4l __attribute__((ext_vector_type(4)));
     // OUT1 (32-channel tiles): the fused 1x1 tail (outconv + last activation, unet_parts.py:338-345) on the ROUNDED, activated
-    // channels: after the widening a lane holds eight consecutive channels of its pixel, the other half-wave the other eight of
-    // the same sixteen; each lane accumulates its 16 products (8 per channel group qp) and the two half-waves are added once
-    // per row.  1: also store the 32-channel map; 2: only the 1-channel map (inference does not need up_x).
+    // channels, as four MFMAs per row (outc_row above).  1: also store the 32-channel map; 2: only the 1-channel map (inference
+    // does not need up_x).
+    // The fused 1x1 outconv on the matrix cores.  The 32x32 accumulator of a row (channel = register index, pixel = lane) IS a B
+    // operand once its registers 8 s .. 8 s + 7 are rounded pairwise to 16 bits -- exactly the rounding the stored map would
+    // get: element j of lane half h is channel 16 s + 8 (j >> 2) + 4 h + (j & 3).  With an A operand whose 32 rows all hold the
+    // outconv weights in that order, every register of D is the lane's pixel's dot product.  The fp32 weights enter as a 16-bit
+    // head and tail (w = hi + lo to 2^-17 |w|): four MFMAs per row replace 16 unpacks + 16 fma + a half-wave exchange.
+    auto outc_frags = [&](vec (&hi)[2], vec (&lo)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float w = sO1[16 * ks + 8 * (j >> 2) + 4 * lh + (j & 3)];
+          const T h = (T)w;
+          hi[ks][j] = h;
+          lo[ks][j] = (T)(w - (float)h);
+        }
+    };
+    // bias + ReLU + rounding of one row's accumulator, then the dot product with the outconv weights (without its bias)
+    auto outc_row = [&](const PcAcc& v, const float* bsrc, const vec (&hi)[2], const vec (&lo)[2]) __attribute__((always_inline)) {
+      vec Bf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        typedef float f32x2o __attribute__((ext_vector_type(2)));
+        typedef short s16x8o __attribute__((ext_vector_type(8)));
+        vec o;
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const int q = 2 * ks + hq;
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bsrc + 8 * q + 4 * lh);
+          const f32x2o s0 = f32x2o{v[4 * q], v[4 * q + 1]} + f32x2o{b[0], b[1]};
+          const f32x2o s1 = f32x2o{v[4 * q + 2], v[4 * q + 3]} + f32x2o{b[2], b[3]};
+          o[4 * hq] = (T)s0[0]; o[4 * hq + 1] = (T)s0[1]; o[4 * hq + 2] = (T)s1[0]; o[4 * hq + 3] = (T)s1[1];
+        }
+        s16x8o si = __builtin_bit_cast(s16x8o, o);
+        si = __builtin_elementwise_max(si, s16x8o{0, 0, 0, 0, 0, 0, 0, 0});        // ReLU on the rounded values
+        Bf[ks] = __builtin_bit_cast(vec, si);
+      }
+      f32x16 d = mfma32x16(hi[0], Bf[0], zero16);
+      d = mfma32x16(lo[0], Bf[0], d);
+      d = mfma32x16(hi[1], Bf[1], d);
+      d = mfma32x16(lo[1], Bf[1], d);
+      return d[0];
+    };
     auto epilogue_lean = [&](const TileCur& c, int tp, auto pool_tag, auto out1_tag) __attribute__((always_inline)) {
       constexpr bool POOL = decltype(pool_tag)::value != 0;
       constexpr int OUT1 = decltype(out1_tag)::value;
@@ -627,11 +668,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           const int gy = (c.ty * TH >> 1) + cw * (MPW / 2) + pr;
           pvoff = ploff + (((unsigned)gy * prowb) | (gy < a.pH ? 0u : BAD));
         }
-        float dot[2] = {0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int qp = 0; qp < 2; ++qp) {
+            if (OUT1 == 2) continue;                 // only the one-channel map is wanted: no widened 16-byte vectors
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 4 * lh);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 8 + 4 * lh);
             s16x8 wv[2];
@@ -646,16 +687,6 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #endif
               if (OUT1 != 2)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, UNCL_PC_STORE_AUX);
-              if (OUT1 != 0) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh + 4);
-                float f[8];
-                E::unpack(__builtin_bit_cast(vec, wv[r]), f);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dot[r] = fmaf(f[i], w0[i], dot[r]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dot[r] = fmaf(f[4 + i], w1[i], dot[r]);
-              }
             }
             if (POOL) {
               // MaxPool2d(2) of the two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
@@ -672,10 +703,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
             }
           }
         if (OUT1 != 0) {
+          // (this path is a test / A-B form: the weight fragments are rebuilt per tile rather than kept in registers)
+          vec o1hi[2], o1lo[2];
+          outc_frags(o1hi, o1lo);
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             const int oy = y0 + 2 * pr + r;
-            const float tot = dot[r] + __shfl_xor(dot[r], 32, 64) + sO1[32];
+            const float tot = outc_row(acc[2 * pr + r][0], sBt, o1hi, o1lo) + sO1[32];
             if (lh == 0 && oy < a.Hout && ox < a.Wout) a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act);
           }
         }
@@ -735,54 +769,50 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values
         return si;
       };
-      // the tile of the intermediate map -> LDS image (the same bits epilogue_lean would have stored); pixels outside the map
-      // are the second layer's zero padding
-      auto mid_epilogue = [&](const TileCur& c, int par) __attribute__((always_inline)) {
+      // the tile of the intermediate map -> registers (the same bits epilogue_lean would have stored); pixels outside the map are
+      // the second layer's zero padding.  Arithmetic first, LDS writes after the barrier that ends chunk 3.
+      s16x8 mid_v[MPW][2];
+      auto mid_compute = [&](const TileCur& c) __attribute__((always_inline)) {
         const int my0 = c.ty * TH + cw * MPW, mx = c.tx * XSTEP + XOFF + lr;
         const bool colok = (unsigned)mx < (unsigned)a.Wout;
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBias + 16 * qp + 4 * lh);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBias + 16 * qp + 8 + 4 * lh);
+#pragma unroll
+          for (int m = 0; m < MPW; ++m) {
+            s16x8 wv = t_widen_relu(t_pack4(acc[m][0], 2 * qp, b0), t_pack4(acc[m][0], 2 * qp + 1, b1));
+            if (!(colok && my0 + m < a.Hout)) wv = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mid_v[m][qp] = wv;
+          }
+        }
+      };
+      auto mid_write = [&](const TileCur& c, int par) __attribute__((always_inline)) {
         char* const cnext = sCarry + (par ^ 1) * 4 * CPL;
         const bool last_of_strip = c.ty == a.tiles_y - 1;
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
 #pragma unroll
           for (int qp = 0; qp < 2; ++qp) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBias + 16 * qp + 4 * lh);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBias + 16 * qp + 8 + 4 * lh);
-            s16x8 wv = t_widen_relu(t_pack4(acc[m][0], 2 * qp, b0), t_pack4(acc[m][0], 2 * qp + 1, b1));
-            if (!(colok && my0 + m < a.Hout)) wv = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<s16x8*>(img + (2 * qp + lh) * XPL + ((2 + cw * MPW + m) * HW + lr) * 16) = wv;
-            if (m >= MPW - 2 && cw == NCW - 1) {
-              if (last_of_strip) wv = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-              *reinterpret_cast<s16x8*>(cnext + (2 * qp + lh) * CPL + ((m - (MPW - 2)) * HW + lr) * 16) = wv;
-            }
+            *reinterpret_cast<s16x8*>(img + (2 * qp + lh) * XPL + ((2 + cw * MPW + m) * HW + lr) * 16) = mid_v[m][qp];
+            if (m >= MPW - 2 && cw == NCW - 1)
+              *reinterpret_cast<s16x8*>(cnext + (2 * qp + lh) * CPL + ((m - (MPW - 2)) * HW + lr) * 16) =
+                  last_of_strip ? s16x8{0, 0, 0, 0, 0, 0, 0, 0} : mid_v[m][qp];
           }
       };
-      // second layer's accumulators -> bias + ReLU + rounding -> 1x1 outconv (each lane its 16 products, the two half-waves
-      // added once per row: the arithmetic of epilogue_lean's OUT1 form) -> last activation -> fp32 store
+      // second layer's accumulators -> bias + ReLU + rounding -> 1x1 outconv on the matrix cores (outc_row) -> last activation
+      // -> fp32 store
+      vec o1hi[2], o1lo[2];
       auto out_epilogue = [&](const TileCur& c, bool store) __attribute__((always_inline)) {
         const int oy0 = c.ty * TH + cw * MPW, ox = c.tx * XSTEP + lr;
         const bool xin = store && lr < XSTEP && ox < a.oW && lh == 0;
         float* const orow = a.out1 + ((size_t)c.n * a.oH + oy0) * a.oW + ox;
+        float tot[MPW];
 #pragma unroll
-        for (int m = 0; m < MPW; ++m) {
-          float dot = 0.f;
+        for (int m = 0; m < MPW; ++m) tot[m] = outc_row(acc[m][0], sB1, o1hi, o1lo) + sO1[32];
 #pragma unroll
-          for (int qp = 0; qp < 2; ++qp) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + 16 * qp + 4 * lh);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + 16 * qp + 8 + 4 * lh);
-            const s16x8 wv = t_widen_relu(t_pack4(acc[m][0], 2 * qp, b0), t_pack4(acc[m][0], 2 * qp + 1, b1));
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(sO1 + 16 * qp + 8 * lh + 4);
-            float f[8];
-            E::unpack(__builtin_bit_cast(vec, wv), f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dot = fmaf(f[i], w0[i], dot);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dot = fmaf(f[4 + i], w1[i], dot);
-          }
-          const float tot = dot + __shfl_xor(dot, 32, 64) + sO1[32];
-          if (xin && oy0 + m < a.oH) orow[(size_t)m * a.oW] = uncl_act(tot, a.out1_act);
-        }
+        for (int m = 0; m < MPW; ++m)
+          if (xin && oy0 + m < a.oH) orow[(size_t)m * a.oW] = uncl_act(tot[m], a.out1_act);
       };
       // B fragments of the image for tap column (ks, tx): rows 0 / 1 of the wave's six come from `p01` (wave 0: the carried
       // rows; the others: the rows the wave above wrote), rows 2..5 are the wave's own
@@ -822,7 +852,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       cur_init<TAIL>(tc, tile0, a);
       int par = 0;
       bool store = !warm;
-      pc_barrier();                         // stage 0 is staged (and the carry buffers are cleared)
+      // (timing builds: phase 0 = the four chunks' MFMAs, 1 = the two epilogues, 2 = barrier waits, 3 = the second layer's MFMAs;
+      // per-kind slots 0 / 1 = wait at the image / second-layer barrier, 2 / 3 = image / result epilogue, 4..7 = chunk barriers)
+      PCT_DECL
+      pc_barrier();                         // stage 0 is staged (and the carry buffers are cleared, the outconv weights in LDS)
+      PCT(2)
+      outc_frags(o1hi, o1lo);
       rd(smem, wres, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
       int s = 0;
@@ -830,27 +865,37 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         // chunks 0..2: as in the loop below
         for (int kc = 0; kc < 3; ++kc) {
           mfma_cols_0_4(smem + (s & 1) * STAGE, wres + kc * WBYTES);
+          PCT(0)
           __builtin_amdgcn_sched_barrier(0);
           pc_barrier();
           __builtin_amdgcn_sched_barrier(0);
+          PCT_K(2, 4 + kc)
           rd(smem + ((s + 1) & 1) * STAGE, wres + (kc + 1) * WBYTES, 0, 0);
           mfma_col(5);
           sched_reads_under_mfmas();
+          PCT(0)
           ++s;
         }
-        // chunk 3 (stage 1): after its barrier nobody reads stage 1 any more -> the image goes there
+        // chunk 3 (stage 1).  Its barrier comes AFTER the tile's conversion arithmetic: the staging waves' heaviest iteration
+        // (the next tile's chunk 0 with the up-conv's MFMAs) runs beside this chunk and gets that much longer; once every wave
+        // is past it nobody reads stage 1 any more and the image goes there
         mfma_cols_0_4(img, wres + 3 * WBYTES);
+        mfma_col(5);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+        PCT(0)
+        mid_compute(tc);
+        zero_acc();
+        PCT_K(1, 2)
         __builtin_amdgcn_sched_barrier(0);
         pc_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_col(5);
-        __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+        PCT_K(2, 7)
         ++s;
-        mid_epilogue(tc, par);
-        zero_acc();
+        mid_write(tc, par);
         __builtin_amdgcn_sched_barrier(0);
         pc_barrier();                       // the image (and the carried rows of the NEXT tile) are written
         __builtin_amdgcn_sched_barrier(0);
+        PCT_K(2, 0)
         const char* const ccur = sCarry + par * 4 * CPL;
         const char* const p01k0 = cw == 0 ? ccur + lh * CPL + lr * 16 : img + boff;
         const char* const p01k1 = cw == 0 ? ccur + (2 + lh) * CPL + lr * 16 : img + boff + 2 * XPL;
@@ -862,19 +907,24 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           mfma_col1(col);
           sched1();
         }
+        PCT(3)
         __builtin_amdgcn_sched_barrier(0);
         pc_barrier();                       // done with the image: the staging waves may overwrite stage 1
         __builtin_amdgcn_sched_barrier(0);
+        PCT_K(2, 1)
         if (t + 1 < tile_end) rd(smem, wres, 0, 0);
         mfma_col1(5);
         if (t + 1 < tile_end) sched_reads_under_mfmas();
+        PCT(3)
         out_epilogue(tc, store);
         zero_acc();
+        PCT_K(1, 3)
         store = true;
         par ^= 1;
         tc.kc = a.nk - 1;
         cur_next<TAIL>(tc, a, tile_end);
       }
+      PCT_FLUSH(0)
       return;
     }
     PCT_DECL
@@ -1408,6 +1458,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       // may be staged there before the second of these barriers (the next tile's chunk 0 already sits in stage 0)
       pc_barrier();
       pc_barrier();
+      PCT(0)
     }
     if (done) break;
   }
@@ -1564,7 +1615,10 @@ int uncl_conv3x3_tail_launch(PipeArgs& a, int dtype, hipStream_t s) {
   if (a.nk != 4 || a.Cout != 32 || a.res != nullptr || a.flat_S != 0 || a.slope != 0.f || a.mask != nullptr || a.accumulate ||
       a.tail_w == nullptr || a.out1_w == nullptr || a.out1_b == nullptr || a.out1 == nullptr || a.up_w == nullptr || a.pad != 2)
     return UNCL_ERR_ARG;
-  static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
+  // wave priorities: none.  Here the STAGING waves are what the multiplying waves wait for (four of them, with the up-conv's
+  // MFMAs in their heaviest iteration): raising the multiplying waves (the default of the other forms) measured 1.113 ms per 200
+  // tiles against 1.085 without priorities, raising the staging waves 1.162
+  static const int prio = [] { const char* e = getenv("UNCL_TAIL_PRIO"); return e ? atoi(e) : 0; }();
   a.pc_prio = prio;
   a.lean = 1;
   a.n_ct = 1;

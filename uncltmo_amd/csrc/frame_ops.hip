@@ -349,3 +349,44 @@ extern "C" int uncl_percentile_lerp(const float* pairs, const double* gamma, con
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// warp_flow (GanTrainer.py:584-595): res = cv2.remap(img, flow + pixel grid, None, cv2.INTER_LINEAR) on an 8-bit image.
+// cv2 is absent from the reference tree and from this image: the kernel restates OpenCV's published fixed-point algorithm for
+// CV_8U + INTER_LINEAR + BORDER_CONSTANT(0) (imgproc/src/imgwarp.cpp, remap / remapBilinear): coordinates are rounded to 1/32 of
+// a pixel (cvRound(x * 32), round-half-even), the four weights are (32 - fy)(32 - fx) * 32 etc. out of 2^15 (exact integers for
+// the bilinear table, so the table's sum correction never fires) and the result is (sum + 2^14) >> 15; a tap outside the image
+// contributes 0.  One thread per output pixel, all channels.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void warp_flow_kernel(const unsigned char* __restrict__ img, const float* __restrict__ flow, unsigned char* __restrict__ out,
+                                 int H, int W, int C, int Hf, int Wf) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Hf * Wf) return;
+  const int y = idx / Wf, x = idx - y * Wf;
+  // flow[:, :, 0] += arange(wf); flow[:, :, 1] += arange(hf)[:, None]  (float32 additions)
+  const float mx = __fadd_rn(flow[2 * idx], (float)x), my = __fadd_rn(flow[2 * idx + 1], (float)y);
+  // cvRound of the float product (exact: a power-of-two scale); non-finite / huge values saturate like saturate_cast<short>
+  const float fx32 = fminf(fmaxf(mx * 32.f, -2147483000.f), 2147483000.f), fy32 = fminf(fmaxf(my * 32.f, -2147483000.f), 2147483000.f);
+  const int sxq = (fx32 == fx32) ? __float2int_rn(fx32) : 0, syq = (fy32 == fy32) ? __float2int_rn(fy32) : 0;
+  const int ax = sxq & 31, ay = syq & 31;
+  const int sx = min(max(sxq >> 5, -32768), 32767), sy = min(max(syq >> 5, -32768), 32767);
+  const int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
+  const bool x0 = sx >= 0 && sx < W, x1 = sx + 1 >= 0 && sx + 1 < W, y0 = sy >= 0 && sy < H, y1 = sy + 1 >= 0 && sy + 1 < H;
+  for (int c = 0; c < C; ++c) {
+    const int p00 = (x0 && y0) ? img[((size_t)sy * W + sx) * C + c] : 0;
+    const int p01 = (x1 && y0) ? img[((size_t)sy * W + sx + 1) * C + c] : 0;
+    const int p10 = (x0 && y1) ? img[((size_t)(sy + 1) * W + sx) * C + c] : 0;
+    const int p11 = (x1 && y1) ? img[((size_t)(sy + 1) * W + sx + 1) * C + c] : 0;
+    out[(size_t)idx * C + c] = (unsigned char)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15);
+  }
+}
+
+extern "C" int uncl_warp_flow(const unsigned char* img, const float* flow, unsigned char* out, int H, int W, int C, int Hf, int Wf,
+                              void* stream) {
+  if (!img || !flow || !out || H <= 0 || W <= 0 || C <= 0 || C > 4 || Hf <= 0 || Wf <= 0 || H > 32767 || W > 32767) return UNCL_ERR_ARG;
+  const int n = Hf * Wf;
+  hipLaunchKernelGGL(warp_flow_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, flow, out, H, W,
+                     C, Hf, Wf);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}

@@ -195,3 +195,23 @@ def to_uint8_outlier(color, on_device=False):
     _hip.check(lib.uncl_to_uint8(cl.data_ptr(), out.data_ptr(), c, h, w, float(im_min), float(im_max), _hip.stream_ptr()),
                "uncl_to_uint8")
     return out
+
+
+def warp_flow(img_u8, flow):
+    """GanTrainer.warp_flow (GanTrainer.py:584-595): cv2.remap(img, flow + pixel grid, None, cv2.INTER_LINEAR) on the device.
+    img_u8: (H,W,C) uint8, flow: (Hf,Wf,2) fp32 displacements (x, y) -> (Hf,Wf,C) uint8.  Unlike the reference this does not add
+    the grid into `flow` in place."""
+    _need_gpu(img_u8, "img")
+    _need_gpu(flow, "flow")
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3:
+        raise TypeError("warp_flow expects an (H,W,C) uint8 image")
+    if flow.dim() != 3 or flow.shape[-1] != 2:
+        raise ValueError("flow must be (Hf,Wf,2)")          # the reference asserts the same
+    img_u8 = img_u8.contiguous()
+    flow = flow.float().contiguous()
+    h, w, c = img_u8.shape
+    hf, wf = flow.shape[:2]
+    out = torch.empty(hf, wf, c, dtype=torch.uint8, device=img_u8.device)
+    _hip.check(_hip.lib().uncl_warp_flow(img_u8.data_ptr(), flow.data_ptr(), out.data_ptr(), h, w, c, hf, wf, _hip.stream_ptr()),
+               "uncl_warp_flow")
+    return out

@@ -24,11 +24,13 @@ def warp_errors(img0_target, img1_aligned, border=32):
 
 
 @torch.no_grad()
-def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame=False, align_fn=None):
+def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame=False, align_fn=None, flow=None):
     """rgb_frames: list of (3,H,W) linear-radiance frames of ONE scene on the GPU (read_hdr_image + hdr_im_transform of the
     reference); f_factor: lambda * 255 * factor_coeff of the scene.  Returns (tmqi_scene, ldr_results[, warp_mse, warp_rel]):
     the mean TMQI over the frames, the tone-mapped 8-bit frames (H,W,3) and, when `align_fn(frame1_u8, frame0_u8)` (the
-    caller's optical-flow alignment of frame 1 onto frame 0) is given, the reference's two warp errors."""
+    caller's optical-flow alignment of frame 1 onto frame 0) is given, the reference's two warp errors.  `flow` (H,W,2 fp32 on the
+    GPU: the inverse flow the reference gets from cv2 DeepFlow, Tester.py:379-384) instead of `align_fn` aligns on the device with
+    frame_util.warp_flow (= align_frames / warp_flow, GanTrainer.py:584-595, 652-666): no host round trip."""
     if len(rgb_frames) == 0:
         raise ValueError("eval_on_video needs at least one frame")
     originals, padded, grays = [], [], []
@@ -55,8 +57,8 @@ def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame
         score = tmqi(originals[i].permute(1, 2, 0).contiguous(), ldr.float())[0]
         total += score
     tmqi_scene = total / len(rgb_frames)
-    if align_fn is None or len(results) < 2:
+    if (align_fn is None and flow is None) or len(results) < 2:
         return tmqi_scene, results
-    aligned = align_fn(results[1], results[0])
+    aligned = frame_util.warp_flow(results[1], flow) if flow is not None else align_fn(results[1], results[0])
     mse, rel = warp_errors(results[0], aligned)
     return tmqi_scene, results, mse, rel
