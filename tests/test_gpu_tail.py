@@ -123,6 +123,6 @@ def test_generator_inference_fused_tail_is_bitwise_the_two_launch_path(dtype, n)
         lib.uncl_conv3x3_set_pc(old_p)
     assert torch.isfinite(y_f).all()
     assert torch.equal(y_f, y_2), (y_f - y_2).abs().max().item()
-    # against the four-wave kernel only the outconv's 32-term dot product differs: an fp32 fma chain there, four MFMAs over the
-    # 16-bit head and tail of the fp32 weights here (w = hi + lo to 2^-17 |w|: ~1e-5 on the logit, a quarter of that behind the sigmoid)
-    assert (y_f - y_4).abs().max().item() < 3e-5
+    # against the four-wave kernel only the outconv's 32-term dot product differs: an fp32 fma chain there, six MFMAs over three
+    # 16-bit pieces of the fp32 weights here (exact products, fp32 accumulation in another order)
+    assert (y_f - y_4).abs().max().item() < 2e-6

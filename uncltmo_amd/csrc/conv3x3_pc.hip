@@ -577,21 +577,25 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     // The fused 1x1 outconv on the matrix cores.  The 32x32 accumulator of a row (channel = register index, pixel = lane) IS a B
     // operand once its registers 8 s .. 8 s + 7 are rounded pairwise to 16 bits -- exactly the rounding the stored map would
     // get: element j of lane half h is channel 16 s + 8 (j >> 2) + 4 h + (j & 3).  With an A operand whose 32 rows all hold the
-    // outconv weights in that order, every register of D is the lane's pixel's dot product.  The fp32 weights enter as a 16-bit
-    // head and tail (w = hi + lo to 2^-17 |w|): four MFMAs per row replace 16 unpacks + 16 fma + a half-wave exchange.
-    auto outc_frags = [&](vec (&hi)[2], vec (&lo)[2]) __attribute__((always_inline)) {
+    // outconv weights in that order, every register of D is the lane's pixel's dot product.  The fp32 weights enter as THREE
+    // 16-bit pieces (w = p0 + p1 + p2 to 2^-25 |w|: the products are exact in the fp32 accumulator, so the result is an fp32 dot
+    // product up to summation order): six MFMAs per row replace 16 unpacks + 16 fma + a half-wave exchange.
+    auto outc_frags = [&](vec (&wp)[3][2]) __attribute__((always_inline)) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float w = sO1[16 * ks + 8 * (j >> 2) + 4 * lh + (j & 3)];
-          const T h = (T)w;
-          hi[ks][j] = h;
-          lo[ks][j] = (T)(w - (float)h);
+          float w = sO1[16 * ks + 8 * (j >> 2) + 4 * lh + (j & 3)];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const T h = (T)w;
+            wp[t][ks][j] = h;
+            w -= (float)h;
+          }
         }
     };
     // bias + ReLU + rounding of one row's accumulator, then the dot product with the outconv weights (without its bias)
-    auto outc_row = [&](const PcAcc& v, const float* bsrc, const vec (&hi)[2], const vec (&lo)[2]) __attribute__((always_inline)) {
+    auto outc_row = [&](const PcAcc& v, const float* bsrc, const vec (&wp)[3][2]) __attribute__((always_inline)) {
       vec Bf[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -610,10 +614,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         si = __builtin_elementwise_max(si, s16x8o{0, 0, 0, 0, 0, 0, 0, 0});        // ReLU on the rounded values
         Bf[ks] = __builtin_bit_cast(vec, si);
       }
-      f32x16 d = mfma32x16(hi[0], Bf[0], zero16);
-      d = mfma32x16(lo[0], Bf[0], d);
-      d = mfma32x16(hi[1], Bf[1], d);
-      d = mfma32x16(lo[1], Bf[1], d);
+      // smallest pieces first
+      f32x16 d = mfma32x16(wp[2][0], Bf[0], zero16);
+      d = mfma32x16(wp[2][1], Bf[1], d);
+      d = mfma32x16(wp[1][0], Bf[0], d);
+      d = mfma32x16(wp[1][1], Bf[1], d);
+      d = mfma32x16(wp[0][0], Bf[0], d);
+      d = mfma32x16(wp[0][1], Bf[1], d);
       return d[0];
     };
     auto epilogue_lean = [&](const TileCur& c, int tp, auto pool_tag, auto out1_tag) __attribute__((always_inline)) {
@@ -704,12 +711,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           }
         if (OUT1 != 0) {
           // (this path is a test / A-B form: the weight fragments are rebuilt per tile rather than kept in registers)
-          vec o1hi[2], o1lo[2];
-          outc_frags(o1hi, o1lo);
+          vec o1w[3][2];
+          outc_frags(o1w);
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             const int oy = y0 + 2 * pr + r;
-            const float tot = outc_row(acc[2 * pr + r][0], sBt, o1hi, o1lo) + sO1[32];
+            const float tot = outc_row(acc[2 * pr + r][0], sBt, o1w) + sO1[32];
             if (lh == 0 && oy < a.Hout && ox < a.Wout) a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act);
           }
         }
@@ -802,14 +809,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       };
       // second layer's accumulators -> bias + ReLU + rounding -> 1x1 outconv on the matrix cores (outc_row) -> last activation
       // -> fp32 store
-      vec o1hi[2], o1lo[2];
+      vec o1w[3][2];
       auto out_epilogue = [&](const TileCur& c, bool store) __attribute__((always_inline)) {
         const int oy0 = c.ty * TH + cw * MPW, ox = c.tx * XSTEP + lr;
         const bool xin = store && lr < XSTEP && ox < a.oW && lh == 0;
         float* const orow = a.out1 + ((size_t)c.n * a.oH + oy0) * a.oW + ox;
         float tot[MPW];
 #pragma unroll
-        for (int m = 0; m < MPW; ++m) tot[m] = outc_row(acc[m][0], sB1, o1hi, o1lo) + sO1[32];
+        for (int m = 0; m < MPW; ++m) tot[m] = outc_row(acc[m][0], sB1, o1w) + sO1[32];
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
           if (xin && oy0 + m < a.oH) orow[(size_t)m * a.oW] = uncl_act(tot[m], a.out1_act);
@@ -857,7 +864,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       PCT_DECL
       pc_barrier();                         // stage 0 is staged (and the carry buffers are cleared, the outconv weights in LDS)
       PCT(2)
-      outc_frags(o1hi, o1lo);
+      outc_frags(o1w);
       rd(smem, wres, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
       int s = 0;
