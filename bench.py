@@ -31,6 +31,7 @@ Extra objects on the JSON line:
                with UNCL_BENCH_INPROC=1 everything runs in the one process.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -91,6 +92,8 @@ def parse(argv=None):
     ap.add_argument("--sustain-seconds", type=float, default=5.0,
                     help="infer mode: after the timed region, repeat the step back to back for about this long and report "
                          "`sustained` (0: skip)")
+    ap.add_argument("--no-eager", action="store_true", help="training legs: skip the eager steps timed beside the replayed graph "
+                                                            "(profiling runs: every launch of the trace is a replayed one)")
     ap.add_argument("--no-4k", action="store_true", help="infer mode: skip the workload_4k sub-object (configs[4], fp16)")
     ap.add_argument("--no-exclusive", action="store_true",
                     help="skip the untimed single-stream pass that measures the dominant kernel alone (profiling runs: "
@@ -545,7 +548,9 @@ def make_trainer(rk, video):
 
     tr._step_graph = None
     tr._step_graph_error = None
-    if not rk.dist and os.environ.get("UNCL_TRAIN_GRAPH", "1") != "0":
+    # data-parallel steps are captured too (the gradient all-reduces then run in-stream at the end of the backward pass:
+    # distributed.GradReducer.in_stream); UNCL_TRAIN_GRAPH=0 keeps the eager step with its overlapped exchange
+    if os.environ.get("UNCL_TRAIN_GRAPH", "1") != "0":
         # one hipGraph replay per optimisation step (uncltmo_amd/step_graph.py); eager launches if the capture fails
         from uncltmo_amd.step_graph import StepGraph
         try:
@@ -620,23 +625,48 @@ def train_numbers(a, rk, video, steps, warmup):
                               "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
                                       "2 bwd (109.7 GFLOP, what the reference runs); both over the median step time"},
            "errD": float(tr.errD.detach()), "errG_d": float(tr.errG_d.detach()), "errG_struct": float(tr.errG_struct.detach())}
-    if getattr(tr, "_eager_step", None) is not None and not rk.dist:
+    if getattr(tr, "_eager_step", None) is not None and not getattr(a, "no_eager", False):
         # beside the replayed step: the same step launched eagerly (no hipGraph).  On an idle host it is the faster of the two on
         # the image step -- the generator's backward then runs its weight gradients on a second stream, which a replayed graph
         # cannot afford on this runtime -- on a slow host it is the host-bound one; `ms_per_step` stays the replay
-        for _ in range(3):
-            tr._eager_step()
-        _, _, eager_ms, eager_host = rk.timed_steps(tr._eager_step, 10)
+        # (on the stream the graph was built on: the parameters' AccumulateGrad nodes belong to it, and autograd warns -- and
+        # synchronises -- when a backward pass runs on another stream than the one they were created on)
+        sg = getattr(tr, "_step_graph", None)
+        ctx = torch.cuda.stream(sg.stream) if sg is not None else contextlib.nullcontext()
+        if sg is not None:
+            sg.stream.wait_stream(torch.cuda.current_stream())
+        with ctx:
+            for _ in range(3):
+                tr._eager_step()
+            _, _, eager_ms, eager_host = rk.timed_steps(tr._eager_step, 10)
+        if sg is not None:
+            torch.cuda.current_stream().wait_stream(sg.stream)
         out["eager"] = {"ms_median": _median(eager_ms), "ms_min": min(eager_ms), "host_enqueue_ms_median": _median(eager_host),
                         "steps": 10}
     if rk.dist:
         # gradient exchange: bytes per step and the time the compute stream spent waiting in DistributedOptimizer.synchronize()
         # (collectives launched during the backward pass that had not finished when the optimiser asked for the gradients)
         from uncltmo_amd.distributed import exposed_allreduce_ms
-        ex = exposed_allreduce_ms([tr.optimizerG, tr.optimizerD])[-steps:]
+        ex = exposed_allreduce_ms([tr.optimizerG, tr.optimizerD])
+        ex = ex[-min(len(ex), 10 if out["mode"] == "graph" else steps):]      # graph mode: the eager comparison steps recorded these
+        # the same bytes as one stand-alone all-reduce on the compute stream: what an in-stream exchange (graph mode) exposes
+        nb = int(sum(p.numel() for p in tr.netG.parameters() if p.requires_grad))
+        probe = torch.zeros(nb, dtype=torch.float32, device=rk.dev)
+        pe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        rk.td.all_reduce(probe)
+        for e0, e1 in pe:
+            e0.record()
+            rk.td.all_reduce(probe)
+            e1.record()
+        torch.cuda.synchronize()
+        standalone = _median([e0.elapsed_time(e1) for e0, e1 in pe])
         out["allreduce"] = {"bytes_per_step": int(sum(p.numel() for p in tr.netG.parameters() if p.requires_grad) * 4 +
                                                    sum(p.numel() for p in tr.netD.parameters()) * 4),
                             "ms_exposed_median": _median(ex) if ex else None, "ms_exposed_max": max(ex) if ex else None,
+                            "ms_exposed_is_of": "the eager steps (overlapped exchange on a side stream)",
+                            "ms_standalone_generator_allreduce": standalone,
+                            "exchange_in_timed_steps": "in-stream inside the replayed graph (exposed: about ms_standalone)"
+                            if out["mode"] == "graph" else "overlapped with the backward pass on a side stream",
                             "world": rk.world}
     return out, per_rank, dt
 

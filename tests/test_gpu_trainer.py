@@ -447,3 +447,46 @@ def test_step_graph_replay_equals_eager_steps():
         ye, _ = G_e(hdr2.reshape(-1, 1, 256, 256).float())
         yg, _ = G_g(hdr2.reshape(-1, 1, 256, 256).float())
     assert torch.equal(ye, yg)
+
+
+def test_data_parallel_step_graph_replay_equals_eager_dp_steps():
+    """The data-parallel optimisation step as ONE hipGraph: under capture the generator's backward pass issues its gradient
+    all-reduces on the capturing stream (distributed.GradReducer, in-stream form) instead of forking to the reducer's side stream,
+    and DistributedOptimizer.step() is captured with them.  On one GPU over RCCL (world size 1, forced data-parallel path) N
+    replays must equal N eager data-parallel steps bit for bit (fp32 mode), for the overlapped and the in-stream eager forms."""
+    import os
+    import torch.distributed as td
+    from uncltmo_amd.distributed import DistributedOptimizer
+    from uncltmo_amd.step_graph import StepGraph
+    os.environ["UNCL_FORCE_DIST"] = "1"
+    td.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29900 + os.getpid() % 90), rank=0, world_size=1,
+                          device_id=torch.device("cuda", 0))
+    try:
+        hdr, pos, neg = step_inputs()
+        after = {}
+        for mode in ("eager", "eager_in_stream", "graph"):
+            tr, G, D = _fp32_trainer(False)
+            tr.optimizerG = DistributedOptimizer(tr.optimizerG, module=G)
+            tr.optimizerD = DistributedOptimizer(tr.optimizerD)
+            G._grad_reducer.in_stream = mode == "eager_in_stream"
+            if mode == "graph":
+                sg = StepGraph(tr, hdr, hdr.clone(), pos, neg, 0, warmup=2)
+                assert G._grad_reducer.pending() == 0
+                for _ in range(3):
+                    sg.replay()
+            else:
+                for _ in range(3):
+                    tr.train_D(hdr, pos, neg, 0)
+                    tr.train_G(hdr, hdr.clone(), pos, neg, 0)
+            torch.cuda.synchronize()
+            after[mode] = ({k: v.clone() for k, v in G.state_dict().items()}, {k: v.clone() for k, v in D.state_dict().items()},
+                           [float(getattr(tr, n).detach()) for n in ("errD", "errG_d", "errG_struct")])
+        for mode in ("eager_in_stream", "graph"):
+            for k in after["eager"][0]:
+                assert torch.equal(after["eager"][0][k], after[mode][0][k]), (mode, k)
+            for k in after["eager"][1]:
+                assert torch.equal(after["eager"][1][k], after[mode][1][k]), (mode, k)
+            assert after["eager"][2] == after[mode][2], mode
+    finally:
+        td.destroy_process_group()
+        os.environ.pop("UNCL_FORCE_DIST", None)

@@ -118,6 +118,16 @@ class _GradSet:
             self.unpack()
             return self.grads()
         self.reduced = True     # the buffers now belong to the reducer: the caller hands autograd NO parameter gradients
+        if red.in_stream or torch.cuda.is_current_stream_capturing():
+            # everything on the caller's stream: the pass, the re-layout, then the collectives in order (a captured step: one
+            # stream, no cross-stream edge; the exchange is exposed, 19.7 MB over xGMI)
+            last_run(None)
+            self.unpack()
+            g = self.grads()
+            for t in (self.flat, self.small, g["gcn.pos_embed"]):
+                red.launch_in_stream(t, self)
+            red.keep(self, g)
+            return g
         ev = torch.cuda.Event()
         ev.record()             # torch creates the hipEvent lazily: record once so that the raw handle exists, the library
         last_run(ev)            # records it again where the decoder's gradients are final

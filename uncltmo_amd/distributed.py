@@ -64,7 +64,13 @@ class GradReducer:
     `reset` (module.zero_grad / optimizer.zero_grad) drops the passes of a step that was never taken."""
 
     def __init__(self, group=None):
+        import os
         self.group = group
+        # in_stream: the all-reduces are issued on the CALLER's stream at the end of the backward pass (synchronous collectives,
+        # no side stream).  A captured optimisation step takes this form always -- a replayed hipGraph pays ~0.2 ms per
+        # cross-stream edge on this runtime, more than the 19.7 MB exchange costs over xGMI -- and an eager step takes it when
+        # UNCL_DP_INSTREAM=1 (A/B against the overlapped form).
+        self.in_stream = os.environ.get("UNCL_DP_INSTREAM") == "1"
         self._streams = {}
         self._passes = []        # finished backward passes since the last step: {"work": [(handle, tensor)], "grads": {...}}
         self._open = None        # the pass whose collectives are being launched
@@ -87,6 +93,13 @@ class GradReducer:
             self._open = {"owner": owner, "work": [], "grads": None}
         self._open["work"].append((td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.group, async_op=True), tensor))
 
+    def launch_in_stream(self, tensor, owner):
+        """the same collective on the current stream, in order behind the kernels that produced `tensor` (capturable)"""
+        if self._open is None or self._open["owner"] is not owner:
+            self._open = {"owner": owner, "work": [], "grads": None}
+        td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.group)
+        self._open["work"].append((None, tensor))
+
     def keep(self, owner, grads):
         """end of a pass: `grads` (state_dict name -> view of the buffers just launched) and the owner (which keeps the
         buffers alive) stay here until finish()"""
@@ -101,7 +114,8 @@ class GradReducer:
     def reset(self):
         for ps in self._passes + ([self._open] if self._open is not None else []):
             for work, _ in ps["work"]:
-                work.wait()
+                if work is not None:
+                    work.wait()
         self._passes, self._open = [], None
 
     def finish(self, named_params):
@@ -112,7 +126,8 @@ class GradReducer:
         world = td.get_world_size(self.group)
         for ps in self._passes:
             for work, t in ps["work"]:
-                work.wait()                  # the current stream waits for the collective; the host does not block
+                if work is not None:
+                    work.wait()              # the current stream waits for the collective; the host does not block
                 if world > 1:
                     t.div_(world)
         for k, p in named_params:
@@ -161,7 +176,8 @@ class DistributedOptimizer:
         collectives that the backward pass launched and that had not finished, plus the averaging (exposed_allreduce_ms)."""
         ev = None
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
-        if params and params[0].is_cuda and td.is_available() and td.is_initialized():
+        capturing = bool(params) and params[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        if params and params[0].is_cuda and td.is_available() and td.is_initialized() and not capturing:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         red = getattr(self.module, "_grad_reducer", None) if self.module is not None else None
