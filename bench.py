@@ -98,7 +98,9 @@ def parse(argv=None):
     ap.add_argument("--no-exclusive", action="store_true",
                     help="skip the untimed single-stream pass that measures the dominant kernel alone (profiling runs: "
                          "keeps every launch of the trace in the product configuration)")
-    ap.add_argument("--leg", default=None, choices=["forward", "train_step", "train_video_step"],
+    ap.add_argument("--video-clips", type=int, default=2,
+                    help="train_video: 512x512 clips of T=5 per GPU and step (4 crops each: 2 -> 8, 8 -> 32 tiles per launch)")
+    ap.add_argument("--leg", default=None, choices=["forward", "train_step", "train_video_step", "train_video_step_b8"],
                     help="(set by bench.py itself) run ONE leg of the default single-GPU line in this process and print its JSON: "
                          "the default run starts each leg as a child of its own, see run_legs()")
     ap.add_argument("--stub", action="store_true",
@@ -274,7 +276,7 @@ def classify_fault(stderr_text):
     return info
 
 
-def run_legs(argv, legs=("train_step", "train_video_step", "forward"), attempts=2):
+def run_legs(argv, legs=("train_step", "train_video_step", "train_video_step_b8", "forward"), attempts=2):
     """The default line carries three workloads (forward = the headline, train_step, train_video_step).  Each runs in a child of
     its own, started before this process has made any GPU call (like launch()): the three do not share an allocator history, and
     a leg that dies (round 3 saw ONE GPU memory fault in ~50 whole-bench runs, in a training leg, never reproduced under the
@@ -303,7 +305,8 @@ def run_legs(argv, legs=("train_step", "train_video_step", "forward"), attempts=
         if leg != "forward":
             line[leg] = got.get(leg, {"error": "leg failed %d times, see leg_failures" % attempts})
     line["leg_failures"] = failures
-    line["legs"] = "one process per leg (forward, train_step, train_video_step), started by bench.py before any GPU call"
+    line["legs"] = ("one process per leg (forward, train_step, train_video_step at 2 clips per GPU, train_video_step_b8 at 8), started "
+                    "by bench.py before any GPU call")
     print(json.dumps(line), flush=True)
     return 0
 
@@ -502,7 +505,7 @@ def common_fields(a, rk, dt, per_rank):
 # ---------------------------------------------------------------------------------------------------------------------
 # training steps (configs[2], configs[3])
 # ---------------------------------------------------------------------------------------------------------------------
-def make_trainer(rk, video):
+def make_trainer(rk, video, clips=2):
     import types
     import torch
     from uncltmo_amd import model_factory, synth
@@ -530,12 +533,13 @@ def make_trainer(rk, video):
     if video:
         # configs[3]: 2 clips of T=5 at 512x512 per GPU -> four spatial 256x256 crops each = 8 clips of 256^2
         from uncltmo_amd.frame_util import clip_to_crops
-        clips = synth.hdr_frames(2 * 5, 512, 512, salt="trv%d" % rk.rank).reshape(2, 5, 1, 512, 512)
-        pclips = synth.ldr_frames(2 * 5, 512, 512, salt="trvp%d" % rk.rank).reshape(2, 5, 1, 512, 512)
-        hdr = clip_to_crops(clips.to(dev))
+        nclip = int(clips)
+        vclips = synth.hdr_frames(nclip * 5, 512, 512, salt="trv%d" % rk.rank).reshape(nclip, 5, 1, 512, 512)
+        pclips = synth.ldr_frames(nclip * 5, 512, 512, salt="trvp%d" % rk.rank).reshape(nclip, 5, 1, 512, 512)
+        hdr = clip_to_crops(vclips.to(dev))
         pos = clip_to_crops(pclips.to(dev))
         neg = pos ** 2
-        B, T = 8, 5
+        B, T = 4 * nclip, 5
     else:
         B, T = 16, 2
         hdr = synth.smooth_hdr_frames(B * T, salt="tr%d" % rk.rank).reshape(B, T, 1, 256, 256).to(dev)
@@ -572,7 +576,7 @@ def _median(v):
     return 0.0 if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
 
 
-def train_numbers(a, rk, video, steps, warmup):
+def train_numbers(a, rk, video, steps, warmup, clips=None):
     """One optimisation step (train_D + train_G) timed `steps` times after `warmup` untimed ones.  `ms_per_step` is the MEDIAN
     of the per-step device times; the mean over the bracketed region, min / max, the whole per-step list, the host
     time to enqueue a step and the garbage collector's activity are reported beside it, so that a number that moves between boxes
@@ -583,7 +587,8 @@ def train_numbers(a, rk, video, steps, warmup):
         from uncltmo_amd.debug_poison import poison_free_memory
         poison_free_memory()
     trace("train leg (video=%s): building the trainer" % video)
-    tr, step, n = make_trainer(rk, video)
+    clips = clips or getattr(a, "video_clips", 2)
+    tr, step, n = make_trainer(rk, video, clips)
     trace("trainer ready, graph=%s; warm-up" % (getattr(tr, "_step_graph", None) is not None))
     for _ in range(warmup):
         step()
@@ -615,8 +620,9 @@ def train_numbers(a, rk, video, steps, warmup):
            "frames_per_s": rk.world * n / (ms * 1e-3), "frames_per_s_wall": rk.world * n * steps / dt,
            "frames_per_step_per_gpu": n, "steps": steps,
            "warmup": warmup, "dtype": "bf16", "device_mallocs_in_timed_steps": dev_allocs, "device_frees_in_timed_steps": dev_frees,
-           "workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, Adam): 2 clips of "
-                        "512x512 x T=5 per GPU cut into 4 crops of 256x256 each, epoch regime 0 (BASELINE configs[3])") if video
+           "workload": ("GanTrainer video step (train_D + train_G, backward through time, all losses, Adam): %d clips of "
+                        "512x512 x T=5 per GPU cut into 4 crops of 256x256 each = %d tiles per launch, epoch regime 0 "
+                        "(BASELINE configs[3])" % (clips, 4 * clips)) if video
            else ("GanTrainerImg step (train_D + train_G, all losses, Adam): 32 frames of 256x256 per GPU, epoch regime 0 "
                  "(BASELINE configs[2])"),
            "generator_mfma": {"peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -938,8 +944,9 @@ def main(argv=None):
             from uncltmo_amd import _hip
             if os.environ.get("UNCL_STREAMS"):        # experiments: 1 = everything on the caller's stream
                 _hip.check(_hip.lib().uncl_gen_set_streams(int(os.environ["UNCL_STREAMS"])), "uncl_gen_set_streams")
-            if a.leg in ("train_step", "train_video_step"):
-                nums, _, _ = train_numbers(a, rk, a.leg == "train_video_step", 30, 5)
+            if a.leg in ("train_step", "train_video_step", "train_video_step_b8"):
+                nums, _, _ = train_numbers(a, rk, a.leg != "train_step", 30 if a.leg != "train_video_step_b8" else 12, 5 if a.leg != "train_video_step_b8" else 3,
+                                           clips=8 if a.leg == "train_video_step_b8" else None)
                 _flush_c_stdio()
                 print(json.dumps(nums), flush=True)
             elif a.mode in ("train", "train_video"):

@@ -34,7 +34,7 @@
 // 1 / 2.conv.conv 0.410 -> 0.370, 0.399 -> 0.358, 0.474 -> 0.434); the fused up-conv layer stores after EVERY slice in exactly
 // that iteration (0.817 -> 0.800 with slot 1) and takes slot 3 (0.758).  Halves from two slots pay the address generation twice.
 #ifndef UNCL_PC_XA_SLOT
-#define UNCL_PC_XA_SLOT (MODE == 4 ? 3 : 1)
+#define UNCL_PC_XA_SLOT (MODE == 4 ? (TAIL ? 2 : 3) : 1)      // (TAIL consumes the up-conv's source fragments one iteration earlier)
 #endif
 // cache-policy bits of the straight-line epilogue's buffer stores (0 default, 2 = nt: streaming)
 #ifndef UNCL_PC_STORE_AUX
@@ -178,13 +178,17 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   constexpr int NPIX = HH * HW;
   constexpr int CT = NT * 32;
   constexpr int WROWS = 9 * CT;
-  constexpr int XPL = pc_plane(NPIX), WPL = pc_plane(WROWS);      // bytes per plane
+  // (TAIL: 14 x 34 = 476 slots = 12 (mod 16) spreads a staging quad's four planes over distinct banks just as well, and the
+  // 8 slots of padding per plane are what lets the second layer's weights fit into the 160 KB)
+  constexpr int XPL = TAIL ? NPIX * 16 : pc_plane(NPIX), WPL = pc_plane(WROWS);      // bytes per plane
+  static_assert(!TAIL || NPIX % 16 == 12 || NPIX % 16 == 4, "unpadded planes: quad writes must land on distinct banks");
+  constexpr int W1PL = 9 * 32 * 16;                                // TAIL: one (unpadded) plane of the second layer's weights
   constexpr int XBYTES = 4 * XPL, WBYTES = 4 * WPL;
   // streamed weights: two stages of [activations | weights]; resident weights: [X stage 0 | X stage 1 | nk weight chunks]
   constexpr int STAGE = RESW ? XBYTES : XBYTES + WBYTES;
-  static_assert(MODE != 4 || (NT == 1 && MPW == 4), "fused up-conv: 16 x 32 tiles of 32 channels");
+  static_assert(MODE != 4 || (NT == 1 && (MPW == 4 || TAIL)), "fused up-conv: 16 x 32 tiles of 32 channels");
   static_assert(MODE != 3 || (NT == 1 && RESW), "fused first layer: 32 -> 32 channels, one chunk, resident weights");
-  static_assert(!TAIL || (NT == 1 && MPW == 4 && RESW && PW == 4 && (MODE == 4 || MODE == 1)), "fused last stage: 16 x 32 x 32 tiles, resident weights");
+  static_assert(!TAIL || (NT == 1 && MPW == 3 && RESW && PW == 8 && MODE == 4), "fused last stage: 12 x 32 x 32 tiles, resident weights");
   constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;            // MODE 3: fp32 image patch under the halo tile
   // TAIL: a tile of the intermediate map is TW columns wide but only XSTEP = TW - 2 columns further than its left neighbour
   // (the second layer's output columns [XSTEP tx, XSTEP tx + XSTEP) need intermediate columns XSTEP tx - 2 ..); its first
@@ -200,7 +204,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   float* const sO1 = sBias + 4 * CT;                                  // fused 1x1 tail: 32 weights + its bias (+ pad)
   float* const sP = sO1 + 64;                                         // MODE 3: [2][PN3] image patches
   float* const sB1 = sO1 + 64;                                        // TAIL: bias of the second layer (32)
-  char* const sCarry = reinterpret_cast<char*>(sB1 + 32);             // TAIL: [2][4 planes][2 rows x HW] last two intermediate rows
+  char* const sW1 = reinterpret_cast<char*>(sB1 + 32);                // TAIL: the second layer's weights, [4 planes][9 taps x 32 rows]
+  char* const sCarry = sW1 + 4 * W1PL;                                // TAIL: [2][4 planes][2 rows x HW] last two intermediate rows
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -576,26 +581,29 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     // does not need up_x).
     // The fused 1x1 outconv on the matrix cores.  The 32x32 accumulator of a row (channel = register index, pixel = lane) IS a B
     // operand once its registers 8 s .. 8 s + 7 are rounded pairwise to 16 bits -- exactly the rounding the stored map would
-    // get: element j of lane half h is channel 16 s + 8 (j >> 2) + 4 h + (j & 3).  With an A operand whose 32 rows all hold the
-    // outconv weights in that order, every register of D is the lane's pixel's dot product.  The fp32 weights enter as THREE
-    // 16-bit pieces (w = p0 + p1 + p2 to 2^-25 |w|: the products are exact in the fp32 accumulator, so the result is an fp32 dot
-    // product up to summation order): six MFMAs per row replace 16 unpacks + 16 fma + a half-wave exchange.
-    auto outc_frags = [&](vec (&wp)[3][2]) __attribute__((always_inline)) {
+    // get: element j of lane half h is channel 16 s + 8 (j >> 2) + 4 h + (j & 3).  The fp32 outconv weights enter as THREE 16-bit
+    // pieces (w = p0 + p1 + p2 to 2^-25 |w|; the products are exact in the fp32 accumulator) in ROWS 0, 1, 2 of the A operand
+    // (the other rows are zero): D rows 0..2 -- registers 0..2 of the lower half-wave -- are the three partial dot products of
+    // the lane's pixel.  Two MFMAs and two adds per row replace 16 unpacks + 16 fma + a half-wave exchange.
+    auto outc_frags = [&](vec (&wp)[2]) __attribute__((always_inline)) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float w = sO1[16 * ks + 8 * (j >> 2) + 4 * lh + (j & 3)];
+          T piece = (T)0.f;
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
             const T h = (T)w;
-            wp[t][ks][j] = h;
+            if (lr == t) piece = h;
             w -= (float)h;
           }
+          wp[ks][j] = piece;
         }
     };
-    // bias + ReLU + rounding of one row's accumulator, then the dot product with the outconv weights (without its bias)
-    auto outc_row = [&](const PcAcc& v, const float* bsrc, const vec (&wp)[3][2]) __attribute__((always_inline)) {
+    // bias + ReLU + rounding of one row's accumulator, then the dot product with the outconv weights (without its bias); the
+    // result is valid in the LOWER half-wave
+    auto outc_row = [&](const PcAcc& v, const float* bsrc, const vec (&wp)[2]) __attribute__((always_inline)) {
       vec Bf[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -614,14 +622,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         si = __builtin_elementwise_max(si, s16x8o{0, 0, 0, 0, 0, 0, 0, 0});        // ReLU on the rounded values
         Bf[ks] = __builtin_bit_cast(vec, si);
       }
-      // smallest pieces first
-      f32x16 d = mfma32x16(wp[2][0], Bf[0], zero16);
-      d = mfma32x16(wp[2][1], Bf[1], d);
-      d = mfma32x16(wp[1][0], Bf[0], d);
-      d = mfma32x16(wp[1][1], Bf[1], d);
-      d = mfma32x16(wp[0][0], Bf[0], d);
-      d = mfma32x16(wp[0][1], Bf[1], d);
-      return d[0];
+      f32x16 d = mfma32x16(wp[0], Bf[0], zero16);
+      d = mfma32x16(wp[1], Bf[1], d);
+      return (d[2] + d[1]) + d[0];             // smallest piece first
     };
     auto epilogue_lean = [&](const TileCur& c, int tp, auto pool_tag, auto out1_tag) __attribute__((always_inline)) {
       constexpr bool POOL = decltype(pool_tag)::value != 0;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           }
         if (OUT1 != 0) {
           // (this path is a test / A-B form: the weight fragments are rebuilt per tile rather than kept in registers)
-          vec o1w[3][2];
+          vec o1w[2];
           outc_frags(o1w);
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
@@ -723,7 +726,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
     };
     const bool lean = fast_relu && a.lean && (NT == 1 || a.out1_w == nullptr);      // wave-uniform
-    auto run_epilogue = [&](const TileCur& c, int tp) __attribute__((always_inline)) {
+    auto run_epilogue = [&](const TileCur& c, auto tp) __attribute__((always_inline)) {      // (generic: instantiated only where called)
       if (lean) {
         if (NT == 1 && a.out1_w != nullptr) {
           if (a.skip_main) epilogue_lean(c, tp, IntTag<0>{}, IntTag<NT == 1 ? 2 : 0>{});
@@ -740,23 +743,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     if constexpr (TAIL) {
       // ===============================================================================================================
       // Fused last decoder stage (inference; unet_parts.py:149-162, 338-345; Unet_singleFrame.py:207-209):
-      //   tile t of a strip:  chunks 0..3 (concat-ssr K = 128) -> 16 x 32 x 32-channel tile of the intermediate map
-      //                       -> bias + ReLU + rounding, written to an LDS image (rows 2..17 of stage 1; image rows 0 / 1 are
+      //   tile t of a strip:  chunks 0..3 (concat-ssr K = 128) -> 12 x 32 x 32-channel tile of the intermediate map
+      //                       -> bias + ReLU + rounding, written to an LDS image (rows 2..13 of stage 1; image rows 0 / 1 are
       //                          the last two rows of the previous tile of the strip, kept in a small double buffer)
-      //                       -> second transposed 3x3 (K = 32 x 9, weights in registers) from that image: 16 rows x 30 columns
+      //                       -> second transposed 3x3 (K = 32 x 9, weights resident in LDS) from that image: 12 rows x 30 columns
       //                       -> bias + ReLU + rounding + 1x1 outconv + last activation -> one fp32 channel to memory.
       // The 32-channel maps of both layers never reach HBM (826 MB written and 1.05 GB read back per 200 tiles otherwise).
       // Barriers per tile: four chunk barriers (before each chunk's last tap column, as in the loop below), one after the
       // image is written, one before the second layer's last tap column; the staging waves take the two extra ones idle.
       // ===============================================================================================================
-      vec A1[2][3][3];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-          for (int tx = 0; tx < 3; ++tx)
-            A1[ks][ty][tx] = ld16v<vec>(a.tail_w + ((ty * 3 + tx) * 32 + lr) * 32 + (2 * ks + lh) * 8);
       char* const img = smem + STAGE;                   // stage 1: every tile's last chunk (3) sits there
       if (cw == 3)                                      // a strip's first tile sees zero rows above it
         for (int i = lane; i < 2 * 4 * CPL / 16; i += 64) *reinterpret_cast<vec*>(sCarry + i * 16) = E::zero();
@@ -809,7 +804,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       };
       // second layer's accumulators -> bias + ReLU + rounding -> 1x1 outconv on the matrix cores (outc_row) -> last activation
       // -> fp32 store
-      vec o1w[3][2];
+      vec o1w[2];
       auto out_epilogue = [&](const TileCur& c, bool store) __attribute__((always_inline)) {
         const int oy0 = c.ty * TH + cw * MPW, ox = c.tx * XSTEP + lr;
         const bool xin = store && lr < XSTEP && ox < a.oW && lh == 0;
@@ -821,39 +816,19 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         for (int m = 0; m < MPW; ++m)
           if (xin && oy0 + m < a.oH) orow[(size_t)m * a.oW] = uncl_act(tot[m], a.out1_act);
       };
-      // B fragments of the image for tap column (ks, tx): rows 0 / 1 of the wave's six come from `p01` (wave 0: the carried
-      // rows; the others: the rows the wave above wrote), rows 2..5 are the wave's own
+      // fragments of the second layer for tap column (ks, tx): A = its weights (LDS, resident), B = the image -- rows 0 / 1 of the
+      // wave's MPW + 2 come from `p01` (wave 0: the carried rows; the others: the rows the wave above wrote), the rest are its own
+      const char* const a1off = sW1 + lh * W1PL + lr * 16;
       auto rd1 = [&](const char* p01k0, const char* p01k1, int set, int col) __attribute__((always_inline)) {
         const int ks = col / 3, tx = col - 3 * ks;
         const char* p01 = ks ? p01k1 : p01k0;
         const char* pb = img + boff + 2 * ks * XPL;
 #pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+          A[set][ty][0] = *reinterpret_cast<const vec*>(a1off + 2 * ks * W1PL + ((ty * 3 + tx) * 32) * 16);
+#pragma unroll
         for (int r = 0; r < MPW + 2; ++r)
           B[set][r] = *reinterpret_cast<const vec*>((r < 2 ? p01 : pb) + (r * HW + tx) * 16);
-      };
-      auto mfma_col1 = [&](int col) __attribute__((always_inline)) {
-        const int set = col & 1, ks = col / 3, tx = col - 3 * ks;
-        if (col == 0) {
-#pragma unroll
-          for (int m = 0; m < MPW; ++m) acc[m][0] = pc_mm(A1[0][0][0], B[set][m], acc[m][0], 0);
-#pragma unroll
-          for (int m = 0; m < MPW; ++m)
-#pragma unroll
-            for (int ty = 1; ty < 3; ++ty) acc[m][0] = pc_mm(A1[0][ty][0], B[set][m + ty], acc[m][0], ty);
-        } else {
-#pragma unroll
-          for (int m = 0; m < MPW; ++m)
-#pragma unroll
-            for (int ty = 0; ty < 3; ++ty) acc[m][0] = pc_mm(A1[ks][ty][tx], B[set][m + ty], acc[m][0], ty);
-        }
-      };
-      auto sched1 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < MPW + 2; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMM - (MPW + 2), 0);
       };
       TileCur tc;
       cur_init<TAIL>(tc, tile0, a);
@@ -907,12 +882,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         const char* const p01k0 = cw == 0 ? ccur + lh * CPL + lr * 16 : img + boff;
         const char* const p01k1 = cw == 0 ? ccur + (2 + lh) * CPL + lr * 16 : img + boff + 2 * XPL;
         rd1(p01k0, p01k1, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MPW + 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
         for (int col = 0; col < 5; ++col) {
           rd1(p01k0, p01k1, (col & 1) ^ 1, col + 1);
-          mfma_col1(col);
-          sched1();
+          mfma_col(col);
+          sched_reads_under_mfmas();
         }
         PCT(3)
         __builtin_amdgcn_sched_barrier(0);
@@ -920,7 +895,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         __builtin_amdgcn_sched_barrier(0);
         PCT_K(2, 1)
         if (t + 1 < tile_end) rd(smem, wres, 0, 0);
-        mfma_col1(5);
+        mfma_col(5);
         if (t + 1 < tile_end) sched_reads_under_mfmas();
         PCT(3)
         out_epilogue(tc, store);
@@ -933,7 +908,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
       PCT_FLUSH(0)
       return;
-    }
+    } else {
     PCT_DECL
     if (MODE == 3) pc_barrier();     // the staging waves' first image patch
     pc_barrier();     // stage 0 is staged
@@ -986,6 +961,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     }
     PCT_FLUSH(0)
     return;
+    }
   }
 
   // ===================================================================================================================
@@ -1241,6 +1217,34 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     }
   };
 
+  // TAIL: the up-conv of the NEXT tile's x1 chunk, arithmetic only (MFMAs, rounding, zero padding) -- run at the end of the
+  // iteration BEFORE the one that stages it: that iteration (the tile's last chunk) is the one the multiplying waves waited
+  // for, and the stage it writes to is not free yet, but registers are
+  vec upv[MT_PER][2];
+  auto up_compute = [&]() __attribute__((always_inline)) {
+    const int iy0h = u_iy0 + (tap >> 1), ix0h = u_ix0 + (tap & 1);
+#pragma unroll
+    for (int i = 0; i < MT_PER; ++i) {
+      const int mt = mt0 + MT_STEP * i;
+      if (mt < MTU) {       // wave-uniform
+        const int sp = mt * 32 + lr, spc = min(sp, UPN - 1);
+        const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;
+        f32x16 cu = cb;
+        cu = mfma32x16(ua[0], xa[2 * i], cu);
+        cu = mfma32x16(ua[1], xa[2 * i + 1], cu);
+        const bool in_img = (unsigned)(iy0h + 2 * spy) < (unsigned)a.H && (unsigned)(ix0h + 2 * spx) < (unsigned)a.W;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = cu[8 * h + e];
+          vec o = E::pack(f);
+          if (!in_img) o = E::zero();
+          upv[i][h] = o;
+        }
+      }
+    }
+  };
   auto write_step = [&](char* st, auto p_tag) __attribute__((always_inline)) {
     constexpr int P = decltype(p_tag)::value;
     constexpr bool SET_A = !CAT || P == 0;
@@ -1309,6 +1313,20 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       for (int k = 0; k < IRN; ++k)
         if (ptid + k * NPROD < PN3) sP[(p3par ^ 1) * PN3 + ptid + k * NPROD] = ir[k];
       p3par ^= 1;
+    } else if (MODE == 4 && P == 0 && TAIL) {
+      // (computed by up_compute() one iteration earlier, while the multiplying waves were still reading this stage)
+#pragma unroll
+      for (int i = 0; i < MT_PER; ++i) {
+        const int mt = mt0 + MT_STEP * i;
+        if (mt < MTU) {
+          const int sp = mt * 32 + lr, spc = min(sp, UPN - 1);
+          const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;
+          char* dst = st + 2 * lh * XPL + ((2 * spy + (tap >> 1)) * HW + 2 * spx + (tap & 1)) * 16;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (sp < UPN) *reinterpret_cast<vec*>(dst + h * XPL) = upv[i][h];
+        }
+      }
     } else if (MODE == 4 && P == 0) {
       // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: per 32 source pixels two MFMAs (K = 32 input channels),
       // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image: a lane's D registers are 16
@@ -1408,6 +1426,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   };
   if (a.out1_w != nullptr && ptid < 33) sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0];     // fused 1x1 tail (CT == 32)
   if (TAIL && ptid < 32) sB1[ptid] = a.tail_b != nullptr ? a.tail_b[ptid] : 0.f;
+  if (TAIL) {
+    // the second layer's weights become resident too: global [tap][cout][cin] -> plane (cin slot) x row (tap * 32 + cout)
+    for (int i = ptid; i < 9 * 32 * 4; i += NPROD)
+      *reinterpret_cast<vec*>(sW1 + (i & 3) * W1PL + (i >> 2) * 16) = ld16v<vec>(a.tail_w + (i >> 2) * 32 + (i & 3) * 8);
+  }
   if (RESW) {
     // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order, and so
     // does its bias (all four slots)
@@ -1432,6 +1455,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     load_next(IntTag<1>{});
     pc_barrier();
   }
+  if (TAIL) up_compute();
   write_step(smem, IntTag<0>{});
   load_next(IntTag<1>{});
   PCT_DECL
@@ -1449,6 +1473,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
     PCT_K(1, Q)
     load_next(IntTag<(Q + 2) & 3>{});
+    if (TAIL && Q == 2 && s + 2 < total) up_compute();      // chunk s + 2 = the next tile's x1 chunk
     PCT_K(2, Q)
     pc_barrier();
     PCT_K(3, 4 + Q)
@@ -1481,9 +1506,12 @@ constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch) {
 // fused last decoder stage: one workgroup per CU walks an even share of the (strip, row tile) steps
 template <typename T, int MODE>
 int launch_tail(PipeArgs& a, hipStream_t s) {
-  constexpr size_t lds = pc_lds_bytes<1, 4>(true, 4, false) + 32 * 4 + 2 * 4 * (size_t)pc_plane(2 * 34);
+  // two activation stages of 14 x 34 halo pixels (unpadded planes), the first layer's four weight chunks, bias ring + outconv
+  // weights + the second layer's bias, the second layer's weights, two carry buffers of two rows
+  constexpr size_t lds = 2 * 4 * (size_t)(14 * 34 * 16) + 4 * 4 * (size_t)pc_plane(9 * 32) + (4 * 32 + 64 + 32) * 4 +
+                         4 * (size_t)(9 * 32 * 16) + 2 * 4 * (size_t)pc_plane(2 * 34);
   static_assert(lds <= 163840, "one workgroup's LDS");
-  auto kern = conv3x3_pc_kernel<T, 1, 4, MODE, 4, true, true>;
+  auto kern = conv3x3_pc_kernel<T, 1, 3, MODE, 8, true, true>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1494,7 +1522,7 @@ int launch_tail(PipeArgs& a, hipStream_t s) {
   if (n_cu <= 0) return UNCL_ERR_LAUNCH;
   const int grid = a.total_tiles < n_cu ? a.total_tiles : n_cu;
   a.tiles_per_wg = (a.total_tiles + grid - 1) / grid;     // (unused by this form: shares are computed from the grid size)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
@@ -1631,7 +1659,7 @@ int uncl_conv3x3_tail_launch(PipeArgs& a, int dtype, hipStream_t s) {
   a.n_ct = 1;
   a.oH = a.Hout + 2; a.oW = a.Wout + 2;
   a.tiles_x = (a.oW + 29) / 30;               // strips of 30 result columns (32 intermediate columns each)
-  a.tiles_y = (a.oH + 15) / 16;               // 16 result rows per step
+  a.tiles_y = (a.oH + 11) / 12;               // 12 result rows per step
   a.total_tiles = a.flat_N * a.tiles_x * a.tiles_y;
   if (dtype == UNCL_F16) return launch_tail<f16_t, 4>(a, s);
   return launch_tail<bf16_t, 4>(a, s);
