@@ -159,6 +159,19 @@ int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, float* dw_pack
  * layers, where it measured faster; 2 = every eligible layer; 0 = none (A/B runs and the tests that compare the two kernels).
  * Returns the previous setting; env UNCL_WG_WIDE sets the initial one. */
 int uncl_wgrad_set_wide(int on);
+/* Deterministic weight / bias gradients (bf16 pass; autograd of nn.Conv2d / nn.ConvTranspose2d parameters, GanTrainerImg.py:338,460):
+ * with a scratch buffer set, uncl_conv_wgrad / uncl_conv_wgrad_bias / uncl_upconv2x2_wgrad called from THIS thread write the
+ * partial sums of their pixel-range groups there and add them up in a fixed order (one extra small launch) instead of using
+ * float atomics -- the same inputs give the same bits.  uncl_gen_backward sets a slice of its own gradient workspace for the
+ * duration of a bf16 pass (env UNCL_BWD_DET=0: atomics).  `scratch`: device memory the caller owns until the launches have run;
+ * uncl_wgrad_scratch_bytes() is enough for every generator layer at full speed, less only lowers the groups per launch;
+ * NULL restores the atomics. */
+int uncl_wgrad_set_scratch(void* scratch, size_t bytes);
+size_t uncl_wgrad_scratch_bytes(void);
+/* uncl_gen_backward in bf16: 1 = deterministic pass (the scratch above is a slice of its gradient workspace; the max-relative
+ * scatter takes its gather form), 0 (default) = float atomics -- faster (N = 32 image step 7.87 vs 8.23 ms), run-to-run different
+ * in the last bits.  fp32 passes are deterministic either way.  Returns the previous setting; env UNCL_BWD_DET sets the first. */
+int uncl_gen_set_deterministic(int on);
 /* packed fp32 gradient -> reference layout (inverse of uncl_pack_conv_weight), written or accumulated */
 int uncl_unpack_conv_wgrad(const float* packed, float* dst, int Cout, int Cin, int k, int transposed, int flip,
                            int accumulate, void* stream);

@@ -484,6 +484,68 @@ def test_fp32_backward_is_deterministic():
     assert all(torch.equal(runs[0][k], runs[1][k]) for k in runs[0])
 
 
+@pytest.mark.parametrize("n,video", [(3, False), (32, False), (1, True)])
+def test_bf16_backward_is_deterministic(n, video):
+    """bf16 training pass in deterministic mode (uncl_gen_set_deterministic): weight / bias gradients come from per-group partial sums
+    reduced in a fixed order (uncl_wgrad_set_scratch, set by uncl_gen_backward around its pass) and the max-relative scatter from its gather form -- no float atomics -- so two
+    passes over the same inputs give bit-identical parameter gradients, at a small batch, at the training batch (many tiles per
+    workgroup, weight gradients on the library's second stream) and through time (one stream, gradients accumulated over frames)."""
+    from uncltmo_amd.generator import UNetVideo
+    cls = UNetVideo if video else UNet
+    net = cls(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0,
+              compute_dtype="bf16")
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().train()
+    net.drop_path_prob = 0.0
+    x = synth.smooth_hdr_frames(n * (3 if video else 1), salt="det16").cuda()
+    if video:
+        x = x.reshape(n, 3, 1, 256, 256)
+    runs = []
+    old = _hip.lib().uncl_gen_set_deterministic(1)
+    try:
+        for _ in range(3):
+            net.zero_grad()
+            y, up = net(x)
+            (y.float().sum() + 1e-3 * up.float().sum()).backward()
+            runs.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        _hip.lib().uncl_gen_set_deterministic(0)
+        net.zero_grad()
+        y, up = net(x)
+        (y.float().sum() + 1e-3 * up.float().sum()).backward()
+        fast = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    finally:
+        _hip.lib().uncl_gen_set_deterministic(old)
+    for r in runs[1:]:
+        for k in runs[0]:
+            assert torch.equal(runs[0][k], r[k]), k
+    # the default (atomics) pass computes the same sums in another order
+    for k in runs[0]:
+        assert rel_l2(fast[k].cpu(), runs[0][k].cpu()) < 2e-4, (k, rel_l2(fast[k].cpu(), runs[0][k].cpu()))
+
+
+def test_wgrad_scratch_form_equals_atomics_within_rounding():
+    """the C-ABI switch itself: with a scratch buffer the kernels store partial sums and reduce them in a fixed order (twice the same
+    bits), without one they use atomics; both are the same sums up to fp32 rounding order"""
+    lib = _hip.lib()
+    cin, cout, h, n = 64, 64, 61, 7
+    x, gy = q(rnd(n, cin, h, h, seed=901)), q(rnd(n, cout, h - 2, h - 2, seed=902))
+    kw = dict(dtype=BF, ksize=3, pad=0, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=h, Cin=cin, Cout=cout, src0=to_nhwc(x, BF), src0_H=h,
+              src0_W=h, src0_C=cin)
+    gyd = to_nhwc(gy, BF)
+    atom = wgrad(gyd, (9, cout, cin), **kw)
+    scratch = torch.empty(lib.uncl_wgrad_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    try:
+        lib.uncl_wgrad_set_scratch(scratch.data_ptr(), scratch.numel())
+        d1 = wgrad(gyd, (9, cout, cin), **kw)
+        d2 = wgrad(gyd, (9, cout, cin), **kw)
+        lib.uncl_wgrad_set_scratch(scratch.data_ptr(), 4 * 9 * cin * cout * 3)        # room for three groups only
+        d3 = wgrad(gyd, (9, cout, cin), **kw)
+    finally:
+        lib.uncl_wgrad_set_scratch(None, 0)
+    assert torch.equal(d1, d2)
+    assert rel_l2(d1.cpu(), atom.cpu()) < 1e-5 and rel_l2(d3.cpu(), atom.cpu()) < 1e-5
+
+
 # ---- 64 x 64 channel-block weight gradient (wgrad3w_kernel): vs autograd, and vs the 32 x 32 kernel on the same inputs ----------
 @pytest.mark.parametrize("cin,cout,h,w,n,pad", [(64, 64, 61, 61, 3, 0), (128, 128, 30, 28, 5, 2), (256, 256, 12, 12, 9, 0),
                                                 (64, 128, 59, 61, 2, 0), (256, 64, 9, 70, 2, 2), (128, 256, 26, 26, 32, 0)])

@@ -625,7 +625,8 @@ static int gcn_maxrel_backward_t(const void* g_out, const void* x, const int32_t
                                         int n, int C, int k, void* stream) {
   if (!g_out || !x || !idx || !g_x_f32 || !g_x_bf16 || C % 8 != 0) return UNCL_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (sizeof(T) == 4 && C % 64 == 0 && (size_t)n * 64 * 4 <= 64 * 1024) {
+  // gather form (one owner per element, fixed order): the fp32 parity mode, and bf16 passes in deterministic mode
+  if ((sizeof(T) == 4 || uncl_wgrad_deterministic()) && C % 64 == 0 && (size_t)n * 64 * 4 <= 64 * 1024) {
     hipLaunchKernelGGL(maxrel_bwd_det_kernel<T>, dim3(N, C / 64), dim3(64), (size_t)n * 64 * 4, s, (const T*)g_out, (const T*)x, idx,
                        (T*)g_x_bf16, n, C, k);
     UNCL_CHECK_LAUNCH();

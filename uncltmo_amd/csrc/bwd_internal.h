@@ -31,3 +31,6 @@ int bwd_inorm_forward(int dtype, void* x, void* zhat, float* rstd, const void* r
 int bwd_inorm_backward(int dtype, void* g, const void* zhat, const float* rstd, int N, int P, int C, hipStream_t s);
 int bwd_maxpool2(int dtype, const void* x, void* y, int N, int H, int W, int C, hipStream_t s);
 int bwd_outc_forward(int dtype, const void* up, const float* w, const float* b, float* out, long long P, int act, hipStream_t s);
+
+// wgrad.hip: true while a scratch buffer for deterministic weight gradients is set on this thread (uncl_wgrad_set_scratch)
+bool uncl_wgrad_deterministic();

@@ -19,6 +19,9 @@ static int g_fused_graph = [] { const char* e = getenv("UNCL_GCN_FUSED"); return
 
 // 1 (default): inference runs the last decoder stage (up_path.3: concat + fused up-conv -> ConvT3x3 -> ConvT3x3 -> outconv) as ONE
 // launch whose 32-channel maps stay in LDS (conv3x3_pc.hip, TAIL); 0: two launches with the 254 x 254 x 32 map in HBM between them
+// bf16 backward pass without float atomics (deterministic); env UNCL_BWD_DET sets the initial state (default 0: atomics, faster)
+static std::atomic<int> g_bwd_det{[] { const char* e = getenv("UNCL_BWD_DET"); return e ? atoi(e) : 0; }()};
+extern "C" int uncl_gen_set_deterministic(int on) { return g_bwd_det.exchange(on ? 1 : 0); }
 static int g_fuse_tail = [] { const char* e = getenv("UNCL_FUSE_TAIL"); return e ? atoi(e) : 1; }();
 extern "C" int uncl_gen_set_fused_tail(int on) {
   const int old = g_fuse_tail;
@@ -450,6 +453,7 @@ size_t bwd_scratch_bytes(int N, size_t es = 2) {
   b += (size_t)N * 126 * 126 * 32 * es;
   b += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
   b += (size_t)CS_CHANNELS * 512 * 4;
+  if (es == 2) b += 2 * uncl_wgrad_scratch_bytes();      // per-group partial sums of the deterministic weight gradients (two streams)
   return b + 4096;
 }
 
@@ -497,6 +501,14 @@ struct BCtx {
   // the ramp-down of its launches.  wfork(): everything issued on `s` so far is ordered before what follows on `ws`.
   hipStream_t ws = nullptr;
   hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
+  // deterministic weight gradients (bf16): scratch for their per-group partial sums, one half per stream they can be launched
+  // on (the graph block's 1x1 gradients stay on the caller's stream, everything else goes to `ws` when it exists)
+  hipStream_t main_s = nullptr;
+  char* wdet = nullptr;
+  size_t wdet_half = 0;
+  void wdet_select() const {
+    if (wdet != nullptr) (void)uncl_wgrad_set_scratch(wdet + (s != main_s ? wdet_half : 0), wdet_half);
+  }
   hipStream_t wfork() const {
     if (!ws) return s;
     if (hipEventRecord(ev_wfork, s) != hipSuccess || hipStreamWaitEvent(ws, ev_wfork, 0) != hipSuccess) return s;
@@ -568,13 +580,17 @@ uncl_conv_desc bdesc(const BCtx& c, int ks, int pad, int h, int w, int cin, int 
 // weight gradient in the pass's element type: matrix-core kernel with fp32 atomics (bf16) or the deterministic fp32 kernel
 int conv_wgrad(const BCtx& c, const uncl_conv_desc& d, const void* gy, float* gw) {
   if (c.dt == UNCL_F32) return bwd_wgrad_f32(&d, gy, gw, c.s);
+  c.wdet_select();
   return uncl_conv_wgrad(&d, gy, gw, c.s);
 }
 // weight AND bias gradient of a 3x3 layer (output gradient gy of oh x ow x cout): bf16 passes take the bias sums from the
 // weight-gradient kernel's own pass over gy (atomics into gb: zeroed at the start of a non-accumulating pass, see
 // uncl_gen_backward); fp32 passes keep the deterministic column-sum kernels
 int conv_wgrad_bias(const BCtx& c, const uncl_conv_desc& d, const void* gy, float* gw, float* gb, int oh, int ow, int cout) {
-  if (c.dt == UNCL_BF16 && c.fused_bias) return uncl_conv_wgrad_bias(&d, gy, gw, gb, c.s);
+  if (c.dt == UNCL_BF16 && c.fused_bias) {
+    c.wdet_select();
+    return uncl_conv_wgrad_bias(&d, gy, gw, gb, c.s);
+  }
   const int rc = conv_wgrad(c, d, gy, gw);
   if (rc != UNCL_OK) return rc;
   return c.colsum(gy, (long long)c.n * oh * ow, cout, gb);
@@ -678,7 +694,10 @@ int backward_all(const BCtx& c) {
       BCtx cw = c;
       cw.s = c.wfork();
       if (c.dt == UNCL_F32) RUN(bwd_upconv2x2_wgrad_f32(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, cw.s));
-      else RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, cw.s));
+      else {
+        cw.wdet_select();
+        RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, cw.s));
+      }
       RUN(cw.colsum(c.G(q.up), (long long)c.n * uh * uw, q.ch, b->gb[q.wi]));
     }
     // the ReLU derivative of the layer that produced x1 is applied by the dgrad kernel (single frames) or, for clips,
@@ -991,7 +1010,19 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   c.sc.f32 = reinterpret_cast<float*>(p); p += (size_t)N * 144 * 256 * 4;
   c.sc.mix = p; p += (size_t)N * 126 * 126 * 32 * es;
   c.sc.misc = reinterpret_cast<float*>(p); p += ((size_t)1024 * 33 + 64 + (size_t)512 * 320 + 320 + (size_t)512 * 512) * 4;
-  c.sc.cs = reinterpret_cast<float*>(p);
+  c.sc.cs = reinterpret_cast<float*>(p); p += (size_t)CS_CHANNELS * 512 * 4;
+  // bf16 passes in deterministic mode (uncl_gen_set_deterministic): weight / bias gradients as per-group partial sums + a
+  // fixed-order reduction, the max-relative scatter in its gather form -- no float atomics, two passes over the same inputs give
+  // the same bits.  Off by default: same box, N = 32 image step, 8.23 ms against 7.87 with atomics (43 more small launches and
+  // ~0.6 GB of partial sums written and read back per step)
+  const int det_on = g_bwd_det.load(std::memory_order_relaxed);
+  struct ScratchGuard {
+    bool on;
+    explicit ScratchGuard(bool o) : on(o) {}
+    ~ScratchGuard() { if (on) (void)uncl_wgrad_set_scratch(nullptr, 0); }
+  } scratch_guard(det_on && es == 2);
+  c.main_s = c.s;
+  if (det_on && es == 2) { c.wdet = p; c.wdet_half = uncl_wgrad_scratch_bytes(); }
   ColsumQueue q;
   c.q = &q;
   // weight gradients beside the data-gradient chain: single-frame bf16 passes (a clip's passes share scratch between frames:
@@ -1017,9 +1048,14 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
                                                   {W_U1B, 64}, {W_U2A, 32}, {W_U2B, 32}, {W_U3A, 32}, {W_U3B, 32}};
     float* lo = b->gb[W_INC1];
     float* hi = b->gb[W_U3B] + 32;
-    // contiguous in weight order (the graph block's and the up-convs' slots in between are overwritten later in the pass)?
-    bool contiguous = hi > lo && (size_t)(hi - lo) <= 8192;
-    for (int i = 0; contiguous && i + 1 < UNCL_G_NUM_WEIGHTS; ++i) contiguous = b->gb[i + 1] > b->gb[i] && b->gb[i + 1] - b->gb[i] <= 512;
+    // ONE array in weight order, every slot exactly behind its predecessor (uncltmo_amd/autograd.py lays them out so)?  Then one
+    // memset covers them -- the graph block's and the up-convs' slots in between belong to the same array and are overwritten
+    // later in the pass.  Anything else (separately allocated slots, however close) is cleared slot by slot: the bytes between
+    // two slots are not this library's to zero.
+    static const int kBias[UNCL_G_NUM_WEIGHTS] = {32, 64, 64, 128, 128, 256, 256, 256, 256, 256, 512, 256, 256, 256, 256, 128, 128,
+                                                  128, 64, 64, 64, 32, 32, 32, 32, 32};
+    bool contiguous = true;
+    for (int i = 0; contiguous && i + 1 < UNCL_G_NUM_WEIGHTS; ++i) contiguous = b->gb[i + 1] == b->gb[i] + kBias[i];
     if (contiguous) {
       if (hipMemsetAsync(lo, 0, (size_t)(hi - lo) * sizeof(float), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
     } else {

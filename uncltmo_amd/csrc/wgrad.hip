@@ -36,7 +36,40 @@ struct WgArgs {
   int groups;           // ks == 1, up_tap < 0: grouped 1x1 conv, blockIdx.y = group (channels g*Cin.. of X, g*Cout.. of gy)
   int up_tap, upH, upW; // ks == 1, up_tap >= 0: gy is the (N,2*upH,2*upW,Cout) output gradient of a 2x2 stride-2
                         // transposed conv and pixel m=(n,y,x) pairs with gy pixel (n, 2y+dy, 2x+dx)
+  // Deterministic form (uncl_wgrad_set_scratch): instead of adding its sums into dw / gb with float atomics, pixel-range group
+  // g = blockIdx.x STORES them at part[g * E + (the element's offset in dw)] / gb_part[g * Cout + co]; every (g, element) is
+  // written by exactly one workgroup, and wgrad_reduce_kernel then adds the groups up in the order 0 .. G - 1.
+  float* part;          // NULL: atomics
+  float* gb_part;
+  long long E;          // elements of dw this launch covers
 };
+
+// partial sums of the G pixel-range groups -> out[i] += sum_g part[g * E + i] in a FIXED order: a block owns 32 elements, its
+// eight 32-thread slices each add up one eighth of the groups (g ascending), the eight slice sums are added 0..7.  (One thread per
+// element over all groups left 9216-element gradients with 36 workgroups and 512 dependent-latency loads each: 1.3 ms per step.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int G, long long E, float* __restrict__ out) {
+  __shared__ float sl[8][32];
+  const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + e;
+  const int g0 = (int)((long long)G * q / 8), g1 = (int)((long long)G * (q + 1) / 8);
+  float s = 0.f;
+  if (i < E)
+    for (int g = g0; g < g1; ++g) s += part[(size_t)g * E + i];
+  sl[q][e] = s;
+  __syncthreads();
+  if (q == 0 && i < E) {
+    float t = sl[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sl[k][e];
+    out[i] += t;
+  }
+}
+
+// accumulate into the gradient: atomics, or this group's slot of the partial buffer
+__device__ __forceinline__ void wg_emit(const WgArgs& a, size_t off, float v) {
+  if (a.part != nullptr) a.part[(size_t)blockIdx.x * a.E + off] = v;
+  else atomicAdd(a.dw + off, v);
+}
 
 __device__ __forceinline__ bf16x8 ld16g(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -212,22 +245,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
     __syncthreads();
     ++tile;
   }
-  // ---- combine the four waves' partial sums through LDS, then one atomic per element
-  for (int i = tid; i < KS * 1024; i += 256) sR[i] = 0.f;
-  __syncthreads();
+  // ---- combine the four waves' partial sums through LDS in a FIXED order (one slab per wave, summed 0..3), then one atomic
+  // (or one partial-buffer store) per element
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int tx = 0; tx < KS; ++tx)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = (i & 3) + 8 * (i >> 2) + 4 * lh;  // accumulator row
-      atomicAdd(&sR[(tx * 32 + co) * 32 + lr], acc[tx][i]);
+      sR[wave * KS * 1024 + (tx * 32 + co) * 32 + lr] = acc[tx][i];
     }
   __syncthreads();
   for (int i = tid; i < KS * 1024; i += 256) {
     const int tx = i >> 10, co = (i >> 5) & 31, ci = i & 31;
     const int tap = KS == 3 ? ty * 3 + tx : (up_tap >= 0 ? up_tap : 0);
-    atomicAdd(a.dw + (size_t)cgrp * a.Cout * a.Cin + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
+    const float v = ((sR[i] + sR[KS * 1024 + i]) + sR[2 * KS * 1024 + i]) + sR[3 * KS * 1024 + i];
+    wg_emit(a, (size_t)cgrp * a.Cout * a.Cin + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, v);
   }
 }
 
@@ -396,7 +429,8 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
       const int sl = tid >> 3, e = tid & 7;
       float t = 0.f;
       for (int p = 0; p < NT / 4; ++p) t += sBs[(p * 4 + sl) * 8 + e];
-      atomicAdd(a.gb + cc * 32 + tid, t);
+      if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + tid] = t;
+      else atomicAdd(a.gb + cc * 32 + tid, t);
     }
     __syncthreads();
   }
@@ -427,7 +461,7 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
 #endif
   for (int i = tid; i < 9 * 1024; i += NT) {
     const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
-    atomicAdd(a.dw + ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
+    wg_emit(a, ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
   }
 }
 
@@ -588,8 +622,40 @@ __global__ __launch_bounds__(384, 3) void wgrad3w_kernel(const WgArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = cc * 64 + 32 * h + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        atomicAdd(a.dw + ((size_t)(ty * 3 + tx) * a.Cout + co) * a.Cin + kc * 64 + 32 * cih + lr, acc[h][tx][i]);
+        wg_emit(a, ((size_t)(ty * 3 + tx) * a.Cout + co) * a.Cin + kc * 64 + 32 * cih + lr, acc[h][tx][i]);
       }
+}
+
+// Deterministic mode: a caller-owned scratch buffer for the per-group partial sums (thread-local: uncl_gen_backward sets it
+// around its pass; every weight-gradient launch of a pass and its reduction run on ONE stream, in order, so the buffer is reused
+// launch after launch).  NULL (default) = float atomics.
+thread_local float* t_wg_scratch = nullptr;
+thread_local size_t t_wg_scratch_floats = 0;
+
+// how many pixel-range groups the scratch holds for a launch that covers E gradient elements (+ Cout bias sums)
+int wg_scratch_groups(const WgArgs& a, int groups) {
+  if (t_wg_scratch == nullptr) return groups;
+  const size_t per = (size_t)a.E + (a.gb != nullptr ? (size_t)a.Cout : 0);
+  const size_t fit = t_wg_scratch_floats / (per ? per : 1);
+  return fit < (size_t)groups ? (int)(fit ? fit : 1) : groups;
+}
+// after `groups` is final: point the launch at the scratch (false: it does not even hold one group -> atomics)
+bool wg_use_scratch(WgArgs& a, int groups) {
+  a.part = nullptr; a.gb_part = nullptr;
+  if (t_wg_scratch == nullptr) return false;
+  const size_t need = (size_t)groups * ((size_t)a.E + (a.gb != nullptr ? (size_t)a.Cout : 0));
+  if (need > t_wg_scratch_floats) return false;
+  a.part = t_wg_scratch;
+  if (a.gb != nullptr) a.gb_part = t_wg_scratch + (size_t)groups * a.E;
+  return true;
+}
+int wg_reduce(const WgArgs& a, int groups, hipStream_t s) {
+  if (a.part == nullptr) return UNCL_OK;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.E + 31) / 32)), dim3(256), 0, s, a.part, groups, a.E, a.dw);
+  if (a.gb_part != nullptr)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.Cout + 31) / 32)), dim3(256), 0, s, a.gb_part, groups, (long long)a.Cout, a.gb);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
 }
 
 template <int MODE>
@@ -614,11 +680,14 @@ int launch_wg3w(WgArgs& a, hipStream_t s) {
   int groups = slots / pairs;
   if (groups < 1) groups = 1;
   if (groups > a.total_tiles) groups = a.total_tiles;
+  a.E = (long long)9 * a.Cout * a.Cin;
+  groups = wg_scratch_groups(a, groups);
   a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
   groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  wg_use_scratch(a, groups);
   hipLaunchKernelGGL(kern, dim3(groups, 1, pairs), dim3(384), lds, s, a);
   UNCL_CHECK_LAUNCH();
-  return UNCL_OK;
+  return wg_reduce(a, groups, s);
 }
 
 template <int MODE>
@@ -635,11 +704,14 @@ int launch_wg3(WgArgs& a, hipStream_t s) {
   int groups = 512 / pairs;      // one persistent workgroup per resident slot, see launch_wg
   if (groups < 1) groups = 1;
   if (groups > a.total_tiles) groups = a.total_tiles;
+  a.E = (long long)9 * a.Cout * a.Cin;
+  groups = wg_scratch_groups(a, groups);
   a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
   groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  wg_use_scratch(a, groups);
   hipLaunchKernelGGL(kern, dim3(groups, 1, pairs), dim3(384), lds, s, a);
   UNCL_CHECK_LAUNCH();
-  return UNCL_OK;
+  return wg_reduce(a, groups, s);
 }
 
 template <int MODE, int KS>
@@ -662,11 +734,15 @@ int launch_wg(WgArgs& a, hipStream_t s) {
   int groups = 512 / (gy_ * pairs);
   if (groups < 1) groups = 1;
   if (groups > a.total_tiles) groups = a.total_tiles;
+  // elements of dw the launch covers: KS taps, or the four taps of the 2x2 kernel, or the groups of a grouped 1x1
+  a.E = (long long)(KS == 3 ? 9 : (a.up_tap >= 0 ? 4 : a.groups)) * a.Cout * a.Cin;
+  groups = wg_scratch_groups(a, groups);
   a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
   groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  wg_use_scratch(a, groups);
   hipLaunchKernelGGL(kern, dim3(groups, gy_, pairs), dim3(256), lds, s, a);
   UNCL_CHECK_LAUNCH();
-  return UNCL_OK;
+  return wg_reduce(a, groups, s);
 }
 
 // column sums of a [rows][C] bf16 matrix -> fp32 (bias gradients), deterministic two-stage
@@ -801,6 +877,19 @@ static std::atomic<int> g_wg_wide{[] { const char* e = getenv("UNCL_WG_WIDE"); r
 // 3x3 layers with Cin and Cout multiples of 64 can use the 64 x 64 channel-block kernel: 1 (default) the skip-concat layers, 2 every
 // eligible layer, 0 none (A/B timing, and the parity tests that compare the two kernels).  Returns the previous setting.
 extern "C" int uncl_wgrad_set_wide(int on) { return g_wg_wide.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
+
+// Deterministic weight gradients: with a scratch buffer set (device memory, `bytes` >= uncl_wgrad_scratch_bytes() for every
+// layer of the generator at full speed; less only reduces the number of pixel-range groups per launch), the weight- and
+// bias-gradient kernels called from THIS thread store per-group partial sums there and add them up in a fixed order instead of
+// using float atomics: two runs on the same inputs give the same bits.  NULL / 0 restores the atomics.
+extern "C" int uncl_wgrad_set_scratch(void* scratch, size_t bytes) {
+  t_wg_scratch = reinterpret_cast<float*>(scratch);
+  t_wg_scratch_floats = scratch ? bytes / sizeof(float) : 0;
+  return UNCL_OK;
+}
+// largest partial buffer a generator layer asks for: up_path.0.conv.conv, 9 x 1024 x 128 elements x 8 groups (+ slack)
+extern "C" size_t uncl_wgrad_scratch_bytes(void) { return (size_t)48 << 20; }
+bool uncl_wgrad_deterministic() { return t_wg_scratch != nullptr; }
 
 // dw_packed must be zeroed by the caller (it is accumulated with atomics).  Descriptor fields used: ksize (3 or 1),
 // pad, src_mode (PLAIN / CONCAT_SSR), N, H, W, Cin, Cout, src0/src1 (+dims); `gy` is (N, Hout, Wout, Cout) bf16.
