@@ -34,7 +34,9 @@
 // 1 / 2.conv.conv 0.410 -> 0.370, 0.399 -> 0.358, 0.474 -> 0.434); the fused up-conv layer stores after EVERY slice in exactly
 // that iteration (0.817 -> 0.800 with slot 1) and takes slot 3 (0.758).  Halves from two slots pay the address generation twice.
 #ifndef UNCL_PC_XA_SLOT
-#define UNCL_PC_XA_SLOT (MODE == 4 ? (TAIL ? 2 : 3) : 1)      // (TAIL consumes the up-conv's source fragments one iteration earlier)
+// (TAIL consumes the up-conv's source fragments one iteration earlier -- up_compute -- and requests the next ones from the
+// iteration after that, its lightest: slot 1 = the load step of iteration 3)
+#define UNCL_PC_XA_SLOT (MODE == 4 ? (TAIL ? 1 : 3) : 1)
 #endif
 // cache-policy bits of the straight-line epilogue's buffer stores (0 default, 2 = nt: streaming)
 #ifndef UNCL_PC_STORE_AUX
@@ -1221,10 +1223,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   // iteration BEFORE the one that stages it: that iteration (the tile's last chunk) is the one the multiplying waves waited
   // for, and the stage it writes to is not free yet, but registers are
   vec upv[MT_PER][2];
-  auto up_compute = [&]() __attribute__((always_inline)) {
+  auto up_compute = [&](auto i0_tag, auto i1_tag) __attribute__((always_inline)) {
+    constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     const int iy0h = u_iy0 + (tap >> 1), ix0h = u_ix0 + (tap & 1);
 #pragma unroll
-    for (int i = 0; i < MT_PER; ++i) {
+    for (int i = I0; i < I1; ++i) {
       const int mt = mt0 + MT_STEP * i;
       if (mt < MTU) {       // wave-uniform
         const int sp = mt * 32 + lr, spc = min(sp, UPN - 1);
@@ -1455,7 +1458,16 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     load_next(IntTag<1>{});
     pc_barrier();
   }
-  if (TAIL) up_compute();
+  if constexpr (TAIL) {
+    up_compute(IntTag<0>{}, IntTag<MT_PER>{});
+    // the second tile's x1 sources (from then on every tile's iteration 3 requests those of the tile after the next)
+    if (total > a.nk) {
+      TileCur la = pc;          // the cursor is at chunk 1
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cur_next<TAIL>(la, a, tile_end);
+      load_step(la, IntTag<0>{}, IntTag<3>{});
+    }
+  }
   write_step(smem, IntTag<0>{});
   load_next(IntTag<1>{});
   PCT_DECL
@@ -1473,7 +1485,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
     PCT_K(1, Q)
     load_next(IntTag<(Q + 2) & 3>{});
-    if (TAIL && Q == 2 && s + 2 < total) up_compute();      // chunk s + 2 = the next tile's x1 chunk
+    // the next tile's x1 chunk (chunk s + 3 / s + 2): one half of its source tiles per iteration, so that neither iteration
+    // outlasts the multiplying waves' chunk by much
+    if (TAIL && Q == 1 && s + 3 < total) up_compute(IntTag<0>{}, IntTag<MT_PER / 2>{});
+    if (TAIL && Q == 2 && s + 2 < total) up_compute(IntTag<MT_PER / 2>{}, IntTag<MT_PER>{});
     PCT_K(2, Q)
     pc_barrier();
     PCT_K(3, 4 + Q)
