@@ -773,6 +773,26 @@ def infer_bench(a, rk):
                      "ms_max": max(s_ms)}
         lib.uncl_prof_read(buf, 4096)             # drop the dominant-kernel records of these steps
         trace("sustained region done")
+    # the fused last decoder stage (one launch, both 32-channel maps in LDS) beside the product default (two launches), same
+    # process, interleaved: which of the two is the default was decided by this comparison
+    tail_ab = None
+    if a.dtype != "fp32" and not a.no_layers:
+        res = {0: [], 1: []}
+        old_tail = lib.uncl_gen_set_fused_tail(0)
+        for rep in range(3):
+            for mode in (0, 1):
+                lib.uncl_gen_set_fused_tail(mode)
+                step()
+                rk.sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                rk.sync()
+                res[mode].append((time.perf_counter() - t0) / 10 * 1e3)
+        lib.uncl_gen_set_fused_tail(old_tail)
+        lib.uncl_prof_read(buf, 4096)
+        tail_ab = {"two_launches_ms_per_step": min(res[0]), "fused_ms_per_step": min(res[1]), "default": "fused" if old_tail else "two launches",
+                   "note": "min of 3 x 10 steps each, interleaved; fused = up_path.3.conv.conv + conv1 + outc in one launch"}
     # The timed steps run the product configuration (several parts on several streams up to the third decoder stage, then the
     # last stage for all 200 tiles on one stream).  The same kernel in a purely single-stream forward is measured separately
     # (untimed) as a cross-check of the live figure.
@@ -906,6 +926,8 @@ def infer_bench(a, rk):
         line["sustained"] = sustained
     if wl4k is not None:
         line["workload_4k"] = wl4k
+    if tail_ab is not None:
+        line["fused_tail_ab"] = tail_ab
     line.update(train)
     if getattr(a, "rank_legs", None) is not None:
         line.update(a.rank_legs[0])

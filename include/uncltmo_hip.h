@@ -130,10 +130,11 @@ int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
  * (measured slower there).  All give bit-identical results; the switch
  * exists for same-process A/B timing and for the tests that compare the structures.  Returns the previous setting. */
 int uncl_conv3x3_set_pc(int on);
-/* Inference, last decoder stage (up_path.3; Unet_singleFrame.py:200-209): 1 (default) = concat + fused up-conv -> ConvT3x3 -> ConvT3x3
- * -> outconv + last activation as ONE launch (uncl_conv_desc.tail_w), the two 32-channel maps stay in LDS; 0 = two launches with the
- * 254 x 254 x 32 map in HBM between them.  Same rounding points either way (the fused form equals uncl_conv3x3_set_pc(3) bit for
- * bit).  Returns the previous setting; env UNCL_FUSE_TAIL sets the initial one. */
+/* Inference, last decoder stage (up_path.3; Unet_singleFrame.py:200-209): 1 = concat + fused up-conv -> ConvT3x3 -> ConvT3x3 ->
+ * outconv + last activation as ONE launch (uncl_conv_desc.tail_w), the two 32-channel maps stay in LDS (1.9 GB less HBM traffic per
+ * 200 tiles); 0 (default) = two launches with the 254 x 254 x 32 map in HBM between them -- the faster launch pair, the whole
+ * forward ties.  Same rounding points either way (the fused form equals uncl_conv3x3_set_pc(3) bit for bit).
+ * Returns the previous setting; env UNCL_FUSE_TAIL sets the initial one. */
 int uncl_gen_set_fused_tail(int on);
 
 /* ConvTranspose2d(k2, s2) + bias, bf16, HBM-bound layout (whole output-row runs per store).

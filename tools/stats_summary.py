@@ -63,7 +63,8 @@ def last_json_line(path):
 def main():
     base, tag = sys.argv[1], sys.argv[2]
     P = os.path.join(ROOT, "profiles")
-    for sub, name, log in [("stats", "bench", "bench_stats.log"), ("train", "train", "train_stats.log"),
+    for sub, name, log in [("stats", "bench", "bench_stats.log"), ("train", "train_replay", "train_stats.log"),
+                           ("train_eager", "train_eager", "train_eager_stats.log"),
                            ("train_video", "train_video", "train_video_stats.log")]:
         dump(os.path.join(base, sub), os.path.join(P, "%s_%s_bf16_kernel_stats.csv" % (tag, name)))
         line = last_json_line(os.path.join(base, log))
@@ -74,7 +75,7 @@ def main():
         open(os.path.join(P, "%s_bench_bf16.json" % tag), "w").write(line + "\n")
     for f in glob.glob(os.path.join(P, tag + "_*")):
         shutil.copy(f, base)
-    for d in ("stats", "train", "train_video", "pmc_fetch", "pmc_write"):      # the databases are tens of MiB each: scratch only
+    for d in ("stats", "train", "train_eager", "train_video", "pmc_fetch", "pmc_write"):      # the databases are tens of MiB each: scratch only
         shutil.rmtree(os.path.join(base, d), ignore_errors=True)
 
 

@@ -17,12 +17,14 @@
 // its workgroup either way); 0: separate kernels
 static int g_fused_graph = [] { const char* e = getenv("UNCL_GCN_FUSED"); return e ? atoi(e) : 2; }();
 
-// 1 (default): inference runs the last decoder stage (up_path.3: concat + fused up-conv -> ConvT3x3 -> ConvT3x3 -> outconv) as ONE
-// launch whose 32-channel maps stay in LDS (conv3x3_pc.hip, TAIL); 0: two launches with the 254 x 254 x 32 map in HBM between them
 // bf16 backward pass without float atomics (deterministic); env UNCL_BWD_DET sets the initial state (default 0: atomics, faster)
 static std::atomic<int> g_bwd_det{[] { const char* e = getenv("UNCL_BWD_DET"); return e ? atoi(e) : 0; }()};
 extern "C" int uncl_gen_set_deterministic(int on) { return g_bwd_det.exchange(on ? 1 : 0); }
-static int g_fuse_tail = [] { const char* e = getenv("UNCL_FUSE_TAIL"); return e ? atoi(e) : 1; }();
+// 1: inference runs the last decoder stage (up_path.3: concat + fused up-conv -> ConvT3x3 -> ConvT3x3 -> outconv) as ONE launch whose
+// 32-channel maps stay in LDS (conv3x3_pc.hip, TAIL): 1.9 GB less HBM traffic per 200 tiles; 0 (default): two launches with the
+// 254 x 254 x 32 map in HBM between them.  Default by measured time: the fused launch takes 1.17 ms against 0.72 + 0.32, the whole
+// step ties (same-box A/B -0.8 % on one box, +0.4 % on another)
+static int g_fuse_tail = [] { const char* e = getenv("UNCL_FUSE_TAIL"); return e ? atoi(e) : 0; }();
 extern "C" int uncl_gen_set_fused_tail(int on) {
   const int old = g_fuse_tail;
   g_fuse_tail = on ? 1 : 0;
