@@ -40,6 +40,7 @@ struct PipeArgs {
   const bf16_t* tail_w; // packed [9 taps][32 cout][32 cin] of the second layer
   const float* tail_b;  // its bias (32) or NULL
   int oH, oW;           // extent of the final one-channel map: Hout + 2, Wout + 2
+  int o1_lds_off;       // conv3x3_pipe: byte offset of the parked outconv fragments in LDS (register-direct 1x1 tail)
 };
 
 // conv3x3_pc.hip: the producer / consumer kernel for the multi-chunk layers; returns UNCL_ERR_ARG when (nt, mpw, mode) is not built

@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned long long pt_now() {
 // the store loop sees a 32-pixel-wide image), the staging area holds their zero-padded input maps back to back, and every
 // lane reads its own window: fragment address = lane base (its pixel's top-left input slot) + tap offset.  A 10 x 10 map
 // fills 78 % of the tile instead of 20 % of a 16 x 32 rectangle.
-template <typename T, int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
+template <typename T, int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false, bool O1D = false>
 __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void conv3x3_pipe_kernel(const PipeArgs a) {
   static_assert(!FLAT || (MODE == 0 && !PREV), "flat tiles: plain source only");
   using E = Elem<T>;
@@ -602,6 +602,32 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     }
   };
 
+  // register-direct outconv (see the epilogue): three 16-bit pieces of the fp32 weights in rows 0..2 of the A operand.  The two
+  // fragments of a lane are parked in LDS (2 KB behind the bias / patch area) and read back per tile: held in registers for the
+  // whole launch they push the 166 / 252-register instances over their budget (16 - 72 bytes of scratch per lane)
+  // (its own instantiation, O1D: beside the LDS epilogue the extra live values spilled 16 - 72 bytes per lane in sixteen others)
+  constexpr bool o1_direct = O1D;
+  static_assert(!O1D || (!FLAT && NT == 1), "register-direct 1x1 tail: 32-channel tiles");
+  char* const sO1F = smem + a.o1_lds_off;
+  if (o1_direct && wave == 0) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      vec f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float w = a.out1_w[16 * ks + 8 * (j >> 2) + 4 * lh + (j & 3)];
+        T piece = (T)0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const T h = (T)w;
+          if (lr == t) piece = h;
+          w -= (float)h;
+        }
+        f[j] = piece;
+      }
+      *reinterpret_cast<vec*>(sO1F + (ks * 64 + lane) * 16) = f;
+    }
+  }
   load_regs(c_n, c_y0, c_x0, c_co, c_kc, true);
   write_lds(true);
   __syncthreads();
@@ -617,8 +643,41 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     mfma_phase();
     __builtin_amdgcn_s_setprio(0);
     PT(1)  // MFMA phase (LDS fragment reads + matrix pipe)
-    // ---- tile finished: epilogue through LDS
-    if (c_kc == a.nk - 1) {
+    // ---- tile finished.  Inference's last layer (only the one-channel map is wanted: outconv + last activation of the ROUNDED,
+    // activated features, unet_parts.py:338-345) never needs the 32-channel tile outside the registers: the 32 x 32 accumulator of
+    // a row (channel = register, pixel = lane) is the B operand of two MFMAs whose A rows 0..2 hold three 16-bit pieces of the
+    // fp32 outconv weights (see outc_row in conv3x3_pc.hip: the same arithmetic, so the two kernels agree bit for bit) -- no LDS
+    // transposition, no barrier, no 64 B per pixel read back and 32 fma per pixel on the vector pipe.
+    if (c_kc == a.nk - 1 && o1_direct) {
+      const vec o1w[2] = {*reinterpret_cast<const vec*>(sO1F + lane * 16), *reinterpret_cast<const vec*>(sO1F + (64 + lane) * 16)};
+      const float o1b = a.out1_b[0];
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) {
+        vec Bf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          typedef float f32x2o __attribute__((ext_vector_type(2)));
+          typedef short s16x8o __attribute__((ext_vector_type(8)));
+          vec o;
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            const int q = 2 * ks + hq;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sB + (8 * q + 4 * lh) * 4);
+            const f32x2o s0 = f32x2o{acc[m][0][4 * q], acc[m][0][4 * q + 1]} + f32x2o{b[0], b[1]};
+            const f32x2o s1 = f32x2o{acc[m][0][4 * q + 2], acc[m][0][4 * q + 3]} + f32x2o{b[2], b[3]};
+            o[4 * hq] = (T)s0[0]; o[4 * hq + 1] = (T)s0[1]; o[4 * hq + 2] = (T)s1[0]; o[4 * hq + 3] = (T)s1[1];
+          }
+          s16x8o si = __builtin_bit_cast(s16x8o, o);
+          si = __builtin_elementwise_max(si, s16x8o{0, 0, 0, 0, 0, 0, 0, 0});
+          Bf[ks] = __builtin_bit_cast(vec, si);
+        }
+        f32x16 d = mfma32x16(o1w[0], Bf[0], zero16);
+        d = mfma32x16(o1w[1], Bf[1], d);
+        const float tot = (d[2] + d[1]) + d[0] + o1b;
+        const int oy = c_y0 + wave * MPW + m, ox = c_x0 + lr;
+        if (lh == 0 && oy < a.Hout && ox < a.Wout) a.out1[((size_t)c_n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act);
+      }
+    } else if (!o1_direct && c_kc == a.nk - 1) {
       __syncthreads();  // every wave is done reading sX / sW
       PT(2)  // barrier: slowest wave's MFMA phase
       // ACT 0: ReLU, applied to the rounded bf16 pair as a signed 16-bit max against zero (one packed op per two
@@ -777,13 +836,15 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   PT_FLUSH()
 }
 
-template <typename T, int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false>
+template <typename T, int NT, int MPW, int WAVES, int MODE, bool PREV, bool FLAT = false, bool O1D = false>
 int launch_pipe(PipeArgs& a, hipStream_t s) {
   constexpr int TH = MPW * WAVES;
   constexpr size_t ximg = (size_t)(TH + 2) * 34 * 80 > (size_t)TH * 32 * NT * 32 * 2 ? (size_t)(TH + 2) * 34 * 80 : (size_t)TH * 32 * NT * 32 * 2;
-  constexpr size_t lds = ximg + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
-                         (MODE == 3 ? (size_t)((TH + 4) * 36 + 32) * 4 : 0);
-  auto kern = conv3x3_pipe_kernel<T, NT, MPW, WAVES, MODE, PREV, FLAT>;
+  constexpr size_t lds0 = ximg + (size_t)9 * NT * 32 * 80 + (size_t)NT * 32 * 4 +
+                          (MODE == 3 ? (size_t)((TH + 4) * 36 + 32) * 4 : 0);
+  constexpr size_t lds = lds0 + (O1D ? 2048 : 0);      // + the parked outconv fragments (register-direct 1x1 tail)
+  a.o1_lds_off = (int)lds0;
+  auto kern = conv3x3_pipe_kernel<T, NT, MPW, WAVES, MODE, PREV, FLAT, O1D>;
   static UnclDevOnce attr_done;
   static std::atomic<int> per_cu_s{0};
   if (attr_done.need()) {
@@ -934,6 +995,11 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
       a.n_ct = 1;
       a.tiles_x = (a.Wout + 31) / 32; a.tiles_y = (a.Hout + 7) / 8;
       a.total_tiles = d->N * a.tiles_x * a.tiles_y;
+      // inference's last layer (only the one-channel map is wanted): the 1x1 tail straight from the accumulators
+      if (d->out1_w != nullptr && d->skip_main_store && d->out1_b != nullptr && a.slope == 0.f && d->res == nullptr &&
+          pool_out == nullptr && mask == nullptr && !accumulate)
+        return d->dtype == UNCL_F16 ? launch_pipe<f16_t, 1, 2, 4, 0, false, false, true>(a, s)
+                                    : launch_pipe<bf16_t, 1, 2, 4, 0, false, false, true>(a, s);
       return dispatch_type<1, 2>(a, d->dtype, d->src_mode, prev, s);
     }
     constexpr int TH = 16;
