@@ -950,7 +950,8 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     // split mode: the halves run everything up to the third decoder stage; the last stage (a quarter of the step in its two
     // largest launches, which fill the chip on their own) then runs once for the whole batch on the caller's stream
     // (same-box A/B: +0.3 ... +0.7 % per step against splitting it too, and the dominant kernel runs undisturbed)
-    const bool tail_whole = split2;
+    static const int tail_whole_on = [] { const char* e = getenv("UNCL_TAIL_WHOLE"); return e ? atoi(e) : 1; }();   // 0: A/B, every part runs its own last stage
+    const bool tail_whole = split2 && tail_whole_on;
     int rc = run_chunk(c, r->x + (size_t)n0 * 256 * 256, r->out + (size_t)n0 * 256 * 256, up,
                        r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr,
                        r->drop_scale ? r->drop_scale + n0 : nullptr,
