@@ -1053,6 +1053,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     for (int k = 0; k < IRN; ++k) ir[k] = 0.f;
   }
 
+  // MODE 3: an fp32 image value as its 16-bit head and tail (x = head + tail to 2^-17 |x|), packed head << 16 | tail
+  auto pack_head_tail = [&](float v) __attribute__((always_inline)) {
+    const T hi = (T)v;
+    const T lo = (T)(v - (float)hi);
+    return ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo);
+  };
   // position of K-chunk kc in the weight's K layout: concat layers store [x2 | x1 | x2^2 | sqrt] and are walked slice by slice
   auto weight_chunk = [&](int kc) __attribute__((always_inline)) {
     if (!CAT) return kc;
@@ -1259,7 +1265,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       // the last barrier) with the matrix cores: per 32 halo pixels two MFMAs over the nine taps of the bf16 head and of the
       // bf16 tail of the fp32 input (x = hi + lo to 2^-17); a lane's D quad q is channels 8q + 4 lh.. of its pixel, i.e. one
       // half of K-slot plane q.  Then park the patch of the NEXT tile (in registers since the last step) in the other buffer.
-      const float* sPt = sP + p3par * PN3;
+      // (the patch is parked as packed (head << 16 | tail) 16-bit pairs: the split of an fp32 value costs ~5 vector instructions
+      // and was done per tap and per halo pixel -- 9 x 1.3 times per image pixel -- by the waves this layer is bound by)
+      const unsigned* sPt = reinterpret_cast<const unsigned*>(sP) + p3par * PN3;
       f32x16 preBv;
 #pragma unroll
       for (int i = 0; i < 16; ++i) preBv[i] = preB[i];
@@ -1272,17 +1280,24 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           const int pix = mt * 32 + lr;
           const int pcl = min(pix, NPIX - 1);
           const int py = (pcl * 241) >> 13, px = pcl - py * HW;   // / 34 for pcl < 2048 (HW == 34)
-          const float* pp = sPt + py * PW3 + px;
-          vec Bh, Bl;
+          const unsigned* pp = sPt + py * PW3 + px;
+          unsigned tp[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int o0 = (j / 3) * PW3 + j % 3;  // tap j (lower half-wave)
-            float v = pp[lh ? 2 * PW3 + 2 : o0];   // upper half-wave: tap 8 in slot 0
-            if (j > 0) v = lh ? 0.f : v;
-            const T hi = (T)v;
-            Bh[j] = hi;
-            Bl[j] = (T)(v - (float)hi);
+            unsigned u = pp[lh ? 2 * PW3 + 2 : o0];   // upper half-wave: tap 8 in slot 0
+            if (j > 0) u = lh ? 0u : u;
+            tp[j] = u;
           }
+          // heads of taps (2k, 2k + 1) -> register k of the head fragment, tails -> the tail fragment: one v_perm_b32 each
+          typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+          u32x4p bh, bl;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            bh[k] = __builtin_amdgcn_perm(tp[2 * k + 1], tp[2 * k], 0x07060302u);
+            bl[k] = __builtin_amdgcn_perm(tp[2 * k + 1], tp[2 * k], 0x05040100u);
+          }
+          const vec Bh = __builtin_bit_cast(vec, bh), Bl = __builtin_bit_cast(vec, bl);
           // the bias is the first MFMA's C operand (sixteen adds per lane and 32 pixels otherwise: the staging waves of this
           // layer issue ~8 vector instructions per MFMA of the whole kernel)
           f32x16 c3 = mfma32x16(preA, Bh, preBv);
@@ -1314,7 +1329,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
 #pragma unroll
       for (int k = 0; k < IRN; ++k)
-        if (ptid + k * NPROD < PN3) sP[(p3par ^ 1) * PN3 + ptid + k * NPROD] = ir[k];
+        if (ptid + k * NPROD < PN3) reinterpret_cast<unsigned*>(sP)[(p3par ^ 1) * PN3 + ptid + k * NPROD] = pack_head_tail(ir[k]);
       p3par ^= 1;
     } else if (MODE == 4 && P == 0 && TAIL) {
       // (computed by up_compute() one iteration earlier, while the multiplying waves were still reading this stage)
@@ -1454,7 +1469,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     // staging wave before the first build
 #pragma unroll
     for (int k = 0; k < IRN; ++k)
-      if (ptid + k * NPROD < PN3) sP[ptid + k * NPROD] = ir[k];
+      if (ptid + k * NPROD < PN3) reinterpret_cast<unsigned*>(sP)[ptid + k * NPROD] = pack_head_tail(ir[k]);
     load_next(IntTag<1>{});
     pc_barrier();
   }
