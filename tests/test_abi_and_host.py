@@ -157,6 +157,12 @@ class _FakePass:
                 "pe": self.small[7:].view(2, 3).t().contiguous()}
 
     def finish(self, red):
+        if red.in_stream:                               # the captured-step form of _GradSet.finish: synchronous, caller's stream
+            g = self.grads()
+            for t in (self.flat, self.small, g["pe"]):
+                red.launch_in_stream(t, self)
+            red.keep(self, g)
+            return g
         red.launch(self.flat[self.cut:], self)          # decoder half: launched while the encoder's kernels still run
         g = self.grads()                                # pos_embed's transposed copy is made before the in-place reductions
         red.launch(self.flat[:self.cut], self)
@@ -172,11 +178,23 @@ def _reducer_worker(rank, world, port, q):
     td.init_process_group("gloo", rank=rank, world_size=world)
     from uncltmo_amd.distributed import DistributedOptimizer
     out = {}
-    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad"):
+    # ownership: an optimizer that updates none of the module's parameters must not take module= (it would replace the
+    # generator's reducer and swallow its gradients), and parameters outside the module still take the bucketed path
+    other = torch.nn.Linear(3, 2)
+    try:
+        DistributedOptimizer(torch.optim.SGD(other.parameters(), lr=1.0), module=_FakeG())
+        raise AssertionError("module= of a foreign network was accepted")
+    except ValueError:
+        pass
+    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad", "in_stream", "extra_params"):
         net = _FakeG()
-        opt = DistributedOptimizer(torch.optim.SGD(net.parameters(), lr=1.0), module=net)
+        extra = torch.nn.Parameter(torch.zeros(4)) if case == "extra_params" else None
+        opt = DistributedOptimizer(torch.optim.SGD(list(net.parameters()) + ([extra] if extra is not None else []), lr=1.0), module=net)
         red = net._grad_reducer
         assert red.active()
+        red.in_stream = case == "in_stream"
+        if extra is not None:
+            extra.grad = torch.full((4,), float(rank + 1))     # mean over the two ranks: 1.5
         if case == "skipped_step":
             _FakePass(rank, 9).finish(red)
             assert red.pending() == 1
@@ -194,6 +212,8 @@ def _reducer_worker(rank, world, port, q):
         opt.step()
         assert red.pending() == 0
         out[case] = {k: p.detach().clone().numpy() for k, p in net.named_parameters()}     # numpy: pickled by value
+        if extra is not None:
+            out[case]["extra"] = extra.detach().clone().numpy()
     q.put((rank, out))
     td.barrier()
     td.destroy_process_group()
@@ -210,7 +230,9 @@ def test_grad_reducer_world2_single_pass_two_pass_and_skipped_step():
     got = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad"):
+    for r in range(2):
+        np.testing.assert_allclose(got[r]["extra_params"]["extra"], -1.5, rtol=1e-6)
+    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad", "in_stream", "extra_params"):
         n_pass = len(got[0][case + ".local"])
         for k in ("enc", "dec", "bias", "pe"):
             mean = sum(got[r][case + ".local"][i][k] for r in range(2) for i in range(n_pass)) / 2.0
