@@ -104,7 +104,12 @@ __device__ __forceinline__ bf16x8 tr_frag_plane(const char* lane_base, int pix_o
   }
   return out;
 }
-constexpr int wg_plane(int rows) { return (rows + ((4 - rows % 16) + 16) % 16) * 16; }
+// (slot count 6 (mod 8): the plane stride is then 24 banks (mod 32) and the four planes a staging quad writes fall on distinct
+// banks -- ds_write_b128 is banked (address / 4) mod 32; the earlier 4 (mod 16) put planes 0 / 2 and 1 / 3 on the same banks)
+#ifndef UNCL_PLANE_RULE
+#define UNCL_PLANE_RULE 1
+#endif
+constexpr int wg_plane(int rows) { return UNCL_PLANE_RULE ? (rows + ((6 - rows % 8) + 8) % 8) * 16 : (rows + ((4 - rows % 16) + 16) % 16) * 16; }
 
 // MODE: 0 plain, 1 concat-ssr.  KS: 3 (three horizontal taps per workgroup) or 1
 template <int MODE, int KS>
