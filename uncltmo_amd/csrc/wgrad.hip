@@ -104,12 +104,13 @@ __device__ __forceinline__ bf16x8 tr_frag_plane(const char* lane_base, int pix_o
   }
   return out;
 }
-// (slot count 6 (mod 8): the plane stride is then 24 banks (mod 32) and the four planes a staging quad writes fall on distinct
-// banks -- ds_write_b128 is banked (address / 4) mod 32; the earlier 4 (mod 16) put planes 0 / 2 and 1 / 3 on the same banks)
-#ifndef UNCL_PLANE_RULE
-#define UNCL_PLANE_RULE 1
-#endif
-constexpr int wg_plane(int rows) { return UNCL_PLANE_RULE ? (rows + ((6 - rows % 8) + 8) % 8) * 16 : (rows + ((4 - rows % 16) + 16) % 16) * 16; }
+// Plane lengths stay 4 (mod 16) slots = a stride of 16 banks (mod 64): the four planes a 32-lane group of ds_read_b64_tr_b16 touches
+// then tile the 64 READ banks exactly.  WRITES are banked mod 32, so with "four lanes = the four planes of a pixel" every staging
+// write here is a two-way conflict (SQ_LDS_BANK_CONFLICT 40 - 50 % of SQ_LDS_IDX_ACTIVE).  Measured and left alone: mapping
+// the staging lanes so that eight consecutive lanes write one plane removes the conflicts (40 % -> 3 %, 40 % fewer LDS cycles) but
+// the same lanes then load eight different pixels' 16-byte slots, and these kernels are bound by the L2 -> L1 path, not by LDS:
+// launches +4 %, step +0.04 ms.  No plane stride serves both the reads (16 or 48 mod 64) and the writes (8 or 24 mod 32).
+constexpr int wg_plane(int rows) { return (rows + ((4 - rows % 16) + 16) % 16) * 16; }
 
 // MODE: 0 plain, 1 concat-ssr.  KS: 3 (three horizontal taps per workgroup) or 1
 template <int MODE, int KS>
