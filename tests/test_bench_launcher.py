@@ -189,3 +189,26 @@ def test_leg_children_of_torchrun_ranks_form_their_own_group(tmp_path):
     assert fails0 == [] and fails1 == [], (fails0, fails1)
     assert got0["train_step"] == {"sum": 3.0, "port": str(port + 17), "leg": "train_step"}
     assert got0["train_video_step"]["port"] == str(port + 20) and got1 == {"train_step": {}, "train_video_step": {}}
+
+
+def test_fault_classification_against_a_memory_map(tmp_path):
+    """bench.classify_fault: the faulting address of a dead training leg against the allocator table that leg wrote before its
+    timed steps (bench.dump_memory_map): inside a live block, inside a freed block, just past a segment, nowhere near."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    mm = tmp_path / "uncl_memmap_train_step_1.json"
+    seg = {"address": 0x7f0000000000, "size": 4 << 20, "pool": [0, 0], "stream": 0,
+           "blocks": [[0, 1 << 20, "active_allocated"], [1 << 20, 1 << 20, "inactive"], [2 << 20, 2 << 20, "active_allocated"]]}
+    mm.write_text(json.dumps({"pid": 1, "tag": "train_step", "segments": [seg]}))
+    head = "[bench] memory map of leg train_step: %s (1 segments)\n" % mm
+
+    def fault(addr):
+        return bench.classify_fault(head + "Memory access fault by GPU node-2 (Agent handle: 0x1) on address %s. Reason: Page not present.\n"
+                                    % hex(addr))
+    assert "active_allocated" in fault(0x7f0000000000 + 4096)["where"]
+    assert "inactive" in fault(0x7f0000000000 + (1 << 20) + 8192)["where"]
+    assert "outside the nearest torch segment" in fault(0x7f0000000000 + (4 << 20) + 4096)["where"]
+    assert "not allocator memory" in fault(0x100000)["where"]
+    assert bench.classify_fault("no fault here") is None
+    assert "no memory map" in bench.classify_fault("Memory access fault by GPU node-2 on address 0x1000. Reason: x")["where"]
