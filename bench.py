@@ -488,6 +488,11 @@ class Ranks:
 
     def close(self):
         if self.dist:
+            # captured graphs that hold RCCL launches must be gone, and the device idle, before the communicator is torn down
+            import gc
+            gc.collect()
+            if not self.stub:
+                self.torch.cuda.synchronize()
             self.td.destroy_process_group()
 
 
