@@ -19,6 +19,16 @@
 #ifndef UNCL_UP_PREFETCH_MAXC
 #define UNCL_UP_PREFETCH_MAXC 256
 #endif
+// input widths from which a workgroup takes a 64-row slice of the virtual channels instead of 128 (512 = never), and whether
+// the narrow form keeps the next tile's fragments in flight (the registers decide between two and three waves per SIMD).
+// Same box, min of 3, ms per 200 tiles (FILES=upconv2x2 tools/ab_variants.sh, tools/ab_layers.sh): 256-channel level 0.059 ->
+// 0.047 - 0.049 with or without the prefetch; the 128-channel level (two wide workgroups per CU already) 0.067 -> 0.071: stays wide.
+#ifndef UNCL_UP_NARROW_MINC
+#define UNCL_UP_NARROW_MINC 256
+#endif
+#ifndef UNCL_UP_PREFETCH_NARROW
+#define UNCL_UP_PREFETCH_NARROW 1
+#endif
 
 namespace {
 
@@ -33,17 +43,21 @@ struct UpArgs {
   int n_tiles;          // ceil(M / 128)
 };
 
-template <typename T, int CIN, bool PREV>
+// CT = virtual output channels (tap-major) per workgroup: 128, or 64 for the wide levels -- with CIN = 256 a 128-row weight slice
+// plus the 128 x 128 result image is 96 KB, i.e. ONE four-wave workgroup per CU, and nothing covers its load / multiply /
+// transpose / store phases; 64 rows are 48 KB (three workgroups per CU)
+template <typename T, int CIN, bool PREV, int CT>
 __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
   using E = Elem<T>;
   using vec = typename Elem<T>::vec;
   using vec4 = typename Elem<T>::vec4;
   constexpr int KS = CIN / 16;           // MFMA k-steps
   constexpr int S = CIN / 8;             // 16-byte slots per weight row
-  constexpr int CT = 128;                // virtual output channels (tap-major) per workgroup
+  constexpr int NTC = CT / 32;           // 32-row MFMA tiles of the slice
+  constexpr int OS = CT / 8;             // 16-byte slots per pixel of the result image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;                       // [CT][CIN] bf16, swizzled
-  char* sO = smem + CT * CIN * 2;        // [128 pixels][CT] bf16, swizzled
+  char* sO = smem + CT * CIN * 2;        // [128 pixels][CT] bf16, swizzled (slot ^ pixel within a pixel's OS slots)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -62,7 +76,7 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
   }
   // bias of the slice's 128 virtual channels (c' = ct*128 + i -> co = c' % Cout) in LDS: sixty-four registers of per-lane
   // copies kept the kernel at two workgroups per CU
-  float* sB = reinterpret_cast<float*>(sO + 128 * 256);
+  float* sB = reinterpret_cast<float*>(sO + 128 * CT * 2);
   if (tid < CT) sB[tid] = a.bias ? a.bias[(ct * CT + tid) % a.Cout] : 0.f;
   __syncthreads();
 
@@ -74,7 +88,7 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
   // this tile's MFMAs, so that their latency runs under the transpose and the stores instead of in front of the next tile's
   // first MFMA (same box, us per 200 tiles, C = 64 / 128 / 256 levels: 146 / 72 / 59 -> 116 / 68 / 59 together with the bias
   // moved from 64 registers per lane into LDS, which took the kernel from two to three workgroups per CU).
-  constexpr bool PRE = CIN <= UNCL_UP_PREFETCH_MAXC && UNCL_UP_PREFETCH;
+  constexpr bool PRE = CIN <= UNCL_UP_PREFETCH_MAXC && UNCL_UP_PREFETCH && (CT == 128 || UNCL_UP_PREFETCH_NARROW);
   auto loadB = [&](int t, vec* Bv) __attribute__((always_inline)) {
     const int mp = min(t * 128 + wave * 32 + lr, a.M - 1);
 #pragma unroll
@@ -94,11 +108,11 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
   for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
     const int m0 = t * 128;
     if (!PRE) loadB(t, B);
-    f32x16 acc[4];
+    f32x16 acc[NTC];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < NTC; ++nt) {
         const int row = nt * 32 + lr;
         const vec A = *reinterpret_cast<const vec*>(sW + row * (CIN * 2) + (wswz(row, 2 * ks + lh) << 4));
         acc[nt] = mfma32x16(A, B[ks], ks == 0 ? zero16 : acc[nt]);
@@ -112,14 +126,14 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
     __syncthreads();  // previous tile's readers are done with sO
     const int pl = wave * 32 + lr;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         vec4 o;
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + nt * 32 + 8 * q + 4 * lh);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (T)(acc[nt][4 * q + r] + b4[r]);
-        *reinterpret_cast<vec4*>(sO + pl * 256 + (((nt * 4 + q) ^ (pl & 15)) << 4) + (lh << 3)) = o;
+        *reinterpret_cast<vec4*>(sO + pl * (CT * 2) + (((nt * 4 + q) ^ (pl & (OS - 1))) << 4) + (lh << 3)) = o;
       }
     __syncthreads();
     // ---- coalesced stores.  A run = the channels of one (pixel, tap-row) that are contiguous in the output:
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
     const int hw = a.H * a.W;
     const int n0 = m0 / hw, rem0 = m0 - n0 * hw;
     const float rcpW = 1.0f / (float)a.W;
-    for (int v = tid; v < 128 * 16; v += 256) {
+    for (int v = tid; v < 128 * OS; v += 256) {
       // order: [run index within pixel][pixel][slot in run]
       const int sl = v & (rs - 1);
       const int p = (v >> rs_sh) & 127;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
       int x = rem - y * a.W;
       if (x < 0) { --y; x += a.W; } else if (x >= a.W) { ++y; x -= a.W; }
       const size_t opix = ((size_t)n * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1);
-      const vec val = *reinterpret_cast<const vec*>(sO + p * 256 + ((slot ^ (p & 15)) << 4));
+      const vec val = *reinterpret_cast<const vec*>(sO + p * (CT * 2) + ((slot ^ (p & (OS - 1))) << 4));
       *reinterpret_cast<vec*>(a.out + opix * a.Cout + co) = val;
     }
     if (PRE) {
@@ -161,18 +175,18 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
   }
 }
 
-template <typename T, int CIN>
-int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
-  constexpr size_t lds = (size_t)128 * CIN * 2 + 128 * 256 + 128 * 4;
+template <typename T, int CIN, int CT>
+int launch_up_ct(const UpArgs& a, bool prev, hipStream_t s) {
+  constexpr size_t lds = (size_t)CT * CIN * 2 + 128 * CT * 2 + CT * 4;
   static UnclDevOnce attr_done[2];
-  auto k0 = upconv2x2_kernel<T, CIN, false>;
-  auto k1 = upconv2x2_kernel<T, CIN, true>;
+  auto k0 = upconv2x2_kernel<T, CIN, false, CT>;
+  auto k1 = upconv2x2_kernel<T, CIN, true, CT>;
   const void* kp = prev ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0);
   if (attr_done[prev].need()) {
     if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UNCL_ERR_LAUNCH;
     attr_done[prev].done();
   }
-  const int n_ct = 4 * a.Cout / 128;
+  const int n_ct = 4 * a.Cout / CT;
   // every workgroup stages its 128-row weight slice (up to 64 KB) before its first tile: a grid of one (CIN >= 128) or two
   // workgroups per resident slot, each walking a strided share of the tiles, instead of one workgroup per tile
   // (measured, 200 tiles: 12^2 x 256 level 105 -> 57 us, 28^2 x 128 106 -> 67 us, 61^2 x 64 158 -> 139 us)
@@ -186,6 +200,13 @@ int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
     hipLaunchKernelGGL(k0, dim3(gx, n_ct), dim3(256), lds, s, a);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
+}
+
+template <typename T, int CIN>
+int launch_up(const UpArgs& a, bool prev, hipStream_t s) {
+  // narrow slices where the wide one leaves a CU with a single workgroup (and the output rows still split into whole runs)
+  if (CIN >= UNCL_UP_NARROW_MINC && a.Cout % 64 == 0 && a.Cout >= 64) return launch_up_ct<T, CIN, 64>(a, prev, s);
+  return launch_up_ct<T, CIN, 128>(a, prev, s);
 }
 
 }  // namespace

@@ -13,6 +13,22 @@ into them.  Data-parallel runs (RCCL inside the step) stay eager.
 import torch
 
 
+def capture_error_mode():
+    """Stream-capture error mode for torch.cuda.graph().  'global' (PyTorch's default) makes a potentially unsafe runtime call by ANY
+    thread of the process an error while the capture runs -- and torch.distributed's RCCL watchdog thread polls the events of
+    earlier collectives (hipEventQuery) whenever it likes: inside a capture window that query fails, the watchdog rethrows and the
+    process dies with SIGABRT and no message (one run in seven of the world-1 RCCL step-graph test; backtrace in
+    DESIGN.md section 5).  With a process group alive the capture is 'thread_local': only the capturing thread is policed; work the
+    autograd engine's thread puts on the capturing stream is captured either way."""
+    try:
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized():
+            return "thread_local"
+    except Exception:
+        pass
+    return "global"
+
+
 class _Snapshot:
     """Parameters and optimiser state of a trainer before StepGraph's warm-up steps: the warm-up is there to bring the library,
     the allocator and the weight packs into their steady state, not to train -- restore() puts every value back IN PLACE (the
@@ -82,7 +98,7 @@ class StepGraph:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode=capture_error_mode()):
             self._eager()
         # the capture pass ran the Python of one step (optimizer step counts went up) but none of its kernels
         for opt in (trainer.optimizerD, trainer.optimizerG):

@@ -104,7 +104,8 @@ class TiledGraph:
         self._keep = model._packed_weights()    # the captured launches read these buffers
         self._pack_key = model._pack_key        # ... of THIS parameter version
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        from .step_graph import capture_error_mode      # a process group's watchdog thread must not trip the capture
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode()):
             self.static_out = test_big_size_image2(self.static_in, model, 0, 0, 0)
         # the captured launches also hold raw pointers into the generator's workspace: keep those tensors alive even if a later
         # call with a larger batch makes the model replace its cached workspace
