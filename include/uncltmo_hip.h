@@ -160,6 +160,17 @@ int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, float* dw_pack
  * layers, where it measured faster; 2 = every eligible layer; 0 = none (A/B runs and the tests that compare the two kernels).
  * Returns the previous setting; env UNCL_WG_WIDE sets the initial one. */
 int uncl_wgrad_set_wide(int on);
+/* The 32 x 32 channel-pair path of the same gradients (autograd of nn.Conv2d / nn.ConvTranspose2d weights, unet_parts.py:19-33,
+ * 149-162; GanTrainerImg.py:338,460): 1 (default) = the split-role kernel (four multiplying waves that hold all nine taps and
+ * walk each halo row once, four staging waves, two LDS stages, one workgroup per CU) wherever a workgroup gets at least
+ * UNCL_WG_ROLL_MIN (4) tiles; 2 = always; 0 = the six-wave kernel (A/B runs, parity tests between the two).  Returns the previous
+ * setting; env UNCL_WG_ROLL sets the initial one. */
+int uncl_wgrad_set_roll(int on);
+/* Skip-concat 3x3 layers (unet_parts.py:149-162, 319-322: the weight gradient of the conv behind torch.cat([x2, x1, x2^2, sqrt])):
+ * 1 (default) = one workgroup per (32-channel skip slice, 32-channel gY chunk) covers all four members -- x1, x2 and gY are read
+ * once per tile, the square and the root derived in registers; 0 = the per-pair kernels.  Returns the previous setting; env
+ * UNCL_WG_CAT sets the initial one. */
+int uncl_wgrad_set_cat(int on);
 /* Deterministic weight / bias gradients (bf16 pass; autograd of nn.Conv2d / nn.ConvTranspose2d parameters, GanTrainerImg.py:338,460):
  * with a scratch buffer set, uncl_conv_wgrad / uncl_conv_wgrad_bias / uncl_upconv2x2_wgrad called from THIS thread write the
  * partial sums of their pixel-range groups there and add them up in a fixed order (one extra small launch) instead of using

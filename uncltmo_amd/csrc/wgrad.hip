@@ -632,6 +632,441 @@ __global__ __launch_bounds__(384, 3) void wgrad3w_kernel(const WgArgs a) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 form with split roles (round 4): 512 threads, ONE workgroup per CU, a two-stage LDS ring.
+//
+//   waves 0-3  multiply: wave w owns output rows 4w .. 4w+3 of the 16 x 32 pixel tile and ALL NINE taps of the (ci chunk, co
+//              chunk) pair -- nine 32 x 32 accumulators.  The X fragments of halo row R serve output rows R, R-1, R-2 (vertical
+//              taps 0, 1, 2), so a wave walks its six halo rows once per 16-pixel half: 18 X + 4 gY transposed fragment reads for
+//              36 MFMAs (0.61 reads per MFMA; wgrad3_kernel above, whose waves own ONE vertical tap each, re-reads every halo row
+//              for each tap: 1.33 per MFMA, which is more than the LDS delivers at the matrix rate).
+//   waves 4-7  stage: global loads of tile t+2 into registers, registers of tile t+1 (square / square-root of the skip slice,
+//              zero padding, the bias sums of gY) into the stage the multiplying waves are not reading.
+//
+// One barrier per tile.  The four row blocks are added up through LDS once, after the workgroup's last tile (fixed order), then
+// one float atomic (or one partial-buffer store) per element as in the other forms.  Same operands, same products; only the
+// order of the fp32 additions differs from wgrad3_kernel.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void wgrad3r_kernel(const WgArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int TH = 16, TW = 32, XH = TH + 2, XW = TW + 2;
+  constexpr int NX = XH * XW, NG = TH * TW, NS = 256, PP = NS / 4;   // staging threads; PP pixels staged per pass
+  constexpr int XV = (NX + PP - 1) / PP, GV = (NG + PP - 1) / PP;
+  constexpr int XPLB = wg_plane(NX), GPLB = wg_plane(NG);     // bytes per plane
+  constexpr int STAGE = 4 * XPLB + 4 * GPLB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kc = blockIdx.z % a.nci, cc = blockIdx.z / a.nci;
+  const int tile0 = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile0 + a.tiles_per_wg, a.total_tiles);
+  if (tile0 >= tile_end) return;
+  const bool do_bias = a.gb != nullptr && kc == 0;      // workgroup-uniform
+  float* const sR = reinterpret_cast<float*>(smem);                 // [9][32][32] after the loop
+  float* const sBs = reinterpret_cast<float*>(smem + 9 * 1024 * 4); // [256][8] after the loop
+
+  f32x16 acc[3][3];
+  if (wave < 4) {
+    // ================================================================================================================
+    // multiplying waves
+    // ================================================================================================================
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ty][tx][i] = 0.f;
+    // per-lane fragment bases (tr_frag_plane): 16-lane group -> channels c0.., pixels kb..; lane li -> pixel li >> 2 of the
+    // 4-pixel block, 16-byte slot (li & 3) >> 1, its lower / upper 8 bytes
+    const int grp = lane >> 4;
+    const int c0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
+    const int li = lane & 15;
+    const int frag_lane = (li >> 2) * 16 + ((li & 1) << 3);
+    const int psel = (c0 >> 3) + ((li & 3) >> 1);
+    const int offX = psel * XPLB + (4 * wave * XW + kb) * 16 + frag_lane;
+    const int offG = 4 * XPLB + psel * GPLB + (4 * wave * TW + kb) * 16 + frag_lane;
+    __syncthreads();                 // stage 0 holds the first tile
+    for (int t = tile0; t < tile_end; ++t) {
+      const char* st = smem + ((t - tile0) & 1) * STAGE;
+      const char* lbX = st + offX;
+      const char* lbG = st + offG;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        vec A[4], B[2][3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) B[0][tx] = tr_frag_plane(lbX, (h * 16 + tx) * 16);
+#pragma unroll
+        for (int R = 0; R < 6; ++R) {
+          if (R < 5) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) B[(R + 1) & 1][tx] = tr_frag_plane(lbX, ((R + 1) * XW + h * 16 + tx) * 16);
+          }
+          if (R < 4) A[R] = tr_frag_plane(lbG, (R * TW + h * 16) * 16);
+#pragma unroll
+          for (int ty = 0; ty < 3; ++ty) {
+            const int r = R - ty;                    // output row (of this wave's four) that halo row R feeds through tap row ty
+            if (r < 0 || r > 3) continue;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+              acc[ty][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[r], B[R & 1][tx], acc[ty][tx], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();               // done with this stage; the other one holds the next tile
+    }
+  } else {
+    // ================================================================================================================
+    // staging waves
+    // ================================================================================================================
+    const int ptid = tid - 256;
+    int g = 0, cbase = kc * 32;
+    if (MODE != 0) { g = cbase / a.s0C; cbase -= g * a.s0C; }
+    vec xr[XV], gr[GV];
+    unsigned xvalid = 0;
+    float bs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bs[i] = 0.f;
+    auto load_tile = [&](int t) {
+      int r = t;
+      const int tx_ = r % a.tiles_x; r /= a.tiles_x;
+      const int ty_ = r % a.tiles_y; r /= a.tiles_y;
+      const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
+      const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+      // the per-thread staging pattern is recomputed per tile (a handful of VALU ops) instead of living in ~30 registers
+      int t4 = ptid;
+      asm volatile("" : "+v"(t4));
+      const int p0 = t4 >> 2, ch = t4 & 3;
+      unsigned valid = 0;
+#pragma unroll
+      for (int j = 0; j < XV; ++j) {
+        const int pix = min(p0 + j * PP, NX - 1);
+        const int hy = pix / XW, hx = pix - hy * XW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        valid |= (ok ? 1u : 0u) << j;
+        if (MODE != 0 && g == 1) {
+          const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
+          const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
+          const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
+          xr[j] = *reinterpret_cast<const vec*>(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
+        } else {
+          const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+          const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
+          xr[j] = *reinterpret_cast<const vec*>(base + off);
+        }
+      }
+      xvalid = valid;
+#pragma unroll
+      for (int j = 0; j < GV; ++j) {
+        const int pix = min(p0 + j * PP, NG - 1);
+        const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
+        const bool ok = gy_ < a.Hout && gx_ < a.Wout;
+        const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
+        const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
+        vec v = *reinterpret_cast<const vec*>(base + off);
+        if (!ok) v = E::zero();
+        gr[j] = v;
+      }
+    };
+    auto write_lds = [&](char* st) {
+      char* sX = st;
+      char* sG = st + 4 * XPLB;
+      int t4 = ptid;
+      asm volatile("" : "+v"(t4));
+      const int p0 = t4 >> 2, ch = t4 & 3;
+#pragma unroll
+      for (int j = 0; j < XV; ++j) {
+        const int pix = p0 + j * PP;
+        if (pix >= NX) continue;
+        vec v = xr[j];
+        if (MODE == 1 && g >= 2) {
+          float f[8];
+          E::unpack(v, f);
+          if (g == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = f[i] * f[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f);
+          }
+          v = E::pack(f);
+        }
+        if (!((xvalid >> j) & 1u)) v = E::zero();
+        *reinterpret_cast<vec*>(sX + ch * XPLB + pix * 16) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < GV; ++j) {
+        const int pix = p0 + j * PP;
+        if (pix >= NG) continue;
+        *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
+        if (do_bias) {
+          float f[8];
+          E::unpack(gr[j], f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bs[i] += f[i];
+        }
+      }
+    };
+    load_tile(tile0);
+    write_lds(smem);
+    if (tile0 + 1 < tile_end) load_tile(tile0 + 1);
+    __syncthreads();
+    for (int t = tile0; t < tile_end; ++t) {
+      if (t + 1 < tile_end) {
+        write_lds(smem + ((t + 1 - tile0) & 1) * STAGE);
+        if (t + 2 < tile_end) load_tile(t + 2);
+      }
+      __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sBs[ptid * 8 + i] = bs[i];
+    }
+  }
+  // ---- both roles: the four row blocks of every tap are summed through LDS in wave order, then one emission per element
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int co = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            float* p = sR + ((ty * 3 + tx) * 32 + co) * 32 + lr;
+            *p = w == 0 ? acc[ty][tx][i] : *p + acc[ty][tx][i];
+          }
+    }
+    __syncthreads();
+  }
+  if (do_bias && tid < 32) {
+    const int sl = tid >> 3, e = tid & 7;
+    float t = 0.f;
+    for (int p = 0; p < NS / 4; ++p) t += sBs[(p * 4 + sl) * 8 + e];
+    if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + tid] = t;
+    else atomicAdd(a.gb + cc * 32 + tid, t);
+  }
+  for (int i = tid; i < 9 * 1024; i += 512) {
+    const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+    wg_emit(a, ((size_t)tap * a.Cout + cc * 32 + co) * a.Cin + kc * 32 + ci, sR[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Skip-concat form with split roles: ONE workgroup covers the FOUR members [x2 | x1 | x2^2 | sqrt(x2 + 1e-8)] of a 32-channel
+// slice of the skip against one 32-channel chunk of gY.  These launches are bound by the bytes they pull in (the per-pair kernels
+// stage 4 x (X tile + gY tile) for what is two tensors' worth of fresh bytes: x2 three times, gY four times; the 252^2 layer ran at
+// 1.8 TB/s of useful traffic): here x1, x2 and gY are read ONCE per tile and the staging waves derive the square and the root in
+// registers (under the previous tile's multiplies).
+//
+//   waves 0-3  multiply: wave m = member m, all nine taps, all 8 rows of the 8 x 32 pixel tile (halo rows walked once: 60 X + 16
+//              gY fragment reads per 144 MFMAs); every wave owns its 9 x 32 x 32 sums for the whole launch -- no cross-wave
+//              reduction, the sums go from the registers to the gradient.
+//   waves 4-7  stage: loads of tile t+1 in flight during tile t's multiplies, x2^2 / sqrt computed from them, then all five
+//              images (4 x 21.8 KB + 16.6 KB: one stage, 104 KB) written between two barriers.
+template <int UNUSED>
+__global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int TH = 8, TW = 32, XH = TH + 2, XW = TW + 2;
+  constexpr int NX = XH * XW, NG = TH * TW, NS = 256, PP = NS / 4;
+  constexpr int XV = (NX + PP - 1) / PP, GV = (NG + PP - 1) / PP;
+  constexpr int XPLB = wg_plane(NX), GPLB = wg_plane(NG);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sG = smem + 16 * XPLB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsl = a.s0C >> 5;                       // 32-channel slices of the skip
+  const int sl = blockIdx.z % nsl, cc = blockIdx.z / nsl;
+  const int tile0 = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile0 + a.tiles_per_wg, a.total_tiles);
+  if (tile0 >= tile_end) return;
+  const bool do_bias = a.gb != nullptr && sl == 0;      // workgroup-uniform
+
+  if (wave < 4) {
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ty][tx][i] = 0.f;
+    const int grp = lane >> 4;
+    const int c0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
+    const int li = lane & 15;
+    const int frag_lane = (li >> 2) * 16 + ((li & 1) << 3);
+    const int psel = (c0 >> 3) + ((li & 3) >> 1);
+    const char* lbX = smem + (4 * wave + psel) * XPLB + kb * 16 + frag_lane;
+    const char* lbG = sG + psel * GPLB + kb * 16 + frag_lane;
+    for (int t = tile0; t < tile_end; ++t) {
+      __syncthreads();               // the stage holds tile t
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        vec A[3], B[2][3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) B[0][tx] = tr_frag_plane(lbX, (h * 16 + tx) * 16);
+#pragma unroll
+        for (int R = 0; R < XH; ++R) {
+          if (R + 1 < XH) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) B[(R + 1) & 1][tx] = tr_frag_plane(lbX, ((R + 1) * XW + h * 16 + tx) * 16);
+          }
+          if (R < TH) A[R % 3] = tr_frag_plane(lbG, (R * TW + h * 16) * 16);
+#pragma unroll
+          for (int ty = 0; ty < 3; ++ty) {
+            const int r = R - ty;
+            if (r < 0 || r >= TH) continue;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+              acc[ty][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[r % 3], B[R & 1][tx], acc[ty][tx], 0, 0, 0);
+          }
+          // (left alone the scheduler requests several halo rows ahead and spills: one row of look-ahead is the design)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();               // done reading: the staging waves may overwrite the stage
+    }
+    // member `wave` occupies channels wave * s0C + 32 sl .. of the weight's K layout
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ci = wave * a.s0C + sl * 32 + lr;
+#if defined(UNCL_WG_ABLATE_ATOMICS)
+    if (a.dw == nullptr)
+#endif
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = cc * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          wg_emit(a, ((size_t)(ty * 3 + tx) * a.Cout + co) * a.Cin + ci, acc[ty][tx][i]);
+        }
+    if (do_bias) { __syncthreads(); __syncthreads(); }     // (the staging waves' bias reduction below)
+    return;
+  }
+  // ==================================================================================================================
+  // staging waves
+  // ==================================================================================================================
+  const int ptid = tid - 256;
+  const int cbase = sl * 32;
+  vec x1r[XV], x2r[XV], sq[XV], rt[XV], gr[GV];
+  unsigned xvalid = 0;
+  float bs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bs[i] = 0.f;
+  auto load_tile = [&](int t) {
+    int r = t;
+    const int tx_ = r % a.tiles_x; r /= a.tiles_x;
+    const int ty_ = r % a.tiles_y; r /= a.tiles_y;
+    const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    int t4 = ptid;
+    asm volatile("" : "+v"(t4));
+    const int p0 = t4 >> 2, ch = t4 & 3;
+    unsigned valid = 0;
+    const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
+    const bf16_t* base1 = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
+    const bf16_t* base2 = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = min(p0 + j * PP, NX - 1);
+      const int hy = pix / XW, hx = pix - hy * XW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      valid |= (ok ? 1u : 0u) << j;
+      // the up-sampled operand, replicate-padded to the skip's extent (unet_parts.py:292-298)
+      const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
+      x1r[j] = *reinterpret_cast<const vec*>(base1 + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
+      const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
+      x2r[j] = *reinterpret_cast<const vec*>(base2 + off);
+    }
+    xvalid = valid;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = min(p0 + j * PP, NG - 1);
+      const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
+      const bool ok = gy_ < a.Hout && gx_ < a.Wout;
+      const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
+      const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
+      vec v = *reinterpret_cast<const vec*>(base + off);
+      if (!ok) v = E::zero();
+      gr[j] = v;
+    }
+  };
+  // x2^2 and sqrt(x2 + 1e-8) of the loaded slice, zero padding applied to all four members (registers only)
+  auto derive = [&]() {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      float f[8], s2[8], rr[8];
+      E::unpack(x2r[j], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s2[i] = f[i] * f[i]; rr[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f); }
+      sq[j] = E::pack(s2);
+      rt[j] = E::pack(rr);
+      if (!((xvalid >> j) & 1u)) { x1r[j] = E::zero(); x2r[j] = E::zero(); sq[j] = E::zero(); rt[j] = E::zero(); }
+    }
+  };
+  auto write_lds = [&]() {
+    int t4 = ptid;
+    asm volatile("" : "+v"(t4));
+    const int p0 = t4 >> 2, ch = t4 & 3;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = p0 + j * PP;
+      if (pix >= NX) continue;
+      char* d = smem + ch * XPLB + pix * 16;
+      *reinterpret_cast<vec*>(d) = x2r[j];                    // member order of the weight's K layout: [x2 | x1 | x2^2 | sqrt]
+      *reinterpret_cast<vec*>(d + 4 * XPLB) = x1r[j];
+      *reinterpret_cast<vec*>(d + 8 * XPLB) = sq[j];
+      *reinterpret_cast<vec*>(d + 12 * XPLB) = rt[j];
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = p0 + j * PP;
+      if (pix >= NG) continue;
+      *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
+      if (do_bias) {
+        float f[8];
+        E::unpack(gr[j], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bs[i] += f[i];
+      }
+    }
+  };
+  load_tile(tile0);
+  derive();
+  write_lds();
+  if (tile0 + 1 < tile_end) load_tile(tile0 + 1);
+  for (int t = tile0; t < tile_end; ++t) {
+    __syncthreads();                 // the stage holds tile t
+    if (t + 1 < tile_end) derive();  // (waits for the loads of tile t + 1; the multiplying waves are busy with tile t)
+    __syncthreads();                 // they are done with it
+    if (t + 1 < tile_end) {
+      write_lds();
+      if (t + 2 < tile_end) load_tile(t + 2);
+    }
+  }
+  if (do_bias) {
+    float* sBs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sBs[ptid * 8 + i] = bs[i];
+    __syncthreads();
+    if (ptid < 32) {
+      const int ch8 = ptid >> 3, e = ptid & 7;
+      float t = 0.f;
+      for (int p = 0; p < NS / 4; ++p) t += sBs[(p * 4 + ch8) * 8 + e];
+      if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + ptid] = t;
+      else atomicAdd(a.gb + cc * 32 + ptid, t);
+    }
+    __syncthreads();
+  }
+}
+
 // Deterministic mode: a caller-owned scratch buffer for the per-group partial sums (thread-local: uncl_gen_backward sets it
 // around its pass; every weight-gradient launch of a pass and its reduction run on ONE stream, in order, so the buffer is reused
 // launch after launch).  NULL (default) = float atomics.
@@ -716,6 +1151,58 @@ int launch_wg3(WgArgs& a, hipStream_t s) {
   groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
   wg_use_scratch(a, groups);
   hipLaunchKernelGGL(kern, dim3(groups, 1, pairs), dim3(384), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return wg_reduce(a, groups, s);
+}
+
+template <int MODE>
+int launch_wg3r(WgArgs& a, hipStream_t s) {
+  constexpr size_t lds = 2 * (4 * (size_t)wg_plane(18 * 34) + 4 * (size_t)wg_plane(16 * 32));
+  auto kern = wgrad3r_kernel<MODE>;
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done.done();
+  }
+  const int pairs = a.nci * (a.Cout / 32);
+  const int cus = uncl_cu_count() > 0 ? uncl_cu_count() : 256;
+  int groups = cus / pairs;      // one persistent workgroup per CU
+  if (groups < 1) groups = 1;
+  if (groups > a.total_tiles) groups = a.total_tiles;
+  a.E = (long long)9 * a.Cout * a.Cin;
+  groups = wg_scratch_groups(a, groups);
+  a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
+  groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  wg_use_scratch(a, groups);
+  hipLaunchKernelGGL(kern, dim3(groups, 1, pairs), dim3(512), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return wg_reduce(a, groups, s);
+}
+
+int launch_wg3c(WgArgs& a, hipStream_t s) {
+  constexpr size_t lds = 16 * (size_t)wg_plane(10 * 34) + 4 * (size_t)wg_plane(8 * 32);
+  auto kern = wgrad3c_kernel<0>;
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done.done();
+  }
+  // 8-row tiles (the caller's tile counts are for 16 rows)
+  a.tiles_y = (a.Hout + 7) / 8;
+  a.total_tiles = (a.total_tiles / ((a.Hout + 15) / 16)) * a.tiles_y;
+  const int blocks = (a.s0C / 32) * (a.Cout / 32);      // (skip slice, gY chunk) pairs, four members each
+  const int cus = uncl_cu_count() > 0 ? uncl_cu_count() : 256;
+  int groups = cus / blocks;
+  if (groups < 1) groups = 1;
+  if (groups > a.total_tiles) groups = a.total_tiles;
+  a.E = (long long)9 * a.Cout * a.Cin;
+  groups = wg_scratch_groups(a, groups);
+  a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
+  groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  wg_use_scratch(a, groups);
+  hipLaunchKernelGGL(kern, dim3(groups, 1, blocks), dim3(512), lds, s, a);
   UNCL_CHECK_LAUNCH();
   return wg_reduce(a, groups, s);
 }
@@ -883,6 +1370,15 @@ static std::atomic<int> g_wg_wide{[] { const char* e = getenv("UNCL_WG_WIDE"); r
 // 3x3 layers with Cin and Cout multiples of 64 can use the 64 x 64 channel-block kernel: 1 (default) the skip-concat layers, 2 every
 // eligible layer, 0 none (A/B timing, and the parity tests that compare the two kernels).  Returns the previous setting.
 extern "C" int uncl_wgrad_set_wide(int on) { return g_wg_wide.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
+static std::atomic<int> g_wg_cat{[] { const char* e = getenv("UNCL_WG_CAT"); return e ? atoi(e) : 1; }()};
+// skip-concat 3x3 layers: 1 (default) one workgroup per (32-channel skip slice, gY chunk) covering all four members; 0 the per-pair
+// kernels.  Returns the previous setting.
+extern "C" int uncl_wgrad_set_cat(int on) { return g_wg_cat.exchange(on ? 1 : 0); }
+static std::atomic<int> g_wg_roll{[] { const char* e = getenv("UNCL_WG_ROLL"); return e ? atoi(e) : 1; }()};
+static const int g_wg_roll_min = [] { const char* e = getenv("UNCL_WG_ROLL_MIN"); return e ? atoi(e) : 4; }();
+// 3x3 layers on the 32 x 32 channel-pair path: 1 (default) the split-role kernel where a workgroup gets enough tiles, 2 always,
+// 0 the six-wave kernel (A/B timing, parity tests between the two).  Returns the previous setting.
+extern "C" int uncl_wgrad_set_roll(int on) { return g_wg_roll.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 
 // Deterministic weight gradients: with a scratch buffer set (device memory, `bytes` >= uncl_wgrad_scratch_bytes() for every
 // layer of the generator at full speed; less only reduces the number of pixel-range groups per launch), the weight- and
@@ -951,7 +1447,17 @@ extern "C" int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, flo
       const int groups = 256 / pairs64 > 0 ? 256 / pairs64 : 1;
       wide = d->N * a.tiles_x * ((a.Hout + 7) / 8) >= 8 * groups;
     }
+    // skip-concat layers: all four members of a slice in one workgroup (wgrad3c_kernel); UNCL_WG_CAT=0: the per-pair kernels
+    if (d->src_mode == UNCL_SRC_CONCAT_SSR && g_wg_cat.load(std::memory_order_relaxed) != 0 && a.gy_ld % 8 == 0) return launch_wg3c(a, s);
     if (wide) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3w<0>(a, s) : launch_wg3w<1>(a, s);
+    // split-role kernel (wgrad3r_kernel): 1 = where it has at least `UNCL_WG_ROLL_MIN` tiles per workgroup, 2 = always, 0 = never
+    const int roll = g_wg_roll.load(std::memory_order_relaxed);
+    if (roll != 0) {
+      const int pairs = a.nci * (d->Cout / 32);
+      const int groups = 256 / pairs > 0 ? 256 / pairs : 1;
+      if (roll == 2 || a.total_tiles >= g_wg_roll_min * groups)
+        return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3r<0>(a, s) : launch_wg3r<1>(a, s);
+    }
     return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3<0>(a, s) : launch_wg3<1>(a, s);
   }
   return launch_wg<0, 1>(a, s);
