@@ -72,6 +72,12 @@ __device__ __forceinline__ void wg_emit(const WgArgs& a, size_t off, float v) {
 }
 
 __device__ __forceinline__ bf16x8 ld16g(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// wave-uniform base + 32-bit per-lane BYTE offset (global_load_dwordx4 v, v_off, s[base]); the empty asm keeps the zero-extension
+// next to the load (conv3x3_args.h: ld16o)
+__device__ __forceinline__ bf16x8 wg_ld16o(const bf16_t* base, unsigned byte_off) {
+  asm volatile("" : "+v"(byte_off));
+  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds_row0_base, int pix0, int c0, int lane) {
   // 8 consecutive pixels (pix0 + 8h' ... handled by caller) x one channel per lane: two 4-pixel transposed reads
@@ -724,51 +730,58 @@ __global__ __launch_bounds__(512, 1) void wgrad3r_kernel(const WgArgs a) {
     int g = 0, cbase = kc * 32;
     if (MODE != 0) { g = cbase / a.s0C; cbase -= g * a.s0C; }
     vec xr[XV], gr[GV];
-    unsigned xvalid = 0;
+    unsigned xvalid = 0, gvalid = 0;
     float bs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bs[i] = 0.f;
-    auto load_tile = [&](int t) {
+    // per-thread constants of the staging pattern (the same for every tile), loads as "wave-uniform sample base + 32-bit lane
+    // offset" (see wgrad3c_kernel)
+    const int p0c = ptid >> 2, chc = ptid & 3;
+    int hyj[XV], hxj[XV], gyj[GV], gxj[GV];
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = min(p0c + j * PP, NX - 1);
+      hyj[j] = pix / XW; hxj[j] = pix - hyj[j] * XW;
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = min(p0c + j * PP, NG - 1);
+      gyj[j] = pix / TW; gxj[j] = pix % TW;
+    }
+    const int dy1 = (a.s0H - a.s1H) >> 1, dx1 = (a.s0W - a.s1W) >> 1;
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
       int r = t;
       const int tx_ = r % a.tiles_x; r /= a.tiles_x;
       const int ty_ = r % a.tiles_y; r /= a.tiles_y;
       const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
       const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
-      // the per-thread staging pattern is recomputed per tile (a handful of VALU ops) instead of living in ~30 registers
-      int t4 = ptid;
-      asm volatile("" : "+v"(t4));
-      const int p0 = t4 >> 2, ch = t4 & 3;
       unsigned valid = 0;
+      const bf16_t* base1 = (MODE != 0 && g == 1) ? a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase : nullptr;
+      const bf16_t* base0 = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+      const bf16_t* baseg = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
 #pragma unroll
       for (int j = 0; j < XV; ++j) {
-        const int pix = min(p0 + j * PP, NX - 1);
-        const int hy = pix / XW, hx = pix - hy * XW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
+        const int iy = iy0 + hyj[j], ix = ix0 + hxj[j];
         const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         valid |= (ok ? 1u : 0u) << j;
         if (MODE != 0 && g == 1) {
-          const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
-          const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
-          const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
-          xr[j] = *reinterpret_cast<const vec*>(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
+          const int sy = min(max(iy - dy1, 0), a.s1H - 1), sx = min(max(ix - dx1, 0), a.s1W - 1);
+          xr[j] = wg_ld16o(base1, (unsigned)((sy * a.s1W + sx) * a.s1C + chc * 8) * 2u);
         } else {
-          const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
-          const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
-          xr[j] = *reinterpret_cast<const vec*>(base + off);
+          xr[j] = wg_ld16o(base0, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
         }
       }
       xvalid = valid;
+      unsigned gval = 0;
 #pragma unroll
       for (int j = 0; j < GV; ++j) {
-        const int pix = min(p0 + j * PP, NG - 1);
-        const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
+        const int gy_ = y0 + gyj[j], gx_ = x0 + gxj[j];
         const bool ok = gy_ < a.Hout && gx_ < a.Wout;
-        const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
-        const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
-        vec v = *reinterpret_cast<const vec*>(base + off);
-        if (!ok) v = E::zero();
-        gr[j] = v;
+        // (no select on the loaded value here: it would make the request wait for its own data -- zeroed at write time)
+        gval |= (ok ? 1u : 0u) << j;
+        gr[j] = wg_ld16o(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
       }
+      gvalid = gval;
     };
     auto write_lds = [&](char* st) {
       char* sX = st;
@@ -800,10 +813,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3r_kernel(const WgArgs a) {
       for (int j = 0; j < GV; ++j) {
         const int pix = p0 + j * PP;
         if (pix >= NG) continue;
-        *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
+        const vec gv = ((gvalid >> j) & 1u) ? gr[j] : E::zero();
+        *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gv;
         if (do_bias) {
           float f[8];
-          E::unpack(gr[j], f);
+          E::unpack(gv, f);
 #pragma unroll
           for (int i = 0; i < 8; ++i) bs[i] += f[i];
         }
@@ -954,64 +968,78 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
   // ==================================================================================================================
   const int ptid = tid - 256;
   const int cbase = sl * 32;
-  vec x1r[XV], x2r[XV], sq[XV], rt[XV], gr[GV];
-  unsigned xvalid = 0;
+  // TWO raw register sets: the loads of tile t + 2 are requested at the start of tile t's multiplies, a whole tile period before
+  // derive() needs them (with one set the request went out just before it was consumed: load latency + derive + write + multiply
+  // ran back to back, 5.7 us per tile for 2.3 us of MFMAs)
+  struct Raw { vec x1[XV], x2[XV], g[GV]; unsigned valid, gvalid; };
+  Raw ra, rb;
+  vec sq[XV], rt[XV];
   float bs[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bs[i] = 0.f;
-  auto load_tile = [&](int t) {
+  // per-thread constants of the staging pattern (the same for every tile): halo pixel (hyj, hxj) of X slot j, tile pixel
+  // (gyj, gxj) of gY slot j, this thread's 16-byte channel group `ch`
+  const int p0c = ptid >> 2, chc = ptid & 3;
+  int hyj[XV], hxj[XV], gyj[GV], gxj[GV];
+#pragma unroll
+  for (int j = 0; j < XV; ++j) {
+    const int pix = min(p0c + j * PP, NX - 1);
+    hyj[j] = pix / XW; hxj[j] = pix - hyj[j] * XW;
+  }
+#pragma unroll
+  for (int j = 0; j < GV; ++j) {
+    const int pix = min(p0c + j * PP, NG - 1);
+    gyj[j] = pix / TW; gxj[j] = pix % TW;
+  }
+  const int dy1 = (a.s0H - a.s1H) >> 1, dx1 = (a.s0W - a.s1W) >> 1;
+  // loads are "wave-uniform sample base + 32-bit per-lane byte offset" (global_load_dwordx4 v, v_off, s[base]): a 64-bit per-lane
+  // address is built by the compiler inside the load's destination registers, two 64-bit vector operations per load
+  auto load_tile = [&](int t, Raw& q) __attribute__((always_inline)) {
     int r = t;
     const int tx_ = r % a.tiles_x; r /= a.tiles_x;
     const int ty_ = r % a.tiles_y; r /= a.tiles_y;
     const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
-    int t4 = ptid;
-    asm volatile("" : "+v"(t4));
-    const int p0 = t4 >> 2, ch = t4 & 3;
     unsigned valid = 0;
-    const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
     const bf16_t* base1 = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
     const bf16_t* base2 = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
+    const bf16_t* baseg = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
 #pragma unroll
     for (int j = 0; j < XV; ++j) {
-      const int pix = min(p0 + j * PP, NX - 1);
-      const int hy = pix / XW, hx = pix - hy * XW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
+      const int iy = iy0 + hyj[j], ix = ix0 + hxj[j];
       const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       valid |= (ok ? 1u : 0u) << j;
       // the up-sampled operand, replicate-padded to the skip's extent (unet_parts.py:292-298)
-      const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
-      x1r[j] = *reinterpret_cast<const vec*>(base1 + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
-      const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
-      x2r[j] = *reinterpret_cast<const vec*>(base2 + off);
+      const int sy = min(max(iy - dy1, 0), a.s1H - 1), sx = min(max(ix - dx1, 0), a.s1W - 1);
+      q.x1[j] = wg_ld16o(base1, (unsigned)((sy * a.s1W + sx) * a.s1C + chc * 8) * 2u);
+      q.x2[j] = wg_ld16o(base2, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
     }
-    xvalid = valid;
+    q.valid = valid;
+    unsigned gval = 0;
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
-      const int pix = min(p0 + j * PP, NG - 1);
-      const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW;
+      const int gy_ = y0 + gyj[j], gx_ = x0 + gxj[j];
       const bool ok = gy_ < a.Hout && gx_ < a.Wout;
-      const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
-      const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
-      vec v = *reinterpret_cast<const vec*>(base + off);
-      if (!ok) v = E::zero();
-      gr[j] = v;
+      // (no select on the loaded value here: it would make the request wait for its own data -- the zeroing happens at write time)
+      gval |= (ok ? 1u : 0u) << j;
+      q.g[j] = wg_ld16o(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
     }
+    q.gvalid = gval;
   };
   // x2^2 and sqrt(x2 + 1e-8) of the loaded slice, zero padding applied to all four members (registers only)
-  auto derive = [&]() {
+  auto derive = [&](Raw& q) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < XV; ++j) {
       float f[8], s2[8], rr[8];
-      E::unpack(x2r[j], f);
+      E::unpack(q.x2[j], f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s2[i] = f[i] * f[i]; rr[i] = __builtin_amdgcn_sqrtf(f[i] + 1e-8f); }
       sq[j] = E::pack(s2);
       rt[j] = E::pack(rr);
-      if (!((xvalid >> j) & 1u)) { x1r[j] = E::zero(); x2r[j] = E::zero(); sq[j] = E::zero(); rt[j] = E::zero(); }
+      if (!((q.valid >> j) & 1u)) { q.x1[j] = E::zero(); q.x2[j] = E::zero(); sq[j] = E::zero(); rt[j] = E::zero(); }
     }
   };
-  auto write_lds = [&]() {
+  auto write_lds = [&](const Raw& q, float bias_w) __attribute__((always_inline)) {
     int t4 = ptid;
     asm volatile("" : "+v"(t4));
     const int p0 = t4 >> 2, ch = t4 & 3;
@@ -1020,8 +1048,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
       const int pix = p0 + j * PP;
       if (pix >= NX) continue;
       char* d = smem + ch * XPLB + pix * 16;
-      *reinterpret_cast<vec*>(d) = x2r[j];                    // member order of the weight's K layout: [x2 | x1 | x2^2 | sqrt]
-      *reinterpret_cast<vec*>(d + 4 * XPLB) = x1r[j];
+      *reinterpret_cast<vec*>(d) = q.x2[j];                   // member order of the weight's K layout: [x2 | x1 | x2^2 | sqrt]
+      *reinterpret_cast<vec*>(d + 4 * XPLB) = q.x1[j];
       *reinterpret_cast<vec*>(d + 8 * XPLB) = sq[j];
       *reinterpret_cast<vec*>(d + 12 * XPLB) = rt[j];
     }
@@ -1029,27 +1057,38 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
     for (int j = 0; j < GV; ++j) {
       const int pix = p0 + j * PP;
       if (pix >= NG) continue;
-      *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
+      const vec gv = ((q.gvalid >> j) & 1u) ? q.g[j] : E::zero();
+      *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gv;
       if (do_bias) {
         float f[8];
-        E::unpack(gr[j], f);
+        E::unpack(gv, f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bs[i] += f[i];
+        for (int i = 0; i < 8; ++i) bs[i] = fmaf(f[i], bias_w, bs[i]);     // (weight 0: the write past the end of the range)
       }
     }
   };
-  load_tile(tile0);
-  derive();
-  write_lds();
-  if (tile0 + 1 < tile_end) load_tile(tile0 + 1);
-  for (int t = tile0; t < tile_end; ++t) {
+  // tile t0 + k lives in set (k & 1): a = even, b = odd.  The steps are STRAIGHT-LINE code: past the end of the range they request
+  // the last tile again and write a stage nobody reads.  With the requests inside `if (t + 2 < tile_end)` the compiler's waitcnt
+  // insertion merges the two paths pessimistically and derive() waits for 12 of the 16 loads just requested (vmcnt(14) .. (4) in
+  // the ISA), i.e. for a full memory latency per tile.
+  const int last = tile_end - 1;
+  load_tile(tile0, ra);
+  load_tile(min(tile0 + 1, last), rb);
+  derive(ra);
+  float bias_on = 1.f;
+  write_lds(ra, bias_on);
+  // one step of the pipeline while the multiplying waves work on tile t (whose successor sits in `nxt`, and whose registers `cur`
+  // are free again): request tile t + 2, derive tile t + 1, hand the stage over, write tile t + 1
+  auto step = [&](int t, Raw& cur, Raw& nxt) __attribute__((always_inline)) {
     __syncthreads();                 // the stage holds tile t
-    if (t + 1 < tile_end) derive();  // (waits for the loads of tile t + 1; the multiplying waves are busy with tile t)
-    __syncthreads();                 // they are done with it
-    if (t + 1 < tile_end) {
-      write_lds();
-      if (t + 2 < tile_end) load_tile(t + 2);
-    }
+    load_tile(min(t + 2, last), cur);
+    derive(nxt);
+    __syncthreads();                 // the multiplying waves are done with tile t
+    write_lds(nxt, t + 1 < tile_end ? 1.f : 0.f);
+  };
+  for (int t = tile0; t < tile_end; t += 2) {
+    step(t, ra, rb);
+    if (t + 1 < tile_end) step(t + 1, rb, ra);
   }
   if (do_bias) {
     float* sBs = reinterpret_cast<float*>(smem);
