@@ -591,14 +591,136 @@ def test_wgrad3x3_wide_blocks_concat_ssr(c, cout, h, w, dy, dx):
               src0=to_nhwc(x2, BF), src0_H=h, src0_W=w, src0_C=c, src1=to_nhwc(x1, BF), src1_H=h - dy, src1_W=w - dx, src1_C=c)
     got = {}
     old = lib.uncl_wgrad_set_wide(1)
+    oldc = lib.uncl_wgrad_set_cat(0)          # (the four-member kernel would take these layers: this test is about the 64 x 64 blocks)
+    oldr = lib.uncl_wgrad_set_roll(0)
     try:
         for wide in (1, 0):
             lib.uncl_wgrad_set_wide(wide)
             got[wide] = unpack(wgrad(to_nhwc(gy, BF), (9, cout, 4 * c), **kw), cout, 4 * c, 3, True, True)
     finally:
         lib.uncl_wgrad_set_wide(old)
+        lib.uncl_wgrad_set_cat(oldc)
+        lib.uncl_wgrad_set_roll(oldr)
     assert rel_l2(got[1], wt.grad) < 3e-3, rel_l2(got[1], wt.grad)
     assert rel_l2(got[1], got[0]) < 2e-5, rel_l2(got[1], got[0])
+
+
+# ---- split-role kernels (wgrad3r_kernel: per pair, wgrad3c_kernel: the four members of a skip slice): vs autograd, vs the six-wave
+# ---- kernel on the same inputs, bias sums, deterministic mode ------------------------------------------------------------------
+def _wg_modes(lib, roll, cat):
+    return lib.uncl_wgrad_set_roll(roll), lib.uncl_wgrad_set_cat(cat)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n,pad", [(32, 32, 70, 45, 3, 0), (64, 96, 33, 40, 3, 2), (32, 64, 126, 126, 2, 0),
+                                                (128, 32, 17, 100, 2, 2), (32, 32, 4, 5, 1, 2), (96, 32, 16, 32, 7, 0),
+                                                (32, 32, 254, 254, 2, 2)])
+def test_wgrad3x3_split_role(cin, cout, h, w, n, pad):
+    """ragged 16 x 32 tiles, one to many tiles per workgroup (odd and even counts: the two-stage ring), halo rows and columns
+    outside the image, both paddings, with the bias sums"""
+    lib = _hip.lib()
+    x = q(rnd(n, cin, h, w, seed=131))
+    if pad == 0:
+        wt, bt = rnd(cout, cin, 3, 3, seed=132, scale=0.1).requires_grad_(True), rnd(cout, seed=134).requires_grad_(True)
+        gy = q(rnd(n, cout, h - 2, w - 2, seed=133))
+        F.conv2d(x, wt, bt).backward(gy)
+    else:
+        wt, bt = rnd(cin, cout, 3, 3, seed=132, scale=0.1).requires_grad_(True), rnd(cout, seed=134).requires_grad_(True)
+        gy = q(rnd(n, cout, h + 2, w + 2, seed=133))
+        F.conv_transpose2d(x, wt, bt).backward(gy)
+    d = _hip.ConvDesc()
+    xs, gys = to_nhwc(x, BF), to_nhwc(gy, BF)
+    for k, v in dict(dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=xs.data_ptr(),
+                     src0_H=h, src0_W=w, src0_C=cin).items():
+        setattr(d, k, v)
+    got = {}
+    old = _wg_modes(lib, 0, 0)
+    try:
+        for roll in (2, 0):
+            lib.uncl_wgrad_set_roll(roll)
+            dw = torch.zeros(9, cout, cin, dtype=torch.float32, device="cuda")
+            gb = torch.zeros(cout, dtype=torch.float32, device="cuda")
+            _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gys.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad_bias")
+            torch.cuda.synchronize()
+            got[roll] = (unpack(dw, cout, cin, 3, pad == 2, pad == 2), gb.cpu())
+    finally:
+        _wg_modes(lib, *old)
+    assert rel_l2(got[2][0], wt.grad) < 2e-3, rel_l2(got[2][0], wt.grad)
+    assert rel_l2(got[2][0], got[0][0]) < 2e-5, rel_l2(got[2][0], got[0][0])       # same products, fp32 sums in another order
+    assert rel_l2(got[2][1], bt.grad) < 1e-5, rel_l2(got[2][1], bt.grad)
+
+
+@pytest.mark.parametrize("c,cout,h,w,dy,dx,n", [(32, 32, 59, 61, 1, 1, 3), (32, 32, 252, 252, 0, 0, 2), (32, 32, 252, 252, 0, 0, 1),
+                                                (64, 32, 26, 26, 2, 2, 5),
+                                                (128, 64, 12, 13, 0, 1, 3), (32, 64, 7, 40, 2, 0, 9), (256, 128, 24, 24, 0, 0, 4)])
+def test_wgrad3x3_concat_members_in_one_workgroup(c, cout, h, w, dy, dx, n):
+    """wgrad3c_kernel: [x2 | x1 | x2^2 | sqrt] of every 32-channel skip slice against every gY chunk; the up-sampled operand up to
+    two pixels smaller (replicate padding), 8-row tiles (ragged last row tile), odd and even tile counts per workgroup (n = 1 at
+    252 x 252: ONE tile per workgroup, the case in which the staging waves' write past the end of the range once raced with the
+    bias partials), bias sums"""
+    lib = _hip.lib()
+    x2, x1 = q(rnd(n, c, h, w, seed=141).abs()), q(rnd(n, c, h - dy, w - dx, seed=142))
+    x1p = F.pad(x1, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2), mode="replicate")
+    cat = torch.cat([x2, x1p, q(x2 ** 2), q((x2 + 1e-8) ** 0.5)], 1)
+    wt, bt = rnd(4 * c, cout, 3, 3, seed=143, scale=0.05).requires_grad_(True), rnd(cout, seed=145).requires_grad_(True)
+    gy = q(rnd(n, cout, h + 2, w + 2, seed=144))
+    F.conv_transpose2d(cat, wt, bt).backward(gy)
+    d = _hip.ConvDesc()
+    x2s, x1s, gys = to_nhwc(x2, BF), to_nhwc(x1, BF), to_nhwc(gy, BF)
+    for k, v in dict(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR, N=n, H=h, W=w, Cin=4 * c, Cout=cout,
+                     src0=x2s.data_ptr(), src0_H=h, src0_W=w, src0_C=c, src1=x1s.data_ptr(), src1_H=h - dy, src1_W=w - dx,
+                     src1_C=c).items():
+        setattr(d, k, v)
+    got = {}
+    old = _wg_modes(lib, 0, 0)
+    oldw = lib.uncl_wgrad_set_wide(0)
+    try:
+        for cat_on in (1, 0):
+            lib.uncl_wgrad_set_cat(cat_on)
+            dw = torch.zeros(9, cout, 4 * c, dtype=torch.float32, device="cuda")
+            gb = torch.zeros(cout, dtype=torch.float32, device="cuda")
+            _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gys.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad_bias")
+            torch.cuda.synchronize()
+            got[cat_on] = (unpack(dw, cout, 4 * c, 3, True, True), gb.cpu())
+    finally:
+        _wg_modes(lib, *old)
+        lib.uncl_wgrad_set_wide(oldw)
+    assert rel_l2(got[1][0], wt.grad) < 3e-3, rel_l2(got[1][0], wt.grad)
+    assert rel_l2(got[1][0], got[0][0]) < 2e-5, rel_l2(got[1][0], got[0][0])
+    assert rel_l2(got[1][1], bt.grad) < 1e-5, rel_l2(got[1][1], bt.grad)
+
+
+def test_wgrad3x3_split_role_kernels_deterministic_with_scratch():
+    """uncl_wgrad_set_scratch: per-group partial sums + fixed-order reduction instead of atomics -- two runs give the same bits, for
+    the per-pair split-role kernel and for the four-member kernel"""
+    lib = _hip.lib()
+    scratch = torch.empty(lib.uncl_wgrad_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    n, c, cout, h, w = 6, 32, 32, 61, 70
+    x2, x1 = to_nhwc(q(rnd(n, c, h, w, seed=151).abs()), BF), to_nhwc(q(rnd(n, c, h, w, seed=152)), BF)
+    gys = to_nhwc(q(rnd(n, cout, h + 2, w + 2, seed=153)), BF)
+    old = _wg_modes(lib, 2, 1)
+    try:
+        for concat in (0, 1):
+            cin = 4 * c if concat else c
+            d = _hip.ConvDesc()
+            kw = dict(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR if concat else _hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin,
+                      Cout=cout, src0=x2.data_ptr(), src0_H=h, src0_W=w, src0_C=c)
+            if concat:
+                kw.update(src1=x1.data_ptr(), src1_H=h, src1_W=w, src1_C=c)
+            for k, v in kw.items():
+                setattr(d, k, v)
+            runs = []
+            for rep in range(3):
+                lib.uncl_wgrad_set_scratch(scratch.data_ptr() if rep < 2 else None, scratch.numel() if rep < 2 else 0)
+                dw = torch.zeros(9, cout, cin, dtype=torch.float32, device="cuda")
+                gb = torch.zeros(cout, dtype=torch.float32, device="cuda")
+                _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gys.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad_bias")
+                torch.cuda.synchronize()
+                runs.append((dw, gb))
+            assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), concat
+            assert rel_l2(runs[0][0].cpu(), runs[2][0].cpu()) < 1e-5 and rel_l2(runs[0][1].cpu(), runs[2][1].cpu()) < 1e-5, concat
+    finally:
+        lib.uncl_wgrad_set_scratch(None, 0)
+        _wg_modes(lib, *old)
 
 
 # ---- bias gradient out of the weight-gradient kernel's own pass over gy (uncl_conv_wgrad_bias) --------------------------------

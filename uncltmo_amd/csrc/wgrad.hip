@@ -1091,7 +1091,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
     if (t + 1 < tile_end) step(t + 1, rb, ra);
   }
   if (do_bias) {
-    float* sBs = reinterpret_cast<float*>(smem);
+    // (a region of its own behind the stage: the last step's write of the stage -- other waves' -- is not ordered against these)
+    float* sBs = reinterpret_cast<float*>(sG + 4 * GPLB);
 #pragma unroll
     for (int i = 0; i < 8; ++i) sBs[ptid * 8 + i] = bs[i];
     __syncthreads();
@@ -1220,7 +1221,7 @@ int launch_wg3r(WgArgs& a, hipStream_t s) {
 }
 
 int launch_wg3c(WgArgs& a, hipStream_t s) {
-  constexpr size_t lds = 16 * (size_t)wg_plane(10 * 34) + 4 * (size_t)wg_plane(8 * 32);
+  constexpr size_t lds = 16 * (size_t)wg_plane(10 * 34) + 4 * (size_t)wg_plane(8 * 32) + 256 * 8 * sizeof(float);   // stage + bias sums
   auto kern = wgrad3c_kernel<0>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
