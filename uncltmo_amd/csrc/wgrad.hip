@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
   const int p0 = tid >> 2, ch = tid & 3;
 
   vec xr[XV], gr[GV];
-  unsigned xvalid = 0;
+  unsigned xvalid = 0, gvalid = 0;
 
   auto load_tile = [&](int t) {
     int r = t;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
       }
     }
     xvalid = valid;
+    unsigned gval = 0;
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
       const int pix = p0 + j * 64;
@@ -189,10 +190,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
         const int yy = rem / a.upW, xx = rem - yy * a.upW;
         off = (((size_t)nn * 2 * a.upH + 2 * yy + (up_tap >> 1)) * (2 * a.upW) + 2 * xx + (up_tap & 1)) * a.gy_ld;
       }
-      vec v = ld16g(a.gy + off + cgrp * a.Cout + cc * 32 + ch * 8);
-      if (!ok) v = E::zero();
-      gr[j] = v;
+      // (zeroed at write time: a select on the value just requested makes the request wait for its own data, i.e. the prefetch
+      // of the next tile would finish before the first MFMA of this one)
+      gval |= (ok ? 1u : 0u) << j;
+      gr[j] = ld16g(a.gy + off + cgrp * a.Cout + cc * 32 + ch * 8);
     }
+    gvalid = gval;
   };
   auto write_lds = [&]() {
 #pragma unroll
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
       const int pix = p0 + j * 64;
-      *reinterpret_cast<vec*>(sG + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = gr[j];
+      *reinterpret_cast<vec*>(sG + pix * 64 + ((ch ^ ((pix >> 2) & 3)) << 4)) = ((gvalid >> j) & 1u) ? gr[j] : E::zero();
     }
   };
 
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
   int g = 0, cbase = kc * 32;
   if (MODE != 0) { g = cbase / a.s0C; cbase -= g * a.s0C; }
   vec xr[XV], gr[GV];
-  unsigned xvalid = 0;
+  unsigned xvalid = 0, gvalid = 0;
   // bias gradient = column sums of gy: the workgroups of the first ci chunk add up the gy vectors they stage anyway (the
   // vector pipe is idle beside the MFMAs of the other waves); summed over the staging threads and added with 32 / 64 atomics
   const bool do_bias = a.gb != nullptr && kc == 0;      // workgroup-uniform
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
       }
     }
     xvalid = valid;
+    unsigned gval = 0;
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
       const int pix = min(p0 + j * PP, NG - 1);
@@ -349,10 +353,10 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
       const bool ok = gy_ < a.Hout && gx_ < a.Wout;
       const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
       const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
-      vec v = *reinterpret_cast<const vec*>(base + off);
-      if (!ok) v = E::zero();
-      gr[j] = v;
+      gval |= (ok ? 1u : 0u) << j;          // (zeroed at write time, see wgrad_kernel)
+      gr[j] = *reinterpret_cast<const vec*>(base + off);
     }
+    gvalid = gval;
   };
   auto write_lds = [&]() {
     int t4 = tid;
@@ -382,10 +386,11 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
     for (int j = 0; j < GV; ++j) {
       const int pix = p0 + j * PP;
       if (pix >= NG) continue;
-      *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gr[j];
+      const vec gv = ((gvalid >> j) & 1u) ? gr[j] : E::zero();
+      *reinterpret_cast<vec*>(sG + ch * GPLB + pix * 16) = gv;
       if (do_bias) {
         float f[8];
-        E::unpack(gr[j], f);
+        E::unpack(gv, f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) bs[i] += f[i];
       }
@@ -546,6 +551,8 @@ __global__ __launch_bounds__(384, 3) void wgrad3w_kernel(const WgArgs a) {
       const bool ok = gy_ < a.Hout && gx_ < a.Wout;
       const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 64;
       const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
+      // (the other kernels zero at write time so that the request does not wait for its own data; this one is at its 168-register
+      // budget -- the concat instantiation already spills 7 -- and off the default paths since wgrad3c_kernel: left as measured)
       vec v = *reinterpret_cast<const vec*>(base + off);
       if (!ok) v = E::zero();
       gr[j] = v;
