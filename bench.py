@@ -581,6 +581,61 @@ def _median(v):
     return 0.0 if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
 
 
+# the generator's seventeen 3x3 layers as the weight-gradient entry sees them: name, member channels (concat) or Cin, Cout,
+# input H (= W), pad, concat
+WGRAD3_LAYERS = [("inc.conv.conv1", 32, 32, 254, 0, 0), ("down_path.0.conv", 32, 64, 126, 0, 0), ("down_path.0.conv1", 64, 64, 124, 0, 0),
+                 ("down_path.1.conv", 64, 128, 61, 0, 0), ("down_path.1.conv1", 128, 128, 59, 0, 0),
+                 ("down_path.2.conv", 128, 256, 28, 0, 0), ("down_path.2.conv1", 256, 256, 26, 0, 0),
+                 ("down_path.3.conv", 256, 256, 12, 0, 0), ("down_path.3.conv1", 256, 256, 10, 2, 0),
+                 ("up_path.0.conv.conv", 256, 128, 24, 2, 1), ("up_path.0.conv.conv1", 128, 128, 26, 2, 0),
+                 ("up_path.1.conv.conv", 128, 64, 57, 2, 1), ("up_path.1.conv.conv1", 64, 64, 59, 2, 0),
+                 ("up_path.2.conv.conv", 64, 32, 122, 2, 1), ("up_path.2.conv.conv1", 32, 32, 124, 2, 0),
+                 ("up_path.3.conv.conv", 32, 32, 252, 2, 1), ("up_path.3.conv.conv1", 32, 32, 254, 2, 0)]
+
+
+def wgrad3_standalone(n, reps=5):
+    """Weight + bias gradients of the generator's seventeen 3x3 layers at a batch of `n` frames, each launch timed ALONE with an
+    event pair (uncl_conv_wgrad_bias on synthetic operands of the layer's shape, the dispatcher's default kernels): what the
+    family costs a backward pass when nothing overlaps it.  The 1x1 / 2x2 layers' gradients (nine more launches) are not in it."""
+    import ctypes as C
+    import torch
+    from uncltmo_amd import _hip
+    lib = _hip.lib()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    per, flops = {}, 0.0
+    for name, c, cout, h, pad, cat in WGRAD3_LAYERS:
+        cin = 4 * c if cat else c
+        ho = h + 2 * pad - 2
+        x = torch.rand(n, h, h, c, generator=g, device="cuda").to(torch.bfloat16)
+        x1 = (torch.rand(n, h, h, c, generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+        gy = (torch.rand(n, ho, ho, cout, generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+        d = _hip.ConvDesc()
+        kw = dict(dtype=_hip.BF16, ksize=3, pad=pad, src_mode=_hip.SRC_CONCAT_SSR if cat else _hip.SRC_PLAIN, N=n, H=h, W=h,
+                  Cin=cin, Cout=cout, src0=x.data_ptr(), src0_H=h, src0_W=h, src0_C=c)
+        if cat:
+            kw.update(src1=x1.data_ptr(), src1_H=h, src1_W=h, src1_C=c)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        dw = torch.zeros(9, cout, cin, dtype=torch.float32, device="cuda")
+        gb = torch.zeros(cout, dtype=torch.float32, device="cuda")
+        call = lambda: _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gy.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()),
+                                  "uncl_conv_wgrad_bias")
+        for _ in range(2):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        per[name] = round(e0.elapsed_time(e1) * 1e3 / reps, 1)
+        flops += 2.0 * 9 * cin * cout * ho * ho * n
+    tot_ms = sum(per.values()) * 1e-3
+    return {"ms": tot_ms, "us_per_layer": per, "tflops": flops / (tot_ms * 1e-3) / 1e12, "frac_of_bf16_peak": flops / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+            "frames": n, "note": "the generator's seventeen 3x3 layers (weights + biases), each launch alone between HIP events, default "
+                                 "kernels (split-role per pair, four-member on the skip-concat layers); 1x1 / 2x2 layers not included"}
+
+
 def train_numbers(a, rk, video, steps, warmup, clips=None):
     """One optimisation step (train_D + train_G) timed `steps` times after `warmup` untimed ones.  `ms_per_step` is the MEDIAN
     of the per-step device times; the mean over the bracketed region, min / max, the whole per-step list, the host
@@ -636,6 +691,12 @@ def train_numbers(a, rk, video, steps, warmup, clips=None):
                               "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
                                       "2 bwd (109.7 GFLOP, what the reference runs); both over the median step time"},
            "errD": float(tr.errD.detach()), "errG_d": float(tr.errG_d.detach()), "errG_struct": float(tr.errG_struct.detach())}
+    if not video and not a.stub and os.environ.get("UNCL_BENCH_WGRAD", "1") != "0":
+        try:
+            out["wgrad_ms"] = (w3 := wgrad3_standalone(n))["ms"]
+            out["wgrad3x3_standalone"] = w3
+        except Exception as e:        # a report beside the step, never the reason a leg fails
+            out["wgrad3x3_standalone"] = {"error": repr(e)}
     if getattr(tr, "_eager_step", None) is not None and not getattr(a, "no_eager", False):
         # beside the replayed step: the same step launched eagerly (no hipGraph).  On an idle host it is the faster of the two on
         # the image step -- the generator's backward then runs its weight gradients on a second stream, which a replayed graph

@@ -12,14 +12,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from uncltmo_amd import _hip  # noqa: E402
 
-# name, member channels (concat) or Cin, Cout, input H (= W), pad, concat
-LAYERS = [("inc.conv.conv1", 32, 32, 254, 0, 0), ("down_path.0.conv", 32, 64, 126, 0, 0), ("down_path.0.conv1", 64, 64, 124, 0, 0),
-          ("down_path.1.conv", 64, 128, 61, 0, 0), ("down_path.1.conv1", 128, 128, 59, 0, 0), ("down_path.2.conv", 128, 256, 28, 0, 0),
-          ("down_path.2.conv1", 256, 256, 26, 0, 0), ("down_path.3.conv", 256, 256, 12, 0, 0), ("down_path.3.conv1", 256, 256, 10, 2, 0),
-          ("up_path.0.conv.conv", 256, 128, 24, 2, 1), ("up_path.0.conv.conv1", 128, 128, 26, 2, 0),
-          ("up_path.1.conv.conv", 128, 64, 57, 2, 1), ("up_path.1.conv.conv1", 64, 64, 59, 2, 0),
-          ("up_path.2.conv.conv", 64, 32, 122, 2, 1), ("up_path.2.conv.conv1", 32, 32, 124, 2, 0),
-          ("up_path.3.conv.conv", 32, 32, 252, 2, 1), ("up_path.3.conv.conv1", 32, 32, 254, 2, 0)]
+import bench  # noqa: E402
+
+LAYERS = bench.WGRAD3_LAYERS
 
 
 def main():
