@@ -78,15 +78,23 @@ def _act(x, activation):
     raise AssertionError("Unsupported activation: {%s}" % activation)
 
 
-def _norm(x, unet_norm):
+def _norm(x, unet_norm, sd=None, q=None, training=False):
+    """unet_parts.py:20-29, 34-37, 72-73, 85-86: the norm between a 3x3 convolution and its activation.  `q` = the state_dict prefix
+    of the norm module ("inc.conv.norm", "...norm1").  nn.BatchNorm2d defaults: affine, eps 1e-5, momentum 0.1; in training mode
+    F.batch_norm normalises with the batch statistics and updates sd's running statistics in place, like the module."""
     if unet_norm in (None, "none"):
         return x
     if unet_norm == "instance_norm":
         return F.instance_norm(x, eps=1e-5)          # nn.InstanceNorm2d default: no affine, no stats
-    raise NotImplementedError("oracle covers unet_norm in {none, instance_norm}")
+    if unet_norm == "batch_norm":
+        if training and (q + ".num_batches_tracked") in sd:
+            sd[q + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"],
+                            training=training, momentum=0.1, eps=1e-5)
+    raise NotImplementedError("oracle covers unet_norm in {none, instance_norm, batch_norm}")
 
 
-def double_conv(sd, p, x, first_transposed, second_transposed, activation="relu", unet_norm="none"):
+def double_conv(sd, p, x, first_transposed, second_transposed, activation="relu", unet_norm="none", training=False):
     """conv -> [norm] -> act -> conv1 -> [norm] -> act with no padding.
 
     unet_parts.py:56-87 (double_conv, valid 3x3), :126-141 (double_last_conv: conv then ConvT),
@@ -94,8 +102,8 @@ def double_conv(sd, p, x, first_transposed, second_transposed, activation="relu"
     """
     f0 = F.conv_transpose2d if first_transposed else F.conv2d
     f1 = F.conv_transpose2d if second_transposed else F.conv2d
-    x = _act(_norm(f0(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"]), unet_norm), activation)
-    x = _act(_norm(f1(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"]), unet_norm), activation)
+    x = _act(_norm(f0(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"]), unet_norm, sd, p + ".norm", training), activation)
+    x = _act(_norm(f1(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"]), unet_norm, sd, p + ".norm1", training), activation)
     return x
 
 
@@ -114,7 +122,7 @@ def skip_concat(x2, x1, con_operator="square_and_square_root"):
     raise AssertionError("Unsupported con_operator request: {}".format(con_operator))
 
 
-def up_block(sd, p, x1, x2, con_operator, activation="relu", unet_norm="none"):
+def up_block(sd, p, x1, x2, con_operator, activation="relu", unet_norm="none", training=False):
     """ConvT 2x2 stride 2, replicate-pad x1 up to x2's size (right/bottom get the odd pixel), concat,
     double transposed conv.  unet_parts.py:283-335 (pad :292-298)."""
     x1 = F.conv_transpose2d(x1, sd[p + ".up.weight"], sd[p + ".up.bias"], stride=2)
@@ -123,7 +131,7 @@ def up_block(sd, p, x1, x2, con_operator, activation="relu", unet_norm="none"):
     if dx or dy:
         x1 = F.pad(x1, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2), mode="replicate")
     x = skip_concat(x2, x1, con_operator)
-    return double_conv(sd, p + ".conv", x, True, True, activation, unet_norm)
+    return double_conv(sd, p + ".conv", x, True, True, activation, unet_norm, training)
 
 
 # --------------------------------------------------------------------------------------------
@@ -237,15 +245,15 @@ def unet_image_forward(sd, x, con_operator="square_and_square_root", last_layer=
         return t
 
     a, n = activation, unet_norm
-    feats = [rec("inc", double_conv(sd, "inc.conv", x, False, False, a, n))]
+    feats = [rec("inc", double_conv(sd, "inc.conv", x, False, False, a, n, training))]
     for i in range(3):
         feats.append(rec("down%d" % i, double_conv(sd, "down_path.%d.mpconv.1" % i, F.max_pool2d(feats[-1], 2),
-                                                   False, False, a, n)))
+                                                   False, False, a, n, training)))
     feats.append(rec("down3", double_conv(sd, "down_path.3.mpconv.1", F.max_pool2d(feats[-1], 2),
-                                          False, True, a, n)))
+                                          False, True, a, n, training)))
     up = rec("gcn", gcn_block(sd, feats[4], drop_keep=drop_keep, training=training, want=want))
     for i in range(4):
-        up = rec("up%d" % i, up_block(sd, "up_path.%d" % i, up, feats[3 - i], con_operator, a, n))
+        up = rec("up%d" % i, up_block(sd, "up_path.%d" % i, up, feats[3 - i], con_operator, a, n, training))
     out = _last_act(F.conv2d(up, sd["outc.conv.weight"], sd["outc.conv.bias"]), last_layer)
     if apply_crop and to_crop:
         out = crop_center(out, diffY, diffX)
@@ -281,11 +289,11 @@ def unet_video_forward(sd, x, con_operator="square_and_square_root", last_layer=
                 return t
             return torch.cat((last[slot], t[:, int(t.shape[1] * ratio):]), 1)
 
-        nx = double_conv(sd, "inc.conv", xf, False, False, a, n)
+        nx = double_conv(sd, "inc.conv", xf, False, False, a, n, training)
         feats = [nx]
         cur.append(head(nx))
         for i in range(4):
-            nx = double_conv(sd, "down_path.%d.mpconv.1" % i, F.max_pool2d(mix(nx, i), 2), False, i == 3, a, n)
+            nx = double_conv(sd, "down_path.%d.mpconv.1" % i, F.max_pool2d(mix(nx, i), 2), False, i == 3, a, n, training)
             feats.append(nx)
             cur.append(head(nx))
         dk = None if drop_keep is None else drop_keep[k]
@@ -293,7 +301,7 @@ def unet_video_forward(sd, x, con_operator="square_and_square_root", last_layer=
                        want=want if (want is not None and k == 0) else None)
         cur.append(head(up))
         for i in range(4):
-            up = up_block(sd, "up_path.%d" % i, mix(up, 5 + i), feats[3 - i], con_operator, a, n)
+            up = up_block(sd, "up_path.%d" % i, mix(up, 5 + i), feats[3 - i], con_operator, a, n, training)
             cur.append(head(up))
         f1 = up.mean(dim=(2, 3), keepdim=True)
         f2 = local_variance(up, win).mean(dim=(2, 3), keepdim=True)

@@ -6,8 +6,12 @@ from .generator import sincos_relative_pos
 
 def synth_state(spec, salt):
     sd = {}
+    import torch
     for k, shape, kind in spec:
-        sd[k] = sincos_relative_pos() if kind == "buffer" else synth.synth_tensor(k, shape, salt)
+        if kind == "bn_count":                      # num_batches_tracked: fill_state_dict leaves the module's zero
+            sd[k] = torch.zeros((), dtype=torch.long)
+        else:
+            sd[k] = sincos_relative_pos() if kind == "buffer" else synth.synth_tensor(k, shape, salt)
     return sd
 
 

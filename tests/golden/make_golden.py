@@ -357,6 +357,33 @@ def capture_generator_inorm(out):
         out["inorm.gradval." + k] = g[torch.from_numpy(pos_)].numpy()
 
 
+def capture_generator_bnorm(out):
+    """The reference generator built with unet_norm='batch_norm' (unet_parts.py:20-21, 34-35: nn.BatchNorm2d between every 3x3
+    convolution and its activation): state_dict keys / shapes, the eval forward (running statistics) on two frames, and -- for the
+    oracle -- a training-mode forward (batch statistics, DropPath mask injected) with the running statistics it leaves behind."""
+    G, _ = build_ref_models(unet_norm="batch_norm")
+    synth.bnorm_state(G.state_dict())
+    sd = G.state_dict()
+    out["bnorm.keys"] = np.array(list(sd.keys()))
+    out["bnorm.shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    G.eval()
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    with torch.no_grad():
+        y, up = G(x)
+    out["bnorm.x_out"] = y.numpy().copy()
+    out.update(summarize(up, "bnorm.up_x"))
+    G.train()
+    DropPath.forced_mask = torch.tensor([1.0, 0.0])
+    with torch.no_grad():
+        y2, up2 = G(x)
+    DropPath.forced_mask = None
+    out.update(summarize(y2, "bnorm_train.x_out", 1024))
+    out.update(summarize(up2, "bnorm_train.up_x"))
+    for k, v in G.state_dict().items():
+        if "running_" in k or k.endswith("num_batches_tracked"):
+            out["bnorm_train.after." + k] = v.double().numpy().copy()
+
+
 def loader_hdr_array():
     """(256, 256, 3) linear radiance, heavy-tailed: already 256 high, so the reference's HDR branch neither resizes nor crops"""
     u = synth.hash_uniform("loader_hdr", 256 * 256 * 3).astype(np.float64) ** 4
@@ -567,13 +594,14 @@ def capture_tester(out):
 
 
 def main():
-    which = sys.argv[1:] or ["generator", "generator_inorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
+    which = sys.argv[1:] or ["generator", "generator_inorm", "generator_bnorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
                              "inference", "tmqi", "loader", "patchd_grad", "tester"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
             "vid_step": lambda o: capture_step(o, True, [0, 7, 10]), "vid_c4": lambda o: capture_step_c4(o),
-            "generator_inorm": lambda o: capture_generator_inorm(o), "loader": lambda o: capture_loader(o),
+            "generator_inorm": lambda o: capture_generator_inorm(o), "generator_bnorm": lambda o: capture_generator_bnorm(o),
+            "loader": lambda o: capture_loader(o),
             "tiler": lambda o: capture_tiler(o), "patchd_grad": lambda o: capture_patchd_grad(o),
             "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o), "tester": lambda o: capture_tester(o)}
     for name in which:

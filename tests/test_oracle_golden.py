@@ -273,3 +273,53 @@ def test_tester_eval_on_video_oracle_vs_reference_golden(golden, sdG):
     check_ldr_frames(res, g, "G")
     assert np.isnan(scene) and np.isnan(g["tester.G.scores"][0])     # the reference's own TMQI is NaN on this pairing (fixture note)
     np.testing.assert_allclose([mse, rel], g["tester.G.scores"][1:], rtol=1e-6)
+
+
+# ---- unet_norm='batch_norm' (unet_parts.py:20-21, 34-35): goldens from the reference built with that flag --------------------------
+@pytest.fixture(scope="module")
+def sdG_bn():
+    return synth.bnorm_state(synth_state(state_spec.generator_spec(unet_norm="batch_norm"), "g0"))
+
+
+def test_batch_norm_state_dict_layout(golden):
+    """key names, order and shapes of the reference's state_dict with nn.BatchNorm2d behind every 3x3 convolution: the checkpoint
+    contract (strict load) -- state_spec, and the HIP module built from it"""
+    g = golden("generator_bnorm")
+    spec = state_spec.generator_spec(unet_norm="batch_norm")
+    assert [k for k, _, _ in spec] == list(g["bnorm.keys"])
+    assert [",".join(str(d) for d in s) for _, s, _ in spec] == list(g["bnorm.shapes"])
+    from uncltmo_amd.generator import UNet
+    net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "batch_norm", "none", "relu", 1, "replicate", 2, 0)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["bnorm.keys"])
+    assert [",".join(str(d) for d in v.shape) for v in sd.values()] == list(g["bnorm.shapes"])
+    assert sd["inc.conv.norm.num_batches_tracked"].dtype == torch.long
+    assert len(state_spec.batch_norm_layers()) == 18
+
+
+def test_generator_batch_norm_eval(golden, sdG_bn):
+    g = golden("generator_bnorm")
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    with torch.no_grad():
+        y, up = OG.unet_image_forward(sdG_bn, x, unet_norm="batch_norm")
+    assert rel_l2(y, g["bnorm.x_out"]) < 1e-5
+    check_summary(up, g, "bnorm.up_x")
+
+
+def test_generator_batch_norm_training_statistics(golden):
+    """training mode: batch statistics in the forward, running statistics updated with momentum 0.1 (unbiased variance) and the
+    batch counter advanced -- the oracle leaves the same state behind as the reference module"""
+    g = golden("generator_bnorm")
+    sd = synth.bnorm_state(synth_state(state_spec.generator_spec(unet_norm="batch_norm"), "g0"))
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    keep = torch.tensor([[1.0, 0.0], [1.0, 0.0]])
+    with torch.no_grad():
+        y, up = OG.unet_image_forward(sd, x, unet_norm="batch_norm", training=True, drop_keep=keep)
+    check_summary(y, g, "bnorm_train.x_out")
+    check_summary(up, g, "bnorm_train.up_x")
+    n = 0
+    for k in list(g):
+        if k.startswith("bnorm_train.after."):
+            np.testing.assert_allclose(sd[k[len("bnorm_train.after."):]].double().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+            n += 1
+    assert n == 54

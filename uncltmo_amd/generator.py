@@ -75,9 +75,8 @@ class _GeneratorBase(nn.Module):
             unsupported.append("decoder must be doubleConvTranspose=1, up_mode=0, bilinear=0, convtranspose_kernel=2")
         if n_channels != 1 or output_dim != 1:
             unsupported.append("n_channels/output_dim must be 1")
-        if unet_norm not in ("none", None, "instance_norm"):
-            # batch_norm would need running statistics in the state_dict; no published configuration uses it
-            unsupported.append("unet_norm=%s (HIP path covers 'none' and 'instance_norm')" % unet_norm)
+        if unet_norm not in ("none", None, "instance_norm", "batch_norm"):
+            unsupported.append("unet_norm=%s (HIP path covers 'none', 'instance_norm' and, for inference, 'batch_norm')" % unet_norm)
         if last_layer not in _LAST:
             unsupported.append("last_layer=%s" % last_layer)
         if stretch_g not in ("none", None):
@@ -96,11 +95,17 @@ class _GeneratorBase(nn.Module):
         self.chunk = chunk
         self.drop_path_prob = 0.05          # dpr = linspace(0.05, 0.1, 1)[0] (Unet_singleFrame.py:62)
         self.forced_drop_keep = None        # optional (2, N) 0/1 keep flags for deterministic train-mode runs
-        for key, shape, kind in generator_spec(filters, layer_factor):
+        for key, shape, kind in generator_spec(filters, layer_factor, self.unet_norm):
             if kind == "buffer":
                 _attach(self, key, sincos_relative_pos(), False)
             elif kind == "embed":
                 _attach(self, key, torch.zeros(shape), True)
+            elif kind in ("bn_mean", "bn_var"):           # nn.BatchNorm2d buffers (unet_parts.py:20-21)
+                _attach(self, key, torch.zeros(shape) if kind == "bn_mean" else torch.ones(shape), None)
+            elif kind == "bn_count":
+                _attach(self, key, torch.zeros((), dtype=torch.long), None)
+            elif kind in ("bn_weight", "bn_bias"):
+                _attach(self, key, torch.ones(shape) if kind == "bn_weight" else torch.zeros(shape), True)
             else:
                 _attach(self, key, torch.empty(shape), True)
         self.reset_parameters()
@@ -152,7 +157,8 @@ class _GeneratorBase(nn.Module):
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
         code = self._dtype_code()
-        key = (code,) + tuple((k, v.data_ptr(), v._version, getattr(v, "_uncl_epoch", 0)) for k, v in sd.items())
+        key = (code, self.training and self.unet_norm == "batch_norm") + \
+            tuple((k, v.data_ptr(), v._version, getattr(v, "_uncl_epoch", 0)) for k, v in sd.items())
         if key == self._pack_key:
             return self._packed
         lib = _hip.lib()
@@ -171,7 +177,33 @@ class _GeneratorBase(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        gw.inc0_w, gw.inc0_b = f32("inc.conv.conv.weight"), f32("inc.conv.conv.bias")
+        # unet_norm='batch_norm', eval mode: y = gamma (conv(x) + b - mean) / sqrt(var + eps) + beta is a convolution again -- the
+        # running statistics are folded into weight and bias here, once per parameter version, and the forward runs the fused
+        # conv + activation kernels of the norm-free topology (unet_parts.py:20-21, 34-35, 57-75; nn.BatchNorm2d eps 1e-5)
+        fold = {}
+        if self.unet_norm == "batch_norm":
+            if self.training:
+                raise NotImplementedError("uncltmo_amd: unet_norm='batch_norm' is built for inference (eval mode: running statistics "
+                                          "folded into the convolutions); training with batch statistics is not -- call .eval()")
+            from .state_spec import batch_norm_layers
+            for cname, nname in batch_norm_layers():
+                scale = sd[nname + ".weight"].detach().double() / torch.sqrt(sd[nname + ".running_var"].detach().double() + 1e-5)
+                fold[cname] = (scale, sd[nname + ".running_mean"].detach().double(), sd[nname + ".bias"].detach().double())
+
+        def folded(name):
+            """(weight, bias) of convolution `name` as fp32 tensors, BatchNorm folded in when there is one behind it"""
+            w, b = sd[name + ".weight"].detach().float(), sd[name + ".bias"].detach().float()
+            if name not in fold:
+                return w, b
+            scale, mean, beta = fold[name]
+            transposed = dict((k, kd) for k, _, kd in generator_spec())[name + ".weight"] == "convT"
+            shape = (1, -1, 1, 1) if transposed else (-1, 1, 1, 1)
+            return (w.double() * scale.reshape(shape)).float(), ((b.double() - mean) * scale + beta).float()
+
+        w0, b0 = folded("inc.conv.conv")
+        w0, b0 = w0.contiguous(), b0.contiguous()
+        keep += [w0, b0]
+        gw.inc0_w, gw.inc0_b = w0.data_ptr(), b0.data_ptr()
         # every re-layout of the step goes into one flat buffer through one batched launch (uncl_pack_conv_weights):
         # jobs = (source fp32 tensor, offset in elements, Cout, Cin, k, transposed, flip)
         jobs, fwd_off, wd_off = [], [], []
@@ -192,9 +224,11 @@ class _GeneratorBase(nn.Module):
             transposed = kind == "convT"
             k = shape[2]
             cout, cin = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
-            src = sd[name + ".weight"].detach().float()
+            src, bsrc = folded(name)
             fwd_off.append(job(src, src.numel(), cout, cin, k, int(transposed), 1 if (transposed and k == 3) else 0))
-            gw.b[i] = f32(name + ".bias")
+            bsrc = bsrc.contiguous()
+            keep.append(bsrc)
+            gw.b[i] = bsrc.data_ptr()
         # weights re-packed for the data-gradient convolutions (the two training dtypes: bf16, and fp32 = parity mode)
         if code in (_hip.BF16, _hip.F32):
             for i in range(_hip.G_NUM_WEIGHTS):
@@ -323,7 +357,8 @@ class UNet(_GeneratorBase):
         return x_out, up_x
 
     def _needs_autograd(self, x):
-        return True
+        # batch_norm is an inference configuration here: the folded weights have no backward pass of their own
+        return self.unet_norm != "batch_norm"
 
     @torch.no_grad()
     def infer(self, x, want_knn=False):
@@ -358,7 +393,7 @@ class UNetVideo(_GeneratorBase):
         if x.dim() != 5:
             raise ValueError("video generator expects (B,T,1,H,W)")
         self._check_input(x, 3)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.unet_norm != "batch_norm":
             from .autograd import generator_video_apply
             x_out, feats = generator_video_apply(self, x)
             if apply_crop and self.to_crop:

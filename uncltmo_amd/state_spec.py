@@ -6,15 +6,26 @@ ConvTranspose2d weights are (Cin, Cout, kh, kw) — transposed layers are flagge
 """
 
 
-def generator_spec(filters=32, layer_factor=4):
-    """[(key, shape, kind)], kind in {"conv", "convT", "bias", "buffer", "embed"} in state_dict order."""
+def generator_spec(filters=32, layer_factor=4, unet_norm="none"):
+    """[(key, shape, kind)], kind in {"conv", "convT", "bias", "buffer", "embed"} in state_dict order.  With
+    unet_norm='batch_norm' every 3x3 convolution of the double-conv blocks is followed by its nn.BatchNorm2d entries
+    (unet_parts.py:20-21, 34-35: `norm` after `conv`, `norm1` after `conv1`), kinds "bn_weight", "bn_bias", "bn_mean", "bn_var",
+    "bn_count"; InstanceNorm2d (no affine, no running statistics) adds nothing."""
     f = filters
     spec = []
+    bn = unet_norm == "batch_norm"
 
     def conv(p, cin, cout, k, transposed=False):
         shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
         spec.append((p + ".weight", shape, "convT" if transposed else "conv"))
         spec.append((p + ".bias", (cout,), "bias"))
+        if bn and k == 3:
+            q = p[:-len("conv")] + "norm" if p.endswith(".conv") else p[:-len("conv1")] + "norm1"
+            spec.append((q + ".weight", (cout,), "bn_weight"))
+            spec.append((q + ".bias", (cout,), "bn_bias"))
+            spec.append((q + ".running_mean", (cout,), "bn_mean"))
+            spec.append((q + ".running_var", (cout,), "bn_var"))
+            spec.append((q + ".num_batches_tracked", (), "bn_count"))
 
     conv("inc.conv.conv", 1, f, 3)
     conv("inc.conv.conv1", f, f, 3)
@@ -62,3 +73,14 @@ def patch_d_spec(ndf=16, n_layers=3):
         idx += 1
     spec += [("model.%d.weight" % idx, (1, ndf * mult, 4, 4), "conv"), ("model.%d.bias" % idx, (1,), "bias")]
     return spec
+
+
+def batch_norm_layers(filters=32, layer_factor=4):
+    """[(conv key prefix, norm key prefix)] of the eighteen convolutions a BatchNorm2d follows, e.g.
+    ("inc.conv.conv", "inc.conv.norm"), ("up_path.3.conv.conv1", "up_path.3.conv.norm1")."""
+    out = []
+    for key, _, kind in generator_spec(filters, layer_factor, "batch_norm"):
+        if kind == "bn_weight":
+            q = key[:-len(".weight")]
+            out.append((q[:-len("norm")] + "conv" if q.endswith("norm") else q[:-len("norm1")] + "conv1", q))
+    return out

@@ -79,6 +79,21 @@ def fill_state_dict(module, salt="w0"):
     return module
 
 
+def bnorm_state(sd):
+    """The BatchNorm entries of a synth-filled state dict made plausible IN PLACE, the same way in the fixture script
+    (tests/golden/make_golden.py) and in the tests: running_var in [0.5, 1.5], running_mean small, gamma around one
+    (fill_state_dict / synth_tensor write zero-mean values into every tensor)."""
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.endswith("running_var"):
+                v.copy_(0.5 + v.abs() * 0.4)          # synth values of a 1-D tensor lie in +-2.45
+            elif k.endswith("running_mean"):
+                v.mul_(0.1)
+            elif (".norm." in k or ".norm1." in k) and k.endswith(".weight"):
+                v.copy_(1.0 + 0.1 * v)
+    return sd
+
+
 def hdr_frames(n, h=256, w=256, salt="hdr0", lam=255.0 * 0.1 * 50.0):
     """(n,1,h,w) float32 log-compressed HDR luminance in [0,1] with a heavy-tailed radiance prior."""
     u = hash_uniform(salt, n * h * w).astype(np.float64) ** 4
