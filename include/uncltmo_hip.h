@@ -171,6 +171,11 @@ int uncl_wgrad_set_roll(int on);
  * once per tile, the square and the root derived in registers; 0 = the per-pair kernels.  Returns the previous setting; env
  * UNCL_WG_CAT sets the initial one. */
 int uncl_wgrad_set_cat(int on);
+/* Plain 3x3 layers whose Cin and Cout are multiples of 64 (same autograd as above): 1 (default) = 64 x 64 channel blocks in the
+ * split-role structure (whole 128-byte pixels staged once for the four 32 x 32 quadrants of a block) where both sides have >= 128
+ * channels and a workgroup gets at least UNCL_WG_QUAD_MIN (6) 8-row tiles -- the layers it measured faster on; 2 = always; 0 = the
+ * per-pair kernels.  Returns the previous setting; env UNCL_WG_QUAD. */
+int uncl_wgrad_set_quad(int on);
 /* Deterministic weight / bias gradients (bf16 pass; autograd of nn.Conv2d / nn.ConvTranspose2d parameters, GanTrainerImg.py:338,460):
  * with a scratch buffer set, uncl_conv_wgrad / uncl_conv_wgrad_bias / uncl_upconv2x2_wgrad called from THIS thread write the
  * partial sums of their pixel-range groups there and add them up in a fixed order (one extra small launch) instead of using

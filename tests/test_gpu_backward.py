@@ -634,6 +634,7 @@ def test_wgrad3x3_split_role(cin, cout, h, w, n, pad):
         setattr(d, k, v)
     got = {}
     old = _wg_modes(lib, 0, 0)
+    oldq = lib.uncl_wgrad_set_quad(0)
     try:
         for roll in (2, 0):
             lib.uncl_wgrad_set_roll(roll)
@@ -644,6 +645,7 @@ def test_wgrad3x3_split_role(cin, cout, h, w, n, pad):
             got[roll] = (unpack(dw, cout, cin, 3, pad == 2, pad == 2), gb.cpu())
     finally:
         _wg_modes(lib, *old)
+        lib.uncl_wgrad_set_quad(oldq)
     assert rel_l2(got[2][0], wt.grad) < 2e-3, rel_l2(got[2][0], wt.grad)
     assert rel_l2(got[2][0], got[0][0]) < 2e-5, rel_l2(got[2][0], got[0][0])       # same products, fp32 sums in another order
     assert rel_l2(got[2][1], bt.grad) < 1e-5, rel_l2(got[2][1], bt.grad)
@@ -687,6 +689,46 @@ def test_wgrad3x3_concat_members_in_one_workgroup(c, cout, h, w, dy, dx, n):
     assert rel_l2(got[1][0], wt.grad) < 3e-3, rel_l2(got[1][0], wt.grad)
     assert rel_l2(got[1][0], got[0][0]) < 2e-5, rel_l2(got[1][0], got[0][0])
     assert rel_l2(got[1][1], bt.grad) < 1e-5, rel_l2(got[1][1], bt.grad)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n,pad", [(64, 64, 61, 61, 3, 0), (128, 128, 30, 28, 5, 2), (256, 256, 12, 12, 9, 0),
+                                                (64, 128, 59, 61, 2, 0), (256, 64, 9, 70, 2, 2), (128, 256, 26, 26, 32, 0),
+                                                (64, 64, 124, 124, 1, 0)])
+def test_wgrad3x3_quad_blocks_split_role(cin, cout, h, w, n, pad):
+    """wgrad3q_kernel: 64 x 64 channel blocks, the four quadrants on the four multiplying waves, 8-row tiles (ragged last tile row,
+    halo rows outside the image), one to many tiles per workgroup, both paddings, bias sums over 64 channels"""
+    lib = _hip.lib()
+    x = q(rnd(n, cin, h, w, seed=161))
+    if pad == 0:
+        wt, bt = rnd(cout, cin, 3, 3, seed=162, scale=0.1).requires_grad_(True), rnd(cout, seed=164).requires_grad_(True)
+        gy = q(rnd(n, cout, h - 2, w - 2, seed=163))
+        F.conv2d(x, wt, bt).backward(gy)
+    else:
+        wt, bt = rnd(cin, cout, 3, 3, seed=162, scale=0.1).requires_grad_(True), rnd(cout, seed=164).requires_grad_(True)
+        gy = q(rnd(n, cout, h + 2, w + 2, seed=163))
+        F.conv_transpose2d(x, wt, bt).backward(gy)
+    d = _hip.ConvDesc()
+    xs, gys = to_nhwc(x, BF), to_nhwc(gy, BF)
+    for k, v in dict(dtype=BF, ksize=3, pad=pad, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=cin, Cout=cout, src0=xs.data_ptr(),
+                     src0_H=h, src0_W=w, src0_C=cin).items():
+        setattr(d, k, v)
+    got = {}
+    old = _wg_modes(lib, 0, 0)
+    oldq = lib.uncl_wgrad_set_quad(0)
+    try:
+        for quad in (2, 0):
+            lib.uncl_wgrad_set_quad(quad)
+            dw = torch.zeros(9, cout, cin, dtype=torch.float32, device="cuda")
+            gb = torch.zeros(cout, dtype=torch.float32, device="cuda")
+            _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gys.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad_bias")
+            torch.cuda.synchronize()
+            got[quad] = (unpack(dw, cout, cin, 3, pad == 2, pad == 2), gb.cpu())
+    finally:
+        _wg_modes(lib, *old)
+        lib.uncl_wgrad_set_quad(oldq)
+    assert rel_l2(got[2][0], wt.grad) < 2e-3, rel_l2(got[2][0], wt.grad)
+    assert rel_l2(got[2][0], got[0][0]) < 2e-5, rel_l2(got[2][0], got[0][0])       # same products, fp32 sums in another order
+    assert rel_l2(got[2][1], bt.grad) < 1e-5, rel_l2(got[2][1], bt.grad)
 
 
 def test_wgrad3x3_split_role_kernels_deterministic_with_scratch():

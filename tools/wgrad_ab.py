@@ -1,7 +1,7 @@
 """Same-box A/B of the 3x3 weight-gradient kernels on the generator's own layer shapes at the image step's batch (N = 32):
 per layer, microseconds per launch of the six-wave per-pair kernel (uncl_wgrad_set_roll(0), uncl_wgrad_set_cat(0)), the split-role
-per-pair kernel (roll 2, cat 0) and what the dispatcher picks by default (roll 1, cat 1: the four-member kernel on the skip-concat
-layers), plus the rel-L2 distance of the default result from the six-wave one.
+per-pair kernel (roll 2, cat 0, quad 0) and what the dispatcher picks by default (roll 1, cat 1, quad 1: the four-member kernel on the
+skip-concat layers, 64 x 64 blocks on the plain layers that have them), plus the rel-L2 distance of the default result from the six-wave one.
    python tools/wgrad_ab.py [N]"""
 import ctypes as C
 import os
@@ -42,6 +42,7 @@ def main():
         for mode in (0, 2, 1):
             old = lib.uncl_wgrad_set_roll(mode)
             oldc = lib.uncl_wgrad_set_cat(1 if mode == 1 else 0)
+            oldq = lib.uncl_wgrad_set_quad(1 if mode == 1 else 0)
             for rep in range(2):
                 _hip.check(lib.uncl_conv_wgrad_bias(C.byref(d), gy.data_ptr(), dw.data_ptr(), gb.data_ptr(), _hip.stream_ptr()), "wgrad")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,6 +60,7 @@ def main():
             dw.zero_(); gb.zero_()
             lib.uncl_wgrad_set_roll(old)
             lib.uncl_wgrad_set_cat(oldc)
+            lib.uncl_wgrad_set_quad(oldq)
             tot[mode] += us[mode]
         rel = float((res[1][0] - res[0][0]).norm() / res[0][0].norm())
         relb = float((res[1][1] - res[0][1]).norm() / res[0][1].norm())

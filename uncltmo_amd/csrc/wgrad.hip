@@ -1114,6 +1114,191 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 64 (ci) x 64 (co) channel blocks with split roles (plain sources): the per-pair kernels read X once per gY chunk and gY once per X
+// chunk, and a 32-channel chunk is HALF of every 128-byte line of a tensor with >= 64 channels -- these launches are bound by the
+// bytes they pull in.  Here a workgroup stages whole 128-byte pixels of both tensors for an 8 x 32 pixel tile (43.5 + 32 KB per
+// stage, two stages) and its four multiplying waves are the four (ci half, co half) quadrants: every wave holds all nine taps of
+// its 32 x 32 quadrant for all 8 rows (halo rows walked once: 60 X + 16 gY fragment reads per 144 MFMAs) and owns its sums for
+// the whole launch -- no cross-wave reduction.  75.5 KB staged per 576 MFMAs where four pairs staged 4 x 71 KB per 1152.
+template <int UNUSED>
+__global__ __launch_bounds__(512, 1) void wgrad3q_kernel(const WgArgs a) {
+  using E = Elem<bf16_t>;
+  using vec = bf16x8;
+  constexpr int TH = 8, TW = 32, XH = TH + 2, XW = TW + 2;
+  constexpr int NX = XH * XW, NG = TH * TW, NS = 256, PP = NS / 8;   // staging threads; PP pixels (x 8 slots of 16 bytes) per pass
+  constexpr int XV = (NX + PP - 1) / PP, GV = (NG + PP - 1) / PP;
+  constexpr int XPLB = wg_plane(NX), GPLB = wg_plane(NG);     // bytes per plane; eight planes per tensor
+  constexpr int STAGE = 8 * XPLB + 8 * GPLB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nci = a.Cin >> 6;
+  const int kc = blockIdx.z % nci, cc = blockIdx.z / nci;     // 64-channel blocks
+  const int tile0 = (int)blockIdx.x * a.tiles_per_wg;
+  const int tile_end = min(tile0 + a.tiles_per_wg, a.total_tiles);
+  if (tile0 >= tile_end) return;
+  const bool do_bias = a.gb != nullptr && kc == 0;      // workgroup-uniform
+
+  if (wave < 4) {
+    const int cih = wave & 1, coh = wave >> 1;
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ty][tx][i] = 0.f;
+    const int grp = lane >> 4;
+    const int c0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
+    const int li = lane & 15;
+    const int frag_lane = (li >> 2) * 16 + ((li & 1) << 3);
+    const int psel = (c0 >> 3) + ((li & 3) >> 1);
+    const int offX = (4 * cih + psel) * XPLB + kb * 16 + frag_lane;
+    const int offG = 8 * XPLB + (4 * coh + psel) * GPLB + kb * 16 + frag_lane;
+    __syncthreads();                 // stage 0 holds the first tile
+    for (int t = tile0; t < tile_end; ++t) {
+      const char* st = smem + ((t - tile0) & 1) * STAGE;
+      const char* lbX = st + offX;
+      const char* lbG = st + offG;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        vec A[3], B[2][3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) B[0][tx] = tr_frag_plane(lbX, (h * 16 + tx) * 16);
+#pragma unroll
+        for (int R = 0; R < XH; ++R) {
+          if (R + 1 < XH) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) B[(R + 1) & 1][tx] = tr_frag_plane(lbX, ((R + 1) * XW + h * 16 + tx) * 16);
+          }
+          if (R < TH) A[R % 3] = tr_frag_plane(lbG, (R * TW + h * 16) * 16);
+#pragma unroll
+          for (int ty = 0; ty < 3; ++ty) {
+            const int r = R - ty;
+            if (r < 0 || r >= TH) continue;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+              acc[ty][tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[r % 3], B[R & 1][tx], acc[ty][tx], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);      // one halo row of look-ahead (see wgrad3c_kernel)
+        }
+      }
+      __syncthreads();               // done with this stage; the other one holds the next tile
+    }
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ci = kc * 64 + 32 * cih + lr;
+#if defined(UNCL_WG_ABLATE_ATOMICS)
+    if (a.dw == nullptr)
+#endif
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = cc * 64 + 32 * coh + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          wg_emit(a, ((size_t)(ty * 3 + tx) * a.Cout + co) * a.Cin + ci, acc[ty][tx][i]);
+        }
+    if (do_bias) { __syncthreads(); __syncthreads(); }     // (the staging waves' bias reduction below)
+    return;
+  }
+  // ==================================================================================================================
+  // staging waves: thread = (pixel p0 + j PP, 16-byte channel group ch of the pixel's 128 bytes)
+  // ==================================================================================================================
+  const int ptid = tid - 256;
+  const int p0c = ptid >> 3, chc = ptid & 7;
+  int hyj[XV], hxj[XV], gyj[GV], gxj[GV];
+#pragma unroll
+  for (int j = 0; j < XV; ++j) {
+    const int pix = min(p0c + j * PP, NX - 1);
+    hyj[j] = pix / XW; hxj[j] = pix - hyj[j] * XW;
+  }
+#pragma unroll
+  for (int j = 0; j < GV; ++j) {
+    const int pix = min(p0c + j * PP, NG - 1);
+    gyj[j] = pix / TW; gxj[j] = pix % TW;
+  }
+  vec xr[XV], gr[GV];
+  unsigned xvalid = 0, gvalid = 0;
+  float bs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bs[i] = 0.f;
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    int r = t;
+    const int tx_ = r % a.tiles_x; r /= a.tiles_x;
+    const int ty_ = r % a.tiles_y; r /= a.tiles_y;
+    const int n = r, y0 = ty_ * TH, x0 = tx_ * TW;
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    unsigned valid = 0, gval = 0;
+    const bf16_t* base0 = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + kc * 64;
+    const bf16_t* baseg = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 64;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int iy = iy0 + hyj[j], ix = ix0 + hxj[j];
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      valid |= (ok ? 1u : 0u) << j;
+      xr[j] = wg_ld16o(base0, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int gy_ = y0 + gyj[j], gx_ = x0 + gxj[j];
+      const bool ok = gy_ < a.Hout && gx_ < a.Wout;
+      gval |= (ok ? 1u : 0u) << j;
+      gr[j] = wg_ld16o(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
+    }
+    xvalid = valid; gvalid = gval;
+  };
+  auto write_lds = [&](char* st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int pix = p0c + j * PP;
+      if (pix >= NX) continue;
+      *reinterpret_cast<vec*>(st + chc * XPLB + pix * 16) = ((xvalid >> j) & 1u) ? xr[j] : E::zero();
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int pix = p0c + j * PP;
+      if (pix >= NG) continue;
+      const vec gv = ((gvalid >> j) & 1u) ? gr[j] : E::zero();
+      *reinterpret_cast<vec*>(st + 8 * XPLB + chc * GPLB + pix * 16) = gv;
+      if (do_bias) {
+        float f[8];
+        E::unpack(gv, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bs[i] += f[i];
+      }
+    }
+  };
+  load_tile(tile0);
+  write_lds(smem);
+  if (tile0 + 1 < tile_end) load_tile(tile0 + 1);
+  __syncthreads();
+  for (int t = tile0; t < tile_end; ++t) {
+    if (t + 1 < tile_end) {
+      write_lds(smem + ((t + 1 - tile0) & 1) * STAGE);
+      if (t + 2 < tile_end) load_tile(t + 2);
+    }
+    __syncthreads();
+  }
+  if (do_bias) {
+    // (every wave is past the last stage barrier: the stages are free) [thread][8] partial sums -> 64 channels
+    float* sBs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sBs[ptid * 8 + i] = bs[i];
+    __syncthreads();
+    if (ptid < 64) {
+      const int ch8 = ptid >> 3, e = ptid & 7;
+      float t = 0.f;
+      for (int p = 0; p < NS / 8; ++p) t += sBs[(p * 8 + ch8) * 8 + e];
+      if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 64 + ptid] = t;
+      else atomicAdd(a.gb + cc * 64 + ptid, t);
+    }
+    __syncthreads();
+  }
+}
+
 // Deterministic mode: a caller-owned scratch buffer for the per-group partial sums (thread-local: uncl_gen_backward sets it
 // around its pass; every weight-gradient launch of a pass and its reduction run on ONE stream, in order, so the buffer is reused
 // launch after launch).  NULL (default) = float atomics.
@@ -1223,6 +1408,33 @@ int launch_wg3r(WgArgs& a, hipStream_t s) {
   groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
   wg_use_scratch(a, groups);
   hipLaunchKernelGGL(kern, dim3(groups, 1, pairs), dim3(512), lds, s, a);
+  UNCL_CHECK_LAUNCH();
+  return wg_reduce(a, groups, s);
+}
+
+int launch_wg3q(WgArgs& a, hipStream_t s) {
+  constexpr size_t lds = 2 * (8 * (size_t)wg_plane(10 * 34) + 8 * (size_t)wg_plane(8 * 32));
+  auto kern = wgrad3q_kernel<0>;
+  static UnclDevOnce attr_done;
+  if (attr_done.need()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNCL_ERR_LAUNCH;
+    attr_done.done();
+  }
+  // 8-row tiles (the caller's tile counts are for 16 rows)
+  a.tiles_y = (a.Hout + 7) / 8;
+  a.total_tiles = (a.total_tiles / ((a.Hout + 15) / 16)) * a.tiles_y;
+  const int blocks = (a.Cin / 64) * (a.Cout / 64);
+  const int cus = uncl_cu_count() > 0 ? uncl_cu_count() : 256;
+  int groups = cus / blocks;
+  if (groups < 1) groups = 1;
+  if (groups > a.total_tiles) groups = a.total_tiles;
+  a.E = (long long)9 * a.Cout * a.Cin;
+  groups = wg_scratch_groups(a, groups);
+  a.tiles_per_wg = (a.total_tiles + groups - 1) / groups;
+  groups = (a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  wg_use_scratch(a, groups);
+  hipLaunchKernelGGL(kern, dim3(groups, 1, blocks), dim3(512), lds, s, a);
   UNCL_CHECK_LAUNCH();
   return wg_reduce(a, groups, s);
 }
@@ -1421,6 +1633,11 @@ static std::atomic<int> g_wg_cat{[] { const char* e = getenv("UNCL_WG_CAT"); ret
 // skip-concat 3x3 layers: 1 (default) one workgroup per (32-channel skip slice, gY chunk) covering all four members; 0 the per-pair
 // kernels.  Returns the previous setting.
 extern "C" int uncl_wgrad_set_cat(int on) { return g_wg_cat.exchange(on ? 1 : 0); }
+static std::atomic<int> g_wg_quad{[] { const char* e = getenv("UNCL_WG_QUAD"); return e ? atoi(e) : 1; }()};
+static const int g_wg_quad_min = [] { const char* e = getenv("UNCL_WG_QUAD_MIN"); return e ? atoi(e) : 6; }();
+// plain 3x3 layers with Cin and Cout multiples of 64: 1 (default) the split-role 64 x 64 block kernel where both sides have >= 128
+// channels and a workgroup gets >= UNCL_WG_QUAD_MIN (6) tiles, 2 always, 0 never (the per-pair kernels).  Returns the previous setting.
+extern "C" int uncl_wgrad_set_quad(int on) { return g_wg_quad.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 static std::atomic<int> g_wg_roll{[] { const char* e = getenv("UNCL_WG_ROLL"); return e ? atoi(e) : 1; }()};
 static const int g_wg_roll_min = [] { const char* e = getenv("UNCL_WG_ROLL_MIN"); return e ? atoi(e) : 4; }();
 // 3x3 layers on the 32 x 32 channel-pair path: 1 (default) the split-role kernel where a workgroup gets enough tiles, 2 always,
@@ -1497,6 +1714,19 @@ extern "C" int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, flo
     // skip-concat layers: all four members of a slice in one workgroup (wgrad3c_kernel); UNCL_WG_CAT=0: the per-pair kernels
     if (d->src_mode == UNCL_SRC_CONCAT_SSR && g_wg_cat.load(std::memory_order_relaxed) != 0 && a.gy_ld % 8 == 0) return launch_wg3c(a, s);
     if (wide) return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3w<0>(a, s) : launch_wg3w<1>(a, s);
+    // plain sources with 64-channel blocks on both sides: the split-role 64 x 64 kernel (UNCL_WG_QUAD: 1 = where a workgroup gets
+    // at least UNCL_WG_QUAD_MIN 8-row tiles, 2 = always, 0 = never)
+    // Measured per layer (tools/wgrad_ab.py, N = 32, us, split-role per pair -> 64 x 64 blocks): 128 -> 128 at 57^2 65.9 -> 60.7,
+    // 256 -> 256 at 24^2 63.3 -> 51.6; 64 -> 64 at 122^2 69.5 -> 74.6, 64 -> 128 at 59^2 45.5 -> 50.6, 128 -> 256 at 26^2 43.8 -> 46.0,
+    // the 10 / 12 pixel maps 41.8 -> 44.4: it pays where both sides have at least two blocks' worth of re-reading to save AND a
+    // workgroup still gets six tiles; mode 1 takes exactly those.
+    const int quad = g_wg_quad.load(std::memory_order_relaxed);
+    if (quad != 0 && d->src_mode == UNCL_SRC_PLAIN && d->Cin % 64 == 0 && d->Cout % 64 == 0 && a.gy_ld % 8 == 0 && d->src0_C % 8 == 0) {
+      const int blocks = (d->Cin / 64) * (d->Cout / 64);
+      const int groups = 256 / blocks > 0 ? 256 / blocks : 1;
+      if (quad == 2 || (d->Cin >= 128 && d->Cout >= 128 && d->N * a.tiles_x * ((a.Hout + 7) / 8) >= g_wg_quad_min * groups))
+        return launch_wg3q(a, s);
+    }
     // split-role kernel (wgrad3r_kernel): 1 = where it has at least `UNCL_WG_ROLL_MIN` tiles per workgroup, 2 = always, 0 = never
     const int roll = g_wg_roll.load(std::memory_order_relaxed);
     if (roll != 0) {
