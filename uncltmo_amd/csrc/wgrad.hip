@@ -830,6 +830,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3r_kernel(const WgArgs a) {
         }
       }
     };
+    // (ONE register set, requests one tile ahead.  Two sets with requests two tiles ahead -- straight-line, exact vmcnt(35 .. 18)
+    // in the ISA -- measured SLOWER on every layer (same box: 82.5 -> 85.9, 51.9 -> 55.9, 69.5 -> 73.3 us ...): with 36 loads per
+    // staging thread in flight the CU's vector-memory queue is what the requests wait in, as on the forward kernels.)
     load_tile(tile0);
     write_lds(smem);
     if (tile0 + 1 < tile_end) load_tile(tile0 + 1);
