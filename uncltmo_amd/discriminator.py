@@ -32,9 +32,8 @@ class _SimpleDFn(torch.autograd.Function):
         dev = xf.device
         st = _hip.stream_ptr()
         g_out = g_out.reshape(n).float().contiguous()
-        g_fea = g_fea.reshape(n, 2).float().contiguous()
-        g_f1 = g_fea[:, 0].contiguous()
-        g_f2 = g_fea[:, 1].contiguous()
+        g_ft = g_fea.reshape(n, 2).float().t().contiguous()      # (2, n): one copy, both feature gradients as contiguous rows
+        g_f1, g_f2 = g_ft[0], g_ft[1]
         # gradient reaching `fea` through the Gaussian local-variance feature; fea lives in the forward workspace
         h1_sz, h2_sz = n * 127 * 127 * 16, n * 62 * 62 * 32
         fea_map = ws[(h1_sz + h2_sz) * 4:(h1_sz + h2_sz + n * 62 * 62) * 4].view(torch.float32).reshape(n, 62, 62)

@@ -11,7 +11,9 @@ from .generator import gauss_stats
 
 
 def _scalar(dev):
-    return torch.zeros(1, dtype=torch.float32, device=dev)
+    # every loss kernel WRITES its result when called with accumulate_loss = 0 (loss_heads.hip: `loss[0] = (accumulate ? loss[0] :
+    # 0) + ...`), which is how every call below calls them: no zero fill (it was ten 4-us launches per optimisation step)
+    return torch.empty(1, dtype=torch.float32, device=dev)
 
 
 class _CganFn(torch.autograd.Function):
@@ -19,17 +21,18 @@ class _CganFn(torch.autograd.Function):
     def forward(ctx, real, fake):
         n = real.numel()
         r, f = real.detach().reshape(n).float().contiguous(), fake.detach().reshape(n).float().contiguous()
-        loss, gr, gf = _scalar(r.device), torch.empty_like(r), torch.empty_like(f)
-        _hip.check(_hip.lib().uncl_cgan_loss(r.data_ptr(), f.data_ptr(), n, 1.0, loss.data_ptr(), gr.data_ptr(), gf.data_ptr(),
-                                             0, _hip.stream_ptr()), "uncl_cgan_loss")
-        ctx.save_for_backward(gr, gf)
+        loss, grf = _scalar(r.device), torch.empty(2, n, dtype=torch.float32, device=r.device)    # both gradients in ONE tensor:
+        _hip.check(_hip.lib().uncl_cgan_loss(r.data_ptr(), f.data_ptr(), n, 1.0, loss.data_ptr(), grf[0].data_ptr(),
+                                             grf[1].data_ptr(), 0, _hip.stream_ptr()), "uncl_cgan_loss")   # one multiply in backward
+        ctx.save_for_backward(grf)
         ctx.shapes = (real.shape, fake.shape)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        gr, gf = ctx.saved_tensors
-        return (gr * g).reshape(ctx.shapes[0]), (gf * g).reshape(ctx.shapes[1])
+        (grf,) = ctx.saved_tensors
+        t = grf * g
+        return t[0].reshape(ctx.shapes[0]), t[1].reshape(ctx.shapes[1])
 
 
 def contrastive_D_loss(real_logits, fake_logits):
@@ -177,7 +180,7 @@ class _FrameStatsFn(torch.autograd.Function):
         xf = x.detach().reshape(n, h, w).float().contiguous()
         st = gauss_stats(xf, n, h, w, 1)
         ctx.save_for_backward(xf)
-        return st[:, 0, 0].contiguous(), st[:, 1, 0].contiguous()
+        return st[:, 0, 0], st[:, 1, 0]           # strided views of (n, 2, 1): the L1 kernel takes a stride, no copies
 
     @staticmethod
     def backward(ctx, g_mean, g_var):
@@ -200,18 +203,30 @@ class _L1PairsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         n = a.numel()
-        af, bf = a.detach().reshape(n).float().contiguous(), b.detach().reshape(n).float().contiguous()
-        loss, ga, gb = _scalar(af.device), torch.empty_like(af), torch.empty_like(bf)
-        _hip.check(_hip.lib().uncl_l1_pairs(af.data_ptr(), 1, bf.data_ptr(), 1, n, 1.0, loss.data_ptr(), ga.data_ptr(),
-                                            gb.data_ptr(), 0, _hip.stream_ptr()), "uncl_l1_pairs")
-        ctx.save_for_backward(ga, gb)
+
+        def flat(t):
+            """(fp32 tensor, element stride): a 1-D view where the layout allows it (strided slices, expanded rows: stride 0) --
+            the kernel reads through a stride, so per-sample statistics and their broadcast partners are not copied"""
+            t = t.detach()
+            if t.dtype != torch.float32:
+                t = t.float()
+            if t.dim() == 1 and t.shape[0] == n:
+                return t, t.stride(0)
+            return t.reshape(n).contiguous(), 1
+
+        (af, sa), (bf, sb) = flat(a), flat(b)
+        loss, gab = _scalar(af.device), torch.empty(2, n, dtype=torch.float32, device=af.device)
+        _hip.check(_hip.lib().uncl_l1_pairs(af.data_ptr(), sa, bf.data_ptr(), sb, n, 1.0, loss.data_ptr(), gab[0].data_ptr(),
+                                            gab[1].data_ptr(), 0, _hip.stream_ptr()), "uncl_l1_pairs")
+        ctx.save_for_backward(gab)
         ctx.shapes = (a.shape, b.shape)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        ga, gb = ctx.saved_tensors
-        return (ga * g).reshape(ctx.shapes[0]), (gb * g).reshape(ctx.shapes[1])
+        (gab,) = ctx.saved_tensors
+        t = gab * g
+        return t[0].reshape(ctx.shapes[0]), t[1].reshape(ctx.shapes[1])
 
 
 def l1_mean(a, b):
