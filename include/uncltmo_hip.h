@@ -176,6 +176,11 @@ int uncl_wgrad_set_cat(int on);
  * channels and a workgroup gets at least UNCL_WG_QUAD_MIN (6) 8-row tiles -- the layers it measured faster on; 2 = always; 0 = the
  * per-pair kernels.  Returns the previous setting; env UNCL_WG_QUAD. */
 int uncl_wgrad_set_quad(int on);
+/* Checked build only (hipcc -DUNCL_CHECKED, __graft_entry__.build_checked() -> libuncltmo_hip_checked.so): the 3x3 convolution,
+ * weight-gradient and 2x2 up-conv kernels (the kernels behind nn.Conv2d / nn.ConvTranspose2d of unet_parts.py:19-33, 98-112,
+ * 149-162, 269 and their autograd) validate every global access against the tensors their launch was given.  out4 = {violations,
+ * first offending address, source line, bytes}; reset != 0 clears the record.  The product library returns UNCL_ERR_ARG. */
+int uncl_checked_report(unsigned long long* out4, int reset);
 /* Deterministic weight / bias gradients (bf16 pass; autograd of nn.Conv2d / nn.ConvTranspose2d parameters, GanTrainerImg.py:338,460):
  * with a scratch buffer set, uncl_conv_wgrad / uncl_conv_wgrad_bias / uncl_upconv2x2_wgrad called from THIS thread write the
  * partial sums of their pixel-range groups there and add them up in a fixed order (one extra small launch) instead of using

@@ -36,6 +36,23 @@ def _poison_free_device_memory(request):
     yield
 
 
+@pytest.fixture(autouse=True)
+def _checked_library_reports_nothing(request):
+    """UNCL_HIP_LIB=uncltmo_amd/libuncltmo_hip_checked.so python -m pytest tests -m gpu: with the CHECKED library (DESIGN.md section 5,
+    __graft_entry__.build_checked()) every GPU test also asserts that no 3x3 convolution / weight-gradient / up-conv launch touched
+    memory outside the tensors it was given -- the tests' ragged shapes are where an index would stray.  A no-op with the product
+    library (uncl_checked_report returns UNCL_ERR_ARG there)."""
+    yield
+    if not os.environ.get("UNCL_HIP_LIB") or "gpu" not in request.keywords or not torch.cuda.is_available():
+        return
+    import ctypes
+    from uncltmo_amd import _hip
+    out = (ctypes.c_ulonglong * 4)()
+    if _hip.lib().uncl_checked_report(out, 1) == 0:
+        assert out[0] == 0, "checked library: %d accesses outside the launch's tensors, first at 0x%x (source line %d, %d bytes)" % (
+            out[0], out[1], out[2], out[3])
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 

@@ -169,6 +169,7 @@ SIGNATURES = {
     "uncl_wgrad_set_roll": (C.c_int, [C.c_int]),
     "uncl_wgrad_set_cat": (C.c_int, [C.c_int]),
     "uncl_wgrad_set_quad": (C.c_int, [C.c_int]),
+    "uncl_checked_report": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "uncl_gcn_tail": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.c_void_p]),
     "uncl_gcn_block": (C.c_int, [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p]),
     "uncl_loader_resize_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cstdlib>
 
 #include "../../include/uncltmo_hip.h"
 
@@ -49,6 +50,51 @@ static inline int uncl_cu_count() {
   }
   return c;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Checked build (-DUNCL_CHECKED; python -c "import __graft_entry__ as g; g.build_checked()" -> uncltmo_amd/libuncltmo_hip_checked.so):
+// every global load / store / atomic of the 3x3 convolution kernels (conv3x3_pc.hip, conv3x3_pipe.hip), the weight-gradient
+// kernels (wgrad.hip) and the 2x2 up-conv (upconv2x2.hip) first looks its address up in the table of tensors the launch was
+// given (base, bytes -- filled by the launcher from the descriptor's own dimensions); an access outside every tensor bumps a
+// device-side counter and records the first address, the source line and the size (uncl_checked_report).  The product build
+// compiles all of it away.
+// ---------------------------------------------------------------------------------------------------------------------
+struct UnclChk {
+  const char* lo[20];
+  const char* hi[20];
+  int n;
+  unsigned long long* bad;      // [0] violations, [1] first address, [2] source line, [3] bytes
+};
+unsigned long long* uncl_chk_record();       // device memory, one record per device (misc_kernels.hip)
+static inline void uncl_chk_reset(UnclChk& c) { c.n = 0; c.bad = uncl_chk_record(); }
+static inline void uncl_chk_add(UnclChk& c, const void* p, unsigned long long bytes) {
+  if (p == nullptr || bytes == 0 || c.n >= 20) return;
+  // positive control (tools/checked_soak.py --control): UNCL_CHECKED_SHRINK=k registers every tensor k bytes SHORT, so that the
+  // accesses to its last bytes must be reported -- a checked run that reports nothing has then really looked
+  static const unsigned long long shrink = [] { const char* e = getenv("UNCL_CHECKED_SHRINK"); return e ? strtoull(e, nullptr, 10) : 0ull; }();
+  c.lo[c.n] = reinterpret_cast<const char*>(p);
+  c.hi[c.n] = c.lo[c.n] + (bytes > shrink ? bytes - shrink : 0);
+  ++c.n;
+}
+#ifdef UNCL_CHECKED
+__device__ __forceinline__ void uncl_chk_access(const UnclChk& c, const void* p, unsigned bytes, int line) {
+  const char* q = reinterpret_cast<const char*>(p);
+  bool ok = false;
+  for (int i = 0; i < c.n; ++i) ok = ok || (q >= c.lo[i] && q + bytes <= c.hi[i]);
+  if (!ok && c.bad != nullptr) {
+    if (atomicAdd(c.bad, 1ull) == 0ull) {
+      c.bad[1] = (unsigned long long)(uintptr_t)q;
+      c.bad[2] = (unsigned long long)line;
+      c.bad[3] = bytes;
+    }
+  }
+}
+#define UNCL_CHK(c, p, bytes) uncl_chk_access((c), (p), (bytes), __LINE__)
+#define UNCL_CHK_MEMBER UnclChk chk;
+#else
+#define UNCL_CHK(c, p, bytes) ((void)0)
+#define UNCL_CHK_MEMBER
+#endif
 
 // Element traits: a "vec" is always 16 bytes, the unit every loader / LDS access moves.
 template <typename T>

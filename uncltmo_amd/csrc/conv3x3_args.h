@@ -41,6 +41,7 @@ struct PipeArgs {
   const float* tail_b;  // its bias (32) or NULL
   int oH, oW;           // extent of the final one-channel map: Hout + 2, Wout + 2
   int o1_lds_off;       // conv3x3_pipe: byte offset of the parked outconv fragments in LDS (register-direct 1x1 tail)
+  UNCL_CHK_MEMBER       // checked build: the tensors of this launch (common.h)
 };
 
 // conv3x3_pc.hip: the producer / consumer kernel for the multi-chunk layers; returns UNCL_ERR_ARG when (nt, mpw, mode) is not built
@@ -93,3 +94,9 @@ __device__ __forceinline__ f32x4 ld16o_f32(const float* base, unsigned byte_off)
 }
 
 }  // namespace
+
+// checked build: the same loads with the address looked up in the launch's tensor table first (`a` = the kernel's PipeArgs)
+#define LD16V(V, p) (UNCL_CHK(a.chk, (p), 16), ld16v<V>(p))
+#define LD16OV(V, base, off) (UNCL_CHK(a.chk, reinterpret_cast<const char*>(base) + (off), 16), ld16ov<V>((base), (off)))
+#define LD16O(base, off) (UNCL_CHK(a.chk, reinterpret_cast<const char*>(base) + (off), 16), ld16o((base), (off)))
+#define LD16O_F32(base, off) (UNCL_CHK(a.chk, reinterpret_cast<const char*>(base) + (off), 16), ld16o_f32((base), (off)))

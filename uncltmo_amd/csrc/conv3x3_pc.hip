@@ -378,13 +378,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
                   E::unpack(v, f);
                   if (a.mask) {
                     float mk[8];
-                    E::unpack(ld16v<vec>(a.mask + e), mk);
+                    E::unpack(LD16V(vec, a.mask + e), mk);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) f[i] = mk[i] > 0.f ? f[i] : a.mask_slope * f[i];
                   }
                   if (a.accumulate) {
                     float o[8];
-                    E::unpack(ld16v<vec>(a.out + e), o);
+                    E::unpack(LD16V(vec, a.out + e), o);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) f[i] += o[i];
                   }
@@ -393,6 +393,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #ifdef UNCL_PC_TIMING
                 if (a.pc_prio & 64) { asm volatile("" ::"v"(v)); continue; }     // experiment: no output stores (wrong results)
 #endif
+                UNCL_CHK(a.chk, a.out + e, 16);
                 *reinterpret_cast<vec*>(a.out + e) = v;
               }
             }
@@ -421,7 +422,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #pragma unroll
           for (int qp = 0; qp < 2; ++qp) {
             const vec v = widen(pooled(nt, 2 * qp), pooled(nt, 2 * qp + 1));
-            if (in) *reinterpret_cast<vec*>(a.pool_out + e0 + nt * 32 + 16 * qp) = v;
+            if (in) { UNCL_CHK(a.chk, a.pool_out + e0 + nt * 32 + 16 * qp, 16); *reinterpret_cast<vec*>(a.pool_out + e0 + nt * 32 + 16 * qp) = v; }
           }
       }
     };
@@ -462,6 +463,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       // already in memory in fp32 and round again -- the operation order of the generic epilogue
       auto grad_ops = [&](vec w, const char* mrow, const char* orow, unsigned off) __attribute__((always_inline)) {
         if (a.mask != nullptr) {
+          UNCL_CHK(a.chk, mrow + off, 16);
           const s16x8 mk = __builtin_bit_cast(s16x8, *reinterpret_cast<const vec*>(mrow + off));
           const s16x8 one = {1, 1, 1, 1, 1, 1, 1, 1}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
           const s16x8 keep = __builtin_elementwise_max(__builtin_elementwise_min(mk, one), zero);
@@ -470,6 +472,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         if (a.accumulate) {
           float f[8], o[8];
           E::unpack(w, f);
+          UNCL_CHK(a.chk, orow + off, 16);
           E::unpack(*reinterpret_cast<const vec*>(orow + off), o);
 #pragma unroll
           for (int i = 0; i < 8; ++i) f[i] += o[i];
@@ -517,7 +520,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
                 // (half-wave exchanges: only the receiving half of each hand-over holds the chain; the final sum is read in
                 // the LOWER half)
                 if (qp == 1 && lh == 0 && oy < a.Hout && xin)
-                  a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(o1sum[r], a.out1_act);
+                  { UNCL_CHK(a.chk, a.out1 + ((size_t)c.n * a.Hout + oy) * a.Wout + ox, 4); a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(o1sum[r], a.out1_act); }
               }
               if (a.skip_main) continue;
 #ifdef UNCL_PC_TIMING
@@ -528,6 +531,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
                   const char* mrow = reinterpret_cast<const char*>(a.mask + ((size_t)c.n * a.Hout + oy) * a.Wout * a.oC + co);
                   wv[r] = grad_ops(wv[r], mrow, rowp, loff + (nt * 32 + 16 * qp) * 2);
                 }
+                UNCL_CHK(a.chk, rowp + loff + (nt * 32 + 16 * qp) * 2, 16);
                 *reinterpret_cast<vec*>(rowp + loff + (nt * 32 + 16 * qp) * 2) = wv[r];
               }
             }
@@ -546,7 +550,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #ifdef UNCL_PC_TIMING
               if (a.pc_prio & 64) { asm volatile("" ::"v"(v)); continue; }
 #endif
-              if (in) *reinterpret_cast<vec*>(rowp + poff + (nt * 32 + 16 * qp) * 2) = __builtin_bit_cast(vec, v);
+              if (in) { UNCL_CHK(a.chk, rowp + poff + (nt * 32 + 16 * qp) * 2, 16); *reinterpret_cast<vec*>(rowp + poff + (nt * 32 + 16 * qp) * 2) = __builtin_bit_cast(vec, v); }
             }
           }
       }
@@ -708,7 +712,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
               if (a.pc_prio & 64) { asm volatile("" ::"v"(wv[r])); continue; }
 #endif
               if (OUT1 != 2)
+              {
+#ifdef UNCL_CHECKED
+                const unsigned bo = voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u;
+                if (bo < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.out) + (size_t)c.n * sample + bo, 16);
+#endif
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, wv[r]), rs, voff[r] + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, UNCL_PC_STORE_AUX);
+              }
             }
             if (POOL) {
               // MaxPool2d(2) of the two rows (unet_parts.py:212,233) on the packed, non-negative values: a signed 16-bit
@@ -721,7 +731,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
               // (the odd lanes hold the same maxima: masked off by EXEC rather than by offset, so that the memory pipeline
               // sees a 32-lane store)
               if ((lr & 1) == 0)
+              {
+#ifdef UNCL_CHECKED
+                const unsigned bo = pvoff + (unsigned)(nt * 32 + 16 * qp) * 2u;
+                if (bo < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.pool_out) + (size_t)c.n * ((unsigned)(a.pH * a.pW * a.oC) * 2u) + bo, 16);
+#endif
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, v), prs, pvoff + (unsigned)(nt * 32 + 16 * qp) * 2u, 0, UNCL_PC_STORE_AUX);
+              }
             }
           }
         if (OUT1 != 0) {
@@ -732,7 +748,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           for (int r = 0; r < 2; ++r) {
             const int oy = y0 + 2 * pr + r;
             const float tot = outc_row(acc[2 * pr + r][0], sBt, o1w) + sO1[32];
-            if (lh == 0 && oy < a.Hout && ox < a.Wout) a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act);
+            if (lh == 0 && oy < a.Hout && ox < a.Wout) { UNCL_CHK(a.chk, a.out1 + ((size_t)c.n * a.Hout + oy) * a.Wout + ox, 4); a.out1[((size_t)c.n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act); }
           }
         }
       }
@@ -826,7 +842,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         for (int m = 0; m < MPW; ++m) tot[m] = outc_row(acc[m][0], sB1, o1w) + sO1[32];
 #pragma unroll
         for (int m = 0; m < MPW; ++m)
-          if (xin && oy0 + m < a.oH) orow[(size_t)m * a.oW] = uncl_act(tot[m], a.out1_act);
+          if (xin && oy0 + m < a.oH) { UNCL_CHK(a.chk, orow + (size_t)m * a.oW, 4); orow[(size_t)m * a.oW] = uncl_act(tot[m], a.out1_act); }
       };
       // fragments of the second layer for tap column (ks, tx): A = its weights (LDS, resident), B = the image -- rows 0 / 1 of the
       // wave's MPW + 2 come from `p01` (wave 0: the carried rows; the others: the rows the wave above wrote), the rest are its own
@@ -1040,9 +1056,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   if (MODE == 4) {
     const int arow = tap * 32 + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) ua[ks] = ld16v<vec>(a.up_w + arow * 32 + (2 * ks + lh) * 8);
+    for (int ks = 0; ks < 2; ++ks) ua[ks] = LD16V(vec, a.up_w + arow * 32 + (2 * ks + lh) * 8);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) cb[i] = a.up_b ? a.up_b[16 * lh + i] : 0.f;
+    for (int i = 0; i < 16; ++i) { if (a.up_b) UNCL_CHK(a.chk, a.up_b + 16 * lh + i, 4); cb[i] = a.up_b ? a.up_b[16 * lh + i] : 0.f; }
   }
 
   // MODE 3: image-patch values in flight, the first layer's weight fragment (cout = lr, k = 8 lh + j -> tap) and the biases
@@ -1055,10 +1071,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * lh + j;
+      if (k < 9) UNCL_CHK(a.chk, a.pre_w + lr * 9 + k, 4);
       preA[j] = (T)(k < 9 ? a.pre_w[lr * 9 + k] : 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) preB[i] = a.pre_b ? a.pre_b[8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f;
+    for (int i = 0; i < 16; ++i) { if (a.pre_b) UNCL_CHK(a.chk, a.pre_b + 8 * (i >> 2) + 4 * lh + (i & 3), 4); preB[i] = a.pre_b ? a.pre_b[8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f; }
 #pragma unroll
     for (int k = 0; k < IRN; ++k) ir[k] = 0.f;
   }
@@ -1081,7 +1098,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     for (int j = 0; j < WVN; ++j) {
       unsigned off = (unsigned)woff0;
       if (W_RAGGED && j == WVN - 1) off = (p0 + WPP * j < WROWS) ? off : 0u;
-      wv[j] = ld16ov<vec>(wb_ + j * wstride, off * 2u);
+      wv[j] = LD16OV(vec, wb_ + j * wstride, off * 2u);
     }
   };
   auto write_weights = [&](char* wst) __attribute__((always_inline)) {
@@ -1127,7 +1144,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
     }
 #pragma unroll
-    for (int j = J0; j < J1; ++j) xr[j] = ld16ov<vec>(base, off[j]);
+    for (int j = J0; j < J1; ++j) xr[j] = LD16OV(vec, base, off[j]);
     return valid;
   };
 
@@ -1171,6 +1188,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       for (int k = 0; k < IRN; ++k) {
         const int idx = min(ptid + k * NPROD, PN3 - 1);
         const int pr = idx / PW3, pcl = idx - pr * PW3;
+        UNCL_CHK(a.chk, ib + (size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pcl, a.imgW - 1), 4);
         ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pcl, a.imgW - 1)];
       }
     } else if (!X_LOAD) {
@@ -1191,7 +1209,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-          xr[2 * i + ks] = ld16ov<vec>(ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
+          xr[2 * i + ks] = LD16OV(vec, ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
       }
     } else if (MODE == 1 && P == 0 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
@@ -1218,7 +1236,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         off[RSN] = (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u;
       }
 #pragma unroll
-      for (int j = XJ0; j < XJ1; ++j) xr[j] = ld16ov<vec>(base, off[j]);
+      for (int j = XJ0; j < XJ1; ++j) xr[j] = LD16OV(vec, base, off[j]);
     } else {
       valid = load_x(xr, xsrc, n, iy0, ix0, cbase, IntTag<XJ0>{}, IntTag<XJ1>{});
     }
@@ -1231,7 +1249,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     if (XA_ONLY) return;
     if (!RESW) {
       load_weights(cout0, kc);
-      if (bp && ptid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)ptid * 16u);
+      if (bp && ptid < CT / 4 && a.bias != nullptr) br = LD16O_F32(a.bias + cout0, (unsigned)ptid * 16u);
     }
   };
 
@@ -1462,12 +1480,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       if (cur_next<TAIL>(pc, a, tile_end) && pc.tile != t_old) ppar = (ppar + 1) & 3;
     }
   };
-  if (a.out1_w != nullptr && ptid < 33) sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0];     // fused 1x1 tail (CT == 32)
-  if (TAIL && ptid < 32) sB1[ptid] = a.tail_b != nullptr ? a.tail_b[ptid] : 0.f;
+  if (a.out1_w != nullptr && ptid < 33) { UNCL_CHK(a.chk, ptid < 32 ? a.out1_w + ptid : a.out1_b, 4); sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0]; }     // fused 1x1 tail (CT == 32)
+  if (TAIL && ptid < 32) { if (a.tail_b != nullptr) UNCL_CHK(a.chk, a.tail_b + ptid, 4); sB1[ptid] = a.tail_b != nullptr ? a.tail_b[ptid] : 0.f; }
   if (TAIL) {
     // the second layer's weights become resident too: global [tap][cout][cin] -> plane (cin slot) x row (tap * 32 + cout)
     for (int i = ptid; i < 9 * 32 * 4; i += NPROD)
-      *reinterpret_cast<vec*>(sW1 + (i & 3) * W1PL + (i >> 2) * 16) = ld16v<vec>(a.tail_w + (i >> 2) * 32 + (i & 3) * 8);
+      *reinterpret_cast<vec*>(sW1 + (i & 3) * W1PL + (i >> 2) * 16) = LD16V(vec, a.tail_w + (i >> 2) * 32 + (i & 3) * 8);
   }
   if (RESW) {
     // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, in the consumers' chunk order, and so
@@ -1477,6 +1495,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       write_weights(wres + kc * WBYTES);
     }
     if (ptid < CT / 4) {
+      if (a.bias != nullptr) UNCL_CHK(a.chk, a.bias + ptid * 4, 16);
       const f32x4 b4 = a.bias != nullptr ? *reinterpret_cast<const f32x4*>(a.bias + ptid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int sl = 0; sl < 4; ++sl) *reinterpret_cast<f32x4*>(sBias + sl * CT + ptid * 4) = b4;

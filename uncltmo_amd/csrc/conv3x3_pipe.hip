@@ -168,10 +168,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * lh + j;
+      if (k < 9) UNCL_CHK(a.chk, a.pre_w + lr * 9 + k, 4);
       preA[j] = (T)(k < 9 ? a.pre_w[lr * 9 + k] : 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) preB[i] = a.pre_b ? a.pre_b[8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f;
+    for (int i = 0; i < 16; ++i) { if (a.pre_b) UNCL_CHK(a.chk, a.pre_b + 8 * (i >> 2) + 4 * lh + (i & 3), 4); preB[i] = a.pre_b ? a.pre_b[8 * (i >> 2) + 4 * lh + (i & 3)] : 0.f; }
 #pragma unroll
     for (int k = 0; k < IRN; ++k) ir[k] = 0.f;
   }
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       for (int k = 0; k < IRN; ++k) {
         const int idx = min(tid + k * NTHR, PN3 - 1);
         const int pr = idx / PW3, pc = idx - pr * PW3;
+        UNCL_CHK(a.chk, ib + (size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pc, a.imgW - 1), 4);
         ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pc, a.imgW - 1)];
       }
       xvalid = 0xffffffffu;
@@ -234,10 +236,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const int sp = v >> 2, sl = v & 3;
         const int spy = sp / UPW, spx = sp - spy * UPW;
         const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
-        xr[k] = ld16ov<vec>(ub, (unsigned)(((yy * a.s1W + xx) * 32 + sl * 8) * 2));
+        xr[k] = LD16OV(vec, ub, (unsigned)(((yy * a.s1W + xx) * 32 + sl * 8) * 2));
       }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) xr[3 + k] = ld16ov<vec>(a.up_w, (unsigned)((t4 + k * NTHR) * 16));
+      for (int k = 0; k < 2; ++k) xr[3 + k] = LD16OV(vec, a.up_w, (unsigned)((t4 + k * NTHR) * 16));
       xvalid = 0xffffffffu;
     } else if (MODE != 0 && MODE != 4 && g == 1 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
@@ -253,14 +255,14 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const bool ok = xok && (unsigned)iy < (unsigned)a.H;
         const int sy = min(max(iy - dy, 0), a.s1H - 1);
         valid |= (ok ? 1u : 0u) << j;
-        xr[j] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
+        xr[j] = LD16OV(vec, base, (unsigned)((sy * a.s1W + sx) * a.s1C) * 2u);
       }
       {
         const int iy = iy0 + ey, ixe = ix0 + 32 + ec;
         const bool ok = e_on && (unsigned)iy < (unsigned)a.H && (unsigned)ixe < (unsigned)a.W;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sxe = min(max(ixe - dx, 0), a.s1W - 1);
         valid |= (ok ? 1u : 0u) << RS;
-        xr[RS] = ld16ov<vec>(base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
+        xr[RS] = LD16OV(vec, base, (unsigned)((sy * a.s1W + sxe) * a.s1C) * 2u);
       }
       xvalid = valid;
     } else if (FLAT) {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const int sj = flat_s[j];
         const bool ok = sj >= 0 && sj < left && (j < RS || e_on);
         valid |= (ok ? 1u : 0u) << j;
-        xr[j] = ld16ov<vec>(base, ok ? flat_off[j] * 2u : 0u);
+        xr[j] = LD16OV(vec, base, ok ? flat_off[j] * 2u : 0u);
       }
       xvalid = valid;
     } else {
@@ -288,8 +290,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const bf16_t* base = xsrc + ((size_t)n * a.s0H * a.s0W + (size_t)iy0 * a.s0W + ix0) * a.s0C + cbase;
         // the stride between slots goes into the scalar base, so one offset VGPR serves all regular slots
 #pragma unroll
-        for (int j = 0; j < RS; ++j) xr[j] = ld16ov<vec>(base + j * 2 * row_el, (unsigned)xoff_r * 2u);
-        xr[RS] = ld16ov<vec>(base, (unsigned)(e_on ? xoff_e : 0) * 2u);
+        for (int j = 0; j < RS; ++j) xr[j] = LD16OV(vec, base + j * 2 * row_el, (unsigned)xoff_r * 2u);
+        xr[RS] = LD16OV(vec, base, (unsigned)(e_on ? xoff_e : 0) * 2u);
         xvalid = 0xffffffffu;
       } else {
         const bf16_t* base = xsrc + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
@@ -309,11 +311,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
           }
           valid |= (ok ? 1u : 0u) << j;
           const unsigned off = ok ? (unsigned)(toff + eoff) : 0u;
-          xr[j] = ld16ov<vec>(base, off * 2u);
+          xr[j] = LD16OV(vec, base, off * 2u);
           if (PREV) {
             const int c = cbase + ch * 8;
             if (c < a.prev_ch) {
-              const vec p = ld16v<vec>(a.prev0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase + off);
+              const vec p = LD16V(vec, a.prev0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase + off);
 #pragma unroll
               for (int i = 0; i < 8; ++i)
                 if (c + i < a.prev_ch) xr[j][i] = p[i];
@@ -330,12 +332,12 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       for (int j = 0; j < WVN; ++j) {
         unsigned off = (unsigned)woff0;
         if (W_RAGGED && j == WVN - 1) off = (p0 + 64 * j < WROWS) ? off : 0u;
-        wr[j] = ld16ov<vec>(wb + j * wstride, off * 2u);
+        wr[j] = LD16OV(vec, wb + j * wstride, off * 2u);
       }
     }
     // last on purpose: the alternative x paths above are laid out one after the other, and the hazard check of a later
     // one waits for whatever an earlier one might have issued -- with the bias load in front that wait was real
-    if (b_pending && tid < CT / 4 && a.bias != nullptr) br = ld16o_f32(a.bias + cout0, (unsigned)tid * 16u);
+    if (b_pending && tid < CT / 4 && a.bias != nullptr) br = LD16O_F32(a.bias + cout0, (unsigned)tid * 16u);
   };
 
   f32x16 acc[MPW][NT];
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         const int v = t4 + k * NTHR, row = v >> 2;
         *reinterpret_cast<vec*>(sUW + row * 64 + (((v & 3) ^ ((row >> 2) & 3)) << 4)) = xr[3 + k];
       }
-      if (t4 < 32) sUB[t4] = a.up_b ? a.up_b[t4] : 0.f;
+      if (t4 < 32) { if (a.up_b) UNCL_CHK(a.chk, a.up_b + t4, 4); sUB[t4] = a.up_b ? a.up_b[t4] : 0.f; }
       __syncthreads();
       // Work split: wave = tap (dy, dx), five M-tiles of 32 source pixels each.  The A rows are read in the order
       // cout(r) = 16*bit2(r) + 4*(r >> 3) + (r & 3), which makes the D registers of a lane 16 CONSECUTIVE output channels
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       vec f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        UNCL_CHK(a.chk, a.out1_w + 16 * ks + 8 * (j >> 2) + 4 * lh + (j & 3), 4);
         float w = a.out1_w[16 * ks + 8 * (j >> 2) + 4 * lh + (j & 3)];
         T piece = (T)0.f;
 #pragma unroll
@@ -650,6 +653,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     // transposition, no barrier, no 64 B per pixel read back and 32 fma per pixel on the vector pipe.
     if (c_kc == a.nk - 1 && o1_direct) {
       const vec o1w[2] = {*reinterpret_cast<const vec*>(sO1F + lane * 16), *reinterpret_cast<const vec*>(sO1F + (64 + lane) * 16)};
+      UNCL_CHK(a.chk, a.out1_b, 4);
       const float o1b = a.out1_b[0];
 #pragma unroll
       for (int m = 0; m < MPW; ++m) {
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
         d = mfma32x16(o1w[1], Bf[1], d);
         const float tot = (d[2] + d[1]) + d[0] + o1b;
         const int oy = c_y0 + wave * MPW + m, ox = c_x0 + lr;
-        if (lh == 0 && oy < a.Hout && ox < a.Wout) a.out1[((size_t)c_n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act);
+        if (lh == 0 && oy < a.Hout && ox < a.Wout) { UNCL_CHK(a.chk, a.out1 + ((size_t)c_n * a.Hout + oy) * a.Wout + ox, 4); a.out1[((size_t)c_n * a.Hout + oy) * a.Wout + ox] = uncl_act(tot, a.out1_act); }
       }
     } else if (!o1_direct && c_kc == a.nk - 1) {
       __syncthreads();  // every wave is done reading sX / sW
@@ -732,10 +736,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 #pragma unroll
             for (int it = 0; it < ST_IT; it += 4) {
               const vec v0 = VAL(it), v1 = VAL(it + 1), v2 = VAL(it + 2), v3 = VAL(it + 3);
-              if (it * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + it * row_stride) = v0;
-              if ((it + 1) * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + (it + 1) * row_stride) = v1;
-              if ((it + 2) * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + (it + 2) * row_stride) = v2;
-              if ((it + 3) * ROWS_PER_IT < rows_left) *reinterpret_cast<vec*>(ob + (it + 3) * row_stride) = v3;
+              if (it * ROWS_PER_IT < rows_left) { UNCL_CHK(a.chk, ob + it * row_stride, 16); *reinterpret_cast<vec*>(ob + it * row_stride) = v0; }
+              if ((it + 1) * ROWS_PER_IT < rows_left) { UNCL_CHK(a.chk, ob + (it + 1) * row_stride, 16); *reinterpret_cast<vec*>(ob + (it + 1) * row_stride) = v1; }
+              if ((it + 2) * ROWS_PER_IT < rows_left) { UNCL_CHK(a.chk, ob + (it + 2) * row_stride, 16); *reinterpret_cast<vec*>(ob + (it + 2) * row_stride) = v2; }
+              if ((it + 3) * ROWS_PER_IT < rows_left) { UNCL_CHK(a.chk, ob + (it + 3) * row_stride, 16); *reinterpret_cast<vec*>(ob + (it + 3) * row_stride) = v3; }
             }
           } else if (a.res == nullptr) {
             // gradient store: ReLU mask of the producing layer and / or accumulation into an existing gradient
@@ -748,16 +752,17 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
                 E::unpack(VAL(it), f);
                 if (mb) {
                   float m[8];
-                  E::unpack(ld16v<vec>(mb + it * row_stride), m);
+                  E::unpack(LD16V(vec, mb + it * row_stride), m);
 #pragma unroll
                   for (int i = 0; i < 8; ++i) f[i] = m[i] > 0.f ? f[i] : a.mask_slope * f[i];
                 }
                 if (a.accumulate) {
                   float o[8];
-                  E::unpack(ld16v<vec>(ob + it * row_stride), o);
+                  E::unpack(LD16V(vec, ob + it * row_stride), o);
 #pragma unroll
                   for (int i = 0; i < 8; ++i) f[i] += o[i];
                 }
+                UNCL_CHK(a.chk, ob + it * row_stride, 16);
                 *reinterpret_cast<vec*>(ob + it * row_stride) = E::pack(f);
               }
             }
@@ -769,9 +774,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
               if (it * ROWS_PER_IT < rows_left) {
                 float f[8], g[8];
                 E::unpack(VAL(it), f);
-                E::unpack(ld16v<vec>(rb + it * row_stride), g);
+                E::unpack(LD16V(vec, rb + it * row_stride), g);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) f[i] += g[i];
+                UNCL_CHK(a.chk, ob + it * row_stride, 16);
                 *reinterpret_cast<vec*>(ob + it * row_stride) = E::pack(f);
               }
             }
@@ -795,6 +801,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
 #pragma unroll
               for (int i = 0; i < 8; ++i) m[i] = qd == 0 ? f[i] : fmaxf(m[i], f[i]);
             }
+            UNCL_CHK(a.chk, pb + (unsigned)((gy * a.pW + gx) * a.oC + sl * 8), 16);
             *reinterpret_cast<vec*>(pb + (unsigned)((gy * a.pW + gx) * a.oC + sl * 8)) = E::pack(m);
           }
         }
@@ -804,6 +811,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
           const int prow = pl / TW, pcol = pl - prow * TW;
           const int oy = c_y0 + prow, ox = c_x0 + pcol;
           if (oy < a.Hout && ox < a.Wout) {
+            UNCL_CHK(a.chk, a.out1_b, 4);
             float sum = a.out1_b[0];
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
@@ -811,8 +819,9 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
               float f[8];
               E::unpack(val, f);
 #pragma unroll
-              for (int i = 0; i < 8; ++i) sum = fmaf(f[i], a.out1_w[sl * 8 + i], sum);
+              for (int i = 0; i < 8; ++i) { UNCL_CHK(a.chk, a.out1_w + sl * 8 + i, 4); sum = fmaf(f[i], a.out1_w[sl * 8 + i], sum); }
             }
+            UNCL_CHK(a.chk, a.out1 + ((size_t)c_n * a.Hout + oy) * a.Wout + ox, 4);
             a.out1[((size_t)c_n * a.Hout + oy) * a.Wout + ox] = uncl_act(sum, a.out1_act);
           }
         }
@@ -966,6 +975,33 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   a.flat_S = 0; a.flat_hw = 0; a.flat_N = d->N;
   a.nk = d->Cin / 32;
   a.tail_w = (const bf16_t*)d->tail_w; a.tail_b = d->tail_b; a.oH = a.oW = 0;
+#ifdef UNCL_CHECKED
+  {
+    // the tensors this launch may touch, from the descriptor's own dimensions (16-bit elements unless stated)
+    const unsigned long long es = 2, N = (unsigned long long)d->N;
+    uncl_chk_reset(a.chk);
+    if (d->src_mode == UNCL_SRC_IMAGE1) uncl_chk_add(a.chk, d->src0, N * d->src0_H * d->src0_W * 4);          // fp32 image
+    else uncl_chk_add(a.chk, d->src0, N * d->src0_H * d->src0_W * d->src0_C * es);
+    uncl_chk_add(a.chk, d->src1, N * d->src1_H * d->src1_W * d->src1_C * es);
+    uncl_chk_add(a.chk, d->prev0, N * d->src0_H * d->src0_W * d->src0_C * es);
+    uncl_chk_add(a.chk, d->weight, 9ull * d->Cout * d->Cin * es);
+    uncl_chk_add(a.chk, d->bias, (unsigned long long)d->Cout * 4);
+    const unsigned long long out_px = (unsigned long long)a.Hout * a.Wout;
+    uncl_chk_add(a.chk, d->res, (d->res_batch_stride0 ? 1ull : N) * out_px * d->out_C * es);
+    uncl_chk_add(a.chk, mask, N * out_px * d->out_C * es);
+    uncl_chk_add(a.chk, d->out, N * out_px * d->out_C * es);
+    uncl_chk_add(a.chk, pool_out, N * (unsigned long long)a.pH * a.pW * d->out_C * es);
+    uncl_chk_add(a.chk, d->out1_w, 32 * 4);
+    uncl_chk_add(a.chk, d->out1_b, 4);
+    uncl_chk_add(a.chk, d->out1, N * (d->tail_w != nullptr ? (unsigned long long)(a.Hout + 2) * (a.Wout + 2) : out_px) * 4);
+    uncl_chk_add(a.chk, d->pre_w, 288 * 4);
+    uncl_chk_add(a.chk, d->pre_b, 32 * 4);
+    uncl_chk_add(a.chk, d->up_w, 4ull * 32 * 32 * es);
+    uncl_chk_add(a.chk, d->up_b, 32 * 4);
+    uncl_chk_add(a.chk, d->tail_w, 9ull * 32 * 32 * es);
+    uncl_chk_add(a.chk, d->tail_b, 32 * 4);
+  }
+#endif
   if (d->tail_w != nullptr) {
     // fused last decoder stage: this layer's output and the next layer's never leave the CU; only out1 is written
     if (d->src_mode != UNCL_SRC_CONCAT_SSR_UP || d->act != UNCL_ACT_RELU || !d->skip_main_store || d->out1_w == nullptr ||

@@ -828,3 +828,40 @@ extern "C" int uncl_device_ok(void) {
   const char* a = p.gcnArchName;
   return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
 }
+
+
+// ---- checked build (common.h: UNCL_CHECKED): the violation record and its C-ABI reader -------------------------------------------
+unsigned long long* uncl_chk_record() {
+#ifdef UNCL_CHECKED
+  static std::atomic<unsigned long long*> rec[32];
+  const int d = uncl_device();
+  unsigned long long* p = rec[d].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    unsigned long long* q = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&q), 4 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(q, 0, 4 * sizeof(unsigned long long));
+    unsigned long long* expect = nullptr;
+    if (rec[d].compare_exchange_strong(expect, q)) p = q;
+    else { (void)hipFree(q); p = expect; }
+  }
+  return p;
+#else
+  return nullptr;
+#endif
+}
+
+// out4 = {violations, first faulting address, source line of the access, bytes}; reset != 0 clears the record afterwards.
+// UNCL_ERR_ARG in the product build (nothing is checked there).  Synchronises the device.
+extern "C" int uncl_checked_report(unsigned long long* out4, int reset) {
+#ifdef UNCL_CHECKED
+  unsigned long long* p = uncl_chk_record();
+  if (p == nullptr || out4 == nullptr) return UNCL_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return UNCL_ERR_LAUNCH;
+  if (hipMemcpy(out4, p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return UNCL_ERR_LAUNCH;
+  if (reset && hipMemset(p, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return UNCL_ERR_LAUNCH;
+  return UNCL_OK;
+#else
+  (void)out4; (void)reset;
+  return UNCL_ERR_ARG;
+#endif
+}

@@ -41,6 +41,7 @@ struct UpArgs {
   int H, W, C, Cout, prev_ch;
   int M;                // N*H*W input pixels
   int n_tiles;          // ceil(M / 128)
+  UNCL_CHK_MEMBER       // checked build: the tensors of this launch (common.h)
 };
 
 // CT = virtual output channels (tap-major) per workgroup: 128, or 64 for the wide levels -- with CIN = 256 a 128-row weight slice
@@ -71,13 +72,14 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
   // stage this slice of the weights once
   for (int v = tid; v < CT * S; v += 256) {
     const int row = v / S, slot = v - row * S;
+    UNCL_CHK(a.chk, a.w + ((size_t)(ct * CT + row)) * CIN + slot * 8, 16);
     const vec wv = *reinterpret_cast<const vec*>(a.w + ((size_t)(ct * CT + row)) * CIN + slot * 8);
     *reinterpret_cast<vec*>(sW + row * (CIN * 2) + (wswz(row, slot) << 4)) = wv;
   }
   // bias of the slice's 128 virtual channels (c' = ct*128 + i -> co = c' % Cout) in LDS: sixty-four registers of per-lane
   // copies kept the kernel at two workgroups per CU
   float* sB = reinterpret_cast<float*>(sO + 128 * CT * 2);
-  if (tid < CT) sB[tid] = a.bias ? a.bias[(ct * CT + tid) % a.Cout] : 0.f;
+  if (tid < CT) { if (a.bias) UNCL_CHK(a.chk, a.bias + (ct * CT + tid) % a.Cout, 4); sB[tid] = a.bias ? a.bias[(ct * CT + tid) % a.Cout] : 0.f; }
   __syncthreads();
 
   f32x16 zero16;
@@ -94,8 +96,10 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const size_t off = (size_t)mp * CIN + ks * 16 + lh * 8;
+      UNCL_CHK(a.chk, a.x + off, 16);
       Bv[ks] = *reinterpret_cast<const vec*>(a.x + off);
       if (PREV && ks * 16 + lh * 8 < a.prev_ch) {
+        UNCL_CHK(a.chk, a.prev + off, 16);
         const vec p = *reinterpret_cast<const vec*>(a.prev + off);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(256) void upconv2x2_kernel(const UpArgs a) {
       if (x < 0) { --y; x += a.W; } else if (x >= a.W) { ++y; x -= a.W; }
       const size_t opix = ((size_t)n * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1);
       const vec val = *reinterpret_cast<const vec*>(sO + p * (CT * 2) + ((slot ^ (p & (OS - 1))) << 4));
+      UNCL_CHK(a.chk, a.out + opix * a.Cout + co, 16);
       *reinterpret_cast<vec*>(a.out + opix * a.Cout + co) = val;
     }
     if (PRE) {
@@ -230,6 +235,14 @@ extern "C" int uncl_upconv2x2_dt(const void* x, const void* prev, int prev_ch, c
   a.x = (const bf16_t*)x; a.prev = (const bf16_t*)prev; a.w = (const bf16_t*)w; a.bias = bias; a.out = (bf16_t*)out;
   a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.prev_ch = prev_ch; a.M = (int)M; a.n_tiles = (int)((M + 127) / 128);
   const bool pv = prev != nullptr && prev_ch > 0;
+#ifdef UNCL_CHECKED
+  uncl_chk_reset(a.chk);
+  uncl_chk_add(a.chk, x, (unsigned long long)M * C * 2);
+  uncl_chk_add(a.chk, prev, (unsigned long long)M * C * 2);
+  uncl_chk_add(a.chk, w, 4ull * Cout * C * 2);
+  uncl_chk_add(a.chk, bias, (unsigned long long)Cout * 4);
+  uncl_chk_add(a.chk, out, (unsigned long long)M * 4 * Cout * 2);
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == UNCL_F16) {
     switch (C) {

@@ -42,6 +42,7 @@ struct WgArgs {
   float* part;          // NULL: atomics
   float* gb_part;
   long long E;          // elements of dw this launch covers
+  UNCL_CHK_MEMBER       // checked build: the tensors of this launch (common.h)
 };
 
 // partial sums of the G pixel-range groups -> out[i] += sum_g part[g * E + i] in a FIXED order: a block owns 32 elements, its
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // accumulate into the gradient: atomics, or this group's slot of the partial buffer
 __device__ __forceinline__ void wg_emit(const WgArgs& a, size_t off, float v) {
-  if (a.part != nullptr) a.part[(size_t)blockIdx.x * a.E + off] = v;
-  else atomicAdd(a.dw + off, v);
+  if (a.part != nullptr) { UNCL_CHK(a.chk, a.part + (size_t)blockIdx.x * a.E + off, 4); a.part[(size_t)blockIdx.x * a.E + off] = v; }
+  else { UNCL_CHK(a.chk, a.dw + off, 4); atomicAdd(a.dw + off, v); }
 }
 
 __device__ __forceinline__ bf16x8 ld16g(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -78,6 +79,11 @@ __device__ __forceinline__ bf16x8 wg_ld16o(const bf16_t* base, unsigned byte_off
   asm volatile("" : "+v"(byte_off));
   return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+
+// checked build: the same loads with the address looked up in the launch's tensor table first (`a` = the kernel's WgArgs)
+#define WG_LD16O(base, off) (UNCL_CHK(a.chk, reinterpret_cast<const char*>(base) + (off), 16), wg_ld16o((base), (off)))
+#define WG_LD16G(p) (UNCL_CHK(a.chk, (p), 16), ld16g(p))
+#define WG_LDV(p) (UNCL_CHK(a.chk, (p), 16), *reinterpret_cast<const vec*>(p))
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds_row0_base, int pix0, int c0, int lane) {
   // 8 consecutive pixels (pix0 + 8h' ... handled by caller) x one channel per lane: two 4-pixel transposed reads
@@ -168,10 +174,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
       if (MODE != 0 && g == 1) {
         const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
-        xr[j] = ld16g(a.src1 + ((size_t)n * a.s1H * a.s1W + (size_t)sy * a.s1W + sx) * a.s1C + cbase + ch * 8);
+        xr[j] = WG_LD16G(a.src1 + ((size_t)n * a.s1H * a.s1W + (size_t)sy * a.s1W + sx) * a.s1C + cbase + ch * 8);
       } else {
         const size_t off = ok ? ((size_t)n * a.s0H * a.s0W + (size_t)iy * a.s0W + ix) * a.s0C : 0;
-        xr[j] = ld16g(a.src0 + off + cgrp * a.Cin + cbase + ch * 8);
+        xr[j] = WG_LD16G(a.src0 + off + cgrp * a.Cin + cbase + ch * 8);
       }
     }
     xvalid = valid;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
       // (zeroed at write time: a select on the value just requested makes the request wait for its own data, i.e. the prefetch
       // of the next tile would finish before the first MFMA of this one)
       gval |= (ok ? 1u : 0u) << j;
-      gr[j] = ld16g(a.gy + off + cgrp * a.Cout + cc * 32 + ch * 8);
+      gr[j] = WG_LD16G(a.gy + off + cgrp * a.Cout + cc * 32 + ch * 8);
     }
     gvalid = gval;
   };
@@ -337,11 +343,11 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
         const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
         const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
-        xr[j] = *reinterpret_cast<const vec*>(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
+        xr[j] = WG_LDV(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
       } else {
         const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
         const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
-        xr[j] = *reinterpret_cast<const vec*>(base + off);
+        xr[j] = WG_LDV(base + off);
       }
     }
     xvalid = valid;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
       const bf16_t* base = a.gy + (size_t)n * a.Hout * a.Wout * a.gy_ld + cc * 32;
       const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
       gval |= (ok ? 1u : 0u) << j;          // (zeroed at write time, see wgrad_kernel)
-      gr[j] = *reinterpret_cast<const vec*>(base + off);
+      gr[j] = WG_LDV(base + off);
     }
     gvalid = gval;
   };
@@ -446,8 +452,8 @@ __global__ __launch_bounds__(384, 3) void wgrad3_kernel(const WgArgs a) {
       const int sl = tid >> 3, e = tid & 7;
       float t = 0.f;
       for (int p = 0; p < NT / 4; ++p) t += sBs[(p * 4 + sl) * 8 + e];
-      if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + tid] = t;
-      else atomicAdd(a.gb + cc * 32 + tid, t);
+      if (a.gb_part != nullptr) { UNCL_CHK(a.chk, a.gb_part + (size_t)blockIdx.x * a.Cout + cc * 32 + tid, 4); a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + tid] = t; }
+      else { UNCL_CHK(a.chk, a.gb + cc * 32 + tid, 4); atomicAdd(a.gb + cc * 32 + tid, t); }
     }
     __syncthreads();
   }
@@ -536,11 +542,11 @@ __global__ __launch_bounds__(384, 3) void wgrad3w_kernel(const WgArgs a) {
         const int dy = (a.s0H - a.s1H) >> 1, dx = (a.s0W - a.s1W) >> 1;
         const int sy = min(max(iy - dy, 0), a.s1H - 1), sx = min(max(ix - dx, 0), a.s1W - 1);
         const bf16_t* base = a.src1 + (size_t)n * a.s1H * a.s1W * a.s1C + cbase;
-        xr[j] = *reinterpret_cast<const vec*>(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
+        xr[j] = WG_LDV(base + (unsigned)((sy * a.s1W + sx) * a.s1C + ch * 8));
       } else {
         const bf16_t* base = a.src0 + (size_t)n * a.s0H * a.s0W * a.s0C + cbase;
         const unsigned off = ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + ch * 8) : 0u;
-        xr[j] = *reinterpret_cast<const vec*>(base + off);
+        xr[j] = WG_LDV(base + off);
       }
     }
     xvalid = valid;
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(384, 3) void wgrad3w_kernel(const WgArgs a) {
       const unsigned off = ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + ch * 8) : 0u;
       // (the other kernels zero at write time so that the request does not wait for its own data; this one is at its 168-register
       // budget -- the concat instantiation already spills 7 -- and off the default paths since wgrad3c_kernel: left as measured)
-      vec v = *reinterpret_cast<const vec*>(base + off);
+      vec v = WG_LDV(base + off);
       if (!ok) v = E::zero();
       gr[j] = v;
     }
@@ -773,9 +779,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3r_kernel(const WgArgs a) {
         valid |= (ok ? 1u : 0u) << j;
         if (MODE != 0 && g == 1) {
           const int sy = min(max(iy - dy1, 0), a.s1H - 1), sx = min(max(ix - dx1, 0), a.s1W - 1);
-          xr[j] = wg_ld16o(base1, (unsigned)((sy * a.s1W + sx) * a.s1C + chc * 8) * 2u);
+          xr[j] = WG_LD16O(base1, (unsigned)((sy * a.s1W + sx) * a.s1C + chc * 8) * 2u);
         } else {
-          xr[j] = wg_ld16o(base0, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
+          xr[j] = WG_LD16O(base0, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
         }
       }
       xvalid = valid;
@@ -786,7 +792,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3r_kernel(const WgArgs a) {
         const bool ok = gy_ < a.Hout && gx_ < a.Wout;
         // (no select on the loaded value here: it would make the request wait for its own data -- zeroed at write time)
         gval |= (ok ? 1u : 0u) << j;
-        gr[j] = wg_ld16o(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
+        gr[j] = WG_LD16O(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
       }
       gvalid = gval;
     };
@@ -871,8 +877,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3r_kernel(const WgArgs a) {
     const int sl = tid >> 3, e = tid & 7;
     float t = 0.f;
     for (int p = 0; p < NS / 4; ++p) t += sBs[(p * 4 + sl) * 8 + e];
-    if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + tid] = t;
-    else atomicAdd(a.gb + cc * 32 + tid, t);
+    if (a.gb_part != nullptr) { UNCL_CHK(a.chk, a.gb_part + (size_t)blockIdx.x * a.Cout + cc * 32 + tid, 4); a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + tid] = t; }
+    else { UNCL_CHK(a.chk, a.gb + cc * 32 + tid, 4); atomicAdd(a.gb + cc * 32 + tid, t); }
   }
   for (int i = tid; i < 9 * 1024; i += 512) {
     const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
@@ -1021,8 +1027,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
       valid |= (ok ? 1u : 0u) << j;
       // the up-sampled operand, replicate-padded to the skip's extent (unet_parts.py:292-298)
       const int sy = min(max(iy - dy1, 0), a.s1H - 1), sx = min(max(ix - dx1, 0), a.s1W - 1);
-      q.x1[j] = wg_ld16o(base1, (unsigned)((sy * a.s1W + sx) * a.s1C + chc * 8) * 2u);
-      q.x2[j] = wg_ld16o(base2, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
+      q.x1[j] = WG_LD16O(base1, (unsigned)((sy * a.s1W + sx) * a.s1C + chc * 8) * 2u);
+      q.x2[j] = WG_LD16O(base2, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
     }
     q.valid = valid;
     unsigned gval = 0;
@@ -1032,7 +1038,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
       const bool ok = gy_ < a.Hout && gx_ < a.Wout;
       // (no select on the loaded value here: it would make the request wait for its own data -- the zeroing happens at write time)
       gval |= (ok ? 1u : 0u) << j;
-      q.g[j] = wg_ld16o(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
+      q.g[j] = WG_LD16O(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
     }
     q.gvalid = gval;
   };
@@ -1110,8 +1116,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3c_kernel(const WgArgs a) {
       const int ch8 = ptid >> 3, e = ptid & 7;
       float t = 0.f;
       for (int p = 0; p < NS / 4; ++p) t += sBs[(p * 4 + ch8) * 8 + e];
-      if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + ptid] = t;
-      else atomicAdd(a.gb + cc * 32 + ptid, t);
+      if (a.gb_part != nullptr) { UNCL_CHK(a.chk, a.gb_part + (size_t)blockIdx.x * a.Cout + cc * 32 + ptid, 4); a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 32 + ptid] = t; }
+      else { UNCL_CHK(a.chk, a.gb + cc * 32 + ptid, 4); atomicAdd(a.gb + cc * 32 + ptid, t); }
     }
     __syncthreads();
   }
@@ -1242,14 +1248,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3q_kernel(const WgArgs a) {
       const int iy = iy0 + hyj[j], ix = ix0 + hxj[j];
       const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       valid |= (ok ? 1u : 0u) << j;
-      xr[j] = wg_ld16o(base0, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
+      xr[j] = WG_LD16O(base0, ok ? (unsigned)((iy * a.s0W + ix) * a.s0C + chc * 8) * 2u : 0u);
     }
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
       const int gy_ = y0 + gyj[j], gx_ = x0 + gxj[j];
       const bool ok = gy_ < a.Hout && gx_ < a.Wout;
       gval |= (ok ? 1u : 0u) << j;
-      gr[j] = wg_ld16o(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
+      gr[j] = WG_LD16O(baseg, ok ? (unsigned)((gy_ * a.Wout + gx_) * a.gy_ld + chc * 8) * 2u : 0u);
     }
     xvalid = valid; gvalid = gval;
   };
@@ -1295,8 +1301,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3q_kernel(const WgArgs a) {
       const int ch8 = ptid >> 3, e = ptid & 7;
       float t = 0.f;
       for (int p = 0; p < NS / 8; ++p) t += sBs[(p * 8 + ch8) * 8 + e];
-      if (a.gb_part != nullptr) a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 64 + ptid] = t;
-      else atomicAdd(a.gb + cc * 64 + ptid, t);
+      if (a.gb_part != nullptr) { UNCL_CHK(a.chk, a.gb_part + (size_t)blockIdx.x * a.Cout + cc * 64 + ptid, 4); a.gb_part[(size_t)blockIdx.x * a.Cout + cc * 64 + ptid] = t; }
+      else { UNCL_CHK(a.chk, a.gb + cc * 64 + ptid, 4); atomicAdd(a.gb + cc * 64 + ptid, t); }
     }
     __syncthreads();
   }
@@ -1323,6 +1329,9 @@ bool wg_use_scratch(WgArgs& a, int groups) {
   if (need > t_wg_scratch_floats) return false;
   a.part = t_wg_scratch;
   if (a.gb != nullptr) a.gb_part = t_wg_scratch + (size_t)groups * a.E;
+#ifdef UNCL_CHECKED
+  uncl_chk_add(a.chk, t_wg_scratch, (unsigned long long)t_wg_scratch_floats * sizeof(float));
+#endif
   return true;
 }
 int wg_reduce(const WgArgs& a, int groups, hipStream_t s) {
@@ -1699,6 +1708,17 @@ extern "C" int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, flo
   a.up_tap = -1; a.upH = a.upW = 0;
   a.groups = (d->ksize == 1 && d->z_mode == UNCL_Z_GROUPS && d->groups > 1) ? d->groups : 1;
   a.gy_ld = d->out_C > 0 ? d->out_C : d->Cout;
+#ifdef UNCL_CHECKED
+  {
+    const unsigned long long N = (unsigned long long)d->N, px_in = (unsigned long long)d->H * d->W;
+    uncl_chk_reset(a.chk);
+    uncl_chk_add(a.chk, d->src0, N * (d->ksize == 3 ? (unsigned long long)d->src0_H * d->src0_W : px_in) * d->src0_C * 2);
+    uncl_chk_add(a.chk, d->src1, N * (unsigned long long)d->src1_H * d->src1_W * d->src1_C * 2);
+    uncl_chk_add(a.chk, gy, N * (d->ksize == 3 ? (unsigned long long)a.Hout * a.Wout : px_in) * a.gy_ld * 2);
+    uncl_chk_add(a.chk, dw_packed, (unsigned long long)(d->ksize == 3 ? 9 : a.groups) * d->Cout * d->Cin * 4);
+    uncl_chk_add(a.chk, gb, (unsigned long long)d->Cout * 4);
+  }
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->ksize == 3) {
     // 64 x 64 channel blocks where the layer has them (concat sources: a 64-channel chunk must lie inside one member)
@@ -1760,6 +1780,12 @@ extern "C" int uncl_upconv2x2_wgrad(const void* x, const void* gy, float* dw_pac
   a.tiles_x = 1; a.tiles_y = (rows + 15) / 16; a.total_tiles = a.tiles_y;
   a.nci = C / 32;
   a.up_tap = 0; a.upH = H; a.upW = W; a.gy_ld = Cout; a.groups = 1;
+#ifdef UNCL_CHECKED
+  uncl_chk_reset(a.chk);
+  uncl_chk_add(a.chk, x, (unsigned long long)M * C * 2);
+  uncl_chk_add(a.chk, gy, (unsigned long long)M * 4 * Cout * 2);
+  uncl_chk_add(a.chk, dw_packed, 4ull * Cout * C * 4);
+#endif
   return launch_wg<0, 1>(a, s);
 }
 
