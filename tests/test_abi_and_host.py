@@ -240,3 +240,28 @@ def test_grad_reducer_world2_single_pass_two_pass_and_skipped_step():
                 mean = mean + 1.0
             for r in range(2):          # SGD, lr 1, from zero: parameter = -(mean gradient); identical on both ranks
                 np.testing.assert_allclose(got[r][case][k], -mean, rtol=1e-6, atol=1e-7, err_msg=case + "." + k)
+
+
+def _capture_mode_worker(port, q):
+    import torch.distributed as td
+    from uncltmo_amd.step_graph import capture_error_mode
+    before = capture_error_mode()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=0, world_size=1)
+    during = capture_error_mode()
+    td.destroy_process_group()
+    q.put((before, during, capture_error_mode()))
+
+
+def test_capture_error_mode_follows_the_process_group():
+    """StepGraph / TiledGraph capture in 'thread_local' error mode exactly while a process group is alive: its watchdog thread polls
+    the events of earlier collectives whenever it likes, and inside a 'global'-mode capture window such a query fails -- the
+    watchdog rethrows and the process dies with SIGABRT (found with rocgdb)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_capture_mode_worker, args=(29650 + os.getpid() % 200, q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(60)
+    assert got == ("global", "thread_local", "global")
