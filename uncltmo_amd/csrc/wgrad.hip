@@ -1755,7 +1755,9 @@ extern "C" int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, flo
     if (roll != 0) {
       const int pairs = a.nci * (d->Cout / 32);
       const int groups = 256 / pairs > 0 ? 256 / pairs : 1;
-      if (roll == 2 || a.total_tiles >= g_wg_roll_min * groups)
+      // (N = 8 video frames, tools/wgrad_ab.py 8: with two tiles per workgroup the split-role kernel still wins on the layers with few
+      // channel pairs -- 32 -> 64 at 124^2 46 -> 35 us, 64 -> 128 at 59^2 41 -> 31 -- and loses where 32 / 64 pairs leave four groups)
+      if (roll == 2 || a.total_tiles >= g_wg_roll_min * groups || (pairs <= 8 && a.total_tiles >= 2 * groups))
         return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3r<0>(a, s) : launch_wg3r<1>(a, s);
     }
     return d->src_mode == UNCL_SRC_PLAIN ? launch_wg3<0>(a, s) : launch_wg3<1>(a, s);
