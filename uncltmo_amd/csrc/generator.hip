@@ -676,14 +676,9 @@ int backward_all(const BCtx& c) {
       d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
       BCtx cw = c;
       cw.s = c.wfork();
-      // the two stages whose weight gradient may run in 64 x 64 channel blocks keep the column-sum kernel for their bias: that
-      // kernel has no registers left for the sums (its slot was cleared with the others: the column sums then ADD or overwrite)
-      if (q.ch % 64 == 0 && q.cout % 64 == 0) {
-        RUN(conv_wgrad(cw, d, c.G(q.a), b->gw[q.wi + 1]));
-        RUN(cw.colsum(c.G(q.a), (long long)c.n * ah * aw, q.cout, b->gb[q.wi + 1]));
-      } else {
-        RUN(conv_wgrad_bias(cw, d, c.G(q.a), b->gw[q.wi + 1], b->gb[q.wi + 1], ah, aw, q.cout));
-      }
+      // (rounds 3 - 4a kept a column-sum launch for the two stages whose weight gradient ran in the old 64 x 64 kernel, which had no
+      // registers left for the bias sums; the four-member kernel that takes every skip-concat layer now sums them itself)
+      RUN(conv_wgrad_bias(cw, d, c.G(q.a), b->gw[q.wi + 1], b->gb[q.wi + 1], ah, aw, q.cout));
     }
     RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
     RUN(bwd_ssr_backward(c.dt, c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
