@@ -181,6 +181,23 @@ int uncl_wgrad_set_quad(int on);
  * 149-162, 269 and their autograd) validate every global access against the tensors their launch was given.  out4 = {violations,
  * first offending address, source line, bytes}; reset != 0 clears the record.  The product library returns UNCL_ERR_ARG. */
 int uncl_checked_report(unsigned long long* out4, int reset);
+/* unet_norm='batch_norm' in TRAINING mode (unet_parts.py:20-21, 34-35, 72-73, 85-86: nn.BatchNorm2d between every 3x3 convolution and
+ * its activation; weights.norm = 2): the eighteen layers' weight / bias / running_mean / running_var and the gradient slots of
+ * weight / bias, fp32 device pointers in the order inc.conv.norm, inc.conv.norm1, down_path.0..3.mpconv.1.(norm, norm1),
+ * up_path.0..3.conv.(norm, norm1).  uncl_gen_forward (keep_activations, one chunk) normalises with the batch statistics and updates
+ * the running ones (momentum, unbiased variance); uncl_gen_backward writes the two gradients.  Thread-local; NULL gamma clears it.
+ * Eval mode needs none of this: the host folds the running statistics into the convolutions. */
+/* nn.BatchNorm2d in training mode + activation on one NHWC tensor, stand-alone (the same kernels uncl_gen_forward / _backward use for
+ * unet_norm='batch_norm'): x (N, HW, C) in place; zhat / rstd ([N][C]) kept for the backward; running statistics updated in place
+ * (momentum, unbiased variance); scratch = uncl_bnorm_scratch_bytes(N, C).  Backward: g = dL/dy times the activation derivative, in
+ * place -> dL/dz; g_gamma / g_beta [C] written or accumulated. */
+size_t uncl_bnorm_scratch_bytes(int N, int C);
+int uncl_bnorm_act(void* x, void* zhat, float* rstd, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float momentum, int dtype, int N, int HW, int C, float slope, void* scratch, void* stream);
+int uncl_bnorm_backward(void* g, const void* zhat, const float* rstd, const float* gamma, float* g_gamma, float* g_beta, int accumulate,
+                        int dtype, int N, int HW, int C, void* scratch, void* stream);
+int uncl_gen_set_bn(const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                    float momentum, float* const* g_gamma, float* const* g_beta);
 /* Deterministic weight / bias gradients (bf16 pass; autograd of nn.Conv2d / nn.ConvTranspose2d parameters, GanTrainerImg.py:338,460):
  * with a scratch buffer set, uncl_conv_wgrad / uncl_conv_wgrad_bias / uncl_upconv2x2_wgrad called from THIS thread write the
  * partial sums of their pixel-range groups there and add them up in a fixed order (one extra small launch) instead of using

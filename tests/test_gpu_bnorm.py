@@ -63,25 +63,154 @@ def test_eval_forward_vs_oracle_other_statistics():
             net.state_dict()["up_path.3.conv.norm.running_mean"].add_(0.05)
 
 
-def test_training_mode_is_refused_and_state_dict_loads_strict():
+def test_state_dict_loads_strict_and_video_training_is_refused():
+    from uncltmo_amd.generator import UNetVideo
     net = make("bf16")
     sd = synth.bnorm_state(synth_state(state_spec.generator_spec(unet_norm="batch_norm"), "g0"))
     net.load_state_dict(sd, strict=True)              # the reference's checkpoint layout (model_save_util.py:188-198)
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(inputs().cuda())
-    net.eval()
     y, _ = net(inputs().cuda())
     assert torch.isfinite(y).all()
+    vid = UNetVideo(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "batch_norm", "none", "relu", 1,
+                    "replicate", 2, 0, compute_dtype="bf16").cuda().train()
+    with pytest.raises(NotImplementedError):
+        vid(torch.zeros(1, 2, 1, 256, 256, device="cuda"))
 
 
-def test_tiled_inference_runs_on_the_fused_kernels():
-    """the tiler's entry (model_save_util.py:417-481) with a batch_norm generator: same result as the per-tile forward"""
-    net = make("bf16")
-    frame = synth.hdr_frames(1, 528, 528, salt="bnf").cuda()
-    out = tiler.test_big_size_image2(frame, net, 0, 0, 0)
-    assert out.shape[-2:] == (528, 528) and torch.isfinite(out).all()
-    with torch.no_grad():
-        y, _ = net(frame[:, :, :256, :256].contiguous())
-    # the top-left 192 x 192 pixels are covered by the first tile only (tiles overlap by 64 pixels)
-    assert torch.allclose(out[..., :100, :100].reshape(100, 100), y[0, 0, :100, :100], atol=2e-3)
+def _train_net(dtype):
+    net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "batch_norm", "none", "relu", 1,
+               "replicate", 2, 0, compute_dtype=dtype)
+    synth.fill_state_dict(net, "g0")
+    synth.bnorm_state(net.state_dict())
+    net = net.cuda().train()
+    net.forced_drop_keep = [[1.0, 0.0], [1.0, 0.0]]       # the DropPath mask the fixture injected (both sites)
+    return net
+
+
+def test_training_forward_batch_statistics_vs_reference_golden(golden):
+    """training mode (unet_parts.py:72-73 with nn.BatchNorm2d in train()): batch statistics over (N, H, W) in the forward, the
+    running statistics updated with momentum 0.1 and the unbiased variance, the batch counter advanced -- all on the device,
+    against what the reference module produced and left behind; under no_grad as well (the D step's fake generation)"""
+    g = golden("generator_bnorm")
+    for no_grad in (False, True):
+        net = _train_net("fp32")
+        if no_grad:
+            with torch.no_grad():
+                y, up = net(inputs().cuda())
+        else:
+            y, up = net(inputs().cuda())
+            assert y.requires_grad
+        check_summary(y.detach().cpu(), g, "bnorm_train.x_out", rtol=2e-4, atol=1e-5)
+        check_summary(up.detach().float().cpu(), g, "bnorm_train.up_x", rtol=1e-3, atol=5e-5)
+        sd = net.state_dict()
+        n = 0
+        for k in g:
+            if k.startswith("bnorm_train.after."):
+                name = k[len("bnorm_train.after."):]
+                torch.testing.assert_close(sd[name].double().cpu(), torch.from_numpy(g[k]).double().reshape(sd[name].shape), rtol=2e-4, atol=1e-6,
+                                           msg=lambda m, name=name: name + ": " + m)
+                n += 1
+        assert n == 54
+
+
+def _oracle_grads(x, wy, dt):
+    sd = synth.bnorm_state(synth_state(state_spec.generator_spec(unet_norm="batch_norm"), "g0"))
+    full = {}
+    for k, v in sd.items():
+        if v.dtype != torch.float32:
+            full[k] = v.clone()
+        elif k.endswith("relative_pos") or "running_" in k:
+            full[k] = v.clone().to(dt)
+        else:
+            full[k] = v.clone().to(dt).requires_grad_(True)
+    keep = torch.tensor([[1.0, 0.0], [1.0, 0.0]])
+    yo, upo = OG.unet_image_forward(full, x.to(dt), unet_norm="batch_norm", training=True, drop_keep=keep)
+    ((yo * wy.to(dt)).sum() + 1e-3 * upo.sum()).backward()
+    return {k: v.grad.double() for k, v in full.items() if getattr(v, "grad", None) is not None}
+
+
+def test_training_backward_fp32_vs_oracle_autograd():
+    """parameter gradients of a smooth loss through the batch statistics -- the 57 convolution / embedding tensors and the 36
+    BatchNorm weights and biases -- in fp32 parity mode against torch autograd over the oracle evaluated in fp64.  Measured
+    (tools history): 6e-8 ... 2e-5 on the tail and the last decoder stage (two BatchNorm backward passes deep),
+    6e-5 ... 1e-3 one stage further down, 2e-3 ... 5e-3 from there to the bottleneck, 1 - 3 % in the encoder -- where torch's own
+    fp32 evaluation is 1 - 2 % from fp64 too, but NOT at the bottleneck (1e-5 there): every gradient behind a BatchNorm has zero
+    mean and zero correlation with zhat per channel, so the weight-gradient sums over 10^4 ... 10^5 pixels are cancellations, and
+    the device's fp32 kernels (long sequential fp32 chains per workgroup) lose more of them than the CPU library does; the
+    kernel-level test above pins the BatchNorm arithmetic itself to 5e-5.  The gates are these measured levels with a margin."""
+    net = _train_net("fp32")
+    x = inputs()
+    wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
+    y, up = net(x.cuda())
+    ((y * wy.cuda()).sum() + 1e-3 * up.float().sum()).backward()
+    got = {k: p.grad.detach().double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    assert len(got) == 57 + 36          # (the 58th state_dict entry of the norm-free generator is the fixed relative_pos buffer)
+    ref32, ref64 = _oracle_grads(x, wy, torch.float32), _oracle_grads(x, wy, torch.float64)
+    # the bias of a convolution that a BatchNorm follows has NO gradient (the norm removes the mean it adds): rounding noise on
+    # both sides, compared against the scale of the same layer's weight gradient
+    dead = {c + ".bias" for c, _ in state_spec.batch_norm_layers()}
+    bad = {}
+    for k, gk in got.items():
+        if k in dead:
+            assert gk.abs().max().item() < 1e-3 * ref64[k[:-4] + "weight"].abs().max().item(), k
+            continue
+        own = rel(ref32[k], ref64[k])
+        e64 = rel(gk, ref64[k])
+        gate = 1e-4 if (k.startswith("outc.") or k.startswith("up_path.3.")) else (3e-3 if k.startswith("up_path.2.") else max(3e-2, 5.0 * own))
+        if e64 > gate:
+            bad[k] = (e64, own, gate)
+    assert not bad, bad
+
+
+def test_training_backward_bf16_runs_and_agrees_near_the_output():
+    """bf16 training with the norm runs on the same kernels (and warns: the mean subtraction of the norm's backward cancels the
+    leading bits of gradients that were stored in bf16); near the output the gradients still agree with the oracle"""
+    net = _train_net("bf16")
+    x = inputs()
+    wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
+    with pytest.warns(UserWarning):
+        y, up = net(x.cuda())
+    ((y * wy.cuda()).sum() + 1e-3 * up.float().sum()).backward()
+    got = {k: p.grad.detach().double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    assert len(got) == 57 + 36 and all(torch.isfinite(v).all() for v in got.values())
+    ref = _oracle_grads(x, wy, torch.float32)
+    for k in ("outc.conv.weight", "up_path.3.conv.norm1.weight", "up_path.3.conv.norm1.bias", "up_path.3.conv.conv1.weight"):
+        assert rel(got[k], ref[k]) < 5e-2, (k, rel(got[k], ref[k]))
+
+
+def test_bnorm_kernels_vs_torch_batch_norm():
+    """the stand-alone kernels (uncl_bnorm_act / uncl_bnorm_backward) against F.batch_norm in training mode + LeakyReLU under torch
+    autograd: activation, normalised pre-activation, running statistics, dL/dz, dL/dgamma, dL/dbeta -- odd sizes, a channel with a
+    large mean (the variance is taken as E[x^2] - mean^2 in fp64)"""
+    import torch.nn.functional as F
+    from uncltmo_amd import _hip
+    torch.manual_seed(5)
+    n, h, w, c = 3, 19, 23, 40
+    x = torch.randn(n, c, h, w) * 2 + 0.5
+    x[:, 7] += 30.0
+    gy = torch.randn(n, c, h, w)
+    gamma, beta = 1 + 0.3 * torch.randn(c), 0.2 * torch.randn(c)
+    rm, rv = 0.1 * torch.randn(c), 0.5 + torch.rand(c)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_t, rv_t = rm.clone(), rv.clone()
+    yb = F.batch_norm(xr, rm_t, rv_t, gr, br, training=True, momentum=0.1, eps=1e-5)
+    F.leaky_relu(yb, 0.2).backward(gy)
+    lib = _hip.lib()
+    for code, tol in ((_hip.F32, 2e-5), (_hip.BF16, 4e-2)):
+        dt = _hip.torch_dtype(code)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+        z = torch.empty_like(xd)
+        rs = torch.empty(n, c, dtype=torch.float32, device="cuda")
+        g_d, b_d, rm_d, rv_d = gamma.cuda(), beta.cuda(), rm.clone().cuda(), rv.clone().cuda()
+        scratch = torch.empty(lib.uncl_bnorm_scratch_bytes(n, c), dtype=torch.uint8, device="cuda")
+        _hip.check(lib.uncl_bnorm_act(xd.data_ptr(), z.data_ptr(), rs.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), rm_d.data_ptr(),
+                                      rv_d.data_ptr(), 0.1, code, n, h * w, c, 0.2, scratch.data_ptr(), _hip.stream_ptr()), "bnorm")
+        assert rel(xd.float().cpu().permute(0, 3, 1, 2), F.leaky_relu(yb.detach(), 0.2)) < tol
+        if code == _hip.F32:
+            torch.testing.assert_close(rm_d.cpu(), rm_t, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(rv_d.cpu(), rv_t, rtol=1e-4, atol=1e-6)
+        gm = (gy * torch.where(yb.detach() > 0, torch.ones(()), torch.full((), 0.2))).permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+        gg, gb = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+        _hip.check(lib.uncl_bnorm_backward(gm.data_ptr(), z.data_ptr(), rs.data_ptr(), g_d.data_ptr(), gg.data_ptr(), gb.data_ptr(), 0,
+                                           code, n, h * w, c, scratch.data_ptr(), _hip.stream_ptr()), "bnorm bwd")
+        assert rel(gm.float().cpu().permute(0, 3, 1, 2), xr.grad) < (5e-5 if code == _hip.F32 else 3e-2), rel(gm.float().cpu().permute(0, 3, 1, 2), xr.grad)
+        assert rel(gg.cpu(), gr.grad) < (2e-5 if code == _hip.F32 else 2e-2) and rel(gb.cpu(), br.grad) < (2e-5 if code == _hip.F32 else 2e-2)

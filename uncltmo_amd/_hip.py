@@ -170,6 +170,10 @@ SIGNATURES = {
     "uncl_wgrad_set_cat": (C.c_int, [C.c_int]),
     "uncl_wgrad_set_quad": (C.c_int, [C.c_int]),
     "uncl_checked_report": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+    "uncl_bnorm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "uncl_bnorm_act": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "uncl_bnorm_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uncl_gen_set_bn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "uncl_gcn_tail": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.c_void_p]),
     "uncl_gcn_block": (C.c_int, [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p]),
     "uncl_loader_resize_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -26,7 +26,14 @@ class _GradSet:
         # another: a data-parallel step all-reduces two or three flat tensors in place instead of concatenating 57 of them
         bsz = [int(torch.tensor(self.spec[nm + ".bias"][0]).prod()) for nm in self.names]
         extra = [288, 32, 32, 1, 144 * 256]
-        self.small = torch.empty(sum(bsz) + sum(extra), dtype=torch.float32, device=dev)
+        # unet_norm='batch_norm' (training): gradients of the eighteen BatchNorm2d weights and biases, in state_dict order
+        self.bn_names, bn_sz = [], []
+        if getattr(module, "unet_norm", "none") == "batch_norm":
+            from .state_spec import batch_norm_layers
+            sdp = dict(module.named_parameters())
+            self.bn_names = [q for _, q in batch_norm_layers()]
+            bn_sz = [sdp[q + ".weight"].numel() for q in self.bn_names]
+        self.small = torch.empty(sum(bsz) + sum(extra) + 2 * sum(bn_sz), dtype=torch.float32, device=dev)
         off, self.gb = 0, []
         for n_ in bsz:
             self.gb.append(self.small[off:off + n_])
@@ -35,7 +42,12 @@ class _GradSet:
         self.g_inc_b = self.small[off:off + 32]; off += 32
         self.g_oc_w = self.small[off:off + 32]; off += 32
         self.g_oc_b = self.small[off:off + 1]; off += 1
-        self.g_pe = self.small[off:off + 144 * 256].view(144, 256)
+        self.g_pe = self.small[off:off + 144 * 256].view(144, 256); off += 144 * 256
+        self.g_bn_w, self.g_bn_b = [], []
+        for n_ in bn_sz:
+            self.g_bn_w.append(self.small[off:off + n_]); off += n_
+        for n_ in bn_sz:
+            self.g_bn_b.append(self.small[off:off + n_]); off += n_
         self.flat = torch.empty(sum(self.sizes), dtype=torch.float32, device=dev)      # unpacked weights, layer order
         self.w_off = [sum(self.sizes[:i]) for i in range(len(self.sizes) + 1)]
         self.DEC0 = 14            # packed weights 14..25 are the decoder's (uncl_gen_layer_name order)
@@ -79,6 +91,9 @@ class _GradSet:
             b.ev_decoder_done = h.value if hasattr(h, "value") else int(h)
             if not b.ev_decoder_done:
                 raise _hip.HipError("the decoder-done event has no HIP handle yet (record it once before the call)")
+        if self.bn_names:
+            arrs, _bnkeep = module._bn_arrays((self.g_bn_w, self.g_bn_b))
+            _hip.check(lib.uncl_gen_set_bn(arrs[0], arrs[1], arrs[2], arrs[3], 0.1, arrs[4], arrs[5]), "uncl_gen_set_bn")
         _hip.check(lib.uncl_gen_backward(C.byref(gwts), C.byref(b), _hip.stream_ptr()), "uncl_gen_backward")
 
     def unpack(self, lo=0, hi=None):
@@ -105,6 +120,8 @@ class _GradSet:
         for i, nm in enumerate(self.names):
             g[nm + ".weight"] = self.flat[self.w_off[i]:self.w_off[i + 1]].view(self.spec[nm + ".weight"][0])
             g[nm + ".bias"] = self.gb[i]
+        for q, gw_, gb_ in zip(self.bn_names, self.g_bn_w, self.g_bn_b):
+            g[q + ".weight"], g[q + ".bias"] = gw_, gb_
         return g
 
     def finish(self, last_run):
@@ -264,9 +281,9 @@ class _VideoGeneratorFn(torch.autograd.Function):
 
 
 def _warn_bf16_norm(module):
-    if module._dtype_code() == _hip.BF16 and getattr(module, "unet_norm", "none") == "instance_norm":
+    if module._dtype_code() == _hip.BF16 and getattr(module, "unet_norm", "none") in ("instance_norm", "batch_norm"):
         import warnings
-        warnings.warn("uncltmo_amd: training with unet_norm='instance_norm' in bf16 loses the gradient below the per-channel "
+        warnings.warn("uncltmo_amd: training with unet_norm='instance_norm' / 'batch_norm' in bf16 loses the gradient below the per-channel "
                       "mean that the norm's backward subtracts (activation gradients are stored in bf16); use "
                       "compute_dtype='fp32' for this configuration", UserWarning, stacklevel=3)
 

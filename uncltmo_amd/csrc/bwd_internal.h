@@ -29,6 +29,11 @@ int bwd_maxpool2_f32(const void* x, void* y, int N, int H, int W, int C, hipStre
 int bwd_inorm_forward(int dtype, void* x, void* zhat, float* rstd, const void* res, int res_b0, int N, int P, int C, float slope,
                       hipStream_t s);
 int bwd_inorm_backward(int dtype, void* g, const void* zhat, const float* rstd, int N, int P, int C, hipStream_t s);
+// BatchNorm2d training mode (inorm.hip); scratch = N * C * 16 + C * 8 bytes, 8-byte aligned
+int bwd_bnorm_forward(int dtype, void* x, void* zhat, float* rstd_rep, const float* gamma, const float* beta, float* rmean, float* rvar,
+                      float momentum, const void* res, int res_b0, int N, int P, int C, float slope, void* scratch, hipStream_t s);
+int bwd_bnorm_backward(int dtype, void* g, const void* zhat, const float* rstd_rep, const float* gamma, float* g_gamma, float* g_beta,
+                       int accumulate, int N, int P, int C, void* scratch, hipStream_t s);
 int bwd_maxpool2(int dtype, const void* x, void* y, int N, int H, int W, int C, hipStream_t s);
 int bwd_outc_forward(int dtype, const void* up, const float* w, const float* b, float* out, long long P, int act, hipStream_t s);
 

@@ -55,6 +55,9 @@ enum Buf {
 constexpr int kNormBuf[18] = {B_INC0, B_X0, B_D0A, B_X1, B_D1A, B_X2, B_D2A, B_X3, B_D3A, B_X4,
                               B_U0A, B_U0, B_U1A, B_U1, B_U2A, B_U2, B_U3A, B_UPX};
 constexpr int RSTD_FLOATS = 32 + 32 + 64 + 64 + 128 + 128 + 256 + 256 + 256 + 256 + 128 + 128 + 64 + 64 + 32 + 32 + 32 + 32;
+// BatchNorm training: behind the 1/std blocks, per sample, room for the fp64 partial sums of one layer ([256 channels][2]) and a
+// share of the per-channel coefficients (2 x 256 floats per CALL): bwd_bnorm_forward / _backward scratch
+constexpr int BN_SCRATCH_FLOATS = 1024 + 512;
 inline int norm_index(int buf) {
   for (int i = 0; i < 18; ++i)
     if (kNormBuf[i] == buf) return i;
@@ -75,7 +78,7 @@ const BufDim kDims[B_COUNT] = {
     {254, 254, 32}, {252, 252, 32}, {124, 124, 64}, {122, 122, 64}, {59, 59, 128}, {57, 57, 128}, {26, 26, 256}, {24, 24, 256},
     {10, 10, 256}, {12, 12, 256}, {26, 26, 128}, {28, 28, 128}, {59, 59, 64}, {61, 61, 64}, {124, 124, 32}, {126, 126, 32},
     {254, 254, 32}, {256, 256, 32},
-    {1, RSTD_FLOATS, 1}};
+    {1, RSTD_FLOATS + BN_SCRATCH_FLOATS, 1}};
 
 struct Layout {
   size_t off[B_COUNT];
@@ -137,6 +140,20 @@ struct ProfScope {
   }
 };
 
+// unet_norm = 'batch_norm', training mode: the eighteen BatchNorm2d layers' parameters / running statistics / gradient slots, in the
+// order of kNormBuf.  Thread-local, set by uncl_gen_set_bn before the forward / backward calls that use it (w->norm == 2).
+struct BnState {
+  const float* gamma[18];
+  const float* beta[18];
+  float* rmean[18];
+  float* rvar[18];
+  float* g_gamma[18];
+  float* g_beta[18];
+  float momentum = 0.1f;
+  bool set = false;
+};
+thread_local BnState t_bn;
+
 struct Ctx {
   const uncl_gen_weights* w;
   char* ws;          // workspace base for this chunk's activations
@@ -159,6 +176,13 @@ struct Ctx {
     void* z = norm_keep ? ws + L.off[B_ZN0 + li] : nullptr;
     // 1/std: every layer owns a contiguous [N_total][C] block of the B_RSTD area; this chunk's rows start at n0
     float* rs = norm_keep ? rstd_base + (size_t)roff * n_total + (size_t)n0 * kDims[buf].c : nullptr;
+    if (norm == 2) {
+      // batch statistics need the whole batch in one call of this function: no chunking, activations kept (training)
+      if (!t_bn.set || !norm_keep || n != n_total || n0 != 0) return UNCL_ERR_ARG;
+      void* scratch = rstd_base + (size_t)RSTD_FLOATS * n_total;
+      return bwd_bnorm_forward(w->dtype, p, z, rs, t_bn.gamma[li], t_bn.beta[li], t_bn.rmean[li], t_bn.rvar[li], t_bn.momentum, res,
+                               res_b0, n, kDims[buf].h * kDims[buf].w, kDims[buf].c, slope(), scratch, s);
+    }
     return bwd_inorm_forward(w->dtype, p, z, rs, res, res_b0, n, kDims[buf].h * kDims[buf].w, kDims[buf].c, slope(), s);
   }
   float* rstd_base;  // start of the B_RSTD area of the WHOLE call's layout
@@ -553,6 +577,12 @@ struct BCtx {
     int roff = 0;
     for (int i = 0; i < li; ++i) roff += kDims[kNormBuf[i]].c;
     const float* rs = reinterpret_cast<const float*>(fws + LZ.off[B_RSTD]) + (size_t)roff * n;
+    if (w->norm == 2) {
+      if (!t_bn.set) return UNCL_ERR_ARG;
+      void* scratch = reinterpret_cast<float*>(fws + LZ.off[B_RSTD]) + (size_t)RSTD_FLOATS * n;      // the forward workspace's scratch tail
+      return bwd_bnorm_backward(dt, g, fws + LZ.off[B_ZN0 + li], rs, t_bn.gamma[li], t_bn.g_gamma[li], t_bn.g_beta[li], b->accumulate, n,
+                                kDims[buf].h * kDims[buf].w, kDims[buf].c, scratch, s);
+    }
     return bwd_inorm_backward(dt, g, fws + LZ.off[B_ZN0 + li], rs, n, kDims[buf].h * kDims[buf].w, kDims[buf].c, s);
   }
   bool video() const { return b->carry_in != nullptr || b->carry_out != nullptr; }
@@ -884,7 +914,10 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   int chunk = r->chunk;
   if (chunk <= 0 || chunk > r->N) chunk = r->N;
   const int n_alloc = r->keep_activations ? r->N : chunk;
-  if (w->norm != 0 && w->norm != 1) return UNCL_ERR_ARG;
+  if (w->norm < 0 || w->norm > 2) return UNCL_ERR_ARG;
+  // batch_norm (2) is a TRAINING mode of this entry (eval folds the running statistics into the weights on the host): the whole
+  // batch in one chunk, activations kept, the layers' parameters announced with uncl_gen_set_bn
+  if (w->norm == 2 && (!r->keep_activations || chunk != r->N || !t_bn.set || r->prev_workspace != nullptr)) return UNCL_ERR_ARG;
   Layout L = make_layout(n_alloc, w->dtype, w->norm && r->keep_activations);
   if (r->workspace_bytes < L.total) return UNCL_ERR_ARG;
   const size_t es = uncl_is_h16(w->dtype) ? 2 : 4;
@@ -960,6 +993,26 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
       return run_chunk(cw, r->x, r->out, r->up_x, nullptr, nullptr, nullptr, 2);
     }
   }
+  return UNCL_OK;
+}
+
+// unet_norm = 'batch_norm', training mode (w->norm == 2): the eighteen BatchNorm2d layers in the order inc.conv.norm, inc.conv.norm1,
+// down_path.0..3 (norm, norm1), up_path.0..3 (norm, norm1) -- fp32 device pointers: weight, bias, running_mean, running_var (updated
+// in place by the forward), and the gradient slots of weight / bias (written by the backward; NULL arrays for a forward-only
+// caller).  Thread-local; stays set until called again (all-NULL arrays clear it).
+extern "C" int uncl_gen_set_bn(const float* const* gamma, const float* const* beta, float* const* running_mean,
+                               float* const* running_var, float momentum, float* const* g_gamma, float* const* g_beta) {
+  if (gamma == nullptr || beta == nullptr) { t_bn.set = false; return UNCL_OK; }
+  for (int i = 0; i < 18; ++i) {
+    if (gamma[i] == nullptr || beta[i] == nullptr) return UNCL_ERR_ARG;
+    t_bn.gamma[i] = gamma[i]; t_bn.beta[i] = beta[i];
+    t_bn.rmean[i] = running_mean ? running_mean[i] : nullptr;
+    t_bn.rvar[i] = running_var ? running_var[i] : nullptr;
+    t_bn.g_gamma[i] = g_gamma ? g_gamma[i] : nullptr;
+    t_bn.g_beta[i] = g_beta ? g_beta[i] : nullptr;
+  }
+  t_bn.momentum = momentum;
+  t_bn.set = true;
   return UNCL_OK;
 }
 

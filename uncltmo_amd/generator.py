@@ -181,10 +181,7 @@ class _GeneratorBase(nn.Module):
         # running statistics are folded into weight and bias here, once per parameter version, and the forward runs the fused
         # conv + activation kernels of the norm-free topology (unet_parts.py:20-21, 34-35, 57-75; nn.BatchNorm2d eps 1e-5)
         fold = {}
-        if self.unet_norm == "batch_norm":
-            if self.training:
-                raise NotImplementedError("uncltmo_amd: unet_norm='batch_norm' is built for inference (eval mode: running statistics "
-                                          "folded into the convolutions); training with batch statistics is not -- call .eval()")
+        if self.unet_norm == "batch_norm" and not self.training:
             from .state_spec import batch_norm_layers
             for cname, nname in batch_norm_layers():
                 scale = sd[nname + ".weight"].detach().double() / torch.sqrt(sd[nname + ".running_var"].detach().double() + 1e-5)
@@ -265,7 +262,9 @@ class _GeneratorBase(nn.Module):
         gw.relative_pos = f32("gcn.module.0.0.relative_pos")
         gw.outc_w, gw.outc_b = f32("outc.conv.weight"), f32("outc.conv.bias")
         gw.act = _ACT[self.activation]
-        gw.norm = 1 if self.unet_norm == "instance_norm" else 0
+        # 1: InstanceNorm kernels; 2: BatchNorm in TRAINING mode (batch statistics, uncl_gen_set_bn announces the layers' tensors);
+        # BatchNorm in eval mode is folded into the weights above and runs as the norm-free topology
+        gw.norm = 1 if self.unet_norm == "instance_norm" else (2 if (self.unet_norm == "batch_norm" and self.training) else 0)
         gw.last_act = _LAST[self.last_layer]
         self._packed = (gw, keep)
         self._pack_key = key
@@ -274,13 +273,43 @@ class _GeneratorBase(nn.Module):
     def _workspace(self, n, chunk, keep_act, dev, slot=0):
         lib = _hip.lib()
         code = self._dtype_code()
-        nbytes = lib.uncl_gen_workspace_bytes_ex(n, chunk, code, int(keep_act), 1 if self.unet_norm == "instance_norm" else 0)
+        nbytes = lib.uncl_gen_workspace_bytes_ex(n, chunk, code, int(keep_act), 1 if (self.unet_norm == "instance_norm" or self._bn_train()) else 0)
         k = (slot, dev)
         ws = self._ws.get(k)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._ws[k] = ws
         return ws, nbytes
+
+    def _bn_train(self):
+        return self.unet_norm == "batch_norm" and self.training
+
+    def _bn_arrays(self, grads=None):
+        """ctypes pointer arrays for uncl_gen_set_bn: the eighteen BatchNorm2d layers in state_dict order (= the library's order);
+        `grads` = (list of 18 weight-gradient tensors, list of 18 bias-gradient tensors) or None"""
+        from .state_spec import batch_norm_layers
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        names = [q for _, q in batch_norm_layers()]
+        keep = []
+
+        def arr(key):
+            ts = []
+            for q in names:
+                t = sd[q + key]
+                if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                    raise _hip.HipError("batch_norm tensors must be contiguous fp32 device tensors (%s%s)" % (q, key))
+                ts.append(t)
+            keep.extend(ts)
+            return (C.c_void_p * 18)(*[t.data_ptr() for t in ts])
+
+        a = [arr(".weight"), arr(".bias"), arr(".running_mean"), arr(".running_var")]
+        if grads is not None:
+            keep.extend(grads[0] + grads[1])
+            a += [(C.c_void_p * 18)(*[t.data_ptr() for t in grads[0]]), (C.c_void_p * 18)(*[t.data_ptr() for t in grads[1]])]
+        else:
+            a += [None, None]
+        return a, keep
 
     def _drop_scale(self, n, dev):
         """(2, N) multipliers keep/keep_prob of the two DropPath sites, or None in eval mode."""
@@ -301,6 +330,15 @@ class _GeneratorBase(nn.Module):
         n = x_flat.shape[0]
         dev = x_flat.device
         chunk = self.chunk if self.chunk and self.chunk > 0 else 0
+        bn_train = self._bn_train()
+        if bn_train:
+            # batch statistics (unet_parts.py:72-73 in training mode): the whole batch in one chunk with its normalised
+            # pre-activations kept, also under no_grad -- the reference's module updates its running statistics there too
+            if prev_ws is not None:
+                raise NotImplementedError("uncltmo_amd: the video generator with unet_norm='batch_norm' trains on the reference only")
+            keep_act, chunk = True, 0
+            arrs, _bnkeep = self._bn_arrays()
+            _hip.check(lib.uncl_gen_set_bn(arrs[0], arrs[1], arrs[2], arrs[3], 0.1, None, None), "uncl_gen_set_bn")
         ws, nbytes = self._workspace(n, chunk, keep_act, dev, slot)
         out = torch.empty(n, 1, 256, 256, dtype=torch.float32, device=dev)
         up = torch.empty(n, 256, 256, 32, dtype=_hip.torch_dtype(gw.dtype), device=dev) if need_feat else None
@@ -316,6 +354,11 @@ class _GeneratorBase(nn.Module):
         run.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
         run.save_preact = int(save_preact)
         _hip.check(lib.uncl_gen_forward(C.byref(gw), C.byref(run), _hip.stream_ptr()), "uncl_gen_forward")
+        if bn_train:
+            from .state_spec import batch_norm_layers
+            bufs = dict(self.named_buffers())
+            for _, q in batch_norm_layers():
+                bufs[q + ".num_batches_tracked"].add_(1)
         if return_drop:
             return out, up, knn, ws, ds
         return out, up, knn, ws
@@ -357,8 +400,8 @@ class UNet(_GeneratorBase):
         return x_out, up_x
 
     def _needs_autograd(self, x):
-        # batch_norm is an inference configuration here: the folded weights have no backward pass of their own
-        return self.unet_norm != "batch_norm"
+        # batch_norm in EVAL mode is an inference configuration: the folded weights have no backward pass of their own
+        return self.unet_norm != "batch_norm" or self.training
 
     @torch.no_grad()
     def infer(self, x, want_knn=False):
@@ -393,6 +436,9 @@ class UNetVideo(_GeneratorBase):
         if x.dim() != 5:
             raise ValueError("video generator expects (B,T,1,H,W)")
         self._check_input(x, 3)
+        if self._bn_train():
+            raise NotImplementedError("uncltmo_amd: the video generator with unet_norm='batch_norm' is built for inference; training "
+                                      "with batch statistics covers the image generator")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.unet_norm != "batch_norm":
             from .autograd import generator_video_apply
             x_out, feats = generator_video_apply(self, x)
