@@ -348,6 +348,14 @@ typedef struct uncl_gen_run {
   int save_preact;            /* 1: also keep the pre-GELU values of the graph block (needed by uncl_gen_backward)    */
   const void* prev_workspace; /* video: workspace of the previous frame (same N, keep_activations=1); the
                                  first C/32 channels entering every down/up stage come from it (Unet.py:244,270) */
+  /* CLIP layout (training, Unet.py:213-289 frame loop): clip_T > 0 says `workspace` is ONE workspace laid out for clip_T * N
+   * samples (uncl_gen_workspace_bytes(clip_T * N, 0, dtype, 1)), every buffer (clip_T * N, ...) with the frames one behind the
+   * other, and this call is frame clip_t: it owns samples [clip_t * N, (clip_t + 1) * N) of every buffer and takes its
+   * hand-off channels from frame clip_t - 1's slice (prev_workspace must be NULL: it is implied).  Needs keep_activations,
+   * no chunking, norm = 0.  The backward pass can then take a clip's weight gradients in ONE launch per layer over all
+   * clip_T * N samples (uncl_gen_bwd.clip_T). */
+  int clip_T;
+  int clip_t;
 } uncl_gen_run;
 
 /* Backward of uncl_gen_forward (bf16, keep_activations = 1, save_preact = 1): gradients of every generator parameter
@@ -379,6 +387,15 @@ typedef struct uncl_gen_bwd {
   void* ev_decoder_done;     /* optional hipEvent_t, recorded on the stream once the weight gradients of the decoder (packed
                                 weights 14..25, outc) are complete while the graph block and the encoder are still to run: a data-
                                 parallel caller starts the all-reduce of that half there (uncltmo_amd/distributed.py)            */
+  /* CLIP layout with DEFERRED weight gradients (GanTrainer.py:338,460 backward over a clip): clip_T > 0 says `workspace` is the
+   * clip workspace of uncl_gen_run.clip_T and `grad_workspace` one arena of uncl_gen_backward_workspace_bytes(clip_T * N); the
+   * call is frame clip_t (frames still visited last to first, prev_workspace NULL = implied, carries as before).  Calls for
+   * frames > 0 run the data-gradient chain only and leave their activation gradients in their slice of the arena; the call
+   * for frame 0 then takes the 3x3 / 2x2 weight and bias gradients ONCE over all clip_T * N samples (a frame's weight
+   * gradients depend on nothing later in the pass) -- 26 launches per clip instead of 26 per frame.  The graph block's 1x1
+   * gradients, outc, the first layer and pos_embed stay per frame. */
+  int clip_T;
+  int clip_t;
 } uncl_gen_bwd;
 size_t uncl_gen_backward_workspace_bytes(int N);
 size_t uncl_gen_carry_bytes(int N);

@@ -57,7 +57,7 @@ class GenRun(C.Structure):
         ("N", C.c_int), ("chunk", C.c_int), ("keep_activations", C.c_int),
         ("x", C.c_void_p), ("out", C.c_void_p), ("up_x", C.c_void_p), ("knn_idx", C.c_void_p),
         ("drop_scale", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("save_preact", C.c_int), ("prev_workspace", C.c_void_p),
+        ("save_preact", C.c_int), ("prev_workspace", C.c_void_p), ("clip_T", C.c_int), ("clip_t", C.c_int),
     ]
 
 
@@ -70,7 +70,7 @@ class GenBwd(C.Structure):
         ("g_inc0_w", C.c_void_p), ("g_inc0_b", C.c_void_p), ("g_outc_w", C.c_void_p), ("g_outc_b", C.c_void_p),
         ("g_pos_embed", C.c_void_p),
         ("accumulate", C.c_int), ("prev_workspace", C.c_void_p), ("carry_in", C.c_void_p), ("carry_out", C.c_void_p),
-        ("ev_decoder_done", C.c_void_p),
+        ("ev_decoder_done", C.c_void_p), ("clip_T", C.c_int), ("clip_t", C.c_int),
     ]
 
 

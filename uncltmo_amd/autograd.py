@@ -5,6 +5,7 @@ gradients, fp32 accumulation, fp32 parameter gradients); 'fp32' is the PARITY mo
 deterministic fixed-order kernels (csrc/bwd_f32.hip) -- slower, used to check a trainer step against the CPU oracle at fp32
 tolerances (tests/test_gpu_trainer.py, tests/test_gpu_backward.py)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -54,13 +55,16 @@ class _GradSet:
         self.ev_half = None
         self.gws = None
 
-    def run(self, xf, out, up, ws, ds, g_out, gup, accumulate=False, prev_ws=None, carry_in=None, carry_out=None, ev_half=None):
-        """One uncl_gen_backward call over the n samples of (xf, out, up, ws)."""
+    def run(self, xf, out, up, ws, ds, g_out, gup, accumulate=False, prev_ws=None, carry_in=None, carry_out=None, ev_half=None,
+            clip=None):
+        """One uncl_gen_backward call over the n samples of (xf, out, up, ws).  clip = (T, t): `ws` is a clip workspace, the
+        gradient arena spans the clip too and the 3x3 / 2x2 weight gradients are taken once, by the call for frame 0
+        (uncl_gen_bwd.clip_T)."""
         lib = _hip.lib()
         module = self.module
         gwts, _keep = module._packed_weights()
         n = xf.shape[0]
-        gbytes = lib.uncl_gen_backward_workspace_bytes_dt(n, module._dtype_code())
+        gbytes = lib.uncl_gen_backward_workspace_bytes_dt(n * clip[0] if clip is not None else n, module._dtype_code())
         # the gradient arena (gigabytes at training batch sizes) lives with the module: one backward pass runs at a time, and
         # allocating it per pass sends the caching allocator through its slow paths once other large blocks have come and gone
         cache = module.__dict__.setdefault("_gws_cache", {})
@@ -83,6 +87,8 @@ class _GradSet:
         b.g_outc_w, b.g_outc_b, b.g_pos_embed = self.g_oc_w.data_ptr(), self.g_oc_b.data_ptr(), self.g_pe.data_ptr()
         b.accumulate = int(accumulate)
         b.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
+        if clip is not None:
+            b.clip_T, b.clip_t, b.prev_workspace = int(clip[0]), int(clip[1]), None
         b.carry_in = carry_in.data_ptr() if carry_in is not None else None
         b.carry_out = carry_out.data_ptr() if carry_out is not None else None
         b.ev_decoder_done = None
@@ -222,7 +228,13 @@ class _GeneratorFn(torch.autograd.Function):
 class _VideoGeneratorFn(torch.autograd.Function):
     """Clip forward (frames sequential, Unet.py:213-289) and backward through time: frames are visited last to first, the
     head-channel gradients of the eight recurrent hand-offs travel between consecutive frames in a small carry arena and
-    the parameter gradients of all frames accumulate in one packed set."""
+    the parameter gradients of all frames accumulate in one packed set.
+
+    Clip layout (`module.clip_wgrad`, default: on for bf16, T > 1, unet_norm 'none'): the frames' activations live in ONE workspace
+    laid out for T * B samples and their activation gradients in one arena of the same shape, so that the 3x3 / 2x2 weight and
+    bias gradients are taken ONCE per clip over all T * B samples after the data-gradient chain has reached frame 0 -- 26
+    launches at T * B samples each instead of 26 per frame at B (a frame's weight gradients depend on nothing later in the
+    pass; at B = 8 every per-frame launch sat on its 27 - 55 us floor)."""
 
     @staticmethod
     def forward(ctx, module, x, *params):
@@ -231,8 +243,23 @@ class _VideoGeneratorFn(torch.autograd.Function):
         dev = x.device
         frames, outs, feats, leases = [], [], [], []
         prev_ws = None
+        use_clip = getattr(module, "clip_wgrad", None)
+        if use_clip is None:     # UNCL_CLIP_WGRAD=0: the per-frame form (A/B timing)
+            use_clip = module._dtype_code() == _hip.BF16 and os.environ.get("UNCL_CLIP_WGRAD", "1") != "0"
+        use_clip = bool(use_clip) and T > 1 and getattr(module, "unet_norm", "none") == "none"
+        ctx.clip = use_clip
+        if use_clip:
+            lease = _WsLease(module, dev, ("clipws", T))
+            lease.install(("clipws", T))
         for t in range(T):
             xf = x[:, t].detach().reshape(B, 256, 256).float().contiguous()
+            if use_clip:
+                out, up, _, ws, ds = module._run(xf, need_feat=True, keep_act=True, slot=("clipws", T), save_preact=True,
+                                                 return_drop=True, clip=(T, t))
+                frames.append((xf, out, up, ws, ds))
+                feats.append(gauss_stats(up, B, 256, 256, 32).reshape(B, 1, 64, 1, 1))
+                outs.append(out.reshape(B, 1, 1, 256, 256))
+                continue
             lease = _WsLease(module, dev, ("clip", t))
             lease.install(("clip", t))
             out, up, _, ws, ds = module._run(xf, need_feat=True, prev_ws=prev_ws, keep_act=True, slot=("clip", t),
@@ -243,6 +270,9 @@ class _VideoGeneratorFn(torch.autograd.Function):
             outs.append(out.reshape(B, 1, 1, 256, 256))
             frames.append((xf, out, up, ws, ds))
             prev_ws = ws
+        if use_clip:
+            lease.take(("clipws", T))
+            leases.append(lease)
         ctx.module, ctx.frames, ctx.leases = module, frames, leases
         return torch.cat(outs, 1), torch.cat(feats, 1)
 
@@ -268,8 +298,13 @@ class _VideoGeneratorFn(torch.autograd.Function):
                                                          _hip.stream_ptr()), "uncl_gauss_stats_backward")
             carry_in = carries[(t + 1) % 2] if t < T - 1 else None      # written by frame t+1
             carry_out = carries[t % 2] if t > 0 else None               # read by frame t-1
-            call = lambda ev, a_=(xf, out, up, ws, ds, go, gup), t_=t, ci=carry_in, co=carry_out: gs.run(
-                *a_, accumulate=(t_ != T - 1), prev_ws=frames[t_ - 1][3] if t_ > 0 else None, carry_in=ci, carry_out=co, ev_half=ev)
+            if ctx.clip:
+                call = lambda ev, a_=(xf, out, up, ws, ds, go, gup), t_=t, ci=carry_in, co=carry_out: gs.run(
+                    *a_, accumulate=(t_ != T - 1), carry_in=ci, carry_out=co, ev_half=ev, clip=(T, t_))
+            else:
+                call = lambda ev, a_=(xf, out, up, ws, ds, go, gup), t_=t, ci=carry_in, co=carry_out: gs.run(
+                    *a_, accumulate=(t_ != T - 1), prev_ws=frames[t_ - 1][3] if t_ > 0 else None, carry_in=ci, carry_out=co,
+                    ev_half=ev)
             if t > 0:
                 call(None)
         grads = gs.finish(call)         # frame 0: the last call of the pass

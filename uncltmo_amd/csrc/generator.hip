@@ -188,7 +188,8 @@ struct Ctx {
   float* rstd_base;  // start of the B_RSTD area of the WHOLE call's layout
   int n_total, n0;   // tiles of the whole call, first tile of this chunk
   void* ptr(int b) const { return ws + L.off[b]; }
-  const void* pptr(int b) const { return prev ? prev + L.off[b] : nullptr; }
+  Layout Lp;         // the previous frame's buffer offsets from `prev` (= L for a workspace of its own, its slice of a clip workspace)
+  const void* pptr(int b) const { return prev ? prev + Lp.off[b] : nullptr; }
 };
 
 uncl_conv_desc base_desc(const Ctx& c, int wi, int ksize, int pad, int cin, int cout, int act) {
@@ -515,6 +516,8 @@ struct BCtx {
   const char* pws;  // previous frame's forward workspace (video, frame > 0) or NULL
   char* gws;   // gradient arena (same layout)
   Layout L;
+  Layout Lp;     // the previous frame's buffer offsets from `pws` (= L for a workspace of its own; its slice of a clip workspace)
+  bool defer = false;   // clip layout: this call leaves the 3x3 / 2x2 weight and bias gradients to the clip's last call
   BwdScratch sc;
   int n;
   int dt;        // UNCL_BF16 (training) or UNCL_F32 (parity mode: deterministic plain-fp32 kernels, bwd_f32.hip)
@@ -592,7 +595,7 @@ struct BCtx {
   const void* mixed(int slot) const {
     const CarrySlot& k = kCarry[slot];
     if (!pws) return F(k.buf);
-    if (bwd_mix_heads(dt, F(k.buf), pws + L.off[k.buf], sc.mix, (long long)n * k.pix, kDims[k.buf].c, k.pc, s) != UNCL_OK) return nullptr;
+    if (bwd_mix_heads(dt, F(k.buf), pws + Lp.off[k.buf], sc.mix, (long long)n * k.pix, kDims[k.buf].c, k.pc, s) != UNCL_OK) return nullptr;
     return sc.mix;
   }
   int handoff(int slot, void* g, const void* mask) const {
@@ -631,6 +634,7 @@ int conv_wgrad_bias(const BCtx& c, const uncl_conv_desc& d, const void* gy, floa
 // weight + bias gradient of a 3x3 layer whose input is buffer `xin` (plain) and whose output gradient is gy
 int wgrad3(const BCtx& c, int wi, int xin, int pad, int cin, int cout, const void* gy, int oh, int ow,
            const void* src = nullptr) {
+  if (c.defer) return UNCL_OK;
   uncl_conv_desc d = bdesc(c, 3, pad, kDims[xin].h, kDims[xin].w, cin, cout);
   d.src0 = src ? src : c.F(xin); d.src0_H = kDims[xin].h; d.src0_W = kDims[xin].w; d.src0_C = kDims[xin].c;
   BCtx cw = c;
@@ -699,7 +703,7 @@ int backward_all(const BCtx& c) {
     RUN(dgrad3(c, q.wi + 2, c.G(q.out), oh, ow, q.cout, 0, q.cout, c.G(q.a), ah, aw, c.F(q.a), 0));
     // conv a (ConvT 3x3 on the concat, 4ch -> cout)
     RUN(c.unnorm(c.G(q.a), q.a));
-    {
+    if (!c.defer) {
       uncl_conv_desc d = bdesc(c, 3, 2, sh, sw, 4 * q.ch, q.cout);
       d.src_mode = UNCL_SRC_CONCAT_SSR;
       d.src0 = c.F(q.skip); d.src0_H = sh; d.src0_W = sw; d.src0_C = q.ch;
@@ -715,9 +719,9 @@ int backward_all(const BCtx& c) {
     // up (ConvT 2x2 s2, ch -> ch): input x1
     const int xh = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].h, xw = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].w;
     const int slot = 4 + i;  // hand-off slot of this stage's input (video): GOUT, U0, U1, U2
-    const void* x1m = c.mixed(slot);
-    if (!x1m) return UNCL_ERR_LAUNCH;
-    {
+    const void* x1m = c.defer ? nullptr : c.mixed(slot);
+    if (!x1m && !c.defer) return UNCL_ERR_LAUNCH;
+    if (!c.defer) {
       BCtx cw = c;
       cw.s = c.wfork();
       if (c.dt == UNCL_F32) RUN(bwd_upconv2x2_wgrad_f32(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, cw.s));
@@ -739,7 +743,7 @@ int backward_all(const BCtx& c) {
     RUN(c.handoff(slot, c.G(q.x1), x1mask));
   }
   // the decoder's parameter gradients are final from here on (biases: staged column sums are flushed first)
-  if (b->ev_decoder_done) {
+  if (b->ev_decoder_done && !c.defer) {
     RUN(c.flush_colsums());
     if (hipEventRecord(reinterpret_cast<hipEvent_t>(b->ev_decoder_done), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
   }
@@ -774,12 +778,14 @@ int backward_all(const BCtx& c) {
   RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, c.sc.tB, 256, 256, b->gw[W_GFC1], true));
   RUN(dgrad1(c, W_GFC1, c.sc.tB, 256, 256, c.G(B_X4), c.G(B_GX1)));
   RUN(bwd_sum_samples(c.dt, c.G(B_X4), b->g_pos_embed, c.n, per256, b->accumulate, c.s));
-  RUN(bwd_mask_minus(c.dt, c.G(B_X4), c.F(B_X4), c.w->pos_embed, c.sc.tA, c.n, per256, c.slope, c.s));
+  // (deferred weight gradients: the masked gradient replaces G(X4) element by element, so that it is still there at the clip's end)
+  void* g4 = c.defer ? c.G(B_X4) : static_cast<void*>(c.sc.tA);
+  RUN(bwd_mask_minus(c.dt, c.G(B_X4), c.F(B_X4), c.w->pos_embed, g4, c.n, per256, c.slope, c.s));
   // ---- encoder
   // down3: conv (valid, pooled X3 -> D3A), ConvT (D3A -> X4)
-  RUN(c.unnorm(c.sc.tA, B_X4));
-  RUN(wgrad3(c, W_D3B, B_D3A, 2, 256, 256, c.sc.tA, 12, 12));
-  RUN(dgrad3(c, W_D3B, c.sc.tA, 12, 12, 256, 0, 256, c.G(B_D3A), 10, 10, c.F(B_D3A), 0));
+  RUN(c.unnorm(g4, B_X4));
+  RUN(wgrad3(c, W_D3B, B_D3A, 2, 256, 256, g4, 12, 12));
+  RUN(dgrad3(c, W_D3B, g4, 12, 12, 256, 0, 256, c.G(B_D3A), 10, 10, c.F(B_D3A), 0));
   struct Enc { int wa, wb, xin, pooled, mid, out, cin, cout; };
   // second conv of each level first (its output gradient is complete), then the first conv + pool backward
   const Enc en[3] = {{W_D2A, W_D2B, B_X2, B_X2P, B_D2A, B_X3, 128, 256},
@@ -787,7 +793,7 @@ int backward_all(const BCtx& c) {
                      {W_D0A, W_D0B, B_X0, B_X0P, B_D0A, B_X1, 32, 64}};
   // down3's first conv reads pooled X3
   RUN(c.unnorm(c.G(B_D3A), B_D3A));
-  {
+  if (!c.defer) {
     const void* xm = c.mixed(3);
     if (!xm) return UNCL_ERR_LAUNCH;
     RUN(wgrad3(c, W_D3A, B_X3P, 0, 256, 256, c.G(B_D3A), 10, 10, xm));
@@ -801,8 +807,8 @@ int backward_all(const BCtx& c) {
     RUN(c.unnorm(c.G(e.out), e.out));
     RUN(wgrad3(c, e.wb, e.mid, 0, e.cout, e.cout, c.G(e.out), oh, oh));
     RUN(dgrad3(c, e.wb, c.G(e.out), oh, oh, e.cout, 2, e.cout, c.G(e.mid), mh, mh, c.F(e.mid), 0));
-    const void* xm = c.mixed(2 - i);
-    if (!xm) return UNCL_ERR_LAUNCH;
+    const void* xm = c.defer ? nullptr : c.mixed(2 - i);
+    if (!xm && !c.defer) return UNCL_ERR_LAUNCH;
     RUN(c.unnorm(c.G(e.mid), e.mid));
     RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh, xm));
     RUN(dgrad3(c, e.wa, c.G(e.mid), mh, mh, e.cout, 2, e.cin, c.sc.gpool, ph, ph, nullptr, 0));
@@ -815,6 +821,78 @@ int backward_all(const BCtx& c) {
   RUN(dgrad3(c, W_INC1, c.G(B_X0), 252, 252, 32, 2, 32, c.G(B_INC0), 254, 254, c.F(B_INC0), 0));
   RUN(c.unnorm(c.G(B_INC0), B_INC0));
   RUN(bwd_conv_in_c1_wgrad(c.dt, c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, b->accumulate, c.sc.misc, c.s));
+#undef RUN
+  return UNCL_OK;
+}
+
+// The 3x3 / 2x2 weight and bias gradients of a whole clip in one launch per layer (uncl_gen_bwd.clip_T): `c` spans all
+// T * nf samples of the clip workspace and of the gradient arena (c.n = T * nf, offsets of frame 0), whose slices the frames'
+// data-gradient chains have filled.  A hand-off stage's input is its frame's buffer with the head channels of the frame
+// before it (frame 0: its own), rebuilt for the whole clip in `mix`.
+int deferred_wgrads(const BCtx& c, int nf, int T) {
+  const uncl_gen_bwd* b = c.b;
+  int rc;
+#define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
+  auto mixed_all = [&](int slot) -> const void* {
+    const CarrySlot& k = kCarry[slot];
+    if (T == 1) return c.F(k.buf);
+    const size_t fb = (size_t)nf * k.pix * kDims[k.buf].c * c.es;     // one frame of this buffer
+    const char* x = static_cast<const char*>(c.F(k.buf));
+    if (hipMemcpyAsync(c.sc.mix, x, fb, hipMemcpyDeviceToDevice, c.s) != hipSuccess) return nullptr;
+    if (bwd_mix_heads(c.dt, x + fb, x, c.sc.mix + fb, (long long)(T - 1) * nf * k.pix, kDims[k.buf].c, k.pc, c.s) != UNCL_OK)
+      return nullptr;
+    return c.sc.mix;
+  };
+  struct Stage { int wi, x1, skip, up, a, out, ch, cout; };
+  const Stage st[4] = {{W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128},
+                       {W_U1UP, B_U0, B_X2, B_U1UP, B_U1A, B_U1, 128, 64},
+                       {W_U2UP, B_U1, B_X1, B_U2UP, B_U2A, B_U2, 64, 32},
+                       {W_U3UP, B_U2, B_X0, B_U3UP, B_U3A, B_UPX, 32, 32}};
+  for (int i = 3; i >= 0; --i) {
+    const Stage& q = st[i];
+    const int oh = kDims[q.out].h, ow = kDims[q.out].w, ah = kDims[q.a].h, aw = kDims[q.a].w;
+    const int sh = kDims[q.skip].h, sw = kDims[q.skip].w, uh = kDims[q.up].h, uw = kDims[q.up].w;
+    RUN(wgrad3(c, q.wi + 2, q.a, 2, q.cout, q.cout, c.G(q.out), oh, ow));
+    {
+      uncl_conv_desc d = bdesc(c, 3, 2, sh, sw, 4 * q.ch, q.cout);
+      d.src_mode = UNCL_SRC_CONCAT_SSR;
+      d.src0 = c.F(q.skip); d.src0_H = sh; d.src0_W = sw; d.src0_C = q.ch;
+      d.src1 = c.F(q.up); d.src1_H = uh; d.src1_W = uw; d.src1_C = q.ch;
+      RUN(conv_wgrad_bias(c, d, c.G(q.a), b->gw[q.wi + 1], b->gb[q.wi + 1], ah, aw, q.cout));
+    }
+    const int xh = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].h, xw = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].w;
+    const void* x1m = mixed_all(4 + i);
+    if (!x1m) return UNCL_ERR_LAUNCH;
+    if (c.dt == UNCL_F32) RUN(bwd_upconv2x2_wgrad_f32(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
+    else {
+      c.wdet_select();
+      RUN(uncl_upconv2x2_wgrad(x1m, c.G(q.up), b->gw[q.wi], c.n, xh, xw, q.ch, q.ch, c.s));
+    }
+    RUN(c.colsum(c.G(q.up), (long long)c.n * uh * uw, q.ch, b->gb[q.wi]));
+  }
+  if (b->ev_decoder_done) {
+    RUN(c.flush_colsums());
+    if (hipEventRecord(reinterpret_cast<hipEvent_t>(b->ev_decoder_done), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
+  }
+  RUN(wgrad3(c, W_D3B, B_D3A, 2, 256, 256, c.G(B_X4), 12, 12));
+  {
+    const void* xm = mixed_all(3);
+    if (!xm) return UNCL_ERR_LAUNCH;
+    RUN(wgrad3(c, W_D3A, B_X3P, 0, 256, 256, c.G(B_D3A), 10, 10, xm));
+  }
+  struct Enc { int wa, wb, pooled, mid, out, cin, cout; };
+  const Enc en[3] = {{W_D2A, W_D2B, B_X2P, B_D2A, B_X3, 128, 256},
+                     {W_D1A, W_D1B, B_X1P, B_D1A, B_X2, 64, 128},
+                     {W_D0A, W_D0B, B_X0P, B_D0A, B_X1, 32, 64}};
+  for (int i = 0; i < 3; ++i) {
+    const Enc& e = en[i];
+    const int oh = kDims[e.out].h, mh = kDims[e.mid].h;
+    RUN(wgrad3(c, e.wb, e.mid, 0, e.cout, e.cout, c.G(e.out), oh, oh));
+    const void* xm = mixed_all(2 - i);
+    if (!xm) return UNCL_ERR_LAUNCH;
+    RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh, xm));
+  }
+  RUN(wgrad3(c, W_INC1, B_INC0, 0, 32, 32, c.G(B_X0), 252, 252));
 #undef RUN
   return UNCL_OK;
 }
@@ -913,7 +991,12 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   if (w->dtype == UNCL_F16 && (r->keep_activations || r->save_preact || r->prev_workspace != nullptr)) return UNCL_ERR_ARG;
   int chunk = r->chunk;
   if (chunk <= 0 || chunk > r->N) chunk = r->N;
-  const int n_alloc = r->keep_activations ? r->N : chunk;
+  // clip layout: one workspace for clip_T frames of N samples, this call is frame clip_t (see uncl_gen_run)
+  const bool clip = r->clip_T > 0;
+  if (clip && (r->clip_t < 0 || r->clip_t >= r->clip_T || !r->keep_activations || chunk != r->N || w->norm != 0 ||
+               r->prev_workspace != nullptr))
+    return UNCL_ERR_ARG;
+  const int n_alloc = clip ? r->clip_T * r->N : (r->keep_activations ? r->N : chunk);
   if (w->norm < 0 || w->norm > 2) return UNCL_ERR_ARG;
   // batch_norm (2) is a TRAINING mode of this entry (eval folds the running statistics into the weights on the host): the whole
   // batch in one chunk, activations kept, the layers' parameters announced with uncl_gen_set_bn
@@ -971,8 +1054,16 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     if (r->keep_activations || split2)
       for (int b = 0; b < B_COUNT; ++b) Lc.off[b] = L.off[b] + L.per_n[b] * (size_t)n0;
     c.L = Lc;
+    c.Lp = Lc;
     c.ws = reinterpret_cast<char*>(r->workspace);
     c.prev = reinterpret_cast<const char*>(r->prev_workspace);
+    if (clip) {
+      for (int b = 0; b < B_COUNT; ++b) {
+        c.L.off[b] = L.off[b] + L.per_n[b] * (size_t)r->clip_t * r->N;
+        c.Lp.off[b] = L.off[b] + L.per_n[b] * (size_t)(r->clip_t > 0 ? r->clip_t - 1 : 0) * r->N;
+      }
+      c.prev = r->clip_t > 0 ? c.ws : nullptr;
+    }
     if (c.prev && !r->keep_activations) { (void)join_sides(); return UNCL_ERR_ARG; }
     void* up = r->up_x ? reinterpret_cast<char*>(r->up_x) + (size_t)n0 * 256 * 256 * 32 * es : nullptr;
     // split mode: the halves run everything up to the third decoder stage; the last stage (a quarter of the step in its two
@@ -1031,24 +1122,39 @@ extern "C" size_t uncl_gen_carry_bytes_dt(int N, int dtype) {
 extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* b, void* stream) {
   if (!w || !b || (w->dtype != UNCL_BF16 && w->dtype != UNCL_F32) || b->N <= 0) return UNCL_ERR_ARG;
   if (!b->x || !b->x_out || !b->g_out || !b->up_x || !b->workspace || !b->grad_workspace) return UNCL_ERR_ARG;
-  if (b->grad_workspace_bytes < uncl_gen_backward_workspace_bytes_dt(b->N, w->dtype)) return UNCL_ERR_ARG;
+  // clip layout (see uncl_gen_bwd): both arenas span clip_T * N samples, this call is frame clip_t and defers the 3x3 / 2x2 weight
+  // gradients to the call for frame 0
+  const bool clip = b->clip_T > 0;
+  if (clip && (b->clip_t < 0 || b->clip_t >= b->clip_T || w->norm != 0 || b->prev_workspace != nullptr)) return UNCL_ERR_ARG;
+  const int NA = clip ? b->clip_T * b->N : b->N;     // samples the arenas are laid out for
+  if (b->grad_workspace_bytes < uncl_gen_backward_workspace_bytes_dt(NA, w->dtype)) return UNCL_ERR_ARG;
   for (int i = 0; i < UNCL_G_NUM_WEIGHTS; ++i)
     if (!b->wd[i] || !b->gw[i] || !b->gb[i]) return UNCL_ERR_ARG;
   if (!b->g_inc0_w || !b->g_inc0_b || !b->g_outc_w || !b->g_outc_b || !b->g_pos_embed) return UNCL_ERR_ARG;
-  if ((b->prev_workspace != nullptr) != (b->carry_out != nullptr)) return UNCL_ERR_ARG;
+  if ((clip ? b->clip_t > 0 : b->prev_workspace != nullptr) != (b->carry_out != nullptr)) return UNCL_ERR_ARG;
   BCtx c;
   c.w = w; c.b = b; c.n = b->N;
   c.dt = w->dtype;
   c.es = w->dtype == UNCL_F32 ? 4 : 2;
-  c.L = make_layout(b->N, w->dtype);
-  c.LZ = make_layout(b->N, w->dtype, w->norm);
+  c.L = make_layout(NA, w->dtype);
+  c.LZ = make_layout(NA, w->dtype, w->norm);
   c.fws = reinterpret_cast<char*>(b->workspace);
   c.pws = reinterpret_cast<const char*>(b->prev_workspace);
   c.gws = reinterpret_cast<char*>(b->grad_workspace);
   c.slope = w->act == UNCL_ACT_LRELU ? 0.2f : 0.f;
   c.s = reinterpret_cast<hipStream_t>(stream);
   char* p = c.gws + c.L.total;
-  const int N = b->N;
+  const Layout Lall = c.L;
+  c.Lp = c.L;
+  if (clip) {
+    for (int i = 0; i < B_COUNT; ++i) {
+      c.L.off[i] = Lall.off[i] + Lall.per_n[i] * (size_t)b->clip_t * b->N;
+      c.Lp.off[i] = Lall.off[i] + Lall.per_n[i] * (size_t)(b->clip_t > 0 ? b->clip_t - 1 : 0) * b->N;
+    }
+    c.pws = b->clip_t > 0 ? c.fws : nullptr;
+    c.defer = true;
+  }
+  const int N = NA;     // the scratch areas are carved for the arena's sample count (`mix` holds a whole clip in the deferred pass)
   const size_t es = c.es;
   c.sc.tmp = nullptr;
   if (es == 4) { c.sc.tmp = p; p += (size_t)N * 252 * 252 * 128 * 4; }
@@ -1083,7 +1189,7 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   // runtime (the N = 32 step: 7.9 ms on one stream, 17 ms with the ~45 forks of this pass captured; eager: 7.83 -> 7.60 ms)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(c.s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-  if (wstream_on && cap == hipStreamCaptureStatusNone && c.dt == UNCL_BF16 && !c.video() && c.pws == nullptr) {
+  if (wstream_on && cap == hipStreamCaptureStatusNone && c.dt == UNCL_BF16 && !c.video() && c.pws == nullptr && !clip) {
     WgradStream* wsd = wgrad_stream_for_current_device();
     if (!wsd) return UNCL_ERR_LAUNCH;
     c.ws = wsd->s; c.ev_wfork = wsd->ev_fork; c.ev_wjoin = wsd->ev_join;
@@ -1093,7 +1199,8 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   // layer otherwise.  UNCL_BWD_FUSED_BIAS=0: separate column-sum kernels as before.
   static const int fused_bias_on = [] { const char* e = getenv("UNCL_BWD_FUSED_BIAS"); return e ? atoi(e) : 1; }();
   c.fused_bias = fused_bias_on && c.dt == UNCL_BF16;
-  if (c.fused_bias && !b->accumulate) {
+  // (clip layout: every bias slot of the 3x3 / 2x2 layers is ADDED to by the deferred pass, whatever the kernel family)
+  if ((c.fused_bias || clip) && !b->accumulate) {
     static const struct { int wi, cout; } k3[] = {{W_INC1, 32}, {W_D0A, 64}, {W_D0B, 64}, {W_D1A, 128}, {W_D1B, 128}, {W_D2A, 256},
                                                   {W_D2B, 256}, {W_D3A, 256}, {W_D3B, 256}, {W_U0A, 128}, {W_U0B, 128}, {W_U1A, 64},
                                                   {W_U1B, 64}, {W_U2A, 32}, {W_U2B, 32}, {W_U3A, 32}, {W_U3B, 32}};
@@ -1109,12 +1216,25 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
     for (int i = 0; contiguous && i + 1 < UNCL_G_NUM_WEIGHTS; ++i) contiguous = b->gb[i + 1] == b->gb[i] + kBias[i];
     if (contiguous) {
       if (hipMemsetAsync(lo, 0, (size_t)(hi - lo) * sizeof(float), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
+    } else if (clip) {
+      for (int i = 0; i < UNCL_G_NUM_WEIGHTS; ++i)
+        if (hipMemsetAsync(b->gb[i], 0, (size_t)kBias[i] * sizeof(float), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
     } else {
       for (const auto& e : k3)
         if (hipMemsetAsync(b->gb[e.wi], 0, (size_t)e.cout * sizeof(float), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
     }
   }
-  const int rc = backward_all(c);
+  int rc = backward_all(c);
+  if (rc == UNCL_OK && clip && b->clip_t == 0) {
+    const int rcf = c.flush_colsums();        // this frame's staged bias sums (the queue is per call)
+    if (rcf != UNCL_OK) return rcf;
+    BCtx ca = c;
+    ca.defer = false;
+    ca.n = NA;
+    ca.L = Lall; ca.Lp = Lall;
+    ca.pws = nullptr;
+    rc = deferred_wgrads(ca, b->N, b->clip_T);
+  }
   const int rc2 = c.flush_colsums();          // joins the weight-gradient stream
   return rc != UNCL_OK ? rc : rc2;
 }

@@ -323,8 +323,10 @@ class _GeneratorBase(nn.Module):
         return (keep / keep_prob).contiguous()
 
     def _run(self, x_flat, need_feat, prev_ws=None, keep_act=False, slot=0, want_knn=False, save_preact=False,
-             return_drop=False):
-        """x_flat: (N,256,256) fp32 on the GPU.  Returns (out (N,1,256,256) fp32, up_x NHWC or None, knn or None, ws)."""
+             return_drop=False, clip=None):
+        """x_flat: (N,256,256) fp32 on the GPU.  Returns (out (N,1,256,256) fp32, up_x NHWC or None, knn or None, ws).
+        clip = (T, t): frame t of a T-frame clip in ONE workspace laid out for T * N samples (uncl_gen_run.clip_T; the previous
+        frame is that workspace's slice t - 1, prev_ws stays None)."""
         lib = _hip.lib()
         gw, _keep = self._packed_weights()
         n = x_flat.shape[0]
@@ -339,7 +341,11 @@ class _GeneratorBase(nn.Module):
             keep_act, chunk = True, 0
             arrs, _bnkeep = self._bn_arrays()
             _hip.check(lib.uncl_gen_set_bn(arrs[0], arrs[1], arrs[2], arrs[3], 0.1, None, None), "uncl_gen_set_bn")
-        ws, nbytes = self._workspace(n, chunk, keep_act, dev, slot)
+        if clip is not None:
+            if prev_ws is not None or not keep_act or bn_train or self.unet_norm != "none":
+                raise _hip.HipError("clip layout: keep_act, no prev_ws (implied), unet_norm 'none'")
+            chunk = 0
+        ws, nbytes = self._workspace(n * clip[0] if clip is not None else n, chunk, keep_act, dev, slot)
         out = torch.empty(n, 1, 256, 256, dtype=torch.float32, device=dev)
         up = torch.empty(n, 256, 256, 32, dtype=_hip.torch_dtype(gw.dtype), device=dev) if need_feat else None
         knn = torch.empty(n, 144, 9, dtype=torch.int32, device=dev) if want_knn else None
@@ -353,6 +359,8 @@ class _GeneratorBase(nn.Module):
         run.workspace, run.workspace_bytes = ws.data_ptr(), nbytes
         run.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
         run.save_preact = int(save_preact)
+        if clip is not None:
+            run.clip_T, run.clip_t = int(clip[0]), int(clip[1])
         _hip.check(lib.uncl_gen_forward(C.byref(gw), C.byref(run), _hip.stream_ptr()), "uncl_gen_forward")
         if bn_train:
             from .state_spec import batch_norm_layers
