@@ -188,6 +188,26 @@ def test_gauss_stats_vs_torch():
     np.testing.assert_allclose(st[:, 1].numpy(), var.numpy(), rtol=2e-4)
 
 
+@pytest.mark.parametrize("n,h,w,c", [(2, 256, 256, 32), (3, 40, 200, 32), (2, 11, 11, 8), (1, 27, 12, 16), (8, 75, 256, 32), (1, 23, 13, 8)])
+def test_gauss_stats_16bit_nhwc_vs_torch_fp64(n, h, w, c):
+    """the 16-bit kernel (pointwise x^2 term, unrolled ring): every band length / trailing-row case, one-window maps, against fp64
+    on the same bf16 values (Unet.py:112-123: compute_contrast + adaptive_avg_pool2d)"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n * 1000 + h + w)
+    # (per-channel spread 0.2 ... 1 around 0.3: mean^2 / variance <= ~50; a flatter channel is ill-conditioned in fp32 for the
+    # reference's own conv2d(x * x) - mu ** 2 as well -- the absolute term below is that conditioning, 16 eps32 E[x^2])
+    xc = (0.3 + torch.rand(n, c, h, w, generator=g) * (0.2 + 0.8 * torch.rand(n, c, 1, 1, generator=g))).to(torch.bfloat16)
+    win = OG.gauss_window().double()
+    xd = xc.double().reshape(n * c, 1, h, w)
+    mu = F.conv2d(xd, win)
+    var = (F.conv2d(xd * xd, win) - mu ** 2).reshape(n, c, -1).mean(-1)
+    st = gauss_stats(xc.permute(0, 2, 3, 1).contiguous().cuda(), n, h, w, c).cpu().double()
+    np.testing.assert_allclose(st[:, 0].numpy(), xd.reshape(n, c, -1).mean(-1).numpy(), rtol=1e-5)
+    e2 = (xd * xd).reshape(n, c, -1).mean(-1).numpy()
+    err = np.abs(st[:, 1].numpy() - var.numpy())
+    assert (err <= 2e-4 * np.abs(var.numpy()) + 16 * 5.96e-8 * e2).all(), (err / np.abs(var.numpy())).max()
+
+
 def test_video_generator_fp32_matches_reference_golden(golden):
     g = golden("video")
     net = make_gv("fp32")

@@ -738,25 +738,30 @@ extern "C" int uncl_gauss_var_backward(const float* x, const float* gscale, floa
 // pixels (the one-channel form above touches 2 of every 64 bytes it pulls in, and writes the same way: 440 us for 8 frames),
 // transposed into per-channel bf16 planes in LDS, each wave runs the four separable passes for eight channels in its own
 // scratch, and the result goes back through LDS as whole pixels.
+// CH = channels per workgroup (blockIdx.z = which group of CH), NWAVE = its waves (CH / NWAVE channels each).  <32, 8>: 109 KB of
+// LDS, one workgroup per CU, its load phase and its arithmetic never overlap; <16, 4>: 55 KB, two workgroups per CU whose phases do
+// (each reads 32 of a pixel's 64 bytes; the other half's reader finds the line in L2).
 constexpr int HT = 16, HM = HT + GW - 1 /*26*/, HI = HM + GW - 1 /*36*/;
-__global__ __launch_bounds__(512) void gauss_stats_bwd32_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gst,
+template <int CH, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gst,
                                                                 bf16_t* __restrict__ gx, int H, int W, int tiles_x, GaussW gw,
                                                                 int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PS = HI * HI + 2;     // plane stride in elements: 649 dwords, so planes 8 apart sit 8 banks apart
-  bf16_t* sx = reinterpret_cast<bf16_t*>(smem);                               // [32][PS] input planes
-  float* tmp = reinterpret_cast<float*>(smem + 32 * PS * 2);                  // per wave: sh[HI*HM] (later sv[HT*HM]), smu[HM*HM]
-  constexpr int TMPW = HI * HM + HM * HM, NWAVE = 8, NTHR = NWAVE * 64;
-  bf16_t* so = reinterpret_cast<bf16_t*>(smem + 32 * PS * 2 + NWAVE * TMPW * 4);  // [HT*HT][32] results
+  bf16_t* sx = reinterpret_cast<bf16_t*>(smem);                               // [CH][PS] input planes
+  float* tmp = reinterpret_cast<float*>(smem + CH * PS * 2);                  // per wave: sh[HI*HM] (later sv[HT*HM]), smu[HM*HM]
+  constexpr int TMPW = HI * HM + HM * HM, NTHR = NWAVE * 64, OCT = CH / 8;
+  bf16_t* so = reinterpret_cast<bf16_t*>(smem + CH * PS * 2 + NWAVE * TMPW * 4);  // [HT*HT][CH] results
+  const int c0 = blockIdx.z * CH;                                             // first channel of this workgroup
   const int n = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
   const int Ho = H - (GW - 1), Wo = W - (GW - 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bf16_t* xn = x + (size_t)n * H * W * 32;
+  const bf16_t* xn = x + (size_t)n * H * W * 32 + c0;
   // two adjacent plane positions per thread: every LDS write is a whole dword (channel i of both pixels)
-  for (int v = tid; v < (HI * HI / 2) * 4; v += NTHR) {
-    const int pair = v >> 2, c8 = v & 3;
+  for (int v = tid; v < (HI * HI / 2) * OCT; v += NTHR) {
+    const int pair = v / OCT, c8 = v - pair * OCT;
     bf16x8 val[2];
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(512) void gauss_stats_bwd32_kernel(const bf16_t* __
       if (gxv - t >= 0 && gxv - t < Wo) wx4[r] += gw.g[t];
     }
   }
-  for (int ci = 0; ci < 32 / NWAVE; ++ci) {
+  for (int ci = 0; ci < CH / NWAVE; ++ci) {
     const int ch = wave + NWAVE * ci;
     const bf16_t* sc_ = sx + ch * PS;
     // 1: sh[ly][lx] = sum_t g[t] x[ly][lx + t]                     (HI rows x HM columns)
@@ -851,8 +856,8 @@ __global__ __launch_bounds__(512) void gauss_stats_bwd32_kernel(const bf16_t* __
     }
     WAVE_SYNC();
     // 4: s[ly][lx] = sum_t g[t] sv[ly][lx + 10 - t]; gradient = g_mean + sc (x wy wx - s)
-    const float gm = gst[((size_t)n * 2 + 0) * 32 + ch] / ((float)H * (float)W);
-    const float scv = gst[((size_t)n * 2 + 1) * 32 + ch] * 2.f / ((float)Ho * (float)Wo);
+    const float gm = gst[((size_t)n * 2 + 0) * 32 + c0 + ch] / ((float)H * (float)W);
+    const float scv = gst[((size_t)n * 2 + 1) * 32 + c0 + ch] * 2.f / ((float)Ho * (float)Wo);
     {
       float in[R + GW - 1];          // sv columns 4 pr .. 4 pr + 13 of row py
 #pragma unroll
@@ -863,19 +868,19 @@ __global__ __launch_bounds__(512) void gauss_stats_bwd32_kernel(const bf16_t* __
 #pragma unroll
         for (int t = 0; t < GW; ++t) acc = fmaf(gw.g[t], in[r + 10 - t], acc);
         const int lx = pr * R + r;
-        so[(py * HT + lx) * 32 + ch] = (bf16_t)(gm + scv * ((float)sc_[(py + 10) * HI + lx + 10] * wy4 * wx4[r] - acc));
+        so[(py * HT + lx) * CH + ch] = (bf16_t)(gm + scv * ((float)sc_[(py + 10) * HI + lx + 10] * wy4 * wx4[r] - acc));
       }
     }
     WAVE_SYNC();
   }
   __syncthreads();
 #undef WAVE_SYNC
-  for (int v = tid; v < HT * HT * 4; v += NTHR) {
-    const int pix = v >> 2, c8 = v & 3, ly = pix / HT, lx = pix - ly * HT;
+  for (int v = tid; v < HT * HT * OCT; v += NTHR) {
+    const int pix = v / OCT, c8 = v - pix * OCT, ly = pix / HT, lx = pix - ly * HT;
     const int gy = y0 + ly, gxx = x0 + lx;
     if (gy < H && gxx < W) {
-      bf16_t* d = gx + ((size_t)n * H * W + (size_t)gy * W + gxx) * 32 + c8 * 8;
-      bf16x8 val = *reinterpret_cast<const bf16x8*>(so + pix * 32 + c8 * 8);
+      bf16_t* d = gx + ((size_t)n * H * W + (size_t)gy * W + gxx) * 32 + c0 + c8 * 8;
+      bf16x8 val = *reinterpret_cast<const bf16x8*>(so + pix * CH + c8 * 8);
       if (accumulate) {
         const bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
 #pragma unroll
@@ -898,17 +903,25 @@ extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* 
   const int tx = (W + GT - 1) / GT, ty = (H + GT - 1) / GT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == UNCL_BF16 && C == 32) {
-    constexpr size_t lds = (size_t)32 * (HI * HI + 2) * 2 + (size_t)8 * (HI * HM + HM * HM) * 4 + (size_t)HT * HT * 32 * 2;
+    constexpr size_t lds32 = (size_t)32 * (HI * HI + 2) * 2 + (size_t)8 * (HI * HM + HM * HM) * 4 + (size_t)HT * HT * 32 * 2;
+    constexpr size_t lds16 = (size_t)16 * (HI * HI + 2) * 2 + (size_t)4 * (HI * HM + HM * HM) * 4 + (size_t)HT * HT * 16 * 2;
     static UnclDevOnce attr;
     if (attr.need()) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_stats_bwd32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_stats_bwd32_kernel<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds32) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_stats_bwd32_kernel<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds16) != hipSuccess)
         return UNCL_ERR_LAUNCH;
       attr.done();
     }
     const int tx16 = (W + HT - 1) / HT, ty16 = (H + HT - 1) / HT;
-    hipLaunchKernelGGL(gauss_stats_bwd32_kernel, dim3(tx16 * ty16, N), dim3(512), lds, st, (const bf16_t*)x, g_stats, (bf16_t*)gx, H, W,
-                       tx16, gw, accumulate);
+    static const int half_on = [] { const char* e = getenv("UNCL_GAUSS_BWD_HALF"); return e ? atoi(e) : 0; }();   // 1: two 16-channel workgroups per tile (measured: a tie, 200 us at 8 samples)
+    if (half_on)
+      hipLaunchKernelGGL((gauss_stats_bwd32_kernel<16, 4>), dim3(tx16 * ty16, N, 2), dim3(256), lds16, st, (const bf16_t*)x, g_stats,
+                         (bf16_t*)gx, H, W, tx16, gw, accumulate);
+    else
+      hipLaunchKernelGGL((gauss_stats_bwd32_kernel<32, 8>), dim3(tx16 * ty16, N), dim3(512), lds32, st, (const bf16_t*)x, g_stats,
+                         (bf16_t*)gx, H, W, tx16, gw, accumulate);
   } else if (dtype == UNCL_BF16)
     hipLaunchKernelGGL(gauss_stats_bwd_kernel<bf16_t>, dim3(tx * ty, N, C), dim3(256), 0, st, (const bf16_t*)x, g_stats, (bf16_t*)gx,
                        H, W, C, tx, gw, accumulate);
