@@ -76,3 +76,59 @@ def test_clip_layout_refused_where_it_does_not_apply():
         net._run(x, need_feat=True, keep_act=False, clip=(3, 0))
     with pytest.raises(_hip.HipError):       # frame index out of range: refused by the library
         net._run(x, need_feat=True, keep_act=True, save_preact=True, clip=(3, 3))
+
+
+def test_clip_form_under_the_data_parallel_reducer_and_in_a_captured_step():
+    """The video trainer's step with the clip form: (a) under DistributedOptimizer(module=G) over RCCL at world size 1 -- the
+    decoder-done event is recorded by the DEFERRED pass (after the clip's decoder weight gradients, not inside frame 0's
+    data-gradient chain), the decoder half is unpacked and reduced on the side stream from there -- the parameters after two
+    steps must equal the plain steps' exactly (fp32 mode: deterministic); (b) the per-frame form gives the same parameters to
+    summation-order rounding; (c) the step replays as one hipGraph with the clip workspace / arena at fixed addresses."""
+    import os
+    import torch.distributed as td
+    from test_gpu_trainer import _fp32_trainer, step_inputs
+    from uncltmo_amd.distributed import DistributedOptimizer
+    from uncltmo_amd.step_graph import StepGraph
+    hdr, pos, neg = step_inputs()
+
+    def run(clip, wrap, graph=False):
+        tr, G, D = _fp32_trainer(True)
+        G.clip_wgrad = clip
+        if wrap:
+            tr.optimizerG = DistributedOptimizer(tr.optimizerG, module=G)
+            tr.optimizerD = DistributedOptimizer(tr.optimizerD)
+        sg = None
+        if graph:
+            sg = StepGraph(tr, hdr, hdr.clone(), pos, neg, 0, warmup=2)
+            for _ in range(2):
+                sg.replay()
+        else:
+            for _ in range(2):
+                tr.train_D(hdr, pos, neg, 0)
+                tr.train_G(hdr, hdr.clone(), pos, neg, 0)
+        torch.cuda.synchronize()
+        out = {k: v.detach().clone() for k, v in G.state_dict().items()}
+        sg = None
+        return out
+
+    plain = run(True, False)
+    per_frame = run(False, False)
+    for k in plain:
+        if plain[k].dtype == torch.float32 and plain[k].numel() > 1:
+            assert rel_l2(plain[k].cpu(), per_frame[k].cpu()) < 1e-6, k
+    replayed = run(True, False, graph=True)
+    for k in plain:
+        assert torch.equal(plain[k], replayed[k]), k
+    os.environ["UNCL_FORCE_DIST"] = "1"
+    td.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29300 + os.getpid() % 200), rank=0, world_size=1,
+                          device_id=torch.device("cuda", 0))
+    try:
+        reduced = run(True, True)
+        for k in plain:
+            assert torch.equal(plain[k], reduced[k]), k
+    finally:
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        td.destroy_process_group()
+        os.environ.pop("UNCL_FORCE_DIST", None)
