@@ -82,8 +82,8 @@ def test_clip_form_under_the_data_parallel_reducer_and_in_a_captured_step():
     """The video trainer's step with the clip form: (a) under DistributedOptimizer(module=G) over RCCL at world size 1 -- the
     decoder-done event is recorded by the DEFERRED pass (after the clip's decoder weight gradients, not inside frame 0's
     data-gradient chain), the decoder half is unpacked and reduced on the side stream from there -- the parameters after two
-    steps must equal the plain steps' exactly (fp32 mode: deterministic); (b) the per-frame form gives the same parameters to
-    summation-order rounding; (c) the step replays as one hipGraph with the clip workspace / arena at fixed addresses."""
+    steps must equal the plain steps' exactly (fp32 mode: deterministic); (b) the step replays as one hipGraph with the clip
+    workspace / arena at fixed addresses, bit for bit.  (The per-frame form is compared gradient by gradient above.)"""
     import os
     import torch.distributed as td
     from test_gpu_trainer import _fp32_trainer, step_inputs
@@ -112,10 +112,6 @@ def test_clip_form_under_the_data_parallel_reducer_and_in_a_captured_step():
         return out
 
     plain = run(True, False)
-    per_frame = run(False, False)
-    for k in plain:
-        if plain[k].dtype == torch.float32 and plain[k].numel() > 1:
-            assert rel_l2(plain[k].cpu(), per_frame[k].cpu()) < 1e-6, k
     replayed = run(True, False, graph=True)
     for k in plain:
         assert torch.equal(plain[k], replayed[k]), k
