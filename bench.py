@@ -691,6 +691,10 @@ def train_numbers(a, rk, video, steps, warmup, clips=None):
                               "note": "executed = 2 fwd + 1 summed bwd of G per frame (73.1 GFLOP); survey convention = 2 fwd + "
                                       "2 bwd (109.7 GFLOP, what the reference runs); both over the median step time"},
            "errD": float(tr.errD.detach()), "errG_d": float(tr.errG_d.detach()), "errG_struct": float(tr.errG_struct.detach())}
+    if video:
+        # the clip's frames in one workspace / arena, 3x3 / 2x2 weight gradients once per clip (uncltmo_amd/autograd.py)
+        out["weight_gradients"] = ("once per clip (clip layout)" if os.environ.get("UNCL_CLIP_WGRAD", "1") != "0"
+                                   else "per frame (UNCL_CLIP_WGRAD=0)")
     if not video and not a.stub and os.environ.get("UNCL_BENCH_WGRAD", "1") != "0":
         try:
             out["wgrad_ms"] = (w3 := wgrad3_standalone(n))["ms"]
