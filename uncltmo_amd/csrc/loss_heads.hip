@@ -742,16 +742,21 @@ extern "C" int uncl_gauss_var_backward(const float* x, const float* gscale, floa
 // LDS, one workgroup per CU, its load phase and its arithmetic never overlap; <16, 4>: 55 KB, two workgroups per CU whose phases do
 // (each reads 32 of a pixel's 64 bytes; the other half's reader finds the line in L2).
 constexpr int HT = 16, HM = HT + GW - 1 /*26*/, HI = HM + GW - 1 /*36*/;
+// row strides of the input planes (bf16: 19 dwords) and of the first pass's output (fp32: 29 dwords), both odd in dwords: the first
+// pass walks DOWN the rows with its lanes (consecutive lanes = consecutive rows of one run of four columns), so a half-wave's 32
+// rows land on 32 banks (row-major units on 18- / 26-dword rows: 414 LDS cycles per channel and tile in that pass, now ~250)
+constexpr int HIP = HI + 2, SHS = HM + 3;
+constexpr int GB_PS = HI * HIP + 2, GB_TMPW = HI * SHS + HM * HM;
 template <int CH, int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gst,
                                                                 bf16_t* __restrict__ gx, int H, int W, int tiles_x, GaussW gw,
                                                                 int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int PS = HI * HI + 2;     // plane stride in elements: 649 dwords, so planes 8 apart sit 8 banks apart
+  constexpr int PS = GB_PS;           // plane stride in elements: 685 dwords (odd), so planes 8 apart sit 8 banks apart
   bf16_t* sx = reinterpret_cast<bf16_t*>(smem);                               // [CH][PS] input planes
   float* tmp = reinterpret_cast<float*>(smem + CH * PS * 2);                  // per wave: sh[HI*HM] (later sv[HT*HM]), smu[HM*HM]
-  constexpr int TMPW = HI * HM + HM * HM, NTHR = NWAVE * 64, OCT = CH / 8;
-  bf16_t* so = reinterpret_cast<bf16_t*>(smem + CH * PS * 2 + NWAVE * TMPW * 4);  // [HT*HT][CH] results
+  constexpr int TMPW = GB_TMPW, NTHR = NWAVE * 64, OCT = CH / 8, SOP = HT * HT + 2;   // SOP: result plane stride
+  bf16_t* so = reinterpret_cast<bf16_t*>(smem + CH * PS * 2 + NWAVE * TMPW * 4);  // [CH][SOP] result planes
   const int c0 = blockIdx.z * CH;                                             // first channel of this workgroup
   const int n = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf1
       typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
       bf16x2_t pk;
       pk[0] = val[0][i]; pk[1] = val[1][i];
-      *reinterpret_cast<bf16x2_t*>(sx + (c8 * 8 + i) * PS + 2 * pair) = pk;
+      *reinterpret_cast<bf16x2_t*>(sx + (c8 * 8 + i) * PS + ((2 * pair) / HI) * HIP + (2 * pair) % HI) = pk;
     }
   }
   __syncthreads();
@@ -786,7 +791,7 @@ __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf1
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
   float* sh = tmp + wave * TMPW;
-  float* smu = sh + HI * HM;
+  float* smu = sh + HI * SHS;
   float* sv = sh;                    // the first pass's buffer is dead when the third pass writes
   // Every pass computes runs of four outputs along the filter direction from 14 inputs held in registers (44 LDS reads
   // become 14).  Unit -> (line, run) maps and the edge weights of the last pass are the same for every channel.
@@ -808,17 +813,17 @@ __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf1
     const int ch = wave + NWAVE * ci;
     const bf16_t* sc_ = sx + ch * PS;
     // 1: sh[ly][lx] = sum_t g[t] x[ly][lx + t]                     (HI rows x HM columns)
-    for (int u = lane; u < HI * NRM; u += 64) {
-      const int ly = u / NRM, lx0 = (u - ly * NRM) * R;
+    for (int u = lane; u < HI * NRM; u += 64) {      // unit = (run of four columns, row), rows fastest
+      const int run = u / HI, ly = u - run * HI, lx0 = run * R;
       float in[R + GW - 1];
 #pragma unroll
-      for (int j = 0; j < R + GW - 1; ++j) in[j] = (float)sc_[ly * HI + min(lx0 + j, HI - 1)];
+      for (int j = 0; j < R + GW - 1; ++j) in[j] = (float)sc_[ly * HIP + min(lx0 + j, HI - 1)];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < GW; ++t) acc = fmaf(gw.g[t], in[r + t], acc);
-        if (lx0 + r < HM) sh[ly * HM + lx0 + r] = acc;
+        if (lx0 + r < HM) sh[ly * SHS + lx0 + r] = acc;
       }
     }
     WAVE_SYNC();
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf1
       const int lr_ = u / HM, lx = u - lr_ * HM, ly0 = lr_ * R;
       float in[R + GW - 1];
 #pragma unroll
-      for (int j = 0; j < R + GW - 1; ++j) in[j] = sh[min(ly0 + j, HI - 1) * HM + lx];
+      for (int j = 0; j < R + GW - 1; ++j) in[j] = sh[min(ly0 + j, HI - 1) * SHS + lx];
       const int ox = x0 - 10 + lx;
       const bool xok = ox >= 0 && ox < Wo;
 #pragma unroll
@@ -862,13 +867,23 @@ __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf1
       float in[R + GW - 1];          // sv columns 4 pr .. 4 pr + 13 of row py
 #pragma unroll
       for (int j = 0; j < R + GW - 1; ++j) in[j] = sv[py * HM + pr * R + j];
+      bf16_t res[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < GW; ++t) acc = fmaf(gw.g[t], in[r + 10 - t], acc);
         const int lx = pr * R + r;
-        so[(py * HT + lx) * CH + ch] = (bf16_t)(gm + scv * ((float)sc_[(py + 10) * HI + lx + 10] * wy4 * wx4[r] - acc));
+        res[r] = (bf16_t)(gm + scv * ((float)sc_[(py + 10) * HIP + lx + 10] * wy4 * wx4[r] - acc));
+      }
+      // results as per-channel PLANES, two pixels per dword write (pixel-major [pixel][channel] rows put all 64 lanes of a write on
+      // ONE bank -- pixels four apart are 64 dwords apart: SQ_LDS_BANK_CONFLICT was 64 % of the kernel's LDS cycles)
+      typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int r = 0; r < R; r += 2) {
+        bf16x2_t pk;
+        pk[0] = res[r]; pk[1] = res[r + 1];
+        *reinterpret_cast<bf16x2_t*>(so + ch * SOP + py * HT + pr * R + r) = pk;
       }
     }
     WAVE_SYNC();
@@ -880,7 +895,9 @@ __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf1
     const int gy = y0 + ly, gxx = x0 + lx;
     if (gy < H && gxx < W) {
       bf16_t* d = gx + ((size_t)n * H * W + (size_t)gy * W + gxx) * 32 + c0 + c8 * 8;
-      bf16x8 val = *reinterpret_cast<const bf16x8*>(so + pix * CH + c8 * 8);
+      bf16x8 val;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) val[i] = so[(c8 * 8 + i) * SOP + pix];
       if (accumulate) {
         const bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
 #pragma unroll
@@ -903,8 +920,9 @@ extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* 
   const int tx = (W + GT - 1) / GT, ty = (H + GT - 1) / GT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == UNCL_BF16 && C == 32) {
-    constexpr size_t lds32 = (size_t)32 * (HI * HI + 2) * 2 + (size_t)8 * (HI * HM + HM * HM) * 4 + (size_t)HT * HT * 32 * 2;
-    constexpr size_t lds16 = (size_t)16 * (HI * HI + 2) * 2 + (size_t)4 * (HI * HM + HM * HM) * 4 + (size_t)HT * HT * 16 * 2;
+    constexpr size_t lds32 = (size_t)32 * GB_PS * 2 + (size_t)8 * GB_TMPW * 4 + (size_t)(HT * HT + 2) * 32 * 2;
+    constexpr size_t lds16 = (size_t)16 * GB_PS * 2 + (size_t)4 * GB_TMPW * 4 + (size_t)(HT * HT + 2) * 16 * 2;
+    static_assert(lds32 <= 160 * 1024, "the 32-channel form must fit one CU's LDS");
     static UnclDevOnce attr;
     if (attr.need()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_stats_bwd32_kernel<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -915,7 +933,7 @@ extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* 
       attr.done();
     }
     const int tx16 = (W + HT - 1) / HT, ty16 = (H + HT - 1) / HT;
-    static const int half_on = [] { const char* e = getenv("UNCL_GAUSS_BWD_HALF"); return e ? atoi(e) : 0; }();   // 1: two 16-channel workgroups per tile (measured: a tie, 200 us at 8 samples)
+    static const int half_on = [] { const char* e = getenv("UNCL_GAUSS_BWD_HALF"); return e ? atoi(e) : 1; }();   // 0: one 32-channel workgroup per tile (8 / 32 samples: 151 / 575 us against 148 / 541)
     if (half_on)
       hipLaunchKernelGGL((gauss_stats_bwd32_kernel<16, 4>), dim3(tx16 * ty16, N, 2), dim3(256), lds16, st, (const bf16_t*)x, g_stats,
                          (bf16_t*)gx, H, W, tx16, gw, accumulate);
