@@ -81,32 +81,35 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// out[c] (+)= sum over `rows` partial rows: 32 columns x 8 row lanes per workgroup, fp64, fixed order.  Eight loads are in flight per
-// thread before the first is added (the additions keep their order r, r + 8, r + 16 ...): one dependent load per addition made
-// the 1024-row sum of the last layer's gradients a 40 us launch of two workgroups on the critical path of every frame.
+// out[c] (+)= sum over `rows` partial rows, fp64, fixed order: CPB columns x (256 / CPB) row lanes per workgroup, every lane's loads
+// in flight before its first addition, the lanes' sums added in lane order by one thread per column.  (Rounds 1 - 4a: 32 columns x 8
+// row lanes with one dependent load per addition -- the 1024-row sum of the last layer's 33 gradient sums was a 32 - 40 us launch of
+// two workgroups on the critical path of every frame; 4 columns x 64 lanes: 16 rows per lane.)
 // `out_tail`: columns >= tail_from go to out_tail[c - tail_from] (the 33 sums of the last layer: 32 weights, 1 bias).
+template <int CPB>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int rows, int cols, float* __restrict__ out,
-                                                          int accumulate, float* __restrict__ out_tail = nullptr, int tail_from = 0) {
-  __shared__ double red[8][33];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+                                                          int accumulate, float* __restrict__ out_tail, int tail_from) {
+  constexpr int LANES = 256 / CPB;
+  __shared__ double red[LANES][CPB + 1];
+  const int cl = threadIdx.x % CPB, rg = threadIdx.x / CPB;
+  const int c = blockIdx.x * CPB + cl;
   double s = 0.0;
   if (c < cols) {
     constexpr int U = 8;
-    for (int r = rg; r < rows; r += 8 * U) {
+    for (int r = rg; r < rows; r += LANES * U) {
       float v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = (r + 8 * u < rows) ? partial[(size_t)(r + 8 * u) * cols + c] : 0.f;
+      for (int u = 0; u < U; ++u) v[u] = (r + LANES * u < rows) ? partial[(size_t)(r + LANES * u) * cols + c] : 0.f;
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (r + 8 * u < rows) s += (double)v[u];
+        if (r + LANES * u < rows) s += (double)v[u];
     }
   }
   red[rg][cl] = s;
   __syncthreads();
   if (rg == 0 && c < cols) {
     double t = 0.0;
-    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    for (int i = 0; i < LANES; ++i) t += red[i][cl];
     float* o = (out_tail != nullptr && c >= tail_from) ? out_tail + (c - tail_from) : out + c;
     *o = accumulate ? *o + (float)t : (float)t;
   }
@@ -467,7 +470,7 @@ static int outc_backward_t(const float* g_out, const float* x_out, const void* g
   hipLaunchKernelGGL(outc_bwd_kernel<T>, dim3(blocks), dim3(256), 0, s, g_out, x_out, (const T*)g_upx, (const T*)up_x, w,
                      (T*)G_up, (float*)workspace, (size_t)P, last_act, slope);
   // the 33 sums go straight to gw[32], gb[1] (round 4: one launch instead of three; same fp64 sums, rounded to fp32 once as before)
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(2), dim3(256), 0, s, (const float*)workspace, blocks, 33, gw, accumulate, gb, 32);
+  hipLaunchKernelGGL(reduce_rows_kernel<4>, dim3(9), dim3(256), 0, s, (const float*)workspace, blocks, 33, gw, accumulate, gb, 32);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
@@ -667,7 +670,7 @@ static int conv_in_c1_wgrad_t(const void* G, const float* x, float* gw, float* g
   float* part = (float*)workspace;
   hipLaunchKernelGGL(conv_in_wgrad_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)G, x, part, N, H, W);
   float* tot = part + (size_t)512 * 320;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(10), dim3(256), 0, s, (const float*)part, blocks, 320, tot, 0, nullptr, 0);
+  hipLaunchKernelGGL(reduce_rows_kernel<4>, dim3(80), dim3(256), 0, s, (const float*)part, blocks, 320, tot, 0, nullptr, 0);
   hipLaunchKernelGGL(conv_in_final_kernel, dim3(5), dim3(64), 0, s, (const float*)tot, gw, gb, accumulate);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
