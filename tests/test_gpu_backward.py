@@ -286,6 +286,27 @@ def test_upconv_backward_full_size():
     assert rel_l2(from_nhwc(gx), x.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("c,h,n", [(256, 12, 8), (256, 12, 3), (128, 28, 8), (128, 28, 1), (64, 61, 2), (32, 126, 1)])
+def test_upconv_dgrad_every_level_and_slice_width(c, h, n):
+    """data gradient of the four 2x2 up-convolutions at their real sizes (unet_parts.py:269 under autograd), with the ReLU mask of
+    the producing layer: small launches take 32- / 64-row Cin slices per workgroup (csrc/upconv2x2.hip), large ones 128"""
+    x = q(rnd(n, c, h, h, seed=128)).requires_grad_(True)
+    wt = q(rnd(c, c, 2, 2, seed=129, scale=0.05))
+    gy = q(rnd(n, c, 2 * h, 2 * h, seed=130))
+    F.conv_transpose2d(F.relu(x), wt, stride=2).backward(gy)
+    gx = torch.full((n, h, h, c), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gyd, wtd, mask = to_nhwc(gy, BF), pack_weight(wt, BF, transposed=False), to_nhwc(x.detach(), BF)   # (kept alive past the launch)
+    _hip.check(_hip.lib().uncl_upconv2x2_dgrad(gyd.data_ptr(), wtd.data_ptr(), mask.data_ptr(), 0.0, gx.data_ptr(), n, h, h, c, c,
+                                               _hip.stream_ptr()), "ud")
+    torch.cuda.synchronize()
+    got = from_nhwc(gx)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, x.grad) < 1e-2
+    ref = x.grad
+    tol = 2.0 ** -7 * ref.abs() + 2.0 ** -7 * ref.pow(2).mean().sqrt()
+    assert ((got - ref).abs() <= tol).all()
+
+
 def test_ssr_and_pool_backward():
     c, h, n = 32, 57, 2
     x2 = q(rnd(n, c, h, h, seed=31).abs() + 0.01).requires_grad_(True)

@@ -12,6 +12,7 @@
 //     instruction writes whole 2*Cout-element runs of an output row (a wave writes contiguous KiBs), instead of
 //     8-byte pieces scattered at a 2-pixel stride.
 #include "common.h"
+#include <cstdlib>
 
 #ifndef UNCL_UP_PREFETCH
 #define UNCL_UP_PREFETCH 1
@@ -273,7 +274,7 @@ struct UpBwdArgs {
   const bf16_t* wt;     // [4][Cin][Cout]
   const bf16_t* mask;   // (N,H,W,Cin) or NULL
   bf16_t* gx;           // (N,H,W,Cin)
-  int H, W, Cin, M, n_tiles, rows;  // rows = min(Cin, 128) handled per workgroup
+  int H, W, Cin, M, n_tiles, rows;  // rows = the Cin slice a workgroup handles: 32, 64 or 128 (<= Cin)
   float slope;
 };
 
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void upconv2x2_dgrad_kernel(const UpBwdArgs a)
   char* sO = smem + 128 * COUT * 2;       // [128 pixels][rows] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int ct = blockIdx.y;              // 128-row slice of Cin
+  const int ct = blockIdx.y;              // `rows`-row slice of Cin
   const int NTI = a.rows / 32;            // N-tiles (ci) per workgroup: 1..4
   auto wswz = [](int row, int slot) {
     const int f = S == 4 ? ((row >> 2) & 3) : (S == 8 ? ((row >> 1) & 7) : (row & 15));
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void upconv2x2_dgrad_kernel(const UpBwdArgs a)
       __syncthreads();  // previous tap's (or tile's) readers are done with sW / sO
       for (int v = tid; v < a.rows * S; v += 256) {
         const int row = v / S, slot = v - row * S;
-        const vec wv = *reinterpret_cast<const vec*>(a.wt + ((size_t)tap * a.Cin + ct * 128 + row) * COUT + slot * 8);
+        const vec wv = *reinterpret_cast<const vec*>(a.wt + ((size_t)tap * a.Cin + ct * a.rows + row) * COUT + slot * 8);
         *reinterpret_cast<vec*>(sW + row * (COUT * 2) + (wswz(row, slot) << 4)) = wv;
       }
       const size_t gp = (((size_t)n * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1)) * COUT;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void upconv2x2_dgrad_kernel(const UpBwdArgs a)
       const int m = m0 + p;
       if (m >= a.M) continue;
       vec val = *reinterpret_cast<const vec*>(sO + p * (a.rows * 2) + ((sl ^ (p & (slots_o - 1))) << 4));
-      const size_t off = (size_t)m * a.Cin + ct * 128 + sl * 8;
+      const size_t off = (size_t)m * a.Cin + ct * a.rows + sl * 8;
       if (a.mask != nullptr) {
         float f[8], mk[8];
         E::unpack(val, f);
@@ -371,7 +372,7 @@ int launch_up_bwd(const UpBwdArgs& a, hipStream_t s) {
       return UNCL_ERR_LAUNCH;
     attr_done.done();
   }
-  const int n_ct = (a.Cin + 127) / 128;
+  const int n_ct = a.Cin / a.rows;
   const int gx = a.n_tiles < 2048 ? a.n_tiles : 2048;
   hipLaunchKernelGGL(kern, dim3(gx, n_ct), dim3(256), lds, s, a);
   UNCL_CHECK_LAUNCH();
@@ -392,6 +393,12 @@ extern "C" int uncl_upconv2x2_dgrad(const void* gy, const void* wt, const void* 
   UpBwdArgs a;
   a.gy = (const bf16_t*)gy; a.wt = (const bf16_t*)wt; a.mask = (const bf16_t*)mask; a.gx = (bf16_t*)gx;
   a.H = H; a.W = W; a.Cin = Cin; a.M = (int)M; a.n_tiles = (int)((M + 127) / 128); a.rows = Cin < 128 ? Cin : 128; a.slope = slope;
+  // A workgroup stages its Cin slice of all four taps' weights (rows x Cout x 2 bytes each) one after the other before it multiplies:
+  // on the 12 x 12 / 28 x 28 levels there are 18 - 72 workgroups of 128 rows and the launch takes 45 us whatever the batch (8 or 32
+  // samples).  Narrower slices give proportionally more workgroups with proportionally shorter staging: down to 32 rows while the
+  // launch has fewer than two workgroups per CU.
+  static const int narrow_on = [] { const char* e = getenv("UNCL_UPBWD_NARROW"); return e ? atoi(e) : 1; }();
+  while (narrow_on && a.rows > 32 && (long long)a.n_tiles * (Cin / a.rows) < 512) a.rows /= 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (Cout) {
     case 32: return launch_up_bwd<32>(a, s);
