@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=${1:-vid}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 export UNCL_BENCH_WGRAD=0
 STEPS=10; WARM=2
-rocprofv3 --kernel-trace --stats -d $O/train_video -o bench -- python3 bench.py --mode train_video --no-eager --steps $STEPS --warmup $WARM > $O/train_video_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/train_video -o bench -- python3 bench.py --mode ${MODE:-train_video} --no-eager --steps $STEPS --warmup $WARM > $O/train_video_stats.log 2>&1
 tail -1 $O/train_video_stats.log | cut -c1-300
 python3 - $O <<'PY'
 import sqlite3, sys, glob
