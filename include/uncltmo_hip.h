@@ -391,9 +391,9 @@ typedef struct uncl_gen_bwd {
    * clip workspace of uncl_gen_run.clip_T and `grad_workspace` one arena of uncl_gen_backward_workspace_bytes(clip_T * N); the
    * call is frame clip_t (frames still visited last to first, prev_workspace NULL = implied, carries as before).  Calls for
    * frames > 0 run the data-gradient chain only and leave their activation gradients in their slice of the arena; the call
-   * for frame 0 then takes the 3x3 / 2x2 weight and bias gradients ONCE over all clip_T * N samples (a frame's weight
-   * gradients depend on nothing later in the pass) -- 26 launches per clip instead of 26 per frame.  The graph block's 1x1
-   * gradients, outc, the first layer and pos_embed stay per frame. */
+   * for frame 0 then takes the 3x3 / 2x2 weight and bias gradients and the graph block's 1x1 ones ONCE over all clip_T * N
+   * samples (a frame's weight gradients depend on nothing later in the pass) -- 26 launches per clip instead of 26 per frame.
+   * outc, the first layer and pos_embed stay per frame. */
   int clip_T;
   int clip_t;
 } uncl_gen_bwd;

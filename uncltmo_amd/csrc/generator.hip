@@ -663,6 +663,7 @@ int dgrad3(const BCtx& c, int wi, const void* gy, int gh, int gw, int gc, int pa
 // 1x1 conv on the 144-node graph tensors: weight gradient / data gradient
 int wgrad1(const BCtx& c, int wi, const void* x, int xc_total, int cin, const void* gy, int gy_total, int cout, float* gw,
            bool bias) {
+  if (c.defer) return UNCL_OK;
   uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, cin, cout);
   d.src0 = x; d.src0_H = 12; d.src0_W = 12; d.src0_C = xc_total;
   d.out_C = gy_total;  // leading dimension of gy
@@ -751,32 +752,40 @@ int backward_all(const BCtx& c) {
   const float* drop0 = b->drop_scale;
   const float* drop1 = b->drop_scale ? b->drop_scale + c.n : nullptr;
   const long long per256 = (long long)NODES * 256, per512 = (long long)NODES * 512;
+  // The five output gradients the 1x1 weight gradients read are scratch in a single pass; a clip pass (deferred weight gradients)
+  // parks them in arena slots of the same width that the backward pass does not use otherwise -- G(FH), G(FHZ), G(GOUT) (free once
+  // its last reader, the residual of fc1's data gradient, has run), G(GGCZ), G(GFC1) -- where the clip's last call finds all frames
+  void* tA1 = c.defer ? c.G(B_FH) : static_cast<void*>(c.sc.tA);
+  void* tB1 = c.defer ? c.G(B_FHZ) : static_cast<void*>(c.sc.tB);
+  void* tA2 = c.defer ? c.G(B_GOUT) : static_cast<void*>(c.sc.tA);
+  void* tC = c.defer ? c.G(B_GGCZ) : static_cast<void*>(c.sc.tC);
+  void* tB2 = c.defer ? c.G(B_GFC1) : static_cast<void*>(c.sc.tB);
   // FFN: GOUT = drop1 * fc2(gelu(fc1(GX1))) + GX1
-  RUN(bwd_scale_rows(c.dt, c.G(B_GOUT), drop1, c.sc.tA, c.n, per256, c.s));
-  RUN(wgrad1(c, W_FFC2, c.F(B_FH), 256, 256, c.sc.tA, 256, 256, b->gw[W_FFC2], true));
-  RUN(dgrad1(c, W_FFC2, c.sc.tA, 256, 256, c.sc.tB, nullptr));
-  RUN(bwd_gelu_backward(c.dt, c.sc.tB, c.F(B_FHZ), c.sc.tB, (long long)c.n * per256, c.s));
-  RUN(wgrad1(c, W_FFC1, c.F(B_GX1), 256, 256, c.sc.tB, 256, 256, b->gw[W_FFC1], true));
-  RUN(dgrad1(c, W_FFC1, c.sc.tB, 256, 256, c.G(B_GX1), c.G(B_GOUT)));
+  RUN(bwd_scale_rows(c.dt, c.G(B_GOUT), drop1, tA1, c.n, per256, c.s));
+  RUN(wgrad1(c, W_FFC2, c.F(B_FH), 256, 256, tA1, 256, 256, b->gw[W_FFC2], true));
+  RUN(dgrad1(c, W_FFC2, tA1, 256, 256, tB1, nullptr));
+  RUN(bwd_gelu_backward(c.dt, tB1, c.F(B_FHZ), tB1, (long long)c.n * per256, c.s));
+  RUN(wgrad1(c, W_FFC1, c.F(B_GX1), 256, 256, tB1, 256, 256, b->gw[W_FFC1], true));
+  RUN(dgrad1(c, W_FFC1, tB1, 256, 256, c.G(B_GX1), c.G(B_GOUT)));
   // Grapher: GX1 = drop0 * fc2(gelu(gconv(maxrel(fc1(X4))))) + X4
-  RUN(bwd_scale_rows(c.dt, c.G(B_GX1), drop0, c.sc.tA, c.n, per256, c.s));
-  RUN(wgrad1(c, W_GFC2, c.F(B_GGC), 512, 512, c.sc.tA, 256, 256, b->gw[W_GFC2], true));
-  RUN(dgrad1(c, W_GFC2, c.sc.tA, 256, 512, c.sc.tC, nullptr));
-  RUN(bwd_gelu_backward(c.dt, c.sc.tC, c.F(B_GGCZ), c.sc.tC, (long long)c.n * per512, c.s));
-  {  // grouped 1x1: four independent 128 -> 128 blocks, one launch (grid.y = group)
+  RUN(bwd_scale_rows(c.dt, c.G(B_GX1), drop0, tA2, c.n, per256, c.s));
+  RUN(wgrad1(c, W_GFC2, c.F(B_GGC), 512, 512, tA2, 256, 256, b->gw[W_GFC2], true));
+  RUN(dgrad1(c, W_GFC2, tA2, 256, 512, tC, nullptr));
+  RUN(bwd_gelu_backward(c.dt, tC, c.F(B_GGCZ), tC, (long long)c.n * per512, c.s));
+  if (!c.defer) {  // grouped 1x1: four independent 128 -> 128 blocks, one launch (grid.y = group)
     uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, 128, 128);
     d.src0 = c.F(B_GMR); d.src0_H = 12; d.src0_W = 12; d.src0_C = 512;
     d.out_C = 512;
     d.z_mode = UNCL_Z_GROUPS; d.groups = 4;
-    RUN(conv_wgrad(c, d, c.sc.tC, b->gw[W_GGC]));
+    RUN(conv_wgrad(c, d, tC, b->gw[W_GGC]));
+    RUN(c.colsum(tC, (long long)c.n * NODES, 512, b->gb[W_GGC]));
   }
-  RUN(c.colsum(c.sc.tC, (long long)c.n * NODES, 512, b->gb[W_GGC]));
-  RUN(dgrad1(c, W_GGC, c.sc.tC, 512, 512, c.sc.tD, nullptr, 4));
+  RUN(dgrad1(c, W_GGC, tC, 512, 512, c.sc.tD, nullptr, 4));
   if (hipMemsetAsync(c.sc.f32, 0, (size_t)c.n * per256 * 4, c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
-  RUN(bwd_gcn_maxrel_backward(c.dt, c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, c.sc.tB, c.n, NODES,
+  RUN(bwd_gcn_maxrel_backward(c.dt, c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, tB2, c.n, NODES,
                                256, 9, c.s));
-  RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, c.sc.tB, 256, 256, b->gw[W_GFC1], true));
-  RUN(dgrad1(c, W_GFC1, c.sc.tB, 256, 256, c.G(B_X4), c.G(B_GX1)));
+  RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, tB2, 256, 256, b->gw[W_GFC1], true));
+  RUN(dgrad1(c, W_GFC1, tB2, 256, 256, c.G(B_X4), c.G(B_GX1)));
   RUN(bwd_sum_samples(c.dt, c.G(B_X4), b->g_pos_embed, c.n, per256, b->accumulate, c.s));
   // (deferred weight gradients: the masked gradient replaces G(X4) element by element, so that it is still there at the clip's end)
   void* g4 = c.defer ? c.G(B_X4) : static_cast<void*>(c.sc.tA);
@@ -874,6 +883,19 @@ int deferred_wgrads(const BCtx& c, int nf, int T) {
     RUN(c.flush_colsums());
     if (hipEventRecord(reinterpret_cast<hipEvent_t>(b->ev_decoder_done), c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
   }
+  // the graph block's five 1x1 layers (their output gradients were parked in the arena by every frame, see backward_all)
+  RUN(wgrad1(c, W_FFC2, c.F(B_FH), 256, 256, c.G(B_FH), 256, 256, b->gw[W_FFC2], true));
+  RUN(wgrad1(c, W_FFC1, c.F(B_GX1), 256, 256, c.G(B_FHZ), 256, 256, b->gw[W_FFC1], true));
+  RUN(wgrad1(c, W_GFC2, c.F(B_GGC), 512, 512, c.G(B_GOUT), 256, 256, b->gw[W_GFC2], true));
+  {
+    uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, 128, 128);
+    d.src0 = c.F(B_GMR); d.src0_H = 12; d.src0_W = 12; d.src0_C = 512;
+    d.out_C = 512;
+    d.z_mode = UNCL_Z_GROUPS; d.groups = 4;
+    RUN(conv_wgrad(c, d, c.G(B_GGCZ), b->gw[W_GGC]));
+    RUN(c.colsum(c.G(B_GGCZ), (long long)c.n * NODES, 512, b->gb[W_GGC]));
+  }
+  RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, c.G(B_GFC1), 256, 256, b->gw[W_GFC1], true));
   RUN(wgrad3(c, W_D3B, B_D3A, 2, 256, 256, c.G(B_X4), 12, 12));
   {
     const void* xm = mixed_all(3);
