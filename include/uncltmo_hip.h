@@ -393,7 +393,9 @@ typedef struct uncl_gen_bwd {
    * frames > 0 run the data-gradient chain only and leave their activation gradients in their slice of the arena; the call
    * for frame 0 then takes the 3x3 / 2x2 weight and bias gradients and the graph block's 1x1 ones ONCE over all clip_T * N
    * samples (a frame's weight gradients depend on nothing later in the pass) -- 26 launches per clip instead of 26 per frame.
-   * outc, the first layer and pos_embed stay per frame. */
+   * outc and pos_embed stay per frame.  The first layer's weight gradient is taken by that last call as well: the `x` of frame 0
+   * must be the start of ONE (clip_T * N, 256, 256) array that holds the clip's frames one behind the other (the `x` of frame t
+   * is its slice t). */
   int clip_T;
   int clip_t;
 } uncl_gen_bwd;

@@ -251,8 +251,11 @@ class _VideoGeneratorFn(torch.autograd.Function):
         if use_clip:
             lease = _WsLease(module, dev, ("clipws", T))
             lease.install(("clipws", T))
+            # the clip's frames one behind the other in ONE array (one copy instead of T): the deferred pass takes the first layer's
+            # weight gradient over all T * B samples from frame 0's pointer (uncl_gen_bwd.clip_T)
+            xs = x.detach().reshape(B, T, 256, 256).transpose(0, 1).float().contiguous().reshape(T * B, 256, 256)
         for t in range(T):
-            xf = x[:, t].detach().reshape(B, 256, 256).float().contiguous()
+            xf = xs[t * B:(t + 1) * B] if use_clip else x[:, t].detach().reshape(B, 256, 256).float().contiguous()
             if use_clip:
                 out, up, _, ws, ds = module._run(xf, need_feat=True, keep_act=True, slot=("clipws", T), save_preact=True,
                                                  return_drop=True, clip=(T, t))

@@ -829,7 +829,9 @@ int backward_all(const BCtx& c) {
   RUN(wgrad3(c, W_INC1, B_INC0, 0, 32, 32, c.G(B_X0), 252, 252));
   RUN(dgrad3(c, W_INC1, c.G(B_X0), 252, 252, 32, 2, 32, c.G(B_INC0), 254, 254, c.F(B_INC0), 0));
   RUN(c.unnorm(c.G(B_INC0), B_INC0));
-  RUN(bwd_conv_in_c1_wgrad(c.dt, c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, b->accumulate, c.sc.misc, c.s));
+  // (clip passes: once per clip, see deferred_wgrads)
+  if (!c.defer)
+    RUN(bwd_conv_in_c1_wgrad(c.dt, c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, b->accumulate, c.sc.misc, c.s));
 #undef RUN
   return UNCL_OK;
 }
@@ -915,6 +917,9 @@ int deferred_wgrads(const BCtx& c, int nf, int T) {
     RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh, xm));
   }
   RUN(wgrad3(c, W_INC1, B_INC0, 0, 32, 32, c.G(B_X0), 252, 252));
+  // first layer (1 -> 32 channels): frame 0's `x` is the start of the clip's (T * nf, 256, 256) input array (uncl_gen_bwd.clip_T);
+  // nothing else writes these two slots in a clip pass, so they are overwritten, not added to
+  RUN(bwd_conv_in_c1_wgrad(c.dt, c.G(B_INC0), b->x, b->g_inc0_w, b->g_inc0_b, c.n, 256, 256, 0, c.sc.misc, c.s));
 #undef RUN
   return UNCL_OK;
 }
