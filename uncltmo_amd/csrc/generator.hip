@@ -489,7 +489,10 @@ size_t bwd_scratch_bytes(int N, size_t es = 2) {
 #endif
 // one weight-gradient stream (+ its fork / join events) per device, created under a lock on first use; at the other priority
 // level, like the forward's side streams: its hardware queue is then never the caller's
-struct WgradStream { hipStream_t s = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+// `pass`: held by a backward pass for as long as it issues work on the stream -- the fork / join events are one pair per device, so
+// two host threads running passes on one device must not interleave their event records (a wait would bind to the other thread's
+// record: a missing dependency); they take turns enqueueing instead, the GPU work still overlaps
+struct WgradStream { hipStream_t s = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; std::mutex* pass = nullptr; };
 static std::mutex g_wgs_mu;
 static std::map<int, WgradStream> g_wgs;
 static WgradStream* wgrad_stream_for_current_device() {
@@ -506,6 +509,7 @@ static WgradStream* wgrad_stream_for_current_device() {
   if (e != hipSuccess || hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming) != hipSuccess)
     return nullptr;
+  w.pass = new std::mutex();      // lives as long as the process, like the stream
   return &(g_wgs[dev] = w);
 }
 
@@ -1212,6 +1216,7 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
   // weight gradients beside the data-gradient chain: single-frame bf16 passes (a clip's passes share scratch between frames:
   // `mix`, the carries), see BCtx::wfork
   static const int wstream_on = [] { const char* e = getenv("UNCL_BWD_WSTREAM"); return e ? atoi(e) : UNCL_BWD_WSTREAM_DEFAULT; }();
+  std::unique_lock<std::mutex> pass_lock;     // taken below iff this pass uses the device's weight-gradient stream; released on return
   // ... and not while the caller's stream is being captured: a replayed hipGraph pays ~0.2 ms per cross-stream edge on this
   // runtime (the N = 32 step: 7.9 ms on one stream, 17 ms with the ~45 forks of this pass captured; eager: 7.83 -> 7.60 ms)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1220,6 +1225,7 @@ extern "C" int uncl_gen_backward(const uncl_gen_weights* w, const uncl_gen_bwd* 
     WgradStream* wsd = wgrad_stream_for_current_device();
     if (!wsd) return UNCL_ERR_LAUNCH;
     c.ws = wsd->s; c.ev_wfork = wsd->ev_fork; c.ev_wjoin = wsd->ev_join;
+    pass_lock = std::unique_lock<std::mutex>(*wsd->pass);
   }
   // bias gradients of the 3x3 layers out of the weight-gradient kernels (bf16): they ADD into gb, so a pass that does not
   // accumulate clears those slots first -- one memset when the caller's slots are one array (uncltmo_amd/autograd.py), one per
