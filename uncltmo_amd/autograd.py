@@ -290,12 +290,15 @@ class _VideoGeneratorFn(torch.autograd.Function):
         code = module._dtype_code()
         cbytes = lib.uncl_gen_carry_bytes_dt(B, code)
         carries = [torch.empty(cbytes, dtype=torch.uint8, device=dev) for _ in range(2)] if T > 1 else []
+        # the incoming gradients frame-major, one copy each instead of one strided copy per frame
+        go_all = None if g_out is None else g_out.reshape(B, T, 256, 256).transpose(0, 1).float().contiguous()
+        gf_all = None if g_feats is None else g_feats.reshape(B, T, 2, 32).transpose(0, 1).float().contiguous()
         for t in range(T - 1, -1, -1):
             xf, out, up, ws, ds = frames[t]
-            go = (torch.zeros_like(out) if g_out is None else g_out[:, t].reshape(B, 1, 256, 256).float().contiguous())
+            go = torch.zeros_like(out) if go_all is None else go_all[t].reshape(B, 1, 256, 256)
             gup = None
-            if g_feats is not None:
-                gst = g_feats[:, t].reshape(B, 2, 32).float().contiguous()
+            if gf_all is not None:
+                gst = gf_all[t]
                 gup = torch.empty_like(up)
                 _hip.check(lib.uncl_gauss_stats_backward(up.data_ptr(), code, gst.data_ptr(), gup.data_ptr(), B, 256, 256, 32, 0,
                                                          _hip.stream_ptr()), "uncl_gauss_stats_backward")

@@ -456,8 +456,10 @@ class UNetVideo(_GeneratorBase):
         B, T = x.shape[0], x.shape[1]
         outs, feats = [], []
         prev_ws = None
+        # the clip's frames one behind the other (one copy instead of T strided ones)
+        xs = x.detach().reshape(B, T, 256, 256).transpose(0, 1).float().contiguous()
         for t in range(T):
-            xf = x[:, t].detach().reshape(B, 256, 256).float().contiguous()
+            xf = xs[t]
             out, up, _, ws = self._run(xf, need_feat=True, prev_ws=prev_ws, keep_act=True, slot=t)
             st = gauss_stats(up, B, 256, 256, 32)                      # (B,2,32)
             feats.append(st.reshape(B, 1, 64, 1, 1))
