@@ -376,24 +376,51 @@ __global__ __launch_bounds__(256) void d_conv1_wgrad_kernel(const float* __restr
   const int n = blockIdx.y;
   const int ty = blockIdx.x / 4, tx = blockIdx.x % 4;
   const int y0 = ty * 16, x0 = tx * 32;
-  for (int i = threadIdx.x; i < 34 * 66; i += 256) {
-    const int ly = i / 66, lx = i % 66;
-    const int gy = min(2 * y0 + ly, H0 - 1), gx = min(2 * x0 + lx, H0 - 1);
-    sx[i] = x[((size_t)n * H0 + gy) * H0 + gx];
-  }
-  for (int i = threadIdx.x; i < 512 * C1; i += 256) {
-    const int p = i / C1, co = i % C1;
-    const int oy = y0 + (p >> 5), ox = x0 + (p & 31);
-    sg[p * 17 + co] = (oy < H1 && ox < H1) ? g_h1pre[(((size_t)n * H1 + oy) * H1 + ox) * C1 + co] : 0.f;
+  // every load of a thread is requested before its first LDS write (a load -> store loop waited for each of its 32 + 9 loads in turn:
+  // 54 us per launch, whatever the batch)
+  {
+    constexpr int NX = (34 * 66 + 255) / 256;      // 9 image samples per thread
+    float vx[NX];
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int i = min(threadIdx.x + 256 * u, 34 * 66 - 1);
+      const int ly = i / 66, lx = i % 66;
+      const int gy = min(2 * y0 + ly, H0 - 1), gx = min(2 * x0 + lx, H0 - 1);
+      vx[u] = x[((size_t)n * H0 + gy) * H0 + gx];
+    }
+    f32x4 vg[8];                                   // 512 pixels x 4 channel quads = 8 float4 per thread
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = threadIdx.x + 256 * u, p = v >> 2, q4 = v & 3;
+      const int oy = y0 + (p >> 5), ox = x0 + (p & 31);
+      vg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (oy < H1 && ox < H1) vg[u] = *reinterpret_cast<const f32x4*>(g_h1pre + (((size_t)n * H1 + oy) * H1 + ox) * C1 + q4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u)
+      if (threadIdx.x + 256 * u < 34 * 66) sx[threadIdx.x + 256 * u] = vx[u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = threadIdx.x + 256 * u, p = v >> 2, q4 = v & 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sg[p * 17 + q4 * 4 + e] = vg[u][e];
+    }
   }
   __syncthreads();
   const int tap = threadIdx.x >> 4, co = threadIdx.x & 15;
   const int ky = tap >> 2, kx = tap & 3;
   float acc = 0.f, bsum = 0.f;
-  for (int p = 0; p < 512; ++p) {
-    const float gv = sg[p * 17 + co];
-    acc = fmaf(gv, sx[(2 * (p >> 5) + ky) * 66 + 2 * (p & 31) + kx], acc);
-    bsum += gv;
+  // rows outside, columns unrolled: both LDS addresses are a row base plus a compile-time offset (the flat loop rebuilt them from p
+  // every iteration -- ten instructions per multiply-add); same order of additions
+  for (int py = 0; py < 16; ++py) {
+    const float* gr = sg + py * 32 * 17 + co;
+    const float* xr = sx + (2 * py + ky) * 66 + kx;
+#pragma unroll
+    for (int px = 0; px < 32; ++px) {
+      const float gv = gr[px * 17];
+      acc = fmaf(gv, xr[2 * px], acc);
+      bsum += gv;
+    }
   }
   float* out = partial + ((size_t)n * 32 + blockIdx.x) * (256 + 16);
   out[co * 16 + tap] = acc;
