@@ -130,6 +130,15 @@ int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
  * (measured slower there).  All give bit-identical results; the switch
  * exists for same-process A/B timing and for the tests that compare the structures.  Returns the previous setting. */
 int uncl_conv3x3_set_pc(int on);
+/* Tiling of the 64-channel-tile 3x3 layers (forward and data gradient) whose maps fill rectangular 8 / 16 x 32-pixel tiles badly
+ * -- the 24 .. 61-pixel levels of unet_parts.py:56-87, 98-112, 149-162, 311-332: 1 (default) = flat M-tiles (csrc/conv3x3_flat.hip:
+ * the output pixels of a sample linearised on the pitch Wout + 2 of the padded input, 32 per M-tile, tiles of 8 / 12 / 16 M-tiles
+ * across sample borders) wherever the launcher's cost figure prefers them; 0 = rectangular tiles everywhere; 2 / 3 / 4 = flat tiles
+ * with that many M-tiles per multiplying wave wherever the kernel applies (tests, A/B).  Bit-identical results either way (same
+ * accumulation order per output element).  Returns the previous setting; env UNCL_FLAT sets the initial one. */
+int uncl_conv3x3_set_flat(int on);
+/* number of launches that took the flat tiles since the library was loaded (tests; bench.py reports it) */
+long long uncl_conv3x3_flat_count(void);
 /* Inference, last decoder stage (up_path.3; Unet_singleFrame.py:200-209): 1 = concat + fused up-conv -> ConvT3x3 -> ConvT3x3 ->
  * outconv + last activation as ONE launch (uncl_conv_desc.tail_w), the two 32-channel maps stay in LDS (1.9 GB less HBM traffic per
  * 200 tiles); 0 (default) = two launches with the 254 x 254 x 32 map in HBM between them -- the faster launch pair, the whole

@@ -99,6 +99,8 @@ SIGNATURES = {
     "uncl_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "uncl_conv3x3_pipe": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p]),
     "uncl_conv3x3_set_pc": (C.c_int, [C.c_int]),
+    "uncl_conv3x3_set_flat": (C.c_int, [C.c_int]),
+    "uncl_conv3x3_flat_count": (C.c_longlong, []),
     "uncl_wgrad_set_scratch": (C.c_int, [C.c_void_p, C.c_size_t]),
     "uncl_wgrad_scratch_bytes": (C.c_size_t, []),
     "uncl_gen_set_deterministic": (C.c_int, [C.c_int]),

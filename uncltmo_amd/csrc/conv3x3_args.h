@@ -41,6 +41,10 @@ struct PipeArgs {
   const float* tail_b;  // its bias (32) or NULL
   int oH, oW;           // extent of the final one-channel map: Hout + 2, Wout + 2
   int o1_lds_off;       // conv3x3_pipe: byte offset of the parked outconv fragments in LDS (register-direct 1x1 tail)
+  // conv3x3_flat: output pixels linearised on the padded input's pitch, M-tiles of 32 of them (conv3x3_flat.hip)
+  int fl_pitch, fl_mts, fl_halo, fl_total_mt;   // Wout + 2, M-tiles per sample, 2 pitch + 2, M-tiles in the batch
+  int fl_cmax, fl_ct_shift;                     // sample borders one tile can span, log2(n_ct)
+  unsigned fl_div_pitch, fl_div_mts;            // floor(2^32 / d) + 1: x / d = umulhi(x, .) for x d < 2^32
   UNCL_CHK_MEMBER       // checked build: the tensors of this launch (common.h)
 };
 
@@ -49,6 +53,10 @@ int uncl_conv3x3_pc_launch(PipeArgs& a, int dtype, int nt, int mpw, int mode, hi
 // conv3x3_pc.hip, TAIL form: concat-ssr + fused up-conv source (mode 4) -> transposed 3x3 -> transposed 3x3 -> 1x1 + last
 // activation as ONE launch; a.Hout / a.Wout = extent of the intermediate map, a.oH / a.oW = extent of the result a.out1
 int uncl_conv3x3_tail_launch(PipeArgs& a, int dtype, hipStream_t s);
+// conv3x3_flat.hip: flat M-tiles for the 64-channel-tile layers of the small / mid-size maps (mode 0 plain, 1 concat-ssr);
+// UNCL_ERR_ARG where it does not apply.  mpw_pref 0: choose the M-tiles per multiplying wave; 2 / 3 / 4: that or nothing;
+// max_cost > 0: only below that cost (rounds of the persistent grid x (M-tiles per wave + 0.35))
+int uncl_conv3x3_flat_launch(PipeArgs& a, int dtype, int mode, int mpw_pref, double max_cost, hipStream_t s);
 
 namespace {
 

@@ -908,6 +908,14 @@ int dispatch_type(PipeArgs& a, int dtype, int mode, bool prev, hipStream_t s) {
 #define UNCL_PC_TWO_DEFAULT 0
 #endif
 static int g_use_pc = [] { const char* e = getenv("UNCL_PC"); return e ? atoi(e) : 2; }();
+// flat M-tiles (conv3x3_flat.hip): 0 off, 1 (default) where the cost model prefers them, 2 / 3 / 4: wherever the kernel applies,
+// with that many M-tiles per multiplying wave (tests, A/B)
+static int g_use_flat = [] { const char* e = getenv("UNCL_FLAT"); return e ? atoi(e) : 1; }();
+extern "C" int uncl_conv3x3_set_flat(int on) {
+  const int old = g_use_flat;
+  g_use_flat = on < 0 ? 0 : (on > 4 ? 4 : on);
+  return old;
+}
 extern "C" int uncl_conv3x3_set_pc(int on) {
   const int old = g_use_pc;
   g_use_pc = on < 0 ? 0 : (on > 3 ? 3 : on);
@@ -1086,7 +1094,20 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     // thresholds of 128 ... 384 tiles measured alike, 768 cost the two-part inference forward 2 %)
     const int tall_tiles = d->N * a.tiles_x * ((a.Hout + 15) / 16) * a.n_ct;
     static const int tall_min = [] { const char* e = getenv("UNCL_PC_TALL_MIN"); return e ? atoi(e) : 256; }();
-    if (tall && ((a.Hout + 15) / 16) * 16 <= ((a.Hout + 7) / 8) * 8 && tall_tiles >= tall_min) {
+    const bool go_tall = tall && ((a.Hout + 15) / 16) * 16 <= ((a.Hout + 7) / 8) * 8 && tall_tiles >= tall_min;
+    if (g_use_flat && (pc_mode == 0 || pc_mode == 1) && pool_out == nullptr) {
+      // flat M-tiles (conv3x3_flat.hip) where the rectangles above leave a large part of their pixels outside the map: the 24 ..
+      // 61-pixel levels.  Chosen by the same cost figure for both tilings: rounds of the persistent grid x (M-tiles per wave +
+      // 0.35); g_use_flat 2 / 3 / 4 (tests) forces that many M-tiles per wave wherever the kernel applies
+      const int n_cu = uncl_cu_count();
+      const long long rect_steps = go_tall ? tall_tiles : a.total_tiles;
+      const double rect_cost = n_cu > 0 ? (double)((rect_steps + n_cu - 1) / n_cu) * ((go_tall ? 4 : 2) + 0.35) : 0.;
+      PipeArgs b = a;
+      const int rc = uncl_conv3x3_flat_launch(b, d->dtype, pc_mode, g_use_flat >= 2 ? g_use_flat : 0,
+                                              g_use_flat >= 2 ? 0. : 0.97 * rect_cost, s);
+      if (rc != UNCL_ERR_ARG) return rc;
+    }
+    if (go_tall) {
       PipeArgs b = a;
       b.tiles_y = (a.Hout + 15) / 16;
       b.total_tiles = tall_tiles;
