@@ -87,7 +87,7 @@ typedef struct uncl_conv_desc {
   const void* prev0;    /* video recurrence: channels [0, prev_ch) of src0 are read from this tensor of the
                            previous frame instead (Unet.py:244,270), NULL if unused             */
   int prev_ch;
-  const void* weight;   /* packed [z][tap][Cout][Cin] in `dtype` (uncl_pack_conv_weight)     */
+  const void* weight;   /* packed by uncl_pack_conv_weight: [z][tap][Cout][Cin] in `dtype` (16-bit 3x3: K-chunk-major) */
   const float* bias;    /* [Cout_total] fp32 or NULL                                         */
   int act;              /* UNCL_ACT_* applied to conv+bias                                   */
   const float* scale_n; /* optional per-sample multiplier (DropPath keep/keep_prob), [N]     */
@@ -285,7 +285,11 @@ int uncl_conv_in_c1_wgrad(const void* G, const float* x, float* gw, float* gb, i
 /* Re-layout one reference-format weight for uncl_conv_igemm.
  * src: fp32, Conv2d layout (Cout, Cin, k, k) or, if transposed != 0, ConvTranspose2d layout (Cin, Cout, k, k).
  * dst: [tap][Cout][Cin] in dtype; for a transposed stride-1 3x3 the taps are flipped (tap' = 8 - tap) so that
- * the kernel runs it as a pad-2 correlation; for the stride-2 2x2 the four taps index (dy, dx) unflipped. */
+ * the kernel runs it as a pad-2 correlation; for the stride-2 2x2 the four taps index (dy, dx) unflipped.
+ * 3x3 weights in a 16-bit dtype with Cin a multiple of 32 are stored K-CHUNK-MAJOR instead, [Cin / 32][9][Cout][32]: the MFMA
+ * kernels stage one 32-channel K-chunk of all nine taps at a time, and this makes that chunk whole 128-byte lines (round 5:
+ * half the L2 -> L1 requests of every layer that streams its weights).  Only this function writes the layout and only the 3x3
+ * kernels read it; a caller never indexes a packed weight. */
 int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int Cout, int Cin, int k, int transposed,
                           int flip, void* stream);
 /* The same re-layout for many weights in one launch per UNCL_PACK_MAX_ITEMS items (a training step re-packs every weight

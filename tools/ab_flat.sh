@@ -1,9 +1,12 @@
 #!/bin/bash
 # run on the GPU box: per-layer times with flat tiles off / on (same library, env switch), three interleaved repetitions
+# tools/ab_flat.sh <tag> "<settings>" <reps>: UNCL_FLAT settings 0 (rectangular) 1 (cost model) 2 / 3 / 4 (forced M-tiles per wave)
 TAG=${1:-abflat}
+SETS=${2:-"0 1"}
+REPS=${3:-3}
 mkdir -p gpurun_out/$TAG
-for rep in 1 2 3; do
-  for f in 0 1; do
+for rep in $(seq 1 $REPS); do
+  for f in $SETS; do
     UNCL_FLAT=$f python tools/layer_times.py > gpurun_out/$TAG/ab_flat${f}_$rep.log 2>&1
   done
 done
@@ -16,7 +19,7 @@ for f in sorted(glob.glob("gpurun_out/$TAG/ab_*_*.log")):
         m = re.match(r"\s*(\d+) (\S+)\s+([\d.]+) ms", l)
         if m: rows[m.group(2)][name].append(float(m.group(3)))
 names = sorted({n for r in rows.values() for n in r})
-print("%-34s" % "layer (min of 3, ms)" + "".join("%8s" % n for n in names))
+print("%-34s" % "layer (min over reps, ms)" + "".join("%8s" % n for n in names))
 tot = collections.defaultdict(float)
 for layer, r in rows.items():
     if max(min(v) for v in r.values()) < 0.01: continue

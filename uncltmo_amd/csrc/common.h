@@ -96,6 +96,15 @@ __device__ __forceinline__ void uncl_chk_access(const UnclChk& c, const void* p,
 #define UNCL_CHK_MEMBER
 #endif
 
+// Packed 3x3 weights of the 16-bit kernels are K-chunk-major, [Cin / 32][9][Cout][32] (misc_kernels.hip, pack_weight_kernel):
+// element (tap, co, ci) of a layer with Cout output channels
+__host__ __device__ __forceinline__ bool uncl_w3_chunk_major(size_t elem_bytes, int kk, int Cin) {
+  return elem_bytes == 2 && kk == 9 && (Cin & 31) == 0;
+}
+__host__ __device__ __forceinline__ size_t uncl_w3_index(int tap, int co, int ci, int Cout) {
+  return (((size_t)(ci >> 5) * 9 + tap) * Cout + co) * 32 + (ci & 31);
+}
+
 // Element traits: a "vec" is always 16 bytes, the unit every loader / LDS access moves.
 template <typename T>
 struct Elem;

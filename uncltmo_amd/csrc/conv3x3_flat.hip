@@ -29,7 +29,39 @@
 
 #include "conv3x3_args.h"
 
+// Ablations (measurement builds only: tools/ab_variants.sh <name> "-DUNCL_FL_ABL_MASK=<bits>" with FILES=conv3x3_flat; compile-time,
+// so that the product's code is otherwise unchanged; WRONG results): 16 no activation loads, 32 no weight loads, 64 no output stores,
+// 128 no MFMAs (fragments still read), 256 no activation staging writes, 512 no square / square-root transforms, 1024 no weight
+// staging writes, 2048 no slot-offset arithmetic
+#ifndef UNCL_FL_ABL_MASK
+#define UNCL_FL_ABL_MASK 0
+#endif
+#define FL_ABL(bit) (((UNCL_FL_ABL_MASK) & (bit)) != 0)
+// streamed weights: 1 = two register sets, a chunk's weights are requested TWO iterations before they are staged (one set: one)
+#ifndef UNCL_FL_W2
+#define UNCL_FL_W2 0
+#endif
+
 namespace {
+
+// Phase timing (measurement builds only, -DUNCL_FL_TIMING; tools/fl_phase_timing.py): wave 0 (multiplying) and wave 4 (staging) of
+// every workgroup accumulate s_memtime deltas per loop phase; the product library compiles all of this away.
+#ifdef UNCL_FL_TIMING
+__device__ unsigned long long g_fl_t[48];
+__device__ __forceinline__ unsigned long long flt_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define FLT_DECL unsigned long long flt_acc[16] = {}; unsigned long long flt_last = flt_now();
+#define FLT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long flt_t = flt_now(); __builtin_amdgcn_sched_barrier(0); \
+                 flt_acc[i] += flt_t - flt_last; flt_last = flt_t; }
+#define FLT_FLUSH(base, cnt) if (lane == 0) { for (int i = 0; i < 16; ++i) atomicAdd(&g_fl_t[base + i], flt_acc[i]); atomicAdd(&g_fl_t[cnt], 1ull); }
+#else
+#define FLT_DECL
+#define FLT(i)
+#define FLT_FLUSH(base, cnt)
+#endif
 
 __device__ __forceinline__ void fl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -128,6 +160,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
     };
     auto mm = [&](int col) __attribute__((always_inline)) {
       const int set = col & 1;
+#if UNCL_FL_ABL_MASK
+      if (FL_ABL(128)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(A[set][nt]));
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) asm volatile("" ::"v"(B[set][m]));
+        return;
+      }
+#endif
 #pragma unroll
       for (int m = 0; m < MPW; ++m)
 #pragma unroll
@@ -246,6 +287,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
 #ifdef UNCL_CHECKED
             if (off < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.out) + sbase + off, 16);
 #endif
+#if UNCL_FL_ABL_MASK
+            if (FL_ABL(64)) { asm volatile("" ::"v"(si)); continue; }
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, si), rs, off, 0, 0);
           }
       }
@@ -257,16 +301,20 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
       for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16;
     int tpar = 0;
     tile_bases(step0, 0u);
+    FLT_DECL
     fl_barrier();                         // stage 0 is staged
+    FLT(10)
     rd(0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
     int s = 0;                            // chunks multiplied so far: chunk s sits in stage s & 1
     for (int t = step0; t < step_end; ++t) {
       for (int kc = 0; kc < a.nk - 1; ++kc) {
         cols_0_16();
+        FLT(kc & 3)
         __builtin_amdgcn_sched_barrier(0);
         fl_barrier();                     // column 17's fragments have landed: done with stage s & 1; stage (s + 1) & 1 is staged
         __builtin_amdgcn_sched_barrier(0);
+        FLT(4 + (kc & 3))
         ++s;
         flip_stage(s & 1, kc + 1);
         rd(0, 0);
@@ -276,9 +324,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
       cols_0_16();
       mm(17);
       __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+      FLT((a.nk - 1) & 3)
       epilogue(t, tpar);
       zero_acc();
+      FLT(8)
       fl_barrier();
+      FLT(4 + ((a.nk - 1) & 3))
       ++s;
       if (t + 1 < step_end) {
         tile_bases(t + 1, (s & 1) ? (unsigned)STAGE : 0u);
@@ -288,7 +339,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
         __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
       }
       tpar = (tpar + 1) & 3;
+      FLT(9)
     }
+    FLT_FLUSH(0, 32)
     return;
   }
 
@@ -301,19 +354,21 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
   constexpr int PPP = NPROD / 4;                     // pixels (slots) per pass
   constexpr int XV = (LMAX + PPP - 1) / PPP;
   constexpr int WPP = NPROD / 4;                     // weight rows per pass
-  static_assert(WPP % CT == 0 || CT % WPP == 0, "a weight pass covers whole taps or a whole fraction of one");
+  static_assert(WPP % CT == 0, "a weight pass covers whole taps");
   constexpr int WVN = (WROWS + WPP - 1) / WPP;
   constexpr bool W_RAGGED = WROWS % WPP != 0;
   const int ch = ptid & 3, p0 = ptid >> 2;
   const int lds_w0 = ch * WPL + p0 * 16;
-  // weight row r = tap * CT + cout (cout within the tile): global [tap][Cout][Cin]
-  auto wrow_off = [&](int r) __attribute__((always_inline)) { return ((r / CT) * a.Cout + (r % CT)) * a.Cin + ch * 8; };
+  // weight row p0 + WPP j = tap (p0 / CT + (WPP / CT) j), cout p0 % CT of the tile: one per-thread offset, the pass stride goes
+  // into the scalar base
+  const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * 32 + ch * 8;      // K-chunk-major weights, [Cin / 32][9][Cout][32] (common.h)
 
   vec xa[XV], xb[XV];       // xb is dead for plain sources
-  vec wv[WVN];
+  constexpr bool W2 = UNCL_FL_W2 && !RESW;
+  vec wv[W2 ? 2 : 1][WVN];
   f32x4 br = {0.f, 0.f, 0.f, 0.f};
-  unsigned offB[XV];     // plain sources: byte offsets of this thread's slots in the current tile (dead for concat sources)
   unsigned validA = 0, validB = 0;
+  int npA = XV, npB = XV;          // passes the registers in xa / xb (plain: xa) hold data for
   int bpar = 0, ppar = 0;
   bool bp = false;
 
@@ -321,55 +376,80 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
     if (!CAT) return kc;
     return ssr_member(kc & 3) * (a.s0C >> 5) + (kc >> 2);
   };
-  auto load_weights = [&](int cout0, int kc) __attribute__((always_inline)) {
-    const bf16_t* wb_ = a.weight + (size_t)cout0 * a.Cin + weight_chunk(kc) * 32;
+  auto load_weights = [&](int cout0, int kc, int set) __attribute__((always_inline)) {
+    const bf16_t* wb_ = a.weight + ((size_t)weight_chunk(kc) * 9 * a.Cout + cout0) * 32;
+    const int wstride = (WPP / CT) * a.Cout * 32;     // taps per pass x one tap
 #pragma unroll
     for (int j = 0; j < WVN; ++j) {
-      const int r = p0 + WPP * j;
-      unsigned off = (unsigned)wrow_off(W_RAGGED && j == WVN - 1 ? min(r, WROWS - 1) : r);
-      wv[j] = LD16OV(vec, wb_, off * 2u);
+      unsigned off = (unsigned)woff0;
+      if (W_RAGGED && j == WVN - 1) off = (p0 + WPP * j < WROWS) ? off : 0u;
+      if (FL_ABL(32)) continue;
+      wv[set][j] = LD16OV(vec, wb_ + j * wstride, off * 2u);
     }
   };
-  auto write_weights = [&](char* wst) __attribute__((always_inline)) {
+  auto write_weights = [&](char* wst, int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < WVN; ++j) {
       if (W_RAGGED && j == WVN - 1 && p0 + WPP * j >= WROWS) continue;
-      *reinterpret_cast<vec*>(wst + lds_w0 + j * WPP * 16) = wv[j];
+      if (FL_ABL(1024)) { asm volatile("" ::"v"(wv[set][j])); continue; }
+      *reinterpret_cast<vec*>(wst + lds_w0 + j * WPP * 16) = wv[set][j];
     }
   };
 
-  // the slots of tile tt: V = V0 + slot -> (sample, padded row, padded column) -> source offsets and validity.
-  // SRC1: offsets into the up-sampled map (replicate-padded to the skip's extent, unet_parts.py:292-298)
-  const int dy1 = (a.s0H - a.s1H) >> 1, dx1 = (a.s0W - a.s1W) >> 1;
-  auto tile_offsets = [&](int tt, unsigned (&off)[XV], bool src1) __attribute__((always_inline)) {
+  // The slots of a tile.  Slot i of tile tt is V = V0 + i -> (sample, padded row, padded column); computed ONCE per tile and kept
+  // as a code per slot -- bit 31 valid (inside the tile's image, the batch and the un-padded input), bits 24..28 sample - first
+  // sample of the tile, bits 12..23 input row, bits 0..11 input column -- from which a request builds its byte offsets with three
+  // 24-bit multiply-adds (full rate; the 32-bit multiplies of a from-scratch address are quarter rate, and a concat layer
+  // requests registers for every 32-channel slice of both sources: the staging waves are what these launches wait for).
+  struct TileCodes { unsigned code[XV]; int tt, n0, np; };
+  // passes 0 .. JMIN - 1 cover the tile's own 32 TM pixels and are always needed; the rest depends on the tile's halo count
+  constexpr int JMIN = (32 * TM) / PPP;
+  auto tile_codes = [&](TileCodes& tc, int tt) __attribute__((always_inline)) {
     const int g0 = tt * TM;
     const int n_first = (int)__umulhi((unsigned)g0, a.fl_div_mts);
     const int g_last = min(g0 + TM, a.fl_total_mt) - 1;
     const int n_last = (int)__umulhi((unsigned)g_last, a.fl_div_mts);
     const unsigned p_first = (unsigned)(g0 - n_first * MTS) * 32u;
     const unsigned L = (unsigned)(32 * TM + (n_last - n_first + 1) * HALO);
-    unsigned valid = 0;
+    tc.tt = tt;
+    tc.n0 = n_first;
+    tc.np = __builtin_amdgcn_readfirstlane((int)((L + PPP - 1) / PPP));
 #pragma unroll
     for (int j = 0; j < XV; ++j) {
+      tc.code[j] = 0u;
+      if (j >= JMIN && j >= tc.np) continue;            // wave-uniform
+      if (FL_ABL(2048)) { tc.code[j] = 0x80000000u | (unsigned)(p0 & 15); continue; }
       const unsigned slot = (unsigned)(p0 + j * PPP);
       unsigned p = p_first + slot;
-      int n = n_first;
+      unsigned dn = 0;
       // (a tile spans at most fl_cmax sample borders: launcher)
       for (int c = 0; c < a.fl_cmax; ++c)
-        if (p >= VS) { p -= VS; ++n; }
-      const unsigned yy = __umulhi(p, a.fl_div_pitch), xx = p - yy * (unsigned)P;
-      const int iy = (int)yy - a.pad, ix = (int)xx - a.pad;
-      const bool ok = slot < L && n < a.flat_N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      unsigned o;
-      if (src1) {
-        const int sy = min(max(iy - dy1, 0), a.s1H - 1), sx = min(max(ix - dx1, 0), a.s1W - 1);
-        o = (unsigned)(((n * a.s1H + sy) * a.s1W + sx) * a.s1C + ch * 8) * 2u;
-      } else {
-        o = (unsigned)(((n * a.s0H + iy) * a.s0W + ix) * a.s0C + ch * 8) * 2u;
-      }
-      off[j] = ok ? o : 0u;
-      valid |= (ok ? 1u : 0u) << j;
+        if (p >= VS) { p -= VS; ++dn; }
+      const unsigned yy = __umulhi(p, a.fl_div_pitch), xx = p - __umul24(yy, (unsigned)P);
+      const unsigned iy = yy - (unsigned)a.pad, ix = xx - (unsigned)a.pad;
+      const bool ok = slot < L && (int)dn + n_first < a.flat_N && iy < (unsigned)a.H && ix < (unsigned)a.W;
+      tc.code[j] = ok ? (0x80000000u | (dn << 24) | (iy << 12) | ix) : 0u;
     }
+  };
+  // SRC1: offsets into the up-sampled map (replicate-padded to the skip's extent, unet_parts.py:292-298)
+  const int dy1 = (a.s0H - a.s1H) >> 1, dx1 = (a.s0W - a.s1W) >> 1;
+  auto slot_offset = [&](unsigned code, int n0, bool src1) __attribute__((always_inline)) {
+    const unsigned n = (unsigned)n0 + ((code >> 24) & 31u);
+    const int iy = (int)((code >> 12) & 0xfffu), ix = (int)(code & 0xfffu);
+    unsigned o;
+    if (src1) {
+      const int sy = min(max(iy - dy1, 0), a.s1H - 1), sx = min(max(ix - dx1, 0), a.s1W - 1);
+      o = __umul24(__umul24(__umul24(n, (unsigned)a.s1H) + (unsigned)sy, (unsigned)a.s1W) + (unsigned)sx, (unsigned)a.s1C * 2u);
+    } else {
+      o = __umul24(__umul24(__umul24(n, (unsigned)a.s0H) + (unsigned)iy, (unsigned)a.s0W) + (unsigned)ix, (unsigned)a.s0C * 2u);
+    }
+    o += (unsigned)ch * 16u;
+    return (int)code < 0 ? o : 0u;
+  };
+  auto codes_valid = [&](const TileCodes& tc) __attribute__((always_inline)) {
+    unsigned valid = 0;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) valid |= (tc.code[j] >> 31) << j;
     return valid;
   };
 
@@ -381,50 +461,57 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
     return ++c.step < step_end;
   };
   Cur pc{step0, 0};
-  int ttB = -1;                      // plain sources: the tile whose offsets offB holds
+  TileCodes tcB, tcA;                // x2 / plain source: the tile of the main cursor; x1 (concat): the tile of the look-ahead
+  tcB.tt = -1; tcA.tt = -1; tcB.n0 = tcA.n0 = 0; tcB.np = tcA.np = XV;
   const int total = (step_end - step0) * a.nk;
   int loaded = 0;
 
-  // (concat sources request a slice's registers once per four chunks: their slot offsets are recomputed at each request instead
-  // of being kept in registers beside two staging sets -- ~15 vector instructions per slot against a multiplying step of ~18 k cycles)
   auto load_xa = [&](const Cur& c) __attribute__((always_inline)) {
     // x1 slice (concat) of the slice that starts at chunk c
-    unsigned off[XV];
-    validA = tile_offsets(c.step >> a.fl_ct_shift, off, true);
+    const int tt = c.step >> a.fl_ct_shift;
+    if (tt != tcA.tt) tile_codes(tcA, tt);
+    validA = codes_valid(tcA);
+    npA = tcA.np;
     const bf16_t* base = a.src1 + (c.kc >> 2) * 32;
 #pragma unroll
-    for (int j = 0; j < XV; ++j) xa[j] = LD16OV(vec, base, off[j]);
+    for (int j = 0; j < XV; ++j) {
+      if (j >= JMIN && j >= npA) continue;
+      if (FL_ABL(16)) continue;
+      xa[j] = LD16OV(vec, base, slot_offset(tcA.code[j], tcA.n0, true));
+    }
   };
   auto load_step = [&](const Cur& c, auto p_tag) __attribute__((always_inline)) {
     constexpr int PH = decltype(p_tag)::value;
     const int tt = c.step >> a.fl_ct_shift, cout0 = (c.step & (a.n_ct - 1)) * CT;
     bp = c.kc == 0;
     bpar = ppar;
-    if (!CAT) {
-      if (tt != ttB) { validB = tile_offsets(tt, offB, false); ttB = tt; }
-      const bf16_t* base = a.src0 + c.kc * 32;
+    if (!CAT || PH == 0) {
+      // plain: this chunk's channels; concat: the x2 slice of this group -- loaded once, staged three times (sqrt, square, as is)
+      if (tt != tcB.tt) tile_codes(tcB, tt);
+      validB = codes_valid(tcB);
+      npB = tcB.np;
+      const bf16_t* base = a.src0 + (CAT ? (c.kc >> 2) : c.kc) * 32;
+      vec (&xr)[XV] = CAT ? xb : xa;
 #pragma unroll
-      for (int j = 0; j < XV; ++j) xa[j] = LD16OV(vec, base, offB[j]);
-    } else if (PH == 0) {
-      // the x2 slice of this group: loaded once, staged three times (sqrt, square, as is)
-      unsigned off[XV];
-      validB = tile_offsets(tt, off, false);
-      const bf16_t* base = a.src0 + (c.kc >> 2) * 32;
-#pragma unroll
-      for (int j = 0; j < XV; ++j) xb[j] = LD16OV(vec, base, off[j]);
+      for (int j = 0; j < XV; ++j) {
+        if (j >= JMIN && j >= npB) continue;
+        if (FL_ABL(16)) continue;
+        xr[j] = LD16OV(vec, base, slot_offset(tcB.code[j], tcB.n0, false));
+      }
     }
     if (!RESW) {
-      load_weights(cout0, c.kc);
+      if (!W2) load_weights(cout0, c.kc, 0);
       if (bp && ptid < CT / 4 && a.bias != nullptr) br = LD16O_F32(a.bias + cout0, (unsigned)ptid * 16u);
     }
   };
-  auto write_step = [&](char* st, auto p_tag) __attribute__((always_inline)) {
+  auto write_step = [&](char* st, auto p_tag, int wset) __attribute__((always_inline)) {
     constexpr int PH = decltype(p_tag)::value;
     constexpr bool SET_A = !CAT || PH == 0;
     vec (&xr)[XV] = SET_A ? xa : xb;
     const unsigned xvalid = (!CAT || !SET_A) ? validB : validA;
+    const int np = (!CAT || !SET_A) ? npB : npA;
     auto transform = [&](vec v) __attribute__((always_inline)) {
-      if (CAT && ssr_member(PH) >= 2) {
+      if (CAT && ssr_member(PH) >= 2 && !FL_ABL(512)) {
         float f[8];
         E::unpack(v, f);
         if (ssr_member(PH) == 2) {
@@ -442,12 +529,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
     if (wave_ok) {
 #pragma unroll
       for (int j = 0; j < XV; ++j) {
+        if (j >= JMIN && j >= np) continue;
         if ((j + 1) * PPP > LMAX && p0 + j * PPP >= LMAX) continue;
+        if (FL_ABL(256)) { asm volatile("" ::"v"(xr[j])); continue; }
         *reinterpret_cast<vec*>(st + ch * XPL + (p0 + j * PPP) * 16) = transform(xr[j]);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < XV; ++j) {
+        if (j >= JMIN && j >= np) continue;
         if ((j + 1) * PPP > LMAX && p0 + j * PPP >= LMAX) continue;
         vec v = transform(xr[j]);
         if (!((xvalid >> j) & 1u)) v = E::zero();
@@ -455,7 +545,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
       }
     }
     if (!RESW) {
-      write_weights(st + XBYTES);
+      write_weights(st + XBYTES, wset);
       if (bp && ptid < CT / 4) *reinterpret_cast<f32x4*>(sBias + bpar * CT + ptid * 4) = br;
     }
   };
@@ -479,8 +569,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
   if (RESW) {
     // the layer's whole weight tensor (one cout tile, nk chunks) becomes resident, and so does its bias (all four slots)
     for (int kc = 0; kc < a.nk; ++kc) {
-      load_weights(0, kc);
-      write_weights(wres + kc * WBYTES);
+      load_weights(0, kc, 0);
+      write_weights(wres + kc * WBYTES, 0);
     }
     if (ptid < CT / 4) {
       if (a.bias != nullptr) UNCL_CHK(a.chk, a.bias + ptid * 4, 16);
@@ -489,13 +579,28 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
       for (int sl = 0; sl < 4; ++sl) *reinterpret_cast<f32x4*>(sBias + sl * CT + ptid * 4) = b4;
     }
   }
+  // W2: the weights' own cursor runs one chunk ahead of the activations'
+  Cur wc{step0, 0};
+  int wloaded = 0;
+  auto load_w_next = [&](int set) __attribute__((always_inline)) {
+    if (W2 && wloaded < total) {
+      load_weights((wc.step & (a.n_ct - 1)) * CT, wc.kc, set);
+      ++wloaded;
+      cur_next(wc);
+    }
+  };
+  load_w_next(0);                       // chunk 0
   if (CAT) load_xa(pc);                 // the first slice's x1
   load_next(IntTag<0>{});
-  write_step(smem, IntTag<0>{});
+  load_w_next(1);                       // chunk 1
+  write_step(smem, IntTag<0>{}, 0);
   load_next(IntTag<1>{});
+  load_w_next(0);                       // chunk 2
+  FLT_DECL
   fl_barrier();                         // stage 0 is staged
+  FLT(12)
   // iteration s (the multiplying waves work on chunk s): chunk s + 1 goes from registers to the stage they left at the last
-  // barrier, then the loads of chunk s + 2 are issued into the same registers
+  // barrier, then the loads of chunk s + 2 (W2: the weights of chunk s + 3) are issued into the same registers
   int s = 0;
   auto iter = [&](auto q_tag) __attribute__((always_inline)) {
     constexpr int Q = decltype(q_tag)::value;
@@ -503,9 +608,13 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
       fl_barrier();                     // the multiplying waves' last chunk
       return true;
     }
-    write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
+    write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{}, W2 ? (Q + 1) & 1 : 0);
+    FLT(Q)
     load_next(IntTag<(Q + 2) & 3>{});
+    load_w_next((Q + 1) & 1);
+    FLT(4 + Q)
     fl_barrier();
+    FLT(8 + Q)
     ++s;
     return false;
   };
@@ -515,6 +624,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
     if (iter(IntTag<2>{})) break;
     if (iter(IntTag<3>{})) break;
   }
+  FLT_FLUSH(16, 33)
 }
 
 template <int NT>
@@ -554,6 +664,18 @@ int fl_dispatch(PipeArgs& a, int mode, bool resw, hipStream_t s) {
 
 }  // namespace
 
+#ifdef UNCL_FL_TIMING
+// measurement builds only: copy (and optionally clear) the per-phase cycle counters
+extern "C" int uncl_fl_timing_read(unsigned long long* out48, int reset) {
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_fl_t), sizeof(unsigned long long) * 48) != hipSuccess) return UNCL_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[48] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fl_t), z, sizeof(z)) != hipSuccess) return UNCL_ERR_LAUNCH;
+  }
+  return UNCL_OK;
+}
+#endif
+
 static std::atomic<long long> g_flat_launches{0};
 // launches that took the flat tiles so far (tests: the cost figure must choose them where they were built for)
 extern "C" long long uncl_conv3x3_flat_count() { return g_flat_launches.load(std::memory_order_relaxed); }
@@ -586,6 +708,10 @@ int uncl_conv3x3_flat_launch(PipeArgs& a, int dtype, int mode, int mpw_pref, dou
   if ((unsigned long long)a.flat_N * a.s0H * a.s0W * a.s0C * 2 >= (1ull << 32)) return UNCL_ERR_ARG;
   if (mode == 1 && (unsigned long long)a.flat_N * a.s1H * a.s1W * a.s1C * 2 >= (1ull << 32)) return UNCL_ERR_ARG;
   if ((unsigned long long)a.Hout * a.Wout * a.oC * 2 >= (1ull << 30)) return UNCL_ERR_ARG;
+  // slot codes: 12-bit rows / columns, 24-bit multiply operands (pixel index in the batch)
+  if (a.H >= 4096 || a.W >= 4096 || (long long)a.flat_N * a.s0H * a.s0W >= (1 << 24) ||
+      (mode == 1 && (long long)a.flat_N * a.s1H * a.s1W >= (1 << 24)))
+    return UNCL_ERR_ARG;
   const bool resw = n_ct == 1 && a.nk * 2 <= 4;
   const int lmax = fl_lmax(2, resw);
   const int n_cu = uncl_cu_count();
@@ -596,7 +722,7 @@ int uncl_conv3x3_flat_launch(PipeArgs& a, int dtype, int mode, int mpw_pref, dou
     if (mpw_pref != 0 && mpw != mpw_pref) continue;
     const int tm = 4 * mpw;
     const int cmax = mts >= tm ? 1 : (tm - 2) / mts + 1;                       // sample borders one tile can span
-    if (32 * tm + (cmax + 1) * halo > lmax) continue;
+    if (32 * tm + (cmax + 1) * halo > lmax || cmax > 31) continue;
     // cost model: rounds of the persistent grid x M-tiles per wave (+ one M-tile's worth per tile-step for the epilogue / hand-over)
     const long long steps = ((total_mt + tm - 1) / tm) * n_ct;
     const long long rounds = (steps + n_cu - 1) / n_cu;

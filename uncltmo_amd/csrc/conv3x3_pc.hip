@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   const int pix_r0 = hy0 * HW + hx;
   const int pix_e = ey * HW + 32 + ec;
   const int lds_w0 = ch * WPL + p0 * 16;             // + XBYTES (streamed) / kc * WBYTES (resident)
-  const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;
+  const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * 32 + ch * 8;      // K-chunk-major weights, [Cin / 32][9][Cout][32] (common.h)
 
   // Staging registers: ONE set.  At step s (the consumers multiply chunk s) chunk s + 1 goes from registers to LDS and the
   // loads of chunk s + 2 are issued into the registers that just became free, so every load has a whole step of the workgroup
@@ -1092,8 +1092,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     return ssr_member(kc & 3) * (a.s0C >> 5) + (kc >> 2);
   };
   auto load_weights = [&](int cout0, int kc) __attribute__((always_inline)) {
-    const bf16_t* wb_ = a.weight + (size_t)cout0 * a.Cin + weight_chunk(kc) * 32;
-    const int wstride = (WPP / CT) * a.Cout * a.Cin;  // taps per pass x one tap
+    const bf16_t* wb_ = a.weight + ((size_t)weight_chunk(kc) * 9 * a.Cout + cout0) * 32;
+    const int wstride = (WPP / CT) * a.Cout * 32;     // taps per pass x one tap
 #pragma unroll
     for (int j = 0; j < WVN; ++j) {
       unsigned off = (unsigned)woff0;

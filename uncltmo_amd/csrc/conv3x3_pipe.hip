@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
   const int pix_r0 = hy0 * HW + hx;                          // + j * 2 * HW
   const int pix_e = ey * HW + 32 + ec;
   const int lds_w0 = p0 * 80 + (ch << 4);  // + j * 64 * 80
-  const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * a.Cin + ch * 8;  // + j * (64 / CT) * Cout * Cin
+  const int woff0 = ((p0 / CT) * a.Cout + (p0 % CT)) * 32 + ch * 8;  // K-chunk-major weights (common.h); + j * (64 / CT) * Cout * 32
 
   // FLAT: source sample (or -1: zero padding / unused slot) and element offset inside the group for each staging slot
   int flat_s[FLAT ? XV : 1];
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
       }
     }
     if (with_w) {
-      const bf16_t* wb = a.weight + (size_t)cout0 * a.Cin + wk * 32;
-      const int wstride = (64 / CT) * a.Cout * a.Cin;  // CT = 32: two taps per pass, CT = 64: one
+      const bf16_t* wb = a.weight + ((size_t)wk * 9 * a.Cout + cout0) * 32;
+      const int wstride = (64 / CT) * a.Cout * 32;  // CT = 32: two taps per pass, CT = 64: one
 #pragma unroll
       for (int j = 0; j < WVN; ++j) {
         unsigned off = (unsigned)woff0;

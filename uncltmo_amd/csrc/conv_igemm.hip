@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int idx = tid; idx < TAPS * CT * 4; idx += 256) {
       const int row = idx >> 2, ch = idx & 3;
       const int tap = row / CT, co = row - tap * CT;
-      const size_t off = w_z_off + ((size_t)(tap * a.Cout + cout0 + co)) * a.Cin + kc * KC + ch * EPV;
+      // (3x3 weights of the 16-bit types are K-chunk-major: common.h)
+      const size_t off = uncl_w3_chunk_major(sizeof(T), TAPS, a.Cin)
+                             ? w_z_off + uncl_w3_index(tap, cout0 + co, kc * KC + ch * EPV, a.Cout)
+                             : w_z_off + ((size_t)(tap * a.Cout + cout0 + co)) * a.Cin + kc * KC + ch * EPV;
       *reinterpret_cast<vec*>(sW + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4)) = ldg<T>(a.weight, off);
     }
     __syncthreads();

@@ -7,17 +7,24 @@
 // ------------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------------
+// Packed layouts.  fp32, 1x1, 2x2 and odd channel counts: [tap][Cout][Cin] (K contiguous).  3x3 in a 16-bit type with Cin a
+// multiple of 32 (every layer of the MFMA 3x3 kernels): K-CHUNK-MAJOR, [Cin / 32][9][Cout][32] (uncl_w3_chunk_major, common.h) --
+// the kernels stage one 32-channel K-chunk of all nine taps at a time, and in the tap-major layout that is 9 * Cout pieces of 64
+// bytes, each half of a 128-byte line (the other half belongs to the next chunk: a CU's 32 KB L1 has long dropped it by then);
+// chunk-major it is one contiguous run per tap (the whole chunk for a layer of one cout tile), whole lines, half the requests
+// between L2 and L1 -- which is what the staging waves of the streamed-weight layers queue on (round 5).
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int Cout, int Cin, int kk,
                                    int transposed, int flip) {
   const size_t total = (size_t)kk * Cout * Cin;
+  const bool cm = uncl_w3_chunk_major(sizeof(T), kk, Cin);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin);
     const int co = (int)((i / Cin) % Cout);
     const int tap = (int)(i / ((size_t)Cin * Cout));
     const int ts = flip ? (kk - 1 - tap) : tap;
     const size_t s = transposed ? (((size_t)ci * Cout + co) * kk + ts) : (((size_t)co * Cin + ci) * kk + ts);
-    dst[i] = (T)src[s];
+    dst[cm ? uncl_w3_index(tap, co, ci, Cout) : i] = (T)src[s];
   }
 }
 
@@ -70,6 +77,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch 
   __shared__ float sm[32 * (32 * 9 + 1)];
   const int pitch = 32 * kk + 1;
   T* dst = reinterpret_cast<T*>(e.dst);
+  const bool cm = uncl_w3_chunk_major(sizeof(T), kk, Cin);
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int a0 = (tile / tb) << 5, b0 = (tile % tb) << 5;
     __syncthreads();
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch 
       const int ts = e.flip ? (kk - 1 - tap) : tap;
       const int a = e.transposed ? ci_l : co_l, bb = e.transposed ? co_l : ci_l;
       const int co = e.transposed ? b0 + co_l : a0 + co_l, ci = e.transposed ? a0 + ci_l : b0 + ci_l;
-      dst[((size_t)tap * Cout + co) * Cin + ci] = (T)sm[a * pitch + bb * kk + ts];
+      dst[cm ? uncl_w3_index(tap, co, ci, Cout) : ((size_t)tap * Cout + co) * Cin + ci] = (T)sm[a * pitch + bb * kk + ts];
     }
   }
 }
