@@ -120,23 +120,24 @@ def test_concat_ssr_layers_at_full_size(name, c, cout, hs, h1):
     assert_elementwise(from_nhwc(out), ref, "bf16", name)
 
 
-def test_fused_upconv_concat_layer_at_full_size():
-    """up_path.3: the 2x2 stride-2 transposed conv recomputed in the concat layer's loader (UNCL_SRC_CONCAT_SSR_UP)"""
-    n, c, h = 2, 32, 126
-    H = 2 * h
-    x2 = q(rnd(n, c, H, H, seed=41).abs() * (rnd(n, c, H, H, seed=42) > -0.4))
-    xs = q(rnd(n, c, h, h, seed=43).abs())
+@pytest.mark.parametrize("c,h,w,n", [(32, 126, 126, 2), (64, 61, 61, 3), (64, 9, 23, 2), (64, 17, 40, 2)])
+def test_fused_upconv_concat_layer_at_full_size(c, h, w, n):
+    """up_path.3 / up_path.2: the 2x2 stride-2 transposed conv (32 -> 32, 64 -> 64 channels) recomputed in the concat layer's
+    loader (UNCL_SRC_CONCAT_SSR_UP; unet_parts.py:269,288,311-332), also at sizes whose tiles hang over every border"""
+    H, W = 2 * h, 2 * w
+    x2 = q(rnd(n, c, H, W, seed=41).abs() * (rnd(n, c, H, W, seed=42) > -0.4))
+    xs = q(rnd(n, c, h, w, seed=43).abs())
     wu, bu = q(rnd(c, c, 2, 2, seed=44, scale=0.15)), rnd(c, seed=45, scale=0.2)
     wt, b = q(rnd(4 * c, 32, 3, 3, seed=46, scale=0.05)), rnd(32, seed=47, scale=0.3)
     x1 = q(F.conv_transpose2d(xs, wu, bu, stride=2))
     cat = torch.cat([x2, x1, q(x2 ** 2), q(torch.sqrt(x2 + 1e-8))], 1)
     ref = F.relu(F.conv_transpose2d(cat, wt, b))
-    out = nan_out(n, H + 2, H + 2, 32)
-    run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR_UP, N=n, H=H, W=H, Cin=4 * c, Cout=32, src0=to_nhwc(x2, BF),
-             src0_H=H, src0_W=H, src0_C=c, src1=to_nhwc(xs, BF), src1_H=h, src1_W=h, src1_C=c,
+    out = nan_out(n, H + 2, W + 2, 32)
+    run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR_UP, N=n, H=H, W=W, Cin=4 * c, Cout=32, src0=to_nhwc(x2, BF),
+             src0_H=H, src0_W=W, src0_C=c, src1=to_nhwc(xs, BF), src1_H=h, src1_W=w, src1_C=c,
              up_w=pack_weight(wu, BF, transposed=True), up_b=bu.cuda(), weight=pack_weight(wt, BF, transposed=True, flip=True),
-             bias=b.cuda(), act=_hip.ACT_RELU, out=out, out_H=H + 2, out_W=H + 2, out_C=32)
-    assert_elementwise(from_nhwc(out), ref, "bf16", "up_path.3.conv.conv + up")
+             bias=b.cuda(), act=_hip.ACT_RELU, out=out, out_H=H + 2, out_W=W + 2, out_C=32)
+    assert_elementwise(from_nhwc(out), ref, "bf16", "concat-ssr + fused up (%d channels)" % c)
 
 
 def test_fused_first_layer_at_full_size():

@@ -36,7 +36,7 @@
 #ifndef UNCL_PC_XA_SLOT
 // (TAIL consumes the up-conv's source fragments one iteration earlier -- up_compute -- and requests the next ones from the
 // iteration after that, its lightest: slot 1 = the load step of iteration 3)
-#define UNCL_PC_XA_SLOT (MODE == 4 ? (TAIL ? 1 : 3) : 1)
+#define UNCL_PC_XA_SLOT ((MODE == 4 || MODE == 5) ? (TAIL ? 1 : 3) : 1)
 #endif
 // cache-policy bits of the straight-line epilogue's buffer stores (0 default, 2 = nt: streaming)
 #ifndef UNCL_PC_STORE_AUX
@@ -135,7 +135,9 @@ __device__ __forceinline__ bool cur_next(TileCur& c, const PipeArgs& a, int tile
 
 // MODE: 0 plain, 1 concat [x2, x1, x2^2, sqrt(x2+1e-8)], 4 = 1 with x1 = ConvTranspose2d(k2, s2)(src1) computed by the
 //       producers (32 channels, same extent as the skip), 3 = the 32-channel source is act(conv3x3_valid(fp32 image)) rebuilt
-//       by the producers' matrix cores from the image patch under the halo tile (inc.conv.conv fused into inc.conv.conv1)
+//       by the producers' matrix cores from the image patch under the halo tile (inc.conv.conv fused into inc.conv.conv1),
+//       5 = 4 for a 64-channel skip: x1 = ConvTranspose2d(64, 64, k2, s2)(src1), one 32-channel slice of its output per x1 chunk
+//       (K = 64: four MFMAs per 32 source pixels; the slice's weight fragments and bias are requested with its source pixels)
 #if defined(UNCL_PC_MFMA16_PROXY)
 // TIMING PROXY ONLY (tools/ab_variants.sh, never the product build): the same operand registers through two
 // v_mfma_f32_16x16x32 per 32x32x16 -- equal FLOP, equal LDS fragment reads, WRONG results -- to see what clock the chip holds on
@@ -199,6 +201,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   // streamed weights: two stages of [activations | weights]; resident weights: [X stage 0 | X stage 1 | nk weight chunks]
   constexpr int STAGE = RESW ? XBYTES : XBYTES + WBYTES;
   static_assert(MODE != 4 || (NT == 1 && (MPW == 4 || TAIL)), "fused up-conv: 16 x 32 tiles of 32 channels");
+  static_assert(MODE != 5 || (NT == 1 && MPW == 4 && !TAIL && !RESW), "fused 64-channel up-conv: 16 x 32 tiles of 32 channels, streamed weights");
   static_assert(MODE != 3 || (NT == 1 && RESW), "fused first layer: 32 -> 32 channels, one chunk, resident weights");
   static_assert(!TAIL || (NT == 1 && MPW == 3 && RESW && PW == 8 && MODE == 4), "fused last stage: 12 x 32 x 32 tiles, resident weights");
   constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;            // MODE 3: fp32 image patch under the halo tile
@@ -218,6 +221,8 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   float* const sB1 = sO1 + 64;                                        // TAIL: bias of the second layer (32)
   char* const sW1 = reinterpret_cast<char*>(sB1 + 32);                // TAIL: the second layer's weights, [4 planes][9 taps x 32 rows]
   char* const sCarry = sW1 + 4 * W1PL;                                // TAIL: [2][4 planes][2 rows x HW] last two intermediate rows
+  float* const sUpB = sO1 + 64;                                       // MODE 5: the up-conv's bias (64) ...
+  char* const sUpW = reinterpret_cast<char*>(sUpB + 64);              // ... and its packed weights [4 taps][64 cout][64 cin] (32 KB)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   //   concat source:  steps of a 32-channel slice are [x1, sqrt(x2), x2^2, x2] (phase = step & 3 -> ssr_member, nk is a multiple of 4):
   //                   xa holds the x1 chunk (MODE 4: the up-conv's source fragments), xb the x2 slice, which is staged three
   //                   times (as is, squared, square-rooted) and so read from memory once
-  constexpr bool CAT = MODE == 1 || MODE == 4;
+  constexpr bool CAT = MODE == 1 || MODE == 4 || MODE == 5;
   vec xa[XV], xb[XV];       // xb is dead (and costs no registers) for plain sources
   vec wv[WVN];
   f32x4 br = {0.f, 0.f, 0.f, 0.f};
@@ -1053,6 +1058,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   const int tap = pwave & 3, mt0 = pwave >> 2;
   vec ua[2];
   f32x16 cb;
+  // MODE 5: the source fragments of the wave's M-tiles (K = 64: four per M-tile); the weight fragments and the bias of a slice
+  // are read from LDS when the slice is built (resident there for the launch: as registers they pushed the eight-staging-wave
+  // form, 168 registers, into 49 spilled ones)
+  // (MODE 5 deals whole M-TILES to the waves, all four taps each: the source fragments of an M-tile are then requested once
+  // instead of by each of the four tap waves -- 32 lines per request, the most expensive loads of the kernel)
+  static_assert(MODE != 5 || MTU <= PW, "MODE 5: one source M-tile per staging wave");
+  vec ubf[4];
+  int u_sl = 0;
   if (MODE == 4) {
     const int arow = tap * 32 + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
 #pragma unroll
@@ -1210,6 +1223,21 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
           xr[2 * i + ks] = LD16OV(vec, ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
+      }
+    } else if (MODE == 5 && P == 0) {
+      // as MODE 4 with 64 input channels: four K-steps per source pixel; the weight fragments (A rows = the 32 output channels
+      // of this slice in the order that makes a lane's D registers 16 consecutive channels) and the bias come with them
+      const int sy0 = iy0 >> 1, sx0 = ix0 >> 1;
+      u_iy0 = iy0; u_ix0 = ix0;
+      u_sl = kc >> 2;
+      const bf16_t* ub = a.src1 + (size_t)n * a.s1H * a.s1W * 64;
+      {
+        const int spc = min(pwave * 32 + lr, UPN - 1);          // (waves past the last M-tile request its last pixels: unused)
+        const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;     // / 17 for spc < 1024
+        const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          ubf[ks] = LD16OV(vec, ub, (unsigned)(((yy * a.s1W + xx) * 64 + (2 * ks + lh) * 8) * 2));
       }
     } else if (MODE == 1 && P == 0 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
@@ -1383,6 +1411,41 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
             if (sp < UPN) *reinterpret_cast<vec*>(dst + h * XPL) = upv[i][h];
         }
       }
+    } else if (MODE == 5 && P == 0) {
+      // x1 slice = 32 output channels of ConvTranspose2d(64, 64, k2, s2)(src1) + bias for the halo tile: four MFMAs per 32 source
+      // pixels, scattered like MODE 4's
+      if (pwave < MTU) {       // wave-uniform: this wave's source M-tile, all four taps
+        const int sp = pwave * 32 + lr, spc = min(sp, UPN - 1);
+        const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;
+        f32x16 cb5;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sUpB + 32 * u_sl + 16 * lh + 4 * q4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cb5[4 * q4 + e] = b4[e];
+        }
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+          // A rows = the 32 output channels of this slice in the order that makes a lane's D registers 16 consecutive channels
+          const int arow = tp * 64 + 32 * u_sl + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
+          f32x16 cu = cb5;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            cu = mfma32x16(*reinterpret_cast<const vec*>(sUpW + arow * 128 + (2 * ks + lh) * 16), ubf[ks], cu);
+          const int oy = u_iy0 + (tp >> 1) + 2 * spy, ox = u_ix0 + (tp & 1) + 2 * spx;
+          const bool in_img = (unsigned)oy < (unsigned)a.H && (unsigned)ox < (unsigned)a.W;
+          char* dst = st + 2 * lh * XPL + ((2 * spy + (tp >> 1)) * HW + 2 * spx + (tp & 1)) * 16;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = cu[8 * h + e];
+            vec o = E::pack(f);
+            if (!in_img) o = E::zero();
+            if (sp < UPN) *reinterpret_cast<vec*>(dst + h * XPL) = o;
+          }
+        }
+      }
     } else if (MODE == 4 && P == 0) {
       // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: per 32 source pixels two MFMAs (K = 32 input channels),
       // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image: a lane's D registers are 16
@@ -1482,6 +1545,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   };
   if (a.out1_w != nullptr && ptid < 33) { UNCL_CHK(a.chk, ptid < 32 ? a.out1_w + ptid : a.out1_b, 4); sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0]; }     // fused 1x1 tail (CT == 32)
   if (TAIL && ptid < 32) { if (a.tail_b != nullptr) UNCL_CHK(a.chk, a.tail_b + ptid, 4); sB1[ptid] = a.tail_b != nullptr ? a.tail_b[ptid] : 0.f; }
+  if (MODE == 5) {
+    // the up-conv's weights and bias become resident (read again per slice and tile by every staging wave)
+    for (int i = ptid; i < 4 * 64 * 64 / 8; i += NPROD) *reinterpret_cast<vec*>(sUpW + i * 16) = LD16V(vec, a.up_w + i * 8);
+    if (ptid < 64) { if (a.up_b) UNCL_CHK(a.chk, a.up_b + ptid, 4); sUpB[ptid] = a.up_b ? a.up_b[ptid] : 0.f; }
+  }
   if (TAIL) {
     // the second layer's weights become resident too: global [tap][cout][cin] -> plane (cin slot) x row (tap * 32 + cout)
     for (int i = ptid; i < 9 * 32 * 4; i += NPROD)
@@ -1567,9 +1635,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 }
 
 template <int NT, int MPW>
-constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch) {
+constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, bool up64 = false) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
-  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0);
+  return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0) +
+         (up64 ? 64 * 4 + 4 * 64 * 64 * 2 : 0);
 }
 
 // fused last decoder stage: one workgroup per CU walks an even share of the (strip, row tile) steps
@@ -1598,15 +1667,15 @@ int launch_tail(PipeArgs& a, hipStream_t s) {
 
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
 int launch_pc(PipeArgs& a, hipStream_t s) {
-  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3);
-  static_assert(pc_lds_bytes<NT, MPW>(false, 0, false) <= 163840, "one workgroup's LDS");
+  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, MODE == 5);
+  static_assert(pc_lds_bytes<NT, MPW>(false, 0, false, MODE == 5) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
   auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3) : lds)) != hipSuccess)
+                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, MODE == 5) : lds)) != hipSuccess)
       return UNCL_ERR_LAUNCH;
     attr_done.done();
   }
@@ -1676,6 +1745,7 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
       if (mode == 0) return launch_pc<T, 1, 4, 0, 8, false>(a, s);
       if (mode == 1) return launch_pc<T, 1, 4, 1, 8, false>(a, s);
       if (mode == 4) return launch_pc<T, 1, 4, 4, 8, false>(a, s);
+      if (mode == 5) return launch_pc<T, 1, 4, 5, 8, false>(a, s);
     }
     return UNCL_ERR_ARG;
   }

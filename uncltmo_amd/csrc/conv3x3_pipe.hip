@@ -948,10 +948,13 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     if (d->src1_H > d->src0_H || d->src1_W > d->src0_W) return UNCL_ERR_ARG;
   }
   if (d->src_mode == UNCL_SRC_CONCAT_SSR_UP) {
-    // src1 is the INPUT of the 2x2 stride-2 transposed conv: 32 channels, its output must have exactly the skip's extent
-    if (d->src1 == nullptr || d->up_w == nullptr || d->src0_C != 32 || d->src1_C != 32 || d->Cin != 128 || d->Cout != 32 ||
-        2 * d->src1_H != d->src0_H || 2 * d->src1_W != d->src0_W || d->prev0 != nullptr || mask != nullptr)
+    // src1 is the INPUT of the 2x2 stride-2 transposed conv: 32 (or, producer / consumer kernel only, 64) channels in and out, its
+    // output must have exactly the skip's extent
+    if (d->src1 == nullptr || d->up_w == nullptr || (d->src0_C != 32 && d->src0_C != 64) || d->src1_C != d->src0_C ||
+        d->Cin != 4 * d->src0_C || d->Cout != 32 || 2 * d->src1_H != d->src0_H || 2 * d->src1_W != d->src0_W ||
+        d->prev0 != nullptr || mask != nullptr)
       return UNCL_ERR_ARG;
+    if (d->src0_C == 64 && d->tail_w != nullptr) return UNCL_ERR_ARG;
   }
   if (d->out1_w != nullptr && (d->Cout != 32 || d->out1 == nullptr)) return UNCL_ERR_ARG;
   // 32-bit element offsets inside one sample
@@ -1004,8 +1007,8 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     uncl_chk_add(a.chk, d->out1, N * (d->tail_w != nullptr ? (unsigned long long)(a.Hout + 2) * (a.Wout + 2) : out_px) * 4);
     uncl_chk_add(a.chk, d->pre_w, 288 * 4);
     uncl_chk_add(a.chk, d->pre_b, 32 * 4);
-    uncl_chk_add(a.chk, d->up_w, 4ull * 32 * 32 * es);
-    uncl_chk_add(a.chk, d->up_b, 32 * 4);
+    uncl_chk_add(a.chk, d->up_w, 4ull * (d->src1_C > 0 ? d->src1_C : 32) * (d->src1_C > 0 ? d->src1_C : 32) * es);
+    uncl_chk_add(a.chk, d->up_b, (unsigned long long)(d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? d->src1_C : 32) * 4);
     uncl_chk_add(a.chk, d->tail_w, 9ull * 32 * 32 * es);
     uncl_chk_add(a.chk, d->tail_b, 32 * 4);
   }
@@ -1021,7 +1024,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // multi-chunk layers: producer / consumer workgroups (conv3x3_pc.hip); everything it does not build falls through
   const int pc_mode = d->src_mode == UNCL_SRC_PLAIN ? (prev ? -1 : 0)
-                      : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? 4
+                      : d->src_mode == UNCL_SRC_CONCAT_SSR ? 1 : d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? (d->src0_C == 64 ? 5 : 4)
                       : d->src_mode == UNCL_SRC_IMAGE1 ? 3 : -1;
   // measured per layer at bench size (tools/pc_phase_timing.py --product): with one staging register set, unpadded LDS planes
   // and resident weights the producer / consumer structure is faster on every layer it builds (3 - 30 %), single-chunk ones
@@ -1063,6 +1066,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
       const int rc = uncl_conv3x3_pc_launch(a, d->dtype, 1, 4, pc_mode, s);
       if (rc != UNCL_ERR_ARG) return rc;
     }
+    if (pc_mode == 5) return UNCL_ERR_ARG;        // the 64-channel fused up-conv exists in the producer / consumer kernel only
     return dispatch_type<1, 4>(a, d->dtype, d->src_mode, prev, s);
   }
   if (d->Cout % 64 != 0) return UNCL_ERR_ARG;

@@ -25,6 +25,8 @@ extern "C" int uncl_gen_set_deterministic(int on) { return g_bwd_det.exchange(on
 // 254 x 254 x 32 map in HBM between them.  Default by measured time: the fused launch takes 1.17 ms against 0.72 + 0.32, the whole
 // step ties (same-box A/B -0.8 % on one box, +0.4 % on another)
 static int g_fuse_tail = [] { const char* e = getenv("UNCL_FUSE_TAIL"); return e ? atoi(e) : 0; }();
+// inference: up_path.2.up (64 -> 64 channels) recomputed inside up_path.2.conv.conv's loader (conv3x3_pc.hip, MODE 5)
+static int g_fuse_up64 = [] { const char* e = getenv("UNCL_FUSE_UP64"); return e ? atoi(e) : 1; }();
 extern "C" int uncl_gen_set_fused_tail(int on) {
   const int old = g_fuse_tail;
   g_fuse_tail = on ? 1 : 0;
@@ -256,8 +258,10 @@ int conv3(const Ctx& c, int wi, int in, int out, int cin, int cout, int pad, boo
 int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int outbuf, int ch, int cout, int prev_ch,
              void* final_out, const uncl_conv_desc* tail) {
   int rc;
-  // inference, last decoder level: the 32-channel up-conv is recomputed per halo tile inside the concat layer's loader
-  const bool fuse_up = c.fuse_up && use_pipe(c) && ch == 32 && cout == 32 && 2 * kDims[x1].h == kDims[skip].h;
+  // inference, last two decoder levels: the 32- / 64-channel up-conv is recomputed per halo tile inside the concat layer's loader
+  // (the 252 x 252 x 32 / 122 x 122 x 64 up-sampled map is neither written nor read back)
+  const bool fuse_up = c.fuse_up && use_pipe(c) && (ch == 32 || (ch == 64 && g_fuse_up64)) && cout == 32 &&
+                       2 * kDims[x1].h == kDims[skip].h && !(prev_ch > 0 && c.prev);
   if (fuse_up) {
     uncl_conv_desc d = base_desc(c, wi_up + 1, 3, 2, 4 * ch, cout, c.w->act);
     set_src0(d, c, skip);
