@@ -138,6 +138,16 @@ def test_fused_upconv_concat_layer_at_full_size(c, h, w, n):
              up_w=pack_weight(wu, BF, transposed=True), up_b=bu.cuda(), weight=pack_weight(wt, BF, transposed=True, flip=True),
              bias=b.cuda(), act=_hip.ACT_RELU, out=out, out_H=H + 2, out_W=W + 2, out_C=32)
     assert_elementwise(from_nhwc(out), ref, "bf16", "concat-ssr + fused up (%d channels)" % c)
+    # the launch is deterministic: a difference between repeated launches is a race (round 5: the staging waves once read the
+    # LDS-resident up-conv weights before every wave had finished writing them -- one run in three showed it)
+    args = dict(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR_UP, N=n, H=H, W=W, Cin=4 * c, Cout=32, src0=to_nhwc(x2, BF),
+                src0_H=H, src0_W=W, src0_C=c, src1=to_nhwc(xs, BF), src1_H=h, src1_W=w, src1_C=c,
+                up_w=pack_weight(wu, BF, transposed=True), up_b=bu.cuda(), weight=pack_weight(wt, BF, transposed=True, flip=True),
+                bias=b.cuda(), act=_hip.ACT_RELU, out_H=H + 2, out_W=W + 2, out_C=32)
+    for _ in range(6):
+        again = nan_out(n, H + 2, W + 2, 32)
+        run_pipe(out=again, **args)
+        assert torch.equal(out, again), "repeated launches differ"
 
 
 def test_fused_first_layer_at_full_size():

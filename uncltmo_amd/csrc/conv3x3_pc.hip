@@ -45,6 +45,12 @@
 #ifndef UNCL_PC_LEAN_DEFAULT
 #define UNCL_PC_LEAN_DEFAULT 1
 #endif
+// fused up-conv: 1 = one source M-tile per staging wave, all four taps, weights resident in LDS; 0 = one tap per wave (round 1 - 4)
+// (MODE 4, the 32-channel up-conv of the dominant launch: a tie, 0.702 against 0.710 ms per 200 tiles in same-box A/B, so it keeps
+// the per-tap form; MODE 5, 64 channels, always takes the M-tile form: 12 -> 4 source requests per wave and slice, 0.526 -> 0.451 ms)
+#ifndef UNCL_PC_UP_TILE
+#define UNCL_PC_UP_TILE 0
+#endif
 #ifndef UNCL_PC_XA_SPLIT
 #define UNCL_PC_XA_SPLIT 0
 #endif
@@ -210,6 +216,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   // column is XSTEP tx + XOFF
   constexpr int XSTEP = TAIL ? TW - 2 : TW, XOFF = TAIL ? -2 : 0;
   constexpr int CPL = pc_plane16(2 * HW);                      // TAIL: one plane of the two carried rows
+  // fused up-conv, UPT form: one source M-tile per staging wave with all four taps, weights and bias resident in LDS (below)
+  constexpr bool UPT = MODE == 5 || (MODE == 4 && !TAIL && PW == 8 && UNCL_PC_UP_TILE);
+  constexpr int UPC = MODE == 5 ? 64 : 32, UKS = UPC / 16;        // up-conv channels (in = out), K-steps per source pixel
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wres = smem + 2 * XBYTES;                               // RESW: chunk kc at wres + kc * WBYTES
@@ -943,7 +952,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       return;
     } else {
     PCT_DECL
-    if (MODE == 3) pc_barrier();     // the staging waves' first image patch
+    if (MODE == 3 || UPT) pc_barrier();     // the staging waves' first image patch / the up-conv's resident weights
     pc_barrier();     // stage 0 is staged
     PCT(2)
     // The barrier of a chunk sits between its LAST fragment read and the MFMAs of its last tap column: "done with the stage" is
@@ -1063,10 +1072,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   // form, 168 registers, into 49 spilled ones)
   // (MODE 5 deals whole M-TILES to the waves, all four taps each: the source fragments of an M-tile are then requested once
   // instead of by each of the four tap waves -- 32 lines per request, the most expensive loads of the kernel)
-  static_assert(MODE != 5 || MTU <= PW, "MODE 5: one source M-tile per staging wave");
+  // UPT: that scheme.  MODE 5 always; MODE 4 (32 channels: K = 32, 8 KB of weights -- what the resident-weight form of the
+  // dominant launch has left of its 160 KB) with eight staging waves outside the fused last stage
+  static_assert(!UPT || MTU <= PW, "one source M-tile per staging wave");
   vec ubf[4];
   int u_sl = 0;
-  if (MODE == 4) {
+  if (MODE == 4 && !UPT) {
     const int arow = tap * 32 + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) ua[ks] = LD16V(vec, a.up_w + arow * 32 + (2 * ks + lh) * 8);
@@ -1206,7 +1217,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
     } else if (!X_LOAD) {
       // x2^2 / sqrt(x2): staged from the x2 registers
-    } else if (MODE == 4 && P == 0) {
+    } else if (MODE == 4 && !UPT && P == 0) {
       // B fragments of the up-conv straight from global memory: source pixel sp = 32 mt + lr of the 9 x 17 patch under the
       // 18 x 34 halo tile, channels 8 (2 ks + lh) .. +7; out-of-image source pixels are clamped (their outputs are outside the
       // image too and are staged as zeros)
@@ -1224,20 +1235,19 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         for (int ks = 0; ks < 2; ++ks)
           xr[2 * i + ks] = LD16OV(vec, ub, (unsigned)(((yy * a.s1W + xx) * 32 + (2 * ks + lh) * 8) * 2));
       }
-    } else if (MODE == 5 && P == 0) {
-      // as MODE 4 with 64 input channels: four K-steps per source pixel; the weight fragments (A rows = the 32 output channels
-      // of this slice in the order that makes a lane's D registers 16 consecutive channels) and the bias come with them
+    } else if (UPT && P == 0) {
+      // the source fragments of this wave's M-tile (UKS K-steps per source pixel); weights and bias are resident in LDS
       const int sy0 = iy0 >> 1, sx0 = ix0 >> 1;
       u_iy0 = iy0; u_ix0 = ix0;
       u_sl = kc >> 2;
-      const bf16_t* ub = a.src1 + (size_t)n * a.s1H * a.s1W * 64;
+      const bf16_t* ub = a.src1 + (size_t)n * a.s1H * a.s1W * UPC;
       {
         const int spc = min(pwave * 32 + lr, UPN - 1);          // (waves past the last M-tile request its last pixels: unused)
         const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;     // / 17 for spc < 1024
         const int yy = min(max(sy0 + spy, 0), a.s1H - 1), xx = min(max(sx0 + spx, 0), a.s1W - 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          ubf[ks] = LD16OV(vec, ub, (unsigned)(((yy * a.s1W + xx) * 64 + (2 * ks + lh) * 8) * 2));
+        for (int ks = 0; ks < UKS; ++ks)
+          ubf[ks] = LD16OV(vec, ub, (unsigned)(((yy * a.s1W + xx) * UPC + (2 * ks + lh) * 8) * 2));
       }
     } else if (MODE == 1 && P == 0 && !same_ext) {
       // upsampled map, replicate-padded to the skip's extent (unet_parts.py:292-298)
@@ -1411,9 +1421,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
             if (sp < UPN) *reinterpret_cast<vec*>(dst + h * XPL) = upv[i][h];
         }
       }
-    } else if (MODE == 5 && P == 0) {
-      // x1 slice = 32 output channels of ConvTranspose2d(64, 64, k2, s2)(src1) + bias for the halo tile: four MFMAs per 32 source
-      // pixels, scattered like MODE 4's
+    } else if (UPT && P == 0) {
+      // x1 slice = 32 output channels of ConvTranspose2d(UPC, UPC, k2, s2)(src1) + bias for the halo tile: UKS MFMAs per 32 source
+      // pixels and tap, results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image: a lane's D registers are 16
+      // consecutive output channels, i.e. K-slot planes 2 lh and 2 lh + 1 of its pixel
       if (pwave < MTU) {       // wave-uniform: this wave's source M-tile, all four taps
         const int sp = pwave * 32 + lr, spc = min(sp, UPN - 1);
         const int spy = (spc * 241) >> 12, spx = spc - spy * UPW;
@@ -1427,11 +1438,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
           // A rows = the 32 output channels of this slice in the order that makes a lane's D registers 16 consecutive channels
-          const int arow = tp * 64 + 32 * u_sl + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
+          const int arow = tp * UPC + 32 * u_sl + (((lr >> 2) & 1) << 4) + ((lr >> 3) << 2) + (lr & 3);
           f32x16 cu = cb5;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-            cu = mfma32x16(*reinterpret_cast<const vec*>(sUpW + arow * 128 + (2 * ks + lh) * 16), ubf[ks], cu);
+          for (int ks = 0; ks < UKS; ++ks)
+            cu = mfma32x16(*reinterpret_cast<const vec*>(sUpW + arow * (UPC * 2) + (2 * ks + lh) * 16), ubf[ks], cu);
           const int oy = u_iy0 + (tp >> 1) + 2 * spy, ox = u_ix0 + (tp & 1) + 2 * spx;
           const bool in_img = (unsigned)oy < (unsigned)a.H && (unsigned)ox < (unsigned)a.W;
           char* dst = st + 2 * lh * XPL + ((2 * spy + (tp >> 1)) * HW + 2 * spx + (tp & 1)) * 16;
@@ -1446,7 +1457,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           }
         }
       }
-    } else if (MODE == 4 && P == 0) {
+    } else if (MODE == 4 && !UPT && P == 0) {
       // x1 = ConvTranspose2d(k2, s2)(src1) + bias for the halo tile: per 32 source pixels two MFMAs (K = 32 input channels),
       // results scattered to output pixel (2 sy + dy, 2 sx + dx) of the staging image: a lane's D registers are 16
       // consecutive output channels, i.e. K-slot planes 2 lh and 2 lh + 1 of its pixel
@@ -1545,10 +1556,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   };
   if (a.out1_w != nullptr && ptid < 33) { UNCL_CHK(a.chk, ptid < 32 ? a.out1_w + ptid : a.out1_b, 4); sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0]; }     // fused 1x1 tail (CT == 32)
   if (TAIL && ptid < 32) { if (a.tail_b != nullptr) UNCL_CHK(a.chk, a.tail_b + ptid, 4); sB1[ptid] = a.tail_b != nullptr ? a.tail_b[ptid] : 0.f; }
-  if (MODE == 5) {
+  if (UPT) {
     // the up-conv's weights and bias become resident (read again per slice and tile by every staging wave)
-    for (int i = ptid; i < 4 * 64 * 64 / 8; i += NPROD) *reinterpret_cast<vec*>(sUpW + i * 16) = LD16V(vec, a.up_w + i * 8);
-    if (ptid < 64) { if (a.up_b) UNCL_CHK(a.chk, a.up_b + ptid, 4); sUpB[ptid] = a.up_b ? a.up_b[ptid] : 0.f; }
+    for (int i = ptid; i < 4 * UPC * UPC / 8; i += NPROD) *reinterpret_cast<vec*>(sUpW + i * 16) = LD16V(vec, a.up_w + i * 8);
+    if (ptid < UPC) { if (a.up_b) UNCL_CHK(a.chk, a.up_b + ptid, 4); sUpB[ptid] = a.up_b ? a.up_b[ptid] : 0.f; }
+    pc_barrier();       // every staging wave reads every row of them (the multiplying waves take this barrier idle)
   }
   if (TAIL) {
     // the second layer's weights become resident too: global [tap][cout][cin] -> plane (cin slot) x row (tap * 32 + cout)
@@ -1635,10 +1647,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 }
 
 template <int NT, int MPW>
-constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, bool up64 = false) {
+constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, int upc = 0) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
   return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0) +
-         (up64 ? 64 * 4 + 4 * 64 * 64 * 2 : 0);
+         (upc ? 64 * 4 + 4 * upc * upc * 2 : 0);       // (the up-conv's bias and weights, where they are resident)
 }
 
 // fused last decoder stage: one workgroup per CU walks an even share of the (strip, row tile) steps
@@ -1667,15 +1679,16 @@ int launch_tail(PipeArgs& a, hipStream_t s) {
 
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
 int launch_pc(PipeArgs& a, hipStream_t s) {
-  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, MODE == 5);
-  static_assert(pc_lds_bytes<NT, MPW>(false, 0, false, MODE == 5) <= 163840, "one workgroup's LDS");
+  constexpr int UPC_LDS = MODE == 5 ? 64 : (MODE == 4 && PW == 8 && UNCL_PC_UP_TILE ? 32 : 0);
+  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS);
+  static_assert(pc_lds_bytes<NT, MPW>(false, 0, false, UPC_LDS) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
   auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, MODE == 5) : lds)) != hipSuccess)
+                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, UPC_LDS) : lds)) != hipSuccess)
       return UNCL_ERR_LAUNCH;
     attr_done.done();
   }
