@@ -51,6 +51,13 @@
 #ifndef UNCL_PC_UP_TILE
 #define UNCL_PC_UP_TILE 0
 #endif
+// compile-time ablations (measurement builds: tools/ab_variants.sh <name> "-DUNCL_PC_ABL_MASK=<bits>"; WRONG results):
+// 1 no stores of the parked tile, 2 no pooled stores, 4 no rebuild of the first layer's halo tile (MODE 3), 8 no MFMAs in the
+// multiplying waves (fragments still read), 16 no parking (the multiplying waves skip their epilogue altogether)
+#ifndef UNCL_PC_ABL_MASK
+#define UNCL_PC_ABL_MASK 0
+#endif
+#define PC_ABL(bit) (((UNCL_PC_ABL_MASK) & (bit)) != 0)
 #ifndef UNCL_PC_XA_SPLIT
 #define UNCL_PC_XA_SPLIT 0
 #endif
@@ -182,7 +189,12 @@ typedef f32x16 PcAcc;
 template <typename V>
 __device__ __forceinline__ PcAcc pc_mm(const V& a, const V& b, const PcAcc& c, int) { return mfma32x16(a, b, c); }
 #endif
-template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool TAIL = false>
+// EPO ("parked epilogue", round 5; single-chunk 32-channel layers): the multiplying waves do not store their tile.  They round it
+// (bias, ReLU, the same packed arithmetic as epilogue_lean: bit-identical values) into one of two LDS buffers and go on to the next
+// tile; the staging waves -- 70 - 80 % idle on these layers, while the multiplying waves spent more than half of their time in the
+// epilogue (tools/pc_phase_timing.py: MFMA 31 - 43 %, epilogue 52 - 66 %) -- read the parked tile after the tile's barrier, build the
+// pooled copy from it and issue the stores beside the next tile's MFMAs.
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool TAIL = false, bool EPO = false>
 // (NT == 1 && MPW == 2 with four staging waves: 8-row tiles, 64 KB of LDS and <= 128 registers, TWO workgroups per CU, so that
 // one workgroup's epilogue runs under the other's MFMAs -- the single-chunk 32-channel layers spend 52 - 61 % of a multiplying
 // wave's time in the epilogue)
@@ -209,6 +221,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   static_assert(MODE != 4 || (NT == 1 && (MPW == 4 || TAIL)), "fused up-conv: 16 x 32 tiles of 32 channels");
   static_assert(MODE != 5 || (NT == 1 && MPW == 4 && !TAIL && !RESW), "fused 64-channel up-conv: 16 x 32 tiles of 32 channels, streamed weights");
   static_assert(MODE != 3 || (NT == 1 && RESW), "fused first layer: 32 -> 32 channels, one chunk, resident weights");
+  static_assert(MPW != 3 || TAIL || EPO, "12-row tiles: the fused last stage, or a parked epilogue (whose pooled copy does not need row pairs per wave)");
   static_assert(!TAIL || (NT == 1 && MPW == 3 && RESW && PW == 8 && MODE == 4), "fused last stage: 12 x 32 x 32 tiles, resident weights");
   constexpr int PW3 = HW + 2, PN3 = (HH + 2) * PW3;            // MODE 3: fp32 image patch under the halo tile
   // TAIL: a tile of the intermediate map is TW columns wide but only XSTEP = TW - 2 columns further than its left neighbour
@@ -230,6 +243,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   float* const sB1 = sO1 + 64;                                        // TAIL: bias of the second layer (32)
   char* const sW1 = reinterpret_cast<char*>(sB1 + 32);                // TAIL: the second layer's weights, [4 planes][9 taps x 32 rows]
   char* const sCarry = sW1 + 4 * W1PL;                                // TAIL: [2][4 planes][2 rows x HW] last two intermediate rows
+  static_assert(!EPO || (NT == 1 && !TAIL && (MODE == 0 || MODE == 3) && RESW), "parked epilogue: 32-channel tiles, resident weights");
+  constexpr int PARKB = TH * 32 * 4 * 16;                             // EPO: one parked tile, [row][K-slot][pixel] 16-byte vectors
+  char* const sPark = MODE == 3 ? reinterpret_cast<char*>(sP + 2 * PN3) : reinterpret_cast<char*>(sO1 + 64);     // EPO: [2][PARKB]
   float* const sUpB = sO1 + 64;                                       // MODE 5: the up-conv's bias (64) ...
   char* const sUpW = reinterpret_cast<char*>(sUpB + 64);              // ... and its packed weights [4 taps][64 cout][64 cin] (32 KB)
 
@@ -287,6 +303,17 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     };
     auto mfma_col = [&](int col) __attribute__((always_inline)) {
       const int set = col & 1;
+#if UNCL_PC_ABL_MASK
+      if (PC_ABL(8)) {
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(A[set][ty][nt]));
+#pragma unroll
+        for (int r = 0; r < MPW + 2; ++r) asm volatile("" ::"v"(B[set][r]));
+        return;
+      }
+#endif
       if (col == 0) {
         // same order as conv3x3_pipe's first column: tap row 0 of every output row, then rows 1 and 2
 #pragma unroll
@@ -768,18 +795,52 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
     };
     const bool lean = fast_relu && a.lean && (NT == 1 || a.out1_w == nullptr);      // wave-uniform
+    // EPO: the tile as epilogue_lean would have stored it (bias + rounding + widening + ReLU), parked in LDS for the staging waves
+    int pk = 0;                           // tiles parked so far: tile k goes to buffer k & 1
+    auto park = [&](int tp) __attribute__((always_inline)) {
+      const float* sBt = sBias + tp * CT;
+      char* const pb = sPark + (pk & 1) * PARKB + ((cw * MPW * 4 + lh) * 32 + lr) * 16;
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + 16 * qp + 4 * lh);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBt + 16 * qp + 8 + 4 * lh);
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+          const PcAcc& v = acc[m][0];
+          auto p4 = [&](int q, const f32x4& b) __attribute__((always_inline)) {
+            const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
+            const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
+            vec4 o;
+            o[0] = (T)s0[0]; o[1] = (T)s0[1]; o[2] = (T)s1[0]; o[3] = (T)s1[1];
+            return o;
+          };
+          const u32x2 d0 = __builtin_bit_cast(u32x2, p4(2 * qp, b0)), d1 = __builtin_bit_cast(u32x2, p4(2 * qp + 1, b1));
+          const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
+          const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
+          s16x8 si = __builtin_bit_cast(s16x8, w);
+          si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values
+          *reinterpret_cast<s16x8*>(pb + ((m * 4 + 2 * qp) * 32) * 16) = si;
+        }
+      }
+      ++pk;
+    };
     auto run_epilogue = [&](const TileCur& c, auto tp) __attribute__((always_inline)) {      // (generic: instantiated only where called)
-      if (lean) {
-        if (NT == 1 && a.out1_w != nullptr) {
-          if (a.skip_main) epilogue_lean(c, tp, IntTag<0>{}, IntTag<NT == 1 ? 2 : 0>{});
-          else epilogue_lean(c, tp, IntTag<0>{}, IntTag<NT == 1 ? 1 : 0>{});
-        } else if (a.pool_out != nullptr) epilogue_lean(c, tp, IntTag<1>{}, IntTag<0>{});
-        else epilogue_lean(c, tp, IntTag<0>{}, IntTag<0>{});
-      } else if (fast_relu) epilogue_fast(c, tp, IntTag<0>{});
-      else if (fast_grad) epilogue_fast(c, tp, IntTag<1>{});
-      else if (a.slope == 0.f) epilogue(c, tp, IntTag<0>{});
-      else if (a.slope == 1.f) epilogue(c, tp, IntTag<1>{});
-      else epilogue(c, tp, IntTag<2>{});
+      if constexpr (EPO) {
+        if (!PC_ABL(16)) park(tp);
+      } else {
+        if (lean) {
+          if (NT == 1 && a.out1_w != nullptr) {
+            if (a.skip_main) epilogue_lean(c, tp, IntTag<0>{}, IntTag<NT == 1 ? 2 : 0>{});
+            else epilogue_lean(c, tp, IntTag<0>{}, IntTag<NT == 1 ? 1 : 0>{});
+          } else if (a.pool_out != nullptr) epilogue_lean(c, tp, IntTag<1>{}, IntTag<0>{});
+          else epilogue_lean(c, tp, IntTag<0>{}, IntTag<0>{});
+        } else if (fast_relu) epilogue_fast(c, tp, IntTag<0>{});
+        else if (fast_grad) epilogue_fast(c, tp, IntTag<1>{});
+        else if (a.slope == 0.f) epilogue(c, tp, IntTag<0>{});
+        else if (a.slope == 1.f) epilogue(c, tp, IntTag<1>{});
+        else epilogue(c, tp, IntTag<2>{});
+      }
       zero_acc();
     };
     if constexpr (TAIL) {
@@ -1342,7 +1403,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 #pragma unroll
       for (int i = 0; i < IT3; ++i) {
         const int mt = pwave + PW * i;           // wave-uniform
-        if (mt < MT3) {
+        if (mt < MT3 && !PC_ABL(4)) {
           const int pix = mt * 32 + lr;
           const int pcl = min(pix, NPIX - 1);
           const int py = (pcl * 241) >> 13, px = pcl - py * HW;   // / 34 for pcl < 2048 (HW == 34)
@@ -1531,6 +1592,80 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     }
   };
 
+  // EPO: the tile the multiplying waves parked before the last barrier goes to memory from here.  A staging thread owns K-slot
+  // (ptid & 3) of pixels (ptid >> 2) & 15 and + 16 of a ROW PAIR (one pair per wave and pass): four 16-byte vectors, each wave
+  // store = 16 whole pixels = 1 KiB of contiguous NHWC bytes; the 2x2 max-pool of the pair (unet_parts.py:212,233) is the signed
+  // 16-bit maximum of the two rows and of the neighbouring pixel's lane (lane ^ 4), stored by the even pixels.  Offsets as in
+  // epilogue_lean: one buffer descriptor per sample, an out-of-image row or column adds 2^30 and the hardware drops the store.
+  TileCur sc;
+  cur_init<TAIL>(sc, tile0, a);
+  int spk = 0;                        // tiles stored so far
+  auto store_parked = [&]() __attribute__((always_inline)) {
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    typedef short s16x8s __attribute__((ext_vector_type(8)));
+    constexpr unsigned BAD = 0x40000000u;
+    const char* const pb = sPark + (spk & 1) * PARKB;
+    const int slot = ptid & 3, px = (ptid >> 2) & 15;
+    const int y0 = sc.ty * TH, x0 = sc.tx * TW;
+    const unsigned sample = (unsigned)(a.Hout * a.Wout * a.oC) * 2u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (size_t)sc.n * sample, (short)0,
+                                                                        (int)sample, 0x00020000);
+    const unsigned rowb = (unsigned)(a.Wout * a.oC) * 2u;
+    const bool pool = a.pool_out != nullptr;          // wave-uniform
+    const unsigned psample = (unsigned)(a.pH * a.pW * a.oC) * 2u;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(pool ? a.pool_out : a.out) + (size_t)sc.n * (pool ? psample : sample), (short)0, (int)(pool ? psample : sample), 0x00020000);
+    const unsigned prowb = (unsigned)(a.pW * a.oC) * 2u;
+#pragma unroll
+    for (int rp = pwave; rp < TH / 2; rp += PW) {
+      s16x8s v[2][2];
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          v[dy][h] = *reinterpret_cast<const s16x8s*>(pb + (((2 * rp + dy) * 4 + slot) * 32 + 16 * h + px) * 16);
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int oy = y0 + 2 * rp + dy;
+        const unsigned ro = ((unsigned)oy * rowb) | (oy < a.Hout ? 0u : BAD);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ox = x0 + 16 * h + px;
+          const unsigned off = (((unsigned)(ox * a.oC + 8 * slot) * 2u) | (ox < a.Wout ? 0u : BAD)) + ro;
+#ifdef UNCL_CHECKED
+          if (off < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.out) + (size_t)sc.n * sample + off, 16);
+#endif
+          if (PC_ABL(1)) { asm volatile("" ::"v"(v[dy][h])); continue; }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v[dy][h]), rs, off, 0, UNCL_PC_STORE_AUX);
+        }
+      }
+      if (pool) {
+        const int gy = (y0 >> 1) + rp;
+        const unsigned ro = ((unsigned)gy * prowb) | (gy < a.pH ? 0u : BAD);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          s16x8s m = __builtin_elementwise_max(v[0][h], v[1][h]);
+          u32x4s u = __builtin_bit_cast(u32x4s, m), o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (unsigned)__builtin_amdgcn_ds_swizzle((int)u[i], 0x101F);      // lane ^ 4: the neighbouring pixel
+          m = __builtin_elementwise_max(m, __builtin_bit_cast(s16x8s, o));
+          const int gx = (x0 >> 1) + 8 * h + (px >> 1);
+          const unsigned off = (((unsigned)(gx * a.oC + 8 * slot) * 2u) | (gx < a.pW ? 0u : BAD)) + ro;
+          if ((px & 1) == 0) {
+#ifdef UNCL_CHECKED
+            if (off < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.pool_out) + (size_t)sc.n * psample + off, 16);
+#endif
+            if (PC_ABL(2)) { asm volatile("" ::"v"(m)); continue; }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, m), prs, off, 0, UNCL_PC_STORE_AUX);
+          }
+        }
+      }
+    }
+    ++spk;
+    sc.kc = a.nk - 1;
+    cur_next<TAIL>(sc, a, tile_end);
+  };
+
   TileCur pc;
   cur_init<TAIL>(pc, tile0, a);
   const int total = (tile_end - tile0) * a.nk;     // chunks this workgroup walks
@@ -1612,8 +1747,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   int s = 0;
   auto iter = [&](auto q_tag) __attribute__((always_inline)) {
     constexpr int Q = decltype(q_tag)::value;
+    if (EPO && s > 0 && s % a.nk == 0) store_parked();     // the tile that ended with chunk s - 1
     if (s + 1 >= total) {
       pc_barrier();                     // the consumers' last chunk
+      if (EPO) store_parked();          // ... and its tile
       return true;
     }
     write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
@@ -1647,10 +1784,11 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 }
 
 template <int NT, int MPW>
-constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, int upc = 0) {
+constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, int upc = 0, bool epo = false) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
   return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0) +
-         (upc ? 64 * 4 + 4 * upc * upc * 2 : 0);       // (the up-conv's bias and weights, where they are resident)
+         (upc ? 64 * 4 + 4 * upc * upc * 2 : 0) +      // (the up-conv's bias and weights, where they are resident)
+         (epo ? 2 * (size_t)(MPW * 4) * 32 * 4 * 16 : 0);   // (two parked tiles)
 }
 
 // fused last decoder stage: one workgroup per CU walks an even share of the (strip, row tile) steps
@@ -1677,18 +1815,18 @@ int launch_tail(PipeArgs& a, hipStream_t s) {
   return UNCL_OK;
 }
 
-template <typename T, int NT, int MPW, int MODE, int PW, bool RESW>
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool EPO = false>
 int launch_pc(PipeArgs& a, hipStream_t s) {
   constexpr int UPC_LDS = MODE == 5 ? 64 : (MODE == 4 && PW == 8 && UNCL_PC_UP_TILE ? 32 : 0);
-  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS);
+  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS, EPO);
   static_assert(pc_lds_bytes<NT, MPW>(false, 0, false, UPC_LDS) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
-  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW>;
+  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW, false, EPO>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(RESW ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, UPC_LDS) : lds)) != hipSuccess)
+                            (int)(RESW && !EPO ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, UPC_LDS) : lds)) != hipSuccess)
       return UNCL_ERR_LAUNCH;
     attr_done.done();
   }
@@ -1749,6 +1887,10 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
       }
       return UNCL_ERR_ARG;
     }
+    // single-chunk layers with the plain forward store (optionally the pooled copy): the epilogue moves to the staging waves
+    static const int epo_on = [] { const char* e = getenv("UNCL_PC_EPO"); return e ? atoi(e) : 1; }();
+    const bool epo = epo_on && resw && a.nk == 1 && fwd_relu && a.lean && a.out1_w == nullptr && !a.skip_main;
+    if (epo && mode == 0) return launch_pc<T, 1, 4, 0, 8, true, true>(a, s);
     if (mode == 3) return resw && a.nk == 1 ? launch_pc<T, 1, 4, 3, 8, true>(a, s) : UNCL_ERR_ARG;
     if (resw) {
       if (mode == 0) return launch_pc<T, 1, 4, 0, 8, true>(a, s);
@@ -1760,6 +1902,16 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
       if (mode == 4) return launch_pc<T, 1, 4, 4, 8, false>(a, s);
       if (mode == 5) return launch_pc<T, 1, 4, 5, 8, false>(a, s);
     }
+    return UNCL_ERR_ARG;
+  }
+  if (nt == 1 && mpw == 3) {
+    // 12-row tiles with the parked epilogue: the fused first layer (two parked tiles + its image patches do not fit beside 16-row
+    // stages; 252 rows are 21 tiles exactly)
+    static const int epo_on = [] { const char* e = getenv("UNCL_PC_EPO"); return e ? atoi(e) : 1; }();
+    if (a.pool_out != nullptr && !fwd_relu) return UNCL_ERR_ARG;
+    if (!(epo_on && resw && a.nk == 1 && fwd_relu && a.lean && a.out1_w == nullptr && !a.skip_main)) return UNCL_ERR_ARG;
+    if (mode == 3) return launch_pc<T, 1, 3, 3, 8, true, true>(a, s);
+    if (mode == 0) return launch_pc<T, 1, 3, 0, 8, true, true>(a, s);
     return UNCL_ERR_ARG;
   }
   if (nt == 1 && mpw == 2) {

@@ -1063,6 +1063,15 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
         const int rc = uncl_conv3x3_pc_launch(b, d->dtype, 1, 2, pc_mode, s);
         if (rc != UNCL_ERR_ARG) return rc;
       }
+      // the fused first layer: 12-row tiles with the epilogue parked for the staging waves (conv3x3_pc.hip, EPO)
+      static const int epo12 = [] { const char* e = getenv("UNCL_PC_EPO12"); return e ? atoi(e) : 1; }();
+      if (epo12 && pc_mode == 3 && a.nk == 1 && d->out1_w == nullptr && !d->skip_main_store) {
+        PipeArgs b = a;
+        b.tiles_y = (a.Hout + 11) / 12;
+        b.total_tiles = d->N * b.tiles_x * b.tiles_y;
+        const int rc = uncl_conv3x3_pc_launch(b, d->dtype, 1, 3, pc_mode, s);
+        if (rc != UNCL_ERR_ARG) return rc;
+      }
       const int rc = uncl_conv3x3_pc_launch(a, d->dtype, 1, 4, pc_mode, s);
       if (rc != UNCL_ERR_ARG) return rc;
     }
