@@ -276,12 +276,14 @@ def classify_fault(stderr_text):
     return info
 
 
-def run_legs(argv, legs=("train_step", "train_video_step", "train_video_step_b8", "forward"), attempts=2):
+def run_legs(argv, legs=("forward", "train_step", "train_video_step", "train_video_step_b8"), attempts=2):
     """The default line carries three workloads (forward = the headline, train_step, train_video_step).  Each runs in a child of
     its own, started before this process has made any GPU call (like launch()): the three do not share an allocator history, and
     a leg that dies (round 3 saw ONE GPU memory fault in ~50 whole-bench runs, in a training leg, never reproduced under the
     uncached allocator, poisoned free memory or 40 repeats -- DESIGN.md) costs that leg one retry instead of the whole line.
-    Every failed attempt is reported in the line's `leg_failures`; nothing is hidden and nothing is measured twice."""
+    Every failed attempt is reported in the line's `leg_failures`; nothing is hidden and nothing is measured twice.
+    The forward leg -- the line itself -- runs FIRST: with four legs of up to two 420 s attempts each, training legs that hang could
+    otherwise eat the whole UNCL_BENCH_TIMEOUT budget and leave the headline a one-second deadline."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     end = time.time() + float(os.environ.get("UNCL_BENCH_TIMEOUT", "1500"))
@@ -636,7 +638,7 @@ def wgrad3_standalone(n, reps=5):
                                  "kernels (split-role per pair, four-member on the skip-concat layers); 1x1 / 2x2 layers not included"}
 
 
-def train_numbers(a, rk, video, steps, warmup, clips=None):
+def train_numbers(a, rk, video, steps, warmup, clips=None, leg=None):
     """One optimisation step (train_D + train_G) timed `steps` times after `warmup` untimed ones.  `ms_per_step` is the MEDIAN
     of the per-step device times; the mean over the bracketed region, min / max, the whole per-step list, the host
     time to enqueue a step and the garbage collector's activity are reported beside it, so that a number that moves between boxes
@@ -655,7 +657,7 @@ def train_numbers(a, rk, video, steps, warmup, clips=None):
     torch.cuda.synchronize()
     trace("timed steps")
     if not a.stub and os.environ.get("UNCL_BENCH_MEMMAP", "1") != "0":
-        dump_memory_map("train_video_step" if video else "train_step")
+        dump_memory_map(leg or ("train_video_step" if video else "train_step"))      # (a b8 fault is reported under its own leg's name)
     st0 = torch.cuda.memory_stats()
     gc0 = [g["collections"] for g in gc.get_stats()]
     dt, per_rank, dev_ms, host_ms = rk.timed_steps(step, steps)
@@ -787,6 +789,49 @@ def stub_bench(a, rk):
         line = {"metric": "stub steps/sec (launcher self-test, no GPU)", "value": rk.world * a.steps / dt, "unit": "steps/s"}
         line.update(common_fields(a, rk, dt, per_rank))
         line.update({"dtype": "f32", "config": {"workload": "stub", "parallelism": "x%d" % rk.world}})
+        print(json.dumps(line), flush=True)
+    elif rk.dist:
+        rk.ranks_seen()
+
+
+TRAIN_LINE_RANK_FIELDS = ("ranks_seen", "per_rank_ms_per_step", "mode", "allreduce")
+ALLREDUCE_FIELDS = ("bytes_per_step", "ms_exposed_median", "ms_exposed_max", "ms_standalone_generator_allreduce",
+                    "exchange_in_timed_steps", "world")
+
+
+def stub_train_bench(a, rk):
+    """--stub --mode train / train_video: the training line's multi-rank fields with a stand-in step (a small matmul and a gloo
+    all-reduce of a 'gradient'): what the first N > 1 run on GPUs will print must be there -- ranks_seen, per-rank step times,
+    `mode`, and the `allreduce` object (bytes, exposed time, stand-alone time, where the exchange ran).  CPU test of the contract
+    only: no number of this line is a measurement of the product."""
+    import torch
+    w = torch.ones(256, 256)
+    grad = torch.ones(1 << 16)
+    exposed = []
+
+    def step():
+        y = (w @ w).sum()
+        if rk.dist:
+            t0 = time.perf_counter()
+            rk.td.all_reduce(grad)
+            exposed.append((time.perf_counter() - t0) * 1e3)
+            grad.div_(rk.world)
+        return y
+
+    dt, per_rank, _ = rk.timed(step, a.steps, a.warmup)
+    if rk.rank == 0:
+        video = a.mode == "train_video"
+        line = {"metric": "stub train steps/sec (launcher self-test, no GPU)", "value": rk.world * a.steps / dt, "unit": "steps/s"}
+        line.update(common_fields(a, rk, dt, per_rank))
+        line.update({"dtype": "f32", "mode": "eager", "graph_replay": False,
+                     "config": {"workload": "stub %s step" % ("video" if video else "image"),
+                                "parallelism": "data-parallel x%d, gradient all-reduce" % rk.world}})
+        if rk.dist:
+            ex = exposed[-a.steps:]
+            line["allreduce"] = {"bytes_per_step": grad.numel() * 4, "ms_exposed_median": _median(ex), "ms_exposed_max": max(ex),
+                                 "ms_exposed_is_of": "the stand-in step's in-line all-reduce",
+                                 "ms_standalone_generator_allreduce": _median(ex),
+                                 "exchange_in_timed_steps": "in line (stub)", "world": rk.world}
         print(json.dumps(line), flush=True)
     elif rk.dist:
         rk.ranks_seen()
@@ -1031,14 +1076,17 @@ def main(argv=None):
     rk = Ranks(a)
     try:
         if a.stub:
-            stub_bench(a, rk)
+            if a.mode in ("train", "train_video"):
+                stub_train_bench(a, rk)
+            else:
+                stub_bench(a, rk)
         else:
             from uncltmo_amd import _hip
             if os.environ.get("UNCL_STREAMS"):        # experiments: 1 = everything on the caller's stream
                 _hip.check(_hip.lib().uncl_gen_set_streams(int(os.environ["UNCL_STREAMS"])), "uncl_gen_set_streams")
             if a.leg in ("train_step", "train_video_step", "train_video_step_b8"):
                 nums, _, _ = train_numbers(a, rk, a.leg != "train_step", 30 if a.leg != "train_video_step_b8" else 12, 5 if a.leg != "train_video_step_b8" else 3,
-                                           clips=8 if a.leg == "train_video_step_b8" else None)
+                                           clips=8 if a.leg == "train_video_step_b8" else None, leg=a.leg)
                 _flush_c_stdio()
                 print(json.dumps(nums), flush=True)
             elif a.mode in ("train", "train_video"):

@@ -33,6 +33,29 @@ def test_launcher_spawns_n_ranks_and_prints_one_line():
         assert k in d
 
 
+def test_two_rank_training_line_carries_every_scaling_field():
+    """The first N > 1 run on GPUs has to be informative by itself (no 1 -> 8 curve has ever been measured): the training line of a
+    2-rank launch must carry ranks_seen, the per-rank step times, `mode`, and the all-reduce object with bytes per step, exposed
+    and stand-alone times and where the exchange ran -- checked on the stub step over gloo, image and video mode."""
+    import bench
+    for mode in ("train", "train_video"):
+        p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub", "--mode", mode],
+                           env=_env(), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        (d,) = _json_lines(p.stdout)
+        for k in bench.TRAIN_LINE_RANK_FIELDS:
+            assert k in d, (mode, k)
+        assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and len(d["per_rank_ms_per_step"]) == 2
+        for k in bench.ALLREDUCE_FIELDS:
+            assert k in d["allreduce"], (mode, k)
+        assert d["allreduce"]["world"] == 2 and d["allreduce"]["bytes_per_step"] > 0
+        assert "data-parallel x2" in d["config"]["parallelism"]
+    # and the real training line is assembled from the same field names (bench.train_numbers / train_bench)
+    src = open(BENCH).read()
+    for k in bench.ALLREDUCE_FIELDS:
+        assert ('"%s"' % k) in src.split("def train_numbers")[1].split("def train_bench")[0], k
+
+
 def test_single_rank_line_has_no_rank_fields():
     p = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "0", "--stub"], env=_env(), capture_output=True,
                        text=True, timeout=300)

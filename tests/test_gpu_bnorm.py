@@ -34,7 +34,8 @@ def rel(a, b):
 def test_eval_forward_vs_reference_golden(golden, dtype, tol):
     g = golden("generator_bnorm")
     net = make(dtype)
-    y, up = net(inputs().cuda())          # grad mode on: the module itself takes the inference path for this configuration
+    with pytest.warns(RuntimeWarning, match="detached from the autograd graph"):
+        y, up = net(inputs().cuda())      # grad mode on: the module takes the inference path for this configuration, and says so
     assert not y.requires_grad
     assert rel(y.cpu(), torch.from_numpy(g["bnorm.x_out"])) < tol
     if dtype == "fp32":

@@ -1684,6 +1684,9 @@ extern "C" int uncl_conv_wgrad_bias(const uncl_conv_desc* d, const void* gy, flo
   if (d->src_mode != UNCL_SRC_PLAIN && d->src_mode != UNCL_SRC_CONCAT_SSR) return UNCL_ERR_ARG;
   if (d->Cin % 32 != 0 || d->Cout % 32 != 0 || d->src0 == nullptr) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_CONCAT_SSR && (d->src1 == nullptr || d->Cin != 4 * d->src0_C)) return UNCL_ERR_ARG;
+  // (the concat kernels walk 32-channel slices of two members of equal width: a member of 8 / 16 / 24 channels passed the Cin % 32
+  // test above and divided by zero in launch_wg3c's workgroup count)
+  if (d->src_mode == UNCL_SRC_CONCAT_SSR && (d->src0_C % 32 != 0 || d->src1_C != d->src0_C)) return UNCL_ERR_ARG;
   WgArgs a;
   a.src0 = (const bf16_t*)d->src0; a.src1 = (const bf16_t*)d->src1; a.gy = (const bf16_t*)gy; a.dw = dw_packed; a.gb = gb;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.pad = d->ksize == 3 ? d->pad : 0; a.ks = d->ksize;

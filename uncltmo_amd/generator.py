@@ -55,6 +55,18 @@ _LAST = {"sigmoid": _hip.ACT_SIGMOID, "tanh": _hip.ACT_TANH, "msig": _hip.ACT_MS
 class _GeneratorBase(nn.Module):
     """Parameter container + packing cache shared by the image and video generators."""
 
+
+    def _warn_detached(self, x):
+        """The reference back-propagates through an eval-mode BatchNorm; the folded inference path here cannot.  A caller with grad
+        enabled and something that requires grad gets outputs detached from the graph: say so (once per module) instead of handing
+        back zero / missing gradients silently."""
+        if torch.is_grad_enabled() and not getattr(self, "_warned_detached", False) and \
+                (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            import warnings
+            warnings.warn("uncltmo_amd: the batch_norm generator in eval() mode runs the folded inference path, which has no backward "
+                          "pass: its outputs are detached from the autograd graph (call it under torch.no_grad(), or use train() mode "
+                          "to back-propagate)", RuntimeWarning, stacklevel=3)
+            self._warned_detached = True
     def __init__(self, n_channels, output_dim, last_layer, depth, layer_factor, con_operator, filters, bilinear,
                  network, dilation, to_crop, unet_norm, stretch_g, activation, doubleConvTranspose,
                  padding_mode, convtranspose_kernel, up_mode=True, recurrent_ch_ratio=1 / 32,
@@ -409,7 +421,10 @@ class UNet(_GeneratorBase):
 
     def _needs_autograd(self, x):
         # batch_norm in EVAL mode is an inference configuration: the folded weights have no backward pass of their own
-        return self.unet_norm != "batch_norm" or self.training
+        if self.unet_norm == "batch_norm" and not self.training:
+            self._warn_detached(x)
+            return False
+        return True
 
     @torch.no_grad()
     def infer(self, x, want_knn=False):
@@ -447,6 +462,8 @@ class UNetVideo(_GeneratorBase):
         if self._bn_train():
             raise NotImplementedError("uncltmo_amd: the video generator with unet_norm='batch_norm' is built for inference; training "
                                       "with batch statistics covers the image generator")
+        if self.unet_norm == "batch_norm":
+            self._warn_detached(x)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.unet_norm != "batch_norm":
             from .autograd import generator_video_apply
             x_out, feats = generator_video_apply(self, x)

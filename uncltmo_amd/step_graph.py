@@ -30,7 +30,7 @@ def capture_error_mode():
 
 
 class _Snapshot:
-    """Parameters and optimiser state of a trainer before StepGraph's warm-up steps: the warm-up is there to bring the library,
+    """Parameters, module buffers, optimiser state and the device's random-number state of a trainer before StepGraph's warm-up steps: the warm-up is there to bring the library,
     the allocator and the weight packs into their steady state, not to train -- restore() puts every value back IN PLACE (the
     addresses the capture records stay the ones the warm-up used)."""
 
@@ -48,9 +48,21 @@ class _Snapshot:
                         self.state.append((inner, group, p, None if not st else
                                            (int(st["step"]), st["exp_avg"].clone(), st["exp_avg_sq"].clone())))
         self.lists = [(lst, len(lst)) for lst in (trainer.D_losses, trainer.G_loss_d, trainer.G_loss_struct)]
+        # module buffers too: a batch_norm generator's train-mode forward updates running_mean / running_var / num_batches_tracked
+        # in place (several forwards per warm-up step), and the DropPath draws consume the device's random-number stream
+        self.buffers = []
+        with torch.no_grad():
+            for net in (getattr(trainer, "netG", None), getattr(trainer, "netD", None)):
+                if net is not None:
+                    self.buffers += [(b, b.detach().clone()) for _, b in net.named_buffers()]
+        self.rng = torch.cuda.get_rng_state() if torch.cuda.is_available() else None
 
     def restore(self):
         with torch.no_grad():
+            for b, saved in self.buffers:
+                b.copy_(saved)
+            if self.rng is not None:
+                torch.cuda.set_rng_state(self.rng)
             for p, saved in self.params:
                 p.copy_(saved)                                       # bumps ._version: the weight packs are rebuilt
                 p.grad = None
