@@ -250,6 +250,14 @@ int uncl_colsum_finish(const uncl_colsum_item* items, int n_items, void* stream)
  * gradient is multiplied by the activation derivative of the layer that produced the tensor it flows into
  * (mask > 0 ? 1 : mask_slope; mask may be NULL) and optionally added to the gradient already in `out`. */
 int uncl_conv3x3_dgrad(const uncl_conv_desc* d, const void* mask, float mask_slope, int accumulate, void* stream);
+/* Data gradient of a skip-concat layer (unet_parts.py:149-162 on the concatenation of :319-322) with the backward of the skip
+ * operator as its epilogue: `d` describes the data-gradient convolution (Cout = 4 C, weights packed with cout_order = 1, d->out
+ * unused), x2 the skip tensor (N, H, W, C) of the forward.  Writes (accumulate_x2: adds to) g_x2 = (g0 + 2 x2 g2 + g3 / (2 sqrt(x2 +
+ * 1e-8))) relu'(x2) and writes g_x1 = g1, both (N, H, W, C); the 4 C-channel gradient of the concatenation never reaches memory
+ * (round 5: 1.8 GB per image step).  bf16, the up-sampled map must have the skip's extent (no replicate pad).  UNCL_ERR_ARG where
+ * the fused form does not apply: the caller then runs uncl_conv3x3_dgrad + uncl_ssr_backward over weights in the plain order. */
+int uncl_conv3x3_dgrad_ssr(const uncl_conv_desc* d, const void* x2, void* g_x2, void* g_x1, float slope, int accumulate_x2,
+                           void* stream);
 /* backward of uncl_upconv2x2: weight gradient (packed [4][Cout][C], zeroed by the caller) and data gradient
  * (wt = the (Cin,Cout,2,2) weight packed as a Conv2d weight: [4][Cin][Cout]) */
 int uncl_upconv2x2_wgrad(const void* x, const void* gy, float* dw_packed, int N, int H, int W, int C, int Cout, void* stream);
@@ -297,7 +305,10 @@ int uncl_pack_conv_weight(const float* src, void* dst, int dtype, int Cout, int 
 typedef struct uncl_pack_item {
   const float* src;
   void* dst;
-  int Cout, Cin, k, transposed, flip, reserved;
+  int Cout, Cin, k, transposed, flip;
+  int cout_order;   /* 0: as they come; 1 (3x3, 16-bit, Cout = 4 C, C a multiple of 16): the data-gradient weight of a skip-concat
+                       layer for uncl_conv3x3_dgrad_ssr -- output channel g C + c (member g of [x2 | x1 | x2^2 | sqrt], channel c) is
+                       stored at position 64 (c / 16) + 16 g + c % 16, so that a 64-channel tile holds the four members of 16 channels */
 } uncl_pack_item;
 int uncl_pack_conv_weights(const uncl_pack_item* items, int n_items, int dtype, void* stream);
 
@@ -411,6 +422,8 @@ typedef struct uncl_gen_bwd {
    * is its slice t). */
   int clip_T;
   int clip_t;
+  int ssr_fused;             /* bit i: decoder stage i's skip-concat data-gradient weights (wd of up_path.i.conv.conv) are packed with
+                                uncl_pack_item.cout_order = 1 and the stage takes uncl_conv3x3_dgrad_ssr (bf16 only)              */
 } uncl_gen_bwd;
 size_t uncl_gen_backward_workspace_bytes(int N);
 size_t uncl_gen_carry_bytes(int N);

@@ -848,3 +848,78 @@ def test_generator_backward_bias_slots_need_not_be_one_array(monkeypatch):
     for k in a:
         # same kernels, float atomics in another order
         assert rel_l2(b[k], a[k]) < 1e-4, (k, rel_l2(b[k], a[k]))
+
+
+# ---- round 5: the skip operator's backward as the epilogue of the concat layer's data gradient (uncl_conv3x3_dgrad_ssr) ---------
+def _pack_items(items, code):
+    arr = (_hip.PackItem * len(items))()
+    keep = []
+    for it, (src, cout, cin, k, tr, fl, order) in zip(arr, items):
+        src = src.float().contiguous().cuda()
+        dst = torch.empty(k * k * cout * cin, dtype=_hip.torch_dtype(code), device="cuda")
+        keep += [src, dst]
+        it.src, it.dst, it.Cout, it.Cin, it.k, it.transposed, it.flip, it.cout_order = src.data_ptr(), dst.data_ptr(), cout, cin, k, tr, fl, order
+    _hip.check(_hip.lib().uncl_pack_conv_weights(arr, len(items), code, _hip.stream_ptr()), "pack")
+    torch.cuda.synchronize()
+    return keep[1::2]
+
+
+@pytest.mark.parametrize("c,cout,h,n,acc", [(32, 32, 252, 2, 0), (64, 32, 122, 3, 0), (32, 32, 40, 2, 1), (64, 64, 17, 3, 0)])
+def test_dgrad_with_skip_operator_backward_epilogue(c, cout, h, n, acc):
+    """up_path.3 / up_path.2 (unet_parts.py:149-162 on the concatenation of :319-322): data gradient of the concat layer with
+    g_x2 = (g0 + 2 x2 g2 + g3 / (2 sqrt(x2 + 1e-8))) relu'(x2) and g_x1 = g1 formed in its epilogue, against (i) torch in fp64 on
+    the same rounded operands and (ii) the two-launch form (uncl_conv3x3_dgrad into a (N, H, W, 4 C) tensor, then
+    uncl_ssr_backward), which rounds the concatenation's gradient to bf16 in between."""
+    BF = _hip.BF16
+    g = torch.Generator().manual_seed(700 + h)
+    q = lambda t: t.to(torch.bfloat16).float()
+    gy = q(torch.randn(n, cout, h + 2, h + 2, generator=g) * 0.5)
+    wt = q(torch.randn(4 * c, cout, 3, 3, generator=g) * 0.05)          # the ConvTranspose2d weight (in = 4 C, out = cout)
+    x2 = q(torch.rand(n, c, h, h, generator=g) * (torch.rand(n, c, h, h, generator=g) > 0.3))     # ReLU outputs: exact zeros too
+    init = q(torch.randn(n, c, h, h, generator=g))
+    # reference: the data gradient of a pad-2 transposed conv is a valid correlation with the weight read as a Conv2d weight
+    gcat = torch.nn.functional.conv2d(gy.double(), wt.double())
+    g0, g1, g2, g3 = gcat.split(c, 1)
+    xd = x2.double()
+    ref2 = (g0 + 2 * xd * g2 + g3 * 0.5 / torch.sqrt(xd + 1e-8)) * (xd > 0)
+    if acc:
+        ref2 = ref2 + init.double()
+    ref1 = g1
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    w_plain, w_perm = _pack_items([(wt, 4 * c, cout, 3, 0, 0, 0), (wt, 4 * c, cout, 3, 0, 0, 1)], BF)
+    gyd, x2d = nhwc(gy), nhwc(x2)
+
+    def desc(weight, out):
+        d = _hip.ConvDesc()
+        for k_, v in dict(dtype=BF, ksize=3, pad=0, src_mode=_hip.SRC_PLAIN, N=n, H=h + 2, W=h + 2, Cin=cout, Cout=4 * c,
+                          src0=gyd.data_ptr(), src0_H=h + 2, src0_W=h + 2, src0_C=cout, weight=weight.data_ptr(), act=_hip.ACT_NONE,
+                          out=out, out_H=h, out_W=h, out_C=4 * c).items():
+            setattr(d, k_, v)
+        return d
+
+    lib = _hip.lib()
+    # fused
+    gx2 = nhwc(init) if acc else torch.full((n, h, h, c), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gx1 = torch.full((n, h, h, c), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _hip.check(lib.uncl_conv3x3_dgrad_ssr(C.byref(desc(w_perm, None)), x2d.data_ptr(), gx2.data_ptr(), gx1.data_ptr(), 0.0, acc,
+                                          _hip.stream_ptr()), "dgrad_ssr")
+    # two launches
+    cat = torch.empty(n, h, h, 4 * c, dtype=torch.bfloat16, device="cuda")
+    _hip.check(lib.uncl_conv3x3_dgrad(C.byref(desc(w_plain, cat.data_ptr())), None, 0.0, 0, _hip.stream_ptr()), "dgrad")
+    ux2 = nhwc(init) if acc else torch.empty(n, h, h, c, dtype=torch.bfloat16, device="cuda")
+    ux1 = torch.empty(n, h, h, c, dtype=torch.bfloat16, device="cuda")
+    _hip.check(lib.uncl_ssr_backward(cat.data_ptr(), x2d.data_ptr(), ux2.data_ptr(), ux1.data_ptr(), n, h, h, c, h, h, 0.0, acc,
+                                     _hip.stream_ptr()), "ssr_backward")
+    torch.cuda.synchronize()
+    back = lambda t: t.float().cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(gx2.float()).all() and torch.isfinite(gx1.float()).all()
+    rel = lambda a_, b_: ((a_ - b_).norm() / b_.norm()).item()
+    # the fused form rounds once (fp32 accumulators -> bf16 result), the two-launch form twice: it must be the closer one
+    e_f2, e_u2 = rel(back(gx2), ref2), rel(back(ux2), ref2)
+    assert e_f2 < 4e-3 and e_f2 <= e_u2 * 1.05 + 1e-4, (e_f2, e_u2)
+    assert rel(back(gx1), ref1) < 4e-3
+    assert torch.equal(gx1, ux1)           # g1 passes through: the same accumulator rounded once in both forms
+    # element-wise on g_x2 (the 1 / sqrt(x2) term is large where x2 is small: gate relative to each element's own magnitude)
+    err = (back(gx2) - ref2).abs()
+    tol = 2.0 ** -7 * ref2.abs() + 2.0 ** -7 * ref2.pow(2).mean().sqrt()
+    assert (err <= tol).all(), int((err > tol).sum())

@@ -32,7 +32,8 @@ def main():
                "replicate", 2, 0, compute_dtype="bf16")
     synth.fill_state_dict(net, "g0")
     net = net.cuda().eval()
-    frames = synth.hdr_frames(8, 1024, 1024, salt="bench0").cuda()
+    nf = int(os.environ.get("UNCL_FRAMES", "8"))       # 4: the 100 tiles one of the two streams of the bench forward sees per launch
+    frames = synth.hdr_frames(nf, 1024, 1024, salt="bench0").cuda()
     for _ in range(3):
         tiler.test_big_size_image2(frames, net, 0, 0, 0)
     buf = (ctypes.c_float * 64)()
@@ -46,7 +47,7 @@ def main():
         n = lib.uncl_prof_read(buf, 64)
         ms = sum(buf[j] for j in range(n)) / max(n, 1)
         cin, cout, ho, taps = SHAPES[name]
-        gf = 2.0 * taps * cin * cout * ho * ho * 200 / 1e9
+        gf = 2.0 * taps * cin * cout * ho * ho * 25 * nf / 1e9
         tot += ms
         print("%2d %-42s %7.3f ms  %8.1f GFLOP  %7.1f TFLOP/s" % (i, name, ms, gf, gf / ms if ms > 0 else 0.0))
     lib.uncl_prof_enable(-1, 0)

@@ -70,7 +70,7 @@ class GenBwd(C.Structure):
         ("g_inc0_w", C.c_void_p), ("g_inc0_b", C.c_void_p), ("g_outc_w", C.c_void_p), ("g_outc_b", C.c_void_p),
         ("g_pos_embed", C.c_void_p),
         ("accumulate", C.c_int), ("prev_workspace", C.c_void_p), ("carry_in", C.c_void_p), ("carry_out", C.c_void_p),
-        ("ev_decoder_done", C.c_void_p), ("clip_T", C.c_int), ("clip_t", C.c_int),
+        ("ev_decoder_done", C.c_void_p), ("clip_T", C.c_int), ("clip_t", C.c_int), ("ssr_fused", C.c_int),
     ]
 
 
@@ -90,7 +90,7 @@ class UnpackItem(C.Structure):
 
 class PackItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("k", C.c_int),
-                ("transposed", C.c_int), ("flip", C.c_int), ("reserved", C.c_int)]
+                ("transposed", C.c_int), ("flip", C.c_int), ("cout_order", C.c_int)]
 
 
 SIGNATURES = {
@@ -100,6 +100,7 @@ SIGNATURES = {
     "uncl_conv3x3_pipe": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p]),
     "uncl_conv3x3_set_pc": (C.c_int, [C.c_int]),
     "uncl_conv3x3_set_flat": (C.c_int, [C.c_int]),
+    "uncl_conv3x3_dgrad_ssr": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "uncl_conv3x3_flat_count": (C.c_longlong, []),
     "uncl_wgrad_set_scratch": (C.c_int, [C.c_void_p, C.c_size_t]),
     "uncl_wgrad_scratch_bytes": (C.c_size_t, []),

@@ -86,6 +86,7 @@ class _GradSet:
         b.g_inc0_w, b.g_inc0_b = self.g_inc_w.data_ptr(), self.g_inc_b.data_ptr()
         b.g_outc_w, b.g_outc_b, b.g_pos_embed = self.g_oc_w.data_ptr(), self.g_oc_b.data_ptr(), self.g_pe.data_ptr()
         b.accumulate = int(accumulate)
+        b.ssr_fused = int(getattr(module, "_ssr_fused", 0))
         b.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
         if clip is not None:
             b.clip_T, b.clip_t, b.prev_workspace = int(clip[0]), int(clip[1]), None

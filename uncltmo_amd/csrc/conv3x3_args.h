@@ -41,6 +41,14 @@ struct PipeArgs {
   const float* tail_b;  // its bias (32) or NULL
   int oH, oW;           // extent of the final one-channel map: Hout + 2, Wout + 2
   int o1_lds_off;       // conv3x3_pipe: byte offset of the parked outconv fragments in LDS (register-direct 1x1 tail)
+  // conv3x3_pc, gradient mode, SSRB epilogue: this launch is the data gradient of a skip-concat layer (cout' = 4 C in the interleaved
+  // order of uncl_pack_item.cout_order = 1) and its epilogue is the backward of the skip operator (unet_parts.py:319-322):
+  // g_x2 = (g0 + 2 x2 g2 + g3 / (2 sqrt(x2 + 1e-8))) relu'(x2) [written or accumulated], g_x1 = g1; the 4 C-channel gradient of
+  // the concatenation never reaches memory
+  const bf16_t* ssr_x2;
+  bf16_t* ssr_gx2;
+  bf16_t* ssr_gx1;
+  int ssr_C, ssr_acc;
   // conv3x3_flat: output pixels linearised on the padded input's pitch, M-tiles of 32 of them (conv3x3_flat.hip)
   int fl_pitch, fl_mts, fl_halo, fl_total_mt;   // Wout + 2, M-tiles per sample, 2 pitch + 2, M-tiles in the batch
   int fl_cmax, fl_ct_shift;                     // sample borders one tile can span, log2(n_ct)

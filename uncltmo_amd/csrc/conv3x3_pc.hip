@@ -24,6 +24,7 @@
 // activations only -- per-CU vector-memory throughput (L2 -> L1, tens of GB/s per CU), not HBM, is what these kernels queue on.
 // The epilogue needs no LDS (lane-widening v_permlane32_swap instead of a transposition).
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv3x3_args.h"
 
@@ -194,7 +195,10 @@ __device__ __forceinline__ PcAcc pc_mm(const V& a, const V& b, const PcAcc& c, i
 // tile; the staging waves -- 70 - 80 % idle on these layers, while the multiplying waves spent more than half of their time in the
 // epilogue (tools/pc_phase_timing.py: MFMA 31 - 43 %, epilogue 52 - 66 %) -- read the parked tile after the tile's barrier, build the
 // pooled copy from it and issue the stores beside the next tile's MFMAs.
-template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool TAIL = false, bool EPO = false>
+// SSRB (round 5, training): the launch is the data gradient of a skip-concat layer and its epilogue the backward of the skip
+// operator -- see PipeArgs.ssr_x2.  64-channel tiles = [g0 | g1 | g2 | g3] of 16 skip channels each (the weights' cout order is
+// interleaved by the pack kernel), so a lane holds all four members of its four channels in its own accumulators.
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool TAIL = false, bool EPO = false, bool SSRB = false>
 // (NT == 1 && MPW == 2 with four staging waves: 8-row tiles, 64 KB of LDS and <= 128 registers, TWO workgroups per CU, so that
 // one workgroup's epilogue runs under the other's MFMAs -- the single-chunk 32-channel layers spend 52 - 61 % of a multiplying
 // wave's time in the epilogue)
@@ -825,8 +829,78 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       }
       ++pk;
     };
+    // SSRB: g_x2 / g_x1 of the tile's 16 skip channels from the accumulators (no bias in a data gradient).  Per row and quad h (the
+    // lane's channels 16 ct + 8 h + 4 lh + r): g0 = acc[m][0][4 h + r], g1 = acc[m][0][8 + 4 h + r], g2 / g3 the same of acc[m][1].
+    // The result quads of the two half-waves are widened to eight consecutive channels per lane (v_permlane32_swap) and leave
+    // as one 16-byte buffer store per lane and tensor; x2 comes in as two 8-byte buffer loads per row (out-of-image lanes read 0).
+    auto epilogue_ssr = [&](const TileCur& c) __attribute__((always_inline)) {
+      static_assert(!SSRB || NT == 2, "the skip operator's backward needs the four members of a channel in one tile");
+      constexpr unsigned BAD = 0x40000000u;
+      const int y0 = c.ty * TH + cw * MPW, ox = c.tx * TW + lr;
+      const int C = a.ssr_C;
+      const unsigned sample = (unsigned)(a.Hout * a.Wout * C) * 2u;
+      const size_t sb = (size_t)c.n * sample;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.ssr_x2)) + sb, (short)0, (int)sample, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.ssr_gx2) + sb, (short)0, (int)sample, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.ssr_gx1) + sb, (short)0, (int)sample, 0x00020000);
+      const unsigned colb = ((unsigned)(ox * C + c.ct * 16) * 2u) | (ox < a.Wout ? 0u : BAD);
+      const unsigned rowb = (unsigned)(a.Wout * C) * 2u;
+      typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) {
+        const int oy = y0 + m;
+        const unsigned po = colb + (((unsigned)oy * rowb) | (oy < a.Hout ? 0u : BAD));
+        u32x2 d2[2], d1[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // this lane's four x2 channels of the quad: 8 bytes at channel 8 h + 4 lh
+          const unsigned xo = po + (unsigned)(8 * h + 4 * lh) * 2u;
+#ifdef UNCL_CHECKED
+          if (xo < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.ssr_x2) + sb + xo, 8);
+#endif
+          const u32x2b xr = __builtin_bit_cast(u32x2b, __builtin_amdgcn_raw_buffer_load_b64(rx, xo, 0, 0));
+          const vec4 xv = __builtin_bit_cast(vec4, xr);
+          vec4 o2, o1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = (float)xv[r];
+            const float g0 = acc[m][0][4 * h + r], g1 = acc[m][0][8 + 4 * h + r], g2 = acc[m][1][4 * h + r], g3 = acc[m][1][8 + 4 * h + r];
+            const float t = g0 + 2.f * x * g2 + g3 * 0.5f / __builtin_amdgcn_sqrtf(x + 1e-8f);
+            o2[r] = (T)(x > 0.f ? t : a.mask_slope * t);
+            o1[r] = (T)g1;
+          }
+          d2[h] = __builtin_bit_cast(u32x2, o2);
+          d1[h] = __builtin_bit_cast(u32x2, o1);
+        }
+        // quads (h = 0, h = 1) of the two half-waves -> eight consecutive channels per lane (lower half-wave: channels 0..7 of the
+        // tile's 16, upper: 8..15)
+        auto widen2 = [&](const u32x2& q0, const u32x2& q1) __attribute__((always_inline)) {
+          const auto sx = __builtin_amdgcn_permlane32_swap(q0[0], q1[0], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(q0[1], q1[1], false, false);
+          return u32x4{sx[0], sy[0], sx[1], sy[1]};
+        };
+        u32x4 w2 = widen2(d2[0], d2[1]);
+        const u32x4 w1 = widen2(d1[0], d1[1]);
+        const unsigned so = po + (unsigned)(8 * lh) * 2u;
+        if (a.ssr_acc) {
+          float f[8], o[8];
+          E::unpack(__builtin_bit_cast(vec, w2), f);
+          E::unpack(__builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b128(r2, so, 0, 0)), o);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] += o[i];
+          w2 = __builtin_bit_cast(u32x4, E::pack(f));
+        }
+#ifdef UNCL_CHECKED
+        if (so < BAD) { UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.ssr_gx2) + sb + so, 16); UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.ssr_gx1) + sb + so, 16); }
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(w2, r2, so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(w1, r1, so, 0, 0);
+      }
+    };
     auto run_epilogue = [&](const TileCur& c, auto tp) __attribute__((always_inline)) {      // (generic: instantiated only where called)
-      if constexpr (EPO) {
+      if constexpr (SSRB) {
+        epilogue_ssr(c);
+      } else if constexpr (EPO) {
         if (!PC_ABL(16)) park(tp);
       } else {
         if (lean) {
@@ -1815,13 +1889,13 @@ int launch_tail(PipeArgs& a, hipStream_t s) {
   return UNCL_OK;
 }
 
-template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool EPO = false>
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool EPO = false, bool SSRB = false>
 int launch_pc(PipeArgs& a, hipStream_t s) {
   constexpr int UPC_LDS = MODE == 5 ? 64 : (MODE == 4 && PW == 8 && UNCL_PC_UP_TILE ? 32 : 0);
   const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS, EPO);
   static_assert(pc_lds_bytes<NT, MPW>(false, 0, false, UPC_LDS) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
-  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW, false, EPO>;
+  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW, false, EPO, SSRB>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
@@ -1920,6 +1994,16 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
     if (!resw || a.nk != 1) return UNCL_ERR_ARG;
     if (mode == 0) return launch_pc<T, 1, 2, 0, 4, true>(a, s);
     if (mode == 3) return launch_pc<T, 1, 2, 3, 4, true>(a, s);
+    return UNCL_ERR_ARG;
+  }
+  if (a.ssr_x2 != nullptr) {
+    // data gradient of a skip-concat layer with the skip operator's backward as its epilogue: 64-channel tiles, plain source,
+    // streamed weights (cout' = 4 C >= 128), bf16 only
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (nt != 2 || mode != 0 || resw || a.pool_out != nullptr || a.out1_w != nullptr) return UNCL_ERR_ARG;
+      if (mpw == 4) return launch_pc<T, 2, 4, 0, 4, false, false, true>(a, s);
+      if (mpw == 2) return launch_pc<T, 2, 2, 0, 4, false, false, true>(a, s);
+    }
     return UNCL_ERR_ARG;
   }
   if (nt == 2 && mpw == 4) {

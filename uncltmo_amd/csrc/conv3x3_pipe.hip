@@ -924,8 +924,9 @@ extern "C" int uncl_conv3x3_set_pc(int on) {
 
 // Same descriptor as uncl_conv_igemm; handles bf16 3x3 with src_mode PLAIN / CONCAT_SSR / CONCAT2.
 // `pool_out` (optional) receives maxpool2x2(out) as NHWC (N, Hout/2, Wout/2, Cout).
+struct SsrBwd { const void* x2; void* g_x2; void* g_x1; int acc; };
 static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void* mask, float mask_slope, int accumulate,
-                             void* stream) {
+                             void* stream, const SsrBwd* ssr = nullptr) {
   if (d == nullptr || !uncl_is_h16(d->dtype) || d->ksize != 3) return UNCL_ERR_ARG;
   if (d->dtype == UNCL_F16 && (mask != nullptr || accumulate)) return UNCL_ERR_ARG;    // fp16: forward only
   if (d->pad != 0 && d->pad != 2) return UNCL_ERR_ARG;
@@ -940,7 +941,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   if (d->z_mode != UNCL_Z_NONE || d->scale_n != nullptr) return UNCL_ERR_ARG;
   if (d->act != UNCL_ACT_NONE && d->act != UNCL_ACT_RELU && d->act != UNCL_ACT_LRELU) return UNCL_ERR_ARG;
   if (d->src0 == nullptr || d->weight == nullptr) return UNCL_ERR_ARG;
-  if (d->out == nullptr && !(d->skip_main_store && d->out1 != nullptr)) return UNCL_ERR_ARG;
+  if (d->out == nullptr && !(d->skip_main_store && d->out1 != nullptr) && ssr == nullptr) return UNCL_ERR_ARG;
   if (d->src_mode == UNCL_SRC_CONCAT_SSR || d->src_mode == UNCL_SRC_CONCAT2) {
     if (d->src1 == nullptr || d->src0_C != d->src1_C || d->src0_C % 32 != 0 || d->prev0 != nullptr) return UNCL_ERR_ARG;
     const int groups = d->src_mode == UNCL_SRC_CONCAT_SSR ? 4 : 2;
@@ -986,6 +987,19 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   a.flat_S = 0; a.flat_hw = 0; a.flat_N = d->N;
   a.nk = d->Cin / 32;
   a.tail_w = (const bf16_t*)d->tail_w; a.tail_b = d->tail_b; a.oH = a.oW = 0;
+  a.ssr_x2 = nullptr; a.ssr_gx2 = nullptr; a.ssr_gx1 = nullptr; a.ssr_C = 0; a.ssr_acc = 0;
+  if (ssr != nullptr) {
+    // data gradient of a skip-concat layer, skip operator's backward in the epilogue: plain source, 4 C output channels in the
+    // interleaved order, bf16, identity activation; only the producer / consumer kernel with 64-channel tiles builds it
+    if (d->dtype != UNCL_BF16 || d->src_mode != UNCL_SRC_PLAIN || d->Cout % 64 != 0 || d->act != UNCL_ACT_NONE || d->res != nullptr ||
+        d->prev0 != nullptr || pool_out != nullptr || mask != nullptr || accumulate || d->out1_w != nullptr || !ssr->x2 || !ssr->g_x2 ||
+        !ssr->g_x1 || !g_use_pc)
+      return UNCL_ERR_ARG;
+    a.ssr_x2 = (const bf16_t*)ssr->x2; a.ssr_gx2 = (bf16_t*)ssr->g_x2; a.ssr_gx1 = (bf16_t*)ssr->g_x1;
+    a.ssr_C = d->Cout / 4; a.ssr_acc = ssr->acc;
+    a.mask_slope = mask_slope;
+    if ((size_t)a.Hout * a.Wout * a.ssr_C * 2 >= (1u << 30)) return UNCL_ERR_ARG;
+  }
 #ifdef UNCL_CHECKED
   {
     // the tensors this launch may touch, from the descriptor's own dimensions (16-bit elements unless stated)
@@ -1011,6 +1025,10 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     uncl_chk_add(a.chk, d->up_b, (unsigned long long)(d->src_mode == UNCL_SRC_CONCAT_SSR_UP ? d->src1_C : 32) * 4);
     uncl_chk_add(a.chk, d->tail_w, 9ull * 32 * 32 * es);
     uncl_chk_add(a.chk, d->tail_b, 32 * 4);
+    if (ssr != nullptr) {
+      const unsigned long long sb = N * out_px * (unsigned long long)(d->Cout / 4) * es;
+      uncl_chk_add(a.chk, ssr->x2, sb); uncl_chk_add(a.chk, ssr->g_x2, sb); uncl_chk_add(a.chk, ssr->g_x1, sb);
+    }
   }
 #endif
   if (d->tail_w != nullptr) {
@@ -1088,7 +1106,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     int S = howo > 0 ? 256 / howo : 0;
     while (S > 1 && S * hpwp > 10 * 34) --S;
     const bool plain_store = pool_out == nullptr && d->out1_w == nullptr && !d->skip_main_store;   // gradient stores are fine
-    if (S >= 1 && S * hpwp <= 10 * 34 && d->src_mode == UNCL_SRC_PLAIN && !prev && plain_store &&
+    if (S >= 1 && S * hpwp <= 10 * 34 && d->src_mode == UNCL_SRC_PLAIN && !prev && plain_store && ssr == nullptr &&
         (d->res == nullptr || !d->res_batch_stride0 || S == 1)) {
       a.flat_S = S; a.flat_hw = howo;
       a.Hout = 8; a.Wout = 32;      // the store loop's view of the tile: 256 consecutive pixels
@@ -1108,7 +1126,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     const int tall_tiles = d->N * a.tiles_x * ((a.Hout + 15) / 16) * a.n_ct;
     static const int tall_min = [] { const char* e = getenv("UNCL_PC_TALL_MIN"); return e ? atoi(e) : 256; }();
     const bool go_tall = tall && ((a.Hout + 15) / 16) * 16 <= ((a.Hout + 7) / 8) * 8 && tall_tiles >= tall_min;
-    if (g_use_flat && (pc_mode == 0 || pc_mode == 1) && pool_out == nullptr) {
+    if (g_use_flat && (pc_mode == 0 || pc_mode == 1) && pool_out == nullptr && ssr == nullptr) {
       // flat M-tiles (conv3x3_flat.hip) where the rectangles above leave a large part of their pixels outside the map: the 24 ..
       // 61-pixel levels.  Chosen by the same cost figure for both tilings: rounds of the persistent grid x (M-tiles per wave +
       // 0.35); g_use_flat 2 / 3 / 4 (tests) forces that many M-tiles per wave wherever the kernel applies
@@ -1130,6 +1148,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     const int rc = uncl_conv3x3_pc_launch(a, d->dtype, 2, 2, pc_mode, s);
     if (rc != UNCL_ERR_ARG) return rc;
   }
+  if (ssr != nullptr) return UNCL_ERR_ARG;       // (the four-wave kernel has no such epilogue)
   return dispatch_type<2, 2>(a, d->dtype, d->src_mode, prev, s);
 }
 
@@ -1154,4 +1173,11 @@ extern "C" int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* 
 // flows into (mask > 0 ? 1 : mask_slope) and optionally added to the gradient already there (skip connections).
 extern "C" int uncl_conv3x3_dgrad(const uncl_conv_desc* d, const void* mask, float mask_slope, int accumulate, void* stream) {
   return conv3x3_pipe_impl(d, nullptr, mask, mask_slope, accumulate, stream);
+}
+
+extern "C" int uncl_conv3x3_dgrad_ssr(const uncl_conv_desc* d, const void* x2, void* g_x2, void* g_x1, float slope, int accumulate_x2,
+                                      void* stream) {
+  if (d == nullptr || d->Cout % 64 != 0) return UNCL_ERR_ARG;
+  const SsrBwd ssr = {x2, g_x2, g_x1, accumulate_x2};
+  return conv3x3_pipe_impl(d, nullptr, nullptr, slope, 0, stream, &ssr);
 }

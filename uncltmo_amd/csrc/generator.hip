@@ -723,8 +723,19 @@ int backward_all(const BCtx& c) {
       // registers left for the bias sums; the four-member kernel that takes every skip-concat layer now sums them itself)
       RUN(conv_wgrad_bias(cw, d, c.G(q.a), b->gw[q.wi + 1], b->gb[q.wi + 1], ah, aw, q.cout));
     }
-    RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
-    RUN(bwd_ssr_backward(c.dt, c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
+    if ((b->ssr_fused >> i) & 1) {
+      // the skip operator's backward as the data-gradient launch's epilogue: the (N, H, W, 4 ch) gradient of the concatenation is
+      // neither written nor read back (the caller packed this layer's data-gradient weights in the interleaved cout order)
+      if (c.dt != UNCL_BF16 || sh != uh || sw != uw) return UNCL_ERR_ARG;
+      uncl_conv_desc d = bdesc(c, 3, 0, ah, aw, q.cout, 4 * q.ch);
+      d.src0 = c.G(q.a); d.src0_H = ah; d.src0_W = aw; d.src0_C = q.cout;
+      d.weight = b->wd[q.wi + 1];
+      d.out = nullptr; d.out_H = sh; d.out_W = sw; d.out_C = 4 * q.ch;
+      RUN(uncl_conv3x3_dgrad_ssr(&d, c.F(q.skip), c.G(q.skip), c.G(q.up), c.slope, 0, c.s));
+    } else {
+      RUN(dgrad3(c, q.wi + 1, c.G(q.a), ah, aw, q.cout, 0, 4 * q.ch, c.sc.gcat, sh, sw, nullptr, 0));
+      RUN(bwd_ssr_backward(c.dt, c.sc.gcat, c.F(q.skip), c.G(q.skip), c.G(q.up), c.n, sh, sw, q.ch, uh, uw, c.slope, 0, c.s));
+    }
     // up (ConvT 2x2 s2, ch -> ch): input x1
     const int xh = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].h, xw = kDims[q.x1].h == 1 ? 12 : kDims[q.x1].w;
     const int slot = 4 + i;  // hand-off slot of this stage's input (video): GOUT, U0, U1, U2

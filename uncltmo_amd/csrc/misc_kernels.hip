@@ -13,6 +13,11 @@
 // bytes, each half of a 128-byte line (the other half belongs to the next chunk: a CU's 32 KB L1 has long dropped it by then);
 // chunk-major it is one contiguous run per tap (the whole chunk for a layer of one cout tile), whole lines, half the requests
 // between L2 and L1 -- which is what the staging waves of the streamed-weight layers queue on (round 5).
+// cout_order 1 (uncl_pack_item): output channel g C + c of a skip-concat layer's data-gradient weight -> 64 (c / 16) + 16 g + c % 16
+__host__ __device__ __forceinline__ int uncl_ssr_cout_pos(int co, int Cout) {
+  const int C = Cout >> 2, g = co / C, c = co - g * C;
+  return 64 * (c >> 4) + 16 * g + (c & 15);
+}
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int Cout, int Cin, int kk,
                                    int transposed, int flip) {
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch 
   const int pitch = 32 * kk + 1;
   T* dst = reinterpret_cast<T*>(e.dst);
   const bool cm = uncl_w3_chunk_major(sizeof(T), kk, Cin);
+  const bool perm = e.cout_order == 1;
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int a0 = (tile / tb) << 5, b0 = (tile % tb) << 5;
     __syncthreads();
@@ -92,7 +98,8 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch 
       const int ts = e.flip ? (kk - 1 - tap) : tap;
       const int a = e.transposed ? ci_l : co_l, bb = e.transposed ? co_l : ci_l;
       const int co = e.transposed ? b0 + co_l : a0 + co_l, ci = e.transposed ? a0 + ci_l : b0 + ci_l;
-      dst[cm ? uncl_w3_index(tap, co, ci, Cout) : ((size_t)tap * Cout + co) * Cin + ci] = (T)sm[a * pitch + bb * kk + ts];
+      const int cp = perm ? uncl_ssr_cout_pos(co, Cout) : co;
+      dst[cm ? uncl_w3_index(tap, cp, ci, Cout) : ((size_t)tap * Cout + cp) * Cin + ci] = (T)sm[a * pitch + bb * kk + ts];
     }
   }
 }
@@ -107,6 +114,8 @@ extern "C" int uncl_pack_conv_weights(const uncl_pack_item* items, int n_items, 
     for (int i = 0; i < n; ++i) {
       const uncl_pack_item& e = items[i0 + i];
       if (!e.src || !e.dst || e.Cout <= 0 || e.Cin <= 0 || e.k <= 0) return UNCL_ERR_ARG;
+      // the interleaved cout order exists for the 3x3 16-bit data-gradient weights of the skip-concat layers only
+      if (e.cout_order != 0 && (e.cout_order != 1 || !uncl_is_h16(dtype) || e.k != 3 || e.Cout % 64 != 0 || e.Cin % 32 != 0)) return UNCL_ERR_ARG;
       t.it[i] = e;
     }
     if (dtype == UNCL_BF16) hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, s, t);

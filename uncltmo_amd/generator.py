@@ -8,6 +8,7 @@ There is no eager / CPU fallback: on a host tensor or without the built library,
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -48,6 +49,8 @@ def _attach(root, dotted, tensor, as_param):
         mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=as_param))
 
 
+# skip-concat layers whose data gradient carries the skip operator's backward in its epilogue (uncl_conv3x3_dgrad_ssr)
+SSR_FUSED_LAYERS = ("up_path.2.conv.conv", "up_path.3.conv.conv")
 _ACT = {"relu": _hip.ACT_RELU, "leakyrelu": _hip.ACT_LRELU}
 _LAST = {"sigmoid": _hip.ACT_SIGMOID, "tanh": _hip.ACT_TANH, "msig": _hip.ACT_MSIG, "none": _hip.ACT_NONE}
 
@@ -217,12 +220,13 @@ class _GeneratorBase(nn.Module):
         # jobs = (source fp32 tensor, offset in elements, Cout, Cin, k, transposed, flip)
         jobs, fwd_off, wd_off = [], [], []
         total = 0
+        ssr_fused = 0
 
-        def job(src, numel, co, ci, kk, tr, fl):
+        def job(src, numel, co, ci, kk, tr, fl, order=0):
             nonlocal total
             src = src.contiguous()
             keep.append(src)
-            jobs.append((src, total, co, ci, kk, tr, fl))
+            jobs.append((src, total, co, ci, kk, tr, fl, order))
             off = total
             total += (numel + 127) & ~127          # 256-byte aligned slices
             return off
@@ -246,7 +250,13 @@ class _GeneratorBase(nn.Module):
                 src = sd[name + ".weight"].detach().float().contiguous()
                 k = shape[2]
                 if kind == "convT" and k == 3:      # dgrad = valid conv with the weight read as a Conv2d weight
-                    wd_off.append(job(src, src.numel(), shape[0], shape[1], 3, 0, 0))
+                    # the skip-concat layers of the last two decoder stages: cout order interleaved for the data-gradient launch
+                    # whose epilogue is the skip operator's backward (uncl_conv3x3_dgrad_ssr; the up-sampled map has the skip's
+                    # extent there -- up_path.1 has the 56 -> 57 replicate pad, up_path.0 runs on flat tiles)
+                    order = 1 if (code == _hip.BF16 and name in SSR_FUSED_LAYERS and os.environ.get("UNCL_SSR_FUSED", "1") != "0") else 0
+                    if order:
+                        ssr_fused |= 1 << int(name.split(".")[1])
+                    wd_off.append(job(src, src.numel(), shape[0], shape[1], 3, 0, 0, order))
                 elif kind == "convT":                # 2x2 stride 2: [4][Cin][Cout]
                     wd_off.append(job(src, src.numel(), shape[0], shape[1], 2, 0, 0))
                 elif name.endswith("graph_conv.gconv.nn.0"):   # grouped 1x1: transpose every 128x128 block
@@ -260,14 +270,15 @@ class _GeneratorBase(nn.Module):
         keep.append(flat)
         esz = flat.element_size()
         items = (_hip.PackItem * len(jobs))()
-        for it, (src, off, co, ci, kk, tr, fl) in zip(items, jobs):
+        for it, (src, off, co, ci, kk, tr, fl, order) in zip(items, jobs):
             it.src, it.dst = src.data_ptr(), flat.data_ptr() + off * esz
-            it.Cout, it.Cin, it.k, it.transposed, it.flip = co, ci, kk, tr, fl
+            it.Cout, it.Cin, it.k, it.transposed, it.flip, it.cout_order = co, ci, kk, tr, fl, order
         _hip.check(lib.uncl_pack_conv_weights(items, len(jobs), code, st), "uncl_pack_conv_weights")
         for i in range(_hip.G_NUM_WEIGHTS):
             gw.w[i] = flat.data_ptr() + fwd_off[i] * esz
         wd = [flat[o:] for o in wd_off]            # views: .data_ptr() is the packed data-gradient weight
         self._wd = wd
+        self._ssr_fused = ssr_fused                # decoder stages whose skip-concat data-gradient weights are interleaved
         pe = sd["gcn.pos_embed"].detach().reshape(256, 144).t().contiguous().to(tdt)    # (144,256) NHWC
         keep.append(pe)
         gw.pos_embed = pe.data_ptr()
