@@ -24,6 +24,9 @@ extern "C" int uncl_gen_set_deterministic(int on) { return g_bwd_det.exchange(on
 // 32-channel maps stay in LDS (conv3x3_pc.hip, TAIL): 1.9 GB less HBM traffic per 200 tiles; 0 (default): two launches with the
 // 254 x 254 x 32 map in HBM between them.  Default by measured time: the fused launch takes 1.17 ms against 0.72 + 0.32, the whole
 // step ties (same-box A/B -0.8 % on one box, +0.4 % on another)
+#ifndef UNCL_SPLIT_PCT_DEFAULT
+#define UNCL_SPLIT_PCT_DEFAULT 50
+#endif
 static int g_fuse_tail = [] { const char* e = getenv("UNCL_FUSE_TAIL"); return e ? atoi(e) : 0; }();
 // inference: up_path.2.up (64 -> 64 channels) recomputed inside up_path.2.conv.conv's loader (conv3x3_pc.hip, MODE 5)
 static int g_fuse_up64 = [] { const char* e = getenv("UNCL_FUSE_UP64"); return e ? atoi(e) : 1; }();
@@ -1069,6 +1072,17 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
       if (hipStreamWaitEvent(ss->side[i], ss->ev_fork, 0) != hipSuccess) return UNCL_ERR_LAUNCH;
     chunk = (r->N + parts - 1) / parts;
   }
+  // Two parts of UNEQUAL size (round 5): with equal halves both streams reach the bottleneck block -- ten dependent launches of
+  // 30 - 110 us that fill a fraction of the chip whatever the batch -- at the same time, and for ~0.35 ms of the step only small
+  // launches run; with a 60 : 40 split the smaller part is through it while the larger one still runs its encoder.
+  // UNCL_SPLIT_PCT: per cent of the tiles in the first part (50: equal halves)
+  static const int split_pct = [] { const char* e = getenv("UNCL_SPLIT_PCT"); const int v = e ? atoi(e) : UNCL_SPLIT_PCT_DEFAULT; return v < 20 ? 20 : (v > 80 ? 80 : v); }();
+  int first_chunk = chunk;
+  if (split2 && parts == 2 && split_pct != 50) {
+    first_chunk = (int)((long long)r->N * split_pct / 100);
+    if (first_chunk < 32) first_chunk = 32;
+    if (r->N - first_chunk < 32) first_chunk = r->N - 32;
+  }
   // whatever happens after the fork, the caller's stream waits for the side streams before this call returns: the caller may
   // free the workspace as soon as its own stream is done
   auto join_sides = [&]() {
@@ -1079,11 +1093,12 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
         rc = UNCL_ERR_LAUNCH;
     return rc;
   };
-  for (int n0 = 0; n0 < r->N; n0 += chunk) {
+  int part_idx = 0;
+  for (int n0 = 0, this_chunk = first_chunk; n0 < r->N; n0 += this_chunk, this_chunk = (split2 && parts == 2) ? r->N - first_chunk : chunk, ++part_idx) {
     Ctx c;
     c.w = w;
     c.L = L;
-    c.n = (r->N - n0 < chunk) ? r->N - n0 : chunk;
+    c.n = (r->N - n0 < this_chunk) ? r->N - n0 : this_chunk;
     c.save_preact = r->save_preact;
     // the backward pass reads inc.conv.conv's output (ReLU mask, weight gradient), the video path hands its channels on
     // a norm sits between the fused layers' convolution and activation: no loader-side recomputation then
@@ -1093,7 +1108,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.norm_keep = w->norm && r->keep_activations;
     c.rstd_base = reinterpret_cast<float*>(reinterpret_cast<char*>(r->workspace) + L.off[B_RSTD]);
     c.n_total = r->N; c.n0 = n0;
-    c.s = (split2 && n0 > 0) ? ss->side[n0 / chunk - 1] : main_s;
+    c.s = (split2 && n0 > 0) ? ss->side[part_idx - 1] : main_s;
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.
     Layout Lc = L;
@@ -1122,7 +1137,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
                        r->drop_scale ? r->drop_scale + n0 : nullptr,
                        r->drop_scale ? r->drop_scale + r->N + n0 : nullptr, tail_whole ? 1 : 0);
     if (rc != UNCL_OK) { (void)join_sides(); return rc; }
-    if (tail_whole && n0 + chunk >= r->N) {
+    if (tail_whole && n0 + this_chunk >= r->N) {
       // join, then the last decoder stage for the whole batch on the caller's stream
       if (join_sides() != UNCL_OK) return UNCL_ERR_LAUNCH;
       Ctx cw = c;
