@@ -24,6 +24,9 @@ extern "C" int uncl_gen_set_deterministic(int on) { return g_bwd_det.exchange(on
 // 32-channel maps stay in LDS (conv3x3_pc.hip, TAIL): 1.9 GB less HBM traffic per 200 tiles; 0 (default): two launches with the
 // 254 x 254 x 32 map in HBM between them.  Default by measured time: the fused launch takes 1.17 ms against 0.72 + 0.32, the whole
 // step ties (same-box A/B -0.8 % on one box, +0.4 % on another)
+#ifndef UNCL_HYBRID_DEFAULT
+#define UNCL_HYBRID_DEFAULT 0
+#endif
 #ifndef UNCL_SPLIT_PCT_DEFAULT
 #define UNCL_SPLIT_PCT_DEFAULT 50
 #endif
@@ -352,12 +355,17 @@ int conv1(const Ctx& c, int wi, int in, int out, int cin, int cout, int act, con
 }
 
 // phase 0: the whole network; 1: everything up to the third decoder stage; 2: the last decoder stage only
+// `segs`: which segments of the network this call runs -- SEG_A the 252 ... 57 pixel encoder levels (inc, down_path.0 / 1), SEG_B the
+// 28 ... 12 pixel levels and their way back up (down_path.2 / 3, graph block, up_path.0 / 1: launches that are latency-bound or
+// fill a fraction of the chip at any batch size), SEG_C up_path.2, SEG_D the last decoder stage.  A multi-stream forward runs
+// different segments at different granularities (uncl_gen_forward).
+enum { SEG_A = 1, SEG_B = 2, SEG_C = 4, SEG_D = 8, SEG_ALL = 15 };
 int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn_out, const float* drop0,
-              const float* drop1, int phase = 0) {
+              const float* drop1, int segs = SEG_ALL) {
   const uncl_gen_weights* w = c.w;
   int rc;
 #define RUN(e) do { if ((rc = (e)) != UNCL_OK) return rc; } while (0)
-  if (phase != 2) {
+  if (segs & SEG_A) {
   // encoder
   if (c.fuse_in) {
     uncl_conv_desc d = base_desc(c, W_INC1, 3, 0, 32, 32, w->act);
@@ -376,6 +384,8 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   RUN(conv3(c, W_D0B, B_D0A, B_X1, 64, 64, 0, false, 0, -1, B_X1P));
   RUN(conv3(c, W_D1A, B_X1, B_D1A, 64, 128, 0, true, 2, B_X1P));
   RUN(conv3(c, W_D1B, B_D1A, B_X2, 128, 128, 0, false, 0, -1, B_X2P));
+  }
+  if (segs & SEG_B) {
   RUN(conv3(c, W_D2A, B_X2, B_D2A, 128, 256, 0, true, 4, B_X2P));
   RUN(conv3(c, W_D2B, B_D2A, B_X3, 256, 256, 0, false, 0, -1, B_X3P));
   RUN(conv3(c, W_D3A, B_X3, B_D3A, 256, 256, 0, true, 8, B_X3P));
@@ -429,9 +439,9 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
   // decoder
   RUN(up_stage(c, W_U0UP, B_GOUT, B_X3, B_U0UP, B_U0A, B_U0, 256, 128, 8, nullptr, nullptr));
   RUN(up_stage(c, W_U1UP, B_U0, B_X2, B_U1UP, B_U1A, B_U1, 128, 64, 4, nullptr, nullptr));
-  RUN(up_stage(c, W_U2UP, B_U1, B_X1, B_U2UP, B_U2A, B_U2, 64, 32, 2, nullptr, nullptr));
   }
-  if (phase == 1) return UNCL_OK;
+  if (segs & SEG_C) RUN(up_stage(c, W_U2UP, B_U1, B_X1, B_U2UP, B_U2A, B_U2, 64, 32, 2, nullptr, nullptr));
+  if (!(segs & SEG_D)) return UNCL_OK;
   uncl_conv_desc tail = {};
   tail.out1_w = w->outc_w; tail.out1_b = w->outc_b; tail.out1 = out; tail.out1_act = w->last_act;
   tail.skip_main_store = up_x == nullptr ? 1 : 0;
@@ -955,6 +965,8 @@ extern "C" int uncl_gen_set_fused_graph(int on) {
 }
 
 // streams an un-chunked inference batch of >= 64 tiles is spread over (1 = the caller's stream only), see uncl_gen_forward
+// hybrid schedule (uncl_gen_forward): 0 off; P > 0: the small-map segment in P parts on P streams, everything else once for the batch
+static int g_hybrid = [] { const char* e = getenv("UNCL_HYBRID"); return e ? atoi(e) : UNCL_HYBRID_DEFAULT; }();
 static int g_streams = 2;     // measured (every conv a one-workgroup-per-CU producer/consumer launch): 1 / 2 / 4 streams = 4.86 / 4.67 / 4.78 ms
 extern "C" int uncl_gen_set_streams(int n) {
   if (n < 1 || n > 4) return UNCL_ERR_ARG;
@@ -1005,7 +1017,7 @@ extern "C" size_t uncl_gen_workspace_bytes_ex(int N, int chunk, int dtype, int k
 struct SideStreams {
   static constexpr int MAX_SIDE = 3;
   hipStream_t side[MAX_SIDE] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[MAX_SIDE] = {};
 };
 static std::mutex g_side_mu;
 static std::map<int, SideStreams> g_side;
@@ -1017,6 +1029,7 @@ static SideStreams* side_streams_for_current_device() {
   if (it != g_side.end()) return &it->second;
   SideStreams ss;
   if (hipEventCreateWithFlags(&ss.ev_fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&ss.ev_fork2, hipEventDisableTiming) != hipSuccess) return nullptr;
   // The runtime deals its hardware queues (GPU_MAX_HW_QUEUES, default 4) to streams round-robin PER PRIORITY LEVEL: a
   // normal-priority side stream created after three other streams (a process that has initialised RCCL has them) lands on the
   // caller's queue and the two parts of the forward serialise -- measured 4.68 instead of 4.25 ms per step, exactly the
@@ -1056,7 +1069,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   // A large un-chunked inference batch runs as up to four contiguous parts on as many streams (the caller's and internal
   // ones, joined by events): the launches of one part fill the ramp-down of the others' persistent grids and the gaps
   // between dependent launches.  Every buffer is (N, ...), so the parts own disjoint slices of the same workspace.
-  const int split_cfg = g_streams;
+  const int split_cfg = g_hybrid > 0 ? (g_hybrid < SideStreams::MAX_SIDE + 1 ? g_hybrid : SideStreams::MAX_SIDE + 1) : g_streams;
   const bool split2 = split_cfg >= 2 && chunk == r->N && r->N >= 64 && !r->keep_activations && !r->save_preact &&
                       r->prev_workspace == nullptr;
   constexpr int MAX_SIDE = SideStreams::MAX_SIDE;
@@ -1093,6 +1106,56 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
         rc = UNCL_ERR_LAUNCH;
     return rc;
   };
+  // HYBRID schedule (round 5, UNCL_HYBRID / uncl_gen_set_streams(-P)): the big-map segments run ONCE for the whole batch on the
+  // caller's stream (they fill the chip by themselves, and a launch of 200 tiles has a smaller tail than two of 100), only the
+  // small-map segment -- whose launches are latency-bound or fill a fraction of the chip whatever the batch -- runs as P parts on
+  // P streams.  Same arithmetic per tile: results are bit-identical to every other schedule.
+  if (split2 && g_hybrid > 0 && !clip) {
+    auto ctx_for = [&](int n0, int n, hipStream_t st) {
+      Ctx c;
+      c.w = w;
+      c.n = n;
+      c.save_preact = r->save_preact;
+      c.fuse_in = uncl_is_h16(w->dtype) && !r->keep_activations && !r->save_preact && r->prev_workspace == nullptr && !w->norm;
+      c.fuse_up = c.fuse_in;
+      c.norm = w->norm;
+      c.norm_keep = w->norm && r->keep_activations;
+      c.rstd_base = reinterpret_cast<float*>(reinterpret_cast<char*>(r->workspace) + L.off[B_RSTD]);
+      c.n_total = r->N; c.n0 = n0;
+      c.s = st;
+      Layout Lc = L;
+      for (int b = 0; b < B_COUNT; ++b) Lc.off[b] = L.off[b] + L.per_n[b] * (size_t)n0;
+      c.L = Lc;
+      c.Lp = Lc;
+      c.ws = reinterpret_cast<char*>(r->workspace);
+      c.prev = nullptr;
+      return c;
+    };
+    const Ctx whole = ctx_for(0, r->N, main_s);
+    int rc = run_chunk(whole, r->x, r->out, r->up_x, nullptr, nullptr, nullptr, SEG_A);
+    if (rc != UNCL_OK) { (void)join_sides(); return rc; }
+    int P = g_hybrid < MAX_SIDE + 1 ? g_hybrid : MAX_SIDE + 1;
+    if (r->N / 32 < P) P = r->N / 32;
+    if (P < 1) P = 1;
+    const int pc = (r->N + P - 1) / P;
+    // (the side streams waited for the fork event recorded BEFORE segment A: they need segment A's results -> a second fork)
+    if (hipEventRecord(ss->ev_fork2, main_s) != hipSuccess) return UNCL_ERR_LAUNCH;
+    for (int i = 0; i < P - 1; ++i)
+      if (hipStreamWaitEvent(ss->side[i], ss->ev_fork2, 0) != hipSuccess) return UNCL_ERR_LAUNCH;
+    for (int pi = 0, n0 = 0; n0 < r->N; ++pi, n0 += pc) {
+      const int n = r->N - n0 < pc ? r->N - n0 : pc;
+      const Ctx cp = ctx_for(n0, n, pi == 0 ? main_s : ss->side[pi - 1]);
+      rc = run_chunk(cp, r->x + (size_t)n0 * 256 * 256, r->out + (size_t)n0 * 256 * 256, nullptr,
+                     r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr, r->drop_scale ? r->drop_scale + n0 : nullptr,
+                     r->drop_scale ? r->drop_scale + r->N + n0 : nullptr, SEG_B);
+      if (rc != UNCL_OK) { (void)join_sides(); return rc; }
+    }
+    // join every side stream that took a part (join_sides covers parts - 1 of them: the same or more)
+    for (int i = 0; i < P - 1; ++i)
+      if (hipEventRecord(ss->ev_join[i], ss->side[i]) != hipSuccess || hipStreamWaitEvent(main_s, ss->ev_join[i], 0) != hipSuccess)
+        return UNCL_ERR_LAUNCH;
+    return run_chunk(whole, r->x, r->out, r->up_x, nullptr, nullptr, nullptr, SEG_C | SEG_D);
+  }
   int part_idx = 0;
   for (int n0 = 0, this_chunk = first_chunk; n0 < r->N; n0 += this_chunk, this_chunk = (split2 && parts == 2) ? r->N - first_chunk : chunk, ++part_idx) {
     Ctx c;
@@ -1135,14 +1198,14 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     int rc = run_chunk(c, r->x + (size_t)n0 * 256 * 256, r->out + (size_t)n0 * 256 * 256, up,
                        r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr,
                        r->drop_scale ? r->drop_scale + n0 : nullptr,
-                       r->drop_scale ? r->drop_scale + r->N + n0 : nullptr, tail_whole ? 1 : 0);
+                       r->drop_scale ? r->drop_scale + r->N + n0 : nullptr, tail_whole ? (SEG_A | SEG_B | SEG_C) : SEG_ALL);
     if (rc != UNCL_OK) { (void)join_sides(); return rc; }
     if (tail_whole && n0 + this_chunk >= r->N) {
       // join, then the last decoder stage for the whole batch on the caller's stream
       if (join_sides() != UNCL_OK) return UNCL_ERR_LAUNCH;
       Ctx cw = c;
       cw.n = r->N; cw.L = L; cw.s = main_s; cw.n0 = 0;
-      return run_chunk(cw, r->x, r->out, r->up_x, nullptr, nullptr, nullptr, 2);
+      return run_chunk(cw, r->x, r->out, r->up_x, nullptr, nullptr, nullptr, SEG_D);
     }
   }
   return UNCL_OK;
