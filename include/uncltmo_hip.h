@@ -661,6 +661,15 @@ int uncl_to_uint8_dev(const float* x, unsigned char* out, int C, int H, int W, c
  * the grid into its argument in place), out: (Hf,Wf,C) uint8.  OpenCV's fixed-point bilinear remap for 8-bit images restated
  * (1/32-pixel coordinates, 15-bit weights, constant-0 border); cv2 is absent here: parity with cv2 unpinned, hand-computed vectors. */
 int uncl_warp_flow(const unsigned char* img, const float* flow, unsigned char* out, int H, int W, int C, int Hf, int Wf, void* stream);
+/* Dense inverse optical flow between two frames for the evaluator's warp error -- the role of `compute_flow(img_to_align,
+ * img_source)` / `estimate_invflow` (GanTrainer.py:597-646; callers Tester.py:379-384, metrics/compute_wrap_error.py:105-114),
+ * which the reference fills with cv2.optflow DeepFlow.  OpenCV is absent from the reference tree and this image (parity with cv2
+ * unpinned); this is coarse-to-fine iterative Lucas-Kanade with 15 x 15 box windows, operation for operation oracle/flow.py, which
+ * is pinned by synthetic motions with known flow.  img_to_align, img_source: (H, W) fp32 planes in [0, 255] (channel 0 of the
+ * frames); flow: (H, W, 2) fp32, flow[..., 0] along x, with img_to_align(p + flow(p)) ~ img_source(p): what uncl_warp_flow takes. */
+size_t uncl_optical_flow_workspace_bytes(int H, int W);
+int uncl_optical_flow(const float* img_to_align, const float* img_source, int H, int W, float* flow, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -164,6 +164,19 @@ def test_eval_on_video_clip_metrics():
     np.testing.assert_allclose(mse, np.mean((a - b) ** 2), rtol=1e-5)
     np.testing.assert_allclose(rel, np.mean(np.abs(a - b) / (1e-8 + a + b)), rtol=1e-5)
     assert s2 == score and all(torch.equal(u, v) for u, v in zip(ldr, ldr2))
+    # the reference's own route (Tester.py:379-389): the flow is ESTIMATED on a frame pair of another method and the result's
+    # frame 1 is warped with it.  With the pair = the results themselves and frame 1 = frame 0 shifted by three pixels the aligned
+    # error must fall well below the unaligned one
+    shifted = torch.roll(ldr[0], shifts=(0, 3), dims=(0, 1))
+    s3, ldr3, mse_a, rel_a = tester.eval_on_video(G, frames, 127.5 * 0.1, flow_images=(ldr[1], ldr[0]))
+    assert s3 == score and mse_a >= 0.0 and rel_a >= 0.0
+    from uncltmo_amd import frame_util
+    f = frame_util.compute_flow(shifted, ldr[0])            # shifted(p + f) ~ frame0(p): f = (+3, 0)
+    inner = f[40:-40, 40:-40]
+    assert (inner[..., 0] - 3.0).abs().median() < 0.25 and inner[..., 1].abs().median() < 0.25
+    mse_al, _ = tester.warp_errors(ldr[0], frame_util.align_frames(shifted, f))
+    mse_un, _ = tester.warp_errors(ldr[0], shifted)
+    assert mse_al < 0.5 * mse_un
 
 
 def test_eval_on_video_vs_reference_golden(golden):

@@ -188,6 +188,8 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     "uncl_to_uint8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uncl_warp_flow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uncl_optical_flow_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "uncl_optical_flow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uncl_rgbe_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     "uncl_rgbe_to_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_prof_enable": (C.c_int, [C.c_int, C.c_int]),

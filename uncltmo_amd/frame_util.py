@@ -215,3 +215,49 @@ def warp_flow(img_u8, flow):
     _hip.check(_hip.lib().uncl_warp_flow(img_u8.data_ptr(), flow.data_ptr(), out.data_ptr(), h, w, c, hf, wf, _hip.stream_ptr()),
                "uncl_warp_flow")
     return out
+
+
+def compute_flow(img_to_align, img_source):
+    """GanTrainer.compute_flow (GanTrainer.py:620-646; the evaluator's optical flow, Tester.py:379-384): both frames (H,W,C) or
+    (H,W), in [0, 255] (or [0, 1] floats, scaled like the reference does), on the GPU -> (H,W,2) fp32 field f with
+    img_to_align(p + f(p)) ~ img_source(p), i.e. what `align_frames` / `warp_flow` take.  Channel 0 of each frame is used, as in the
+    reference.  The reference's estimator is cv2 DeepFlow (absent here: parity unpinned); this is pyramidal Lucas-Kanade on the
+    device (csrc/flow.hip, oracle/flow.py)."""
+    _need_gpu(img_to_align, "img_to_align")
+    _need_gpu(img_source, "img_source")
+
+    def plane(t):
+        t = t if t.dim() == 2 else t[:, :, 0]
+        if t.dtype == torch.uint8:
+            return t.float().contiguous()
+        t = t.float()
+        if float(t.max()) <= 1.0:                       # GanTrainer.py:632-637: [0, 1] images are brought to 8 bits first
+            t = (t * 255).clamp(0, 255)
+        return torch.floor(t).contiguous()              # astype(np.uint8) truncates
+
+    a, s = plane(img_to_align), plane(img_source)
+    if a.shape != s.shape:
+        raise ValueError("compute_flow: the two frames differ in size: %s vs %s" % (tuple(a.shape), tuple(s.shape)))
+    h, w = a.shape
+    lib = _hip.lib()
+    nb = lib.uncl_optical_flow_workspace_bytes(h, w)
+    if nb == 0:
+        raise ValueError("compute_flow needs frames of at least 2 x 2 pixels")
+    ws = torch.empty(nb, dtype=torch.uint8, device=a.device)
+    flow = torch.empty(h, w, 2, dtype=torch.float32, device=a.device)
+    _hip.check(lib.uncl_optical_flow(a.data_ptr(), s.data_ptr(), h, w, flow.data_ptr(), ws.data_ptr(), nb, _hip.stream_ptr()),
+               "uncl_optical_flow")
+    return flow
+
+
+def align_frames(img_to_align, flow):
+    """GanTrainer.align_frames (GanTrainer.py:648-666): 8-bit conversion of a [0, 1] image, then warp_flow."""
+    _need_gpu(img_to_align, "img_to_align")
+    t = img_to_align
+    if t.dtype != torch.uint8:
+        t = t.float()
+        if float(t.max()) <= 1.0:
+            t = (t * 255).clamp(0, 255)
+        t = t.to(torch.uint8)
+    return warp_flow(t if t.dim() == 3 else t.unsqueeze(-1), flow)
+

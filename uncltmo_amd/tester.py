@@ -4,8 +4,10 @@ overlap tiler over the whole clip with the recurrent video generator, percentile
 stretch (tensor_to_numpy / to_0_1_range_outlier, :393-410) and the clip's mean TMQI -- with every stage on the device.
 
 The warp error of the reference needs an optical flow between two frames (cv2 DeepFlow on tone-mapped images of ANOTHER method
-read from disk, :379-386): neither cv2 nor those files exist here, so the flow / alignment stays with the caller
-(`align_fn`), and `warp_errors` evaluates the reference's two formulas (:387-389) on the aligned pair."""
+read from disk, :379-386).  cv2 does not exist here (parity with DeepFlow unpinned): `frame_util.compute_flow` is a pyramidal
+Lucas-Kanade estimator on the device with the same contract (round 5), `flow_images=(frame1, frame0)` hands eval_on_video the pair
+the flow is estimated on (the reference reads it from the other method's output directory), `flow=` a ready field, `align_fn` the
+caller's own alignment; `warp_errors` evaluates the reference's two formulas (:387-389) on the aligned pair."""
 import torch
 
 from . import frame_util
@@ -24,7 +26,7 @@ def warp_errors(img0_target, img1_aligned, border=32):
 
 
 @torch.no_grad()
-def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame=False, align_fn=None, flow=None):
+def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame=False, align_fn=None, flow=None, flow_images=None):
     """rgb_frames: list of (3,H,W) linear-radiance frames of ONE scene on the GPU (read_hdr_image + hdr_im_transform of the
     reference); f_factor: lambda * 255 * factor_coeff of the scene.  Returns (tmqi_scene, ldr_results[, warp_mse, warp_rel]):
     the mean TMQI over the frames, the tone-mapped 8-bit frames (H,W,3) and, when `align_fn(frame1_u8, frame0_u8)` (the
@@ -57,8 +59,11 @@ def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame
         score = tmqi(originals[i].permute(1, 2, 0).contiguous(), ldr.float())[0]
         total += score
     tmqi_scene = total / len(rgb_frames)
-    if (align_fn is None and flow is None) or len(results) < 2:
+    if (align_fn is None and flow is None and flow_images is None) or len(results) < 2:
         return tmqi_scene, results
+    if flow is None and flow_images is not None:
+        # Tester.py:379-384: flow = compute_flow(img1, img0) on the OTHER method's frames 1 and 0 of the scene
+        flow = frame_util.compute_flow(flow_images[0], flow_images[1])
     aligned = frame_util.warp_flow(results[1], flow) if flow is not None else align_fn(results[1], results[0])
     mse, rel = warp_errors(results[0], aligned)
     return tmqi_scene, results, mse, rel
