@@ -1,7 +1,7 @@
 """One step's kernel timeline from a rocprofv3 --kernel-trace database: start offset, duration, queue, kernel (short name).
 Run on the GPU box (cd /tmp first):
     rocprofv3 --kernel-trace -d gpurun_out/tl -o bench -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-train --no-exclusive --no-layers --no-4k --sustain-seconds 0
-    python3 tools/timeline.py gpurun_out/tl [step_index_from_the_end]"""
+    python3 tools/timeline.py gpurun_out/tl [step_index_from_the_end] [marker kernel substring: once per step, first]"""
 import glob
 import os
 import re
@@ -21,12 +21,13 @@ def short(n):
 def main():
     d = sys.argv[1]
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    marker = sys.argv[3] if len(sys.argv) > 3 else "tile_gather"      # a kernel that runs once per step, first
     f = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)[0]
     c = sqlite3.connect(f)
     rows = c.execute("select S.kernel_name, K.start, K.end, K.queue_id from rocpd_kernel_dispatch K inner join rocpd_info_kernel_symbol S "
                      "on S.id = K.kernel_id and S.guid = K.guid order by K.start").fetchall()
     # a step starts at a tile_gather launch
-    starts = [i for i, r in enumerate(rows) if "tile_gather" in r[0]]
+    starts = [i for i, r in enumerate(rows) if marker in r[0]]
     i0 = starts[-back]
     i1 = starts[-back + 1] if back > 1 else len(rows)
     t0 = rows[i0][1]

@@ -122,8 +122,22 @@ class GanTrainer:
     def contrastive_D_loss(self, real_logits, fake_logits):
         return L.contrastive_D_loss(real_logits, fake_logits)
 
+    def _d_batched(self, tensors):
+        """netD on several (N,1,256,256) batches in ONE call: the discriminator has no cross-sample operation (Discriminator.py:
+        88-126: convolutions, a per-sample linear layer, per-sample feature statistics), so D(cat(a, b)) = cat(D(a), D(b)) sample for
+        sample, and at N = 32 each of its launches is latency-bound -- the reference's seven D forwards per step (three in train_D,
+        four in train_G, GanTrainerImg.py:206-216, 276-283) were 0.9 ms of a 7 ms step in launches of 5 - 40 us.  Returns the
+        per-batch (logits, features).  `UNCL_D_BATCHED=0`, or a discriminator that is not sample-wise (PatchGAN with batch
+        statistics would be), keeps one call per batch."""
+        from .discriminator import SimpleDiscriminator
+        import os
+        if len(tensors) == 1 or not isinstance(self.netD, SimpleDiscriminator) or os.environ.get("UNCL_D_BATCHED", "1") == "0":
+            return [self.netD(t) for t in tensors]
+        ns = [int(t.shape[0]) for t in tensors]
+        out, fea = self.netD(torch.cat([t.float() for t in tensors], 0))
+        return list(zip(out.split(ns, 0), fea.split(ns, 0)))
+
     def D_real_fake_pass(self, real_ldr_pos, real_ldr_neg, hdr_input, epoch):
-        d_real_pos, _ = self.netD(_flat(real_ldr_pos))
         if not self.pre_train_mode:
             with torch.no_grad():
                 fake, _ = self._generate(hdr_input)
@@ -131,7 +145,7 @@ class GanTrainer:
             fake = _flat(hdr_input)
             if self.to_crop:
                 fake = crop_input_hdr_batch(fake, self.final_shape_addition, self.final_shape_addition)
-        d_fake, _ = self.netD(fake.detach())
+        (d_real_pos, _), (d_fake, _) = self._d_batched([_flat(real_ldr_pos), fake.detach()])
         scale = 1.0 if epoch <= self.epoch_step1 else 1e-6
         self.errD = float(self.adv_weight_list[0]) * scale * self.contrastive_D_loss(d_real_pos, d_fake)
         self.errD.backward()
@@ -151,9 +165,8 @@ class GanTrainer:
             try:
                 d_fake_bp, d_fea_fake = self.netD(fake.float())
                 with torch.no_grad():
-                    d_real_pos_bp, d_fea_real_pos = self.netD(_flat(real_ldr_pos))
-                    _, d_fea_real_neg = self.netD(_flat(real_ldr_neg))
-                    _, d_fea_input = self.netD(hdr_flat)
+                    (d_real_pos_bp, d_fea_real_pos), (_, d_fea_real_neg), (_, d_fea_input) = self._d_batched(
+                        [_flat(real_ldr_pos), _flat(real_ldr_neg), hdr_flat])
                 self.update_g_d_loss(d_fake_bp, d_real_pos_bp, None, d_fea_fake, d_fea_real_pos, d_fea_real_neg, d_fea_input,
                                      fea_fake, fake, hdr_flat, _flat(real_ldr_pos), _flat(real_ldr_neg), epoch)
             finally:
