@@ -373,52 +373,6 @@ __global__ __launch_bounds__(256) void maxrel_bwd_kernel(const T* __restrict__ g
   }
 }
 
-// The scatter of the fast path once more with the sample's whole fp32 gradient (144 x 256 floats = 147 KB) in LDS: one workgroup
-// per sample, LDS float adds instead of 2.4 M global float atomics per pass, and the 16-bit result written straight from LDS (no
-// fp32 buffer to clear, no conversion launch): 100 -> ~15 us per N = 32 pass (round 5).  Same sums in another order of addition.
-template <typename T>
-__global__ __launch_bounds__(1024) void maxrel_bwd_lds_kernel(const T* __restrict__ g_out, const T* __restrict__ x,
-                                                             const int32_t* __restrict__ idx, T* __restrict__ g_x, int n, int C, int k) {
-  extern __shared__ float acc_s[];                   // [n][C]
-  const int b = blockIdx.x, VC = C / 8;
-  for (int i = threadIdx.x; i < n * C / 4; i += 1024) reinterpret_cast<f32x4*>(acc_s)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  for (int t = threadIdx.x; t < n * VC; t += 1024) {
-    const int cv = t % VC, i = t / VC;
-    const size_t node = (size_t)b * n + i;
-    float xi[8], m[8], g0[16];
-    int arg[8];
-    ld8(x + node * C + cv * 8, xi);
-    ld8(g_out + node * 2 * C + (size_t)cv * 16, g0);
-    ld8(g_out + node * 2 * C + (size_t)cv * 16 + 8, g0 + 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; arg[e] = 0; }
-    for (int r = 0; r < k; ++r) {
-      const int j = idx[node * k + r];
-      float xj[8];
-      ld8(x + ((size_t)b * n + j) * C + cv * 8, xj);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = xj[e] - xi[e];
-        if (d > m[e]) { m[e] = d; arg[e] = j; }   // first maximum, like torch.max
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float gx = g0[2 * e], gr = g0[2 * e + 1];
-      atomicAdd(acc_s + i * C + cv * 8 + e, gx - gr);
-      atomicAdd(acc_s + arg[e] * C + cv * 8 + e, gr);
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < n * VC; t += 1024) {
-    float o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = acc_s[(size_t)t * 8 + e];
-    st8(g_x + ((size_t)b * n) * C + (size_t)t * 8, o);
-  }
-}
-
 // the same without atomics (fp32 parity mode: bit-reproducible): one thread per (sample, channel) walks the nodes in order and
 // adds into its own column of an LDS image [n][64]
 template <typename T>
@@ -688,20 +642,6 @@ static int gcn_maxrel_backward_t(const void* g_out, const void* x, const int32_t
   if ((sizeof(T) == 4 || uncl_wgrad_deterministic()) && C % 64 == 0 && (size_t)n * 64 * 4 <= 64 * 1024) {
     hipLaunchKernelGGL(maxrel_bwd_det_kernel<T>, dim3(N, C / 64), dim3(64), (size_t)n * 64 * 4, s, (const T*)g_out, (const T*)x, idx,
                        (T*)g_x_bf16, n, C, k);
-    UNCL_CHECK_LAUNCH();
-    return UNCL_OK;
-  }
-  // 16-bit fast path: the sample's gradient accumulates in LDS where it fits (the generator's 144 x 256 graph does, by 16 KB)
-  static const int lds_on = [] { const char* e = getenv("UNCL_MAXREL_LDS"); return e ? atoi(e) : 1; }();
-  if (lds_on && sizeof(T) == 2 && (size_t)n * C * 4 <= 160 * 1024 - 1024) {
-    auto kern = maxrel_bwd_lds_kernel<T>;
-    static UnclDevOnce attr_done;
-    if (attr_done.need()) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-        return UNCL_ERR_LAUNCH;
-      attr_done.done();
-    }
-    hipLaunchKernelGGL(kern, dim3(N), dim3(1024), (size_t)n * C * 4, s, (const T*)g_out, (const T*)x, idx, (T*)g_x_bf16, n, C, k);
     UNCL_CHECK_LAUNCH();
     return UNCL_OK;
   }
