@@ -80,6 +80,38 @@ def test_state_dict_contract_and_no_cpu_fallback():
     g.load_state_dict(generator_state("g0"), strict=True)
 
 
+def test_round5_entry_points_refuse_bad_arguments_before_any_launch():
+    """The round-5 additions to the C ABI validate their arguments on the host (no GPU here): the fused skip backward needs a
+    64-channel-tile data gradient in bf16, the interleaved cout order exists for 3x3 16-bit weights only, the optical flow needs a
+    workspace of its own size, and the tiling switches return the previous setting."""
+    import ctypes as C
+    from uncltmo_amd import _hip
+    lib = _hip.lib()
+    ERR_ARG = lib.uncl_conv3x3_dgrad_ssr(None, None, None, None, 0.0, 0, None)
+    assert ERR_ARG != 0
+    d = _hip.ConvDesc()
+    d.dtype, d.ksize, d.pad, d.N, d.H, d.W, d.Cin, d.Cout = _hip.BF16, 3, 0, 1, 34, 34, 32, 96          # 96 is not 4 C with C % 16 == 0
+    assert lib.uncl_conv3x3_dgrad_ssr(C.byref(d), None, None, None, 0.0, 0, None) == ERR_ARG
+    d.Cout = 128                                                                                            # shape fine, tensors missing
+    assert lib.uncl_conv3x3_dgrad_ssr(C.byref(d), None, None, None, 0.0, 0, None) == ERR_ARG
+    it = (_hip.PackItem * 1)()
+    buf = (C.c_float * 16)()
+    it[0].src, it[0].dst = C.addressof(buf), C.addressof(buf)
+    it[0].Cout, it[0].Cin, it[0].k, it[0].cout_order = 128, 32, 2, 1                                       # 2x2 weights have no such order
+    assert lib.uncl_pack_conv_weights(it, 1, _hip.BF16, None) == ERR_ARG
+    it[0].k, it[0].Cout = 3, 96                                                                            # not four members of 16 channels
+    assert lib.uncl_pack_conv_weights(it, 1, _hip.BF16, None) == ERR_ARG
+    it[0].Cout = 128
+    assert lib.uncl_pack_conv_weights(it, 1, _hip.F32, None) == ERR_ARG                                    # fp32 packs stay tap-major
+    assert lib.uncl_optical_flow_workspace_bytes(1, 100) == 0
+    need = lib.uncl_optical_flow_workspace_bytes(270, 480)
+    assert need >= (16 * 270 * 480 + 2 * (135 * 240 + 68 * 120 + 34 * 60 + 17 * 30)) * 4
+    assert lib.uncl_optical_flow(C.addressof(buf), C.addressof(buf), 270, 480, C.addressof(buf), C.addressof(buf), need - 1, None) == ERR_ARG
+    assert lib.uncl_optical_flow(None, C.addressof(buf), 270, 480, C.addressof(buf), C.addressof(buf), need, None) == ERR_ARG
+    old = lib.uncl_conv3x3_set_flat(0)
+    assert lib.uncl_conv3x3_set_flat(old) == 0 and lib.uncl_conv3x3_flat_count() >= 0
+
+
 def test_relative_pos_buffer_matches_reference_golden(golden):
     from uncltmo_amd.generator import sincos_relative_pos
     np.testing.assert_allclose(sincos_relative_pos().numpy(), golden("generator")["relative_pos"], rtol=0, atol=1e-6)
