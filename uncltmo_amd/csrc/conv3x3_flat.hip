@@ -38,6 +38,9 @@
 #endif
 #define FL_ABL(bit) (((UNCL_FL_ABL_MASK) & (bit)) != 0)
 // streamed weights: 1 = two register sets, a chunk's weights are requested TWO iterations before they are staged (one set: one)
+#ifndef UNCL_FL_PRIO_DEFAULT
+#define UNCL_FL_PRIO_DEFAULT 1
+#endif
 #ifndef UNCL_FL_W2
 #define UNCL_FL_W2 0
 #endif
@@ -124,7 +127,10 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
     for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
     // fragment bases (LDS byte addresses): weights row lr of K-slot plane lh; per (M-tile, tap row) the lane's first pixel
     unsigned abase = (unsigned)(lh * WPL + lr * 16) + (RESW ? 2u * XBYTES : (unsigned)XBYTES);
-    unsigned bb[MPW][3];
+    // (eight staging waves: 168 registers for everybody -- one base per M-tile, the tap row's offset added per read)
+    constexpr int NB = PW == 8 ? 1 : 3;
+    unsigned bb[MPW][NB];
+    const unsigned ty_step = (unsigned)P * 16u;
     const unsigned blane = (unsigned)(lh * XPL + (cw * MPW * 32 + lr) * 16);
     // the tile's geometry: crossings before each of this wave's M-tiles (and whether the M-tile exists)
     int mt_n[MPW], mt_q0[MPW];
@@ -143,7 +149,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
         // (an M-tile past the end keeps the slot its index has: inside the image, contents irrelevant)
         const unsigned cro = (unsigned)((g < a.fl_total_mt ? cj : 0) * HALO) * 16u;
 #pragma unroll
-        for (int ty = 0; ty < 3; ++ty) bb[m][ty] = stage_off + blane + cro + (unsigned)(ty * P) * 16u;
+        for (int ty = 0; ty < NB; ++ty) bb[m][ty] = stage_off + blane + cro + (unsigned)(ty * P) * 16u;
       }
     };
 
@@ -156,7 +162,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
         A[set][nt] = *reinterpret_cast<const vec*>(smem + abase + 2 * ks * WPL + ((ty * 3 + tx) * CT + nt * 32) * 16);
 #pragma unroll
       for (int m = 0; m < MPW; ++m)
-        B[set][m] = *reinterpret_cast<const vec*>(smem + bb[m][ty] + 2 * ks * XPL + (m * 32 + tx) * 16);
+        B[set][m] = *reinterpret_cast<const vec*>(smem + (NB == 3 ? bb[m][ty] : bb[m][0] + (unsigned)ty * ty_step) + 2 * ks * XPL + (m * 32 + tx) * 16);
     };
     auto mm = [&](int col) __attribute__((always_inline)) {
       const int set = col & 1;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
 #pragma unroll
       for (int m = 0; m < MPW; ++m)
 #pragma unroll
-        for (int ty = 0; ty < 3; ++ty) bb[m][ty] += d;
+        for (int ty = 0; ty < NB; ++ty) bb[m][ty] += d;
       if (RESW) abase = (unsigned)(lh * WPL + lr * 16) + 2u * XBYTES + (unsigned)next_kc * WBYTES;
       else abase += d;
     };
@@ -655,8 +661,20 @@ int launch_fl(PipeArgs& a, hipStream_t s) {
   return UNCL_OK;
 }
 
+// Staging waves: 4 or 8.  Eight need the multiplying waves in 168 registers (three waves per SIMD): MPW <= 3, one fragment base per
+// M-tile instead of one per (M-tile, tap row).  UNCL_FL_PW8: 0 = four everywhere, 1 = eight for the concat form, 2 (default) = for
+// the plain forward form too.  Same-box A/B, ms per 200 tiles, four -> eight: up_path.1.conv.conv 0.336 -> 0.305, up_path.0.conv.conv
+// 0.238 -> 0.233, down_path.1 first conv 0.122 -> 0.117, up_path.1.conv.conv1 0.063 -> 0.060; whole forward 3.80 -> 3.76 ms.
+#ifndef UNCL_FL_PW8_DEFAULT
+#define UNCL_FL_PW8_DEFAULT 2
+#endif
 template <typename T, int MPW, bool GRAD>
 int fl_dispatch(PipeArgs& a, int mode, bool resw, hipStream_t s) {
+  static const int pw8 = [] { const char* e = getenv("UNCL_FL_PW8"); return e ? atoi(e) : UNCL_FL_PW8_DEFAULT; }();
+  if constexpr (MPW <= 3 && !GRAD) {
+    if (pw8 && mode == 1 && !resw) return launch_fl<T, 2, MPW, 1, 8, false, GRAD>(a, s);
+    if (pw8 >= 2 && mode == 0) return resw ? launch_fl<T, 2, MPW, 0, 8, true, GRAD>(a, s) : launch_fl<T, 2, MPW, 0, 8, false, GRAD>(a, s);
+  }
   if (mode == 0) return resw ? launch_fl<T, 2, MPW, 0, 4, true, GRAD>(a, s) : launch_fl<T, 2, MPW, 0, 4, false, GRAD>(a, s);
   if (mode == 1) return resw ? UNCL_ERR_ARG : launch_fl<T, 2, MPW, 1, 4, false, GRAD>(a, s);    // (nk >= 4: never resident)
   return UNCL_ERR_ARG;
@@ -737,7 +755,8 @@ int uncl_conv3x3_flat_launch(PipeArgs& a, int dtype, int mode, int mpw_pref, dou
   a.fl_ct_shift = n_ct == 1 ? 0 : (n_ct == 2 ? 1 : (n_ct == 4 ? 2 : (n_ct == 8 ? 3 : 4)));
   if ((1 << a.fl_ct_shift) != n_ct) return UNCL_ERR_ARG;
   a.total_tiles = (int)(((total_mt + 4 * best - 1) / (4 * best)) * n_ct);
-  static const int prio = [] { const char* e = getenv("UNCL_PC_PRIO"); return e ? atoi(e) : 1; }();
+  // wave priorities: 1 = multiplying waves raised (the rectangular kernel's default), 2 = staging waves raised, 0 = none
+  static const int prio = [] { const char* e = getenv("UNCL_FL_PRIO"); return e ? atoi(e) : UNCL_FL_PRIO_DEFAULT; }();
   a.pc_prio = prio;
   g_flat_launches.fetch_add(1, std::memory_order_relaxed);
 #define UNCL_FL_GO(T, G)                                     \
