@@ -26,12 +26,12 @@ pytestmark = pytest.mark.gpu
 def test_bf16_trajectory_tracks_fp32_mode(video, steps, frames, k):
     import trajectory
     r = trajectory.run(video=video, steps=steps, frames=frames, n_batches=4, every=4, verbose=False, yardstick=True)
-    print("loss curves, largest relative difference:", {k: round(v, 5) for k, v in r["loss_rel_diff"].items()})
+    print("loss curves, largest relative difference:", {name: round(v, 5) for name, v in r["loss_rel_diff"].items()})
     print("drift per level (bf16 vs fp32, fp32 one ulp apart vs fp32):",
-          {k: (round(t["drift"], 4), round(t["drift_fp32_one_ulp"], 4)) for k, t in r["levels"].items()})
-    for k, v in r["loss_rel_diff"].items():
-        assert v <= 2e-2, (k, v)
-    bad = {k: (t["drift"], t["drift_fp32_one_ulp"]) for k, t in r["levels"].items()
+          {name: (round(t["drift"], 4), round(t["drift_fp32_one_ulp"], 4)) for name, t in r["levels"].items()})
+    for name, v in r["loss_rel_diff"].items():
+        assert v <= 2e-2, (name, v)
+    bad = {name: (t["drift"], t["drift_fp32_one_ulp"]) for name, t in r["levels"].items()
            if t["drift"] > max(k * t["drift_fp32_one_ulp"], 0.05)}
     assert not bad, bad
     # the runs actually trained: the generator's structural loss fell

@@ -2021,6 +2021,13 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
   if (nt == 2 && mpw == 2) {
     // 64-channel tiles: the multiplying waves need 234 registers (two fragment sets of ten vectors), which leaves room for two
     // waves per SIMD, i.e. four staging waves
+    // Round 5: ... the 8-row form itself fits 168 registers, i.e. three waves per SIMD and EIGHT staging waves (UNCL_PC_NT2_PW8: 1 =
+    // plain sources, 2 = concat sources too).  Same-box A/B at 200 tiles: down_path.2 second conv (24 x 24: the layer that keeps
+    // 8-row tiles) 0.166 -> 0.155 ms; forcing 8-row tiles with eight staging waves where 16-row tiles with four are chosen today
+    // loses (down_path.1 second conv 0.202 -> 0.219), so the choice between the two tile heights stays as it was.
+    static const int pw8 = [] { const char* e = getenv("UNCL_PC_NT2_PW8"); return e ? atoi(e) : 1; }();
+    if (pw8 && mode == 0) return resw ? launch_pc<T, 2, 2, 0, 8, true>(a, s) : launch_pc<T, 2, 2, 0, 8, false>(a, s);
+    if (pw8 >= 2 && mode == 1 && !resw) return launch_pc<T, 2, 2, 1, 8, false>(a, s);
     if (resw) {
       if (mode == 0) return launch_pc<T, 2, 2, 0, 4, true>(a, s);
       if (mode == 1) return launch_pc<T, 2, 2, 1, 4, true>(a, s);
