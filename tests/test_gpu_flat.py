@@ -52,6 +52,8 @@ PLAIN = [  # cin, cout, input h, w, n, pad
     (64, 64, 3, 3, 70, 0),          # 1 x 1 outputs: one M-tile per sample, one valid pixel each
     (64, 64, 5, 34, 2, 2),          # 7 x 36 output, pitch 38: a row is longer than an M-tile
     (32, 64, 30, 30, 3, 0),         # single chunk
+    (256, 256, 12, 12, 9, 0),       # down_path.3 first conv: 10 x 10 outputs, 4 M-tiles per sample (whole-sample tiles otherwise)
+    (256, 256, 10, 10, 7, 2),       # down_path.3 second conv (transposed): 12 x 12 outputs, 6 M-tiles per sample
 ]
 
 

@@ -82,6 +82,12 @@ constexpr int fl_lmax(int nt, bool resw) {
   return slots;
 }
 
+// sample of a global M-tile index: floor(g / MTS) by reciprocal multiply (exact below 2^24, checked by the launcher); MTS = 1 has no
+// 32-bit reciprocal (2^32 / 1 + 1 wraps) and needs none
+__device__ __forceinline__ int fl_sample_of(const PipeArgs& a, int g) {
+  return a.fl_mts == 1 ? g : (int)__umulhi((unsigned)g, a.fl_div_mts);
+}
+
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool GRAD>
 __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_kernel(const PipeArgs a) {
   constexpr int NCW = 4;
@@ -137,12 +143,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
     auto tile_bases = [&](int step, unsigned stage_off) __attribute__((always_inline)) {
       const int tt = step >> a.fl_ct_shift;
       const int g0 = tt * TM;
-      const int n_first = (int)__umulhi((unsigned)g0, a.fl_div_mts);
+      const int n_first = fl_sample_of(a, g0);
 #pragma unroll
       for (int m = 0; m < MPW; ++m) {
         const int g = g0 + cw * MPW + m;
         const int gc = min(g, a.fl_total_mt - 1);          // M-tiles past the end of the batch read the last one's pixels
-        const int n = (int)__umulhi((unsigned)gc, a.fl_div_mts);
+        const int n = fl_sample_of(a, gc);
         mt_n[m] = g < a.fl_total_mt ? n : -1;
         mt_q0[m] = (gc - n * MTS) * 32;
         const int cj = n - n_first;
@@ -412,9 +418,9 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : 2) void conv3x3_fl_ker
   constexpr int JMIN = (32 * TM) / PPP;
   auto tile_codes = [&](TileCodes& tc, int tt) __attribute__((always_inline)) {
     const int g0 = tt * TM;
-    const int n_first = (int)__umulhi((unsigned)g0, a.fl_div_mts);
+    const int n_first = fl_sample_of(a, g0);
     const int g_last = min(g0 + TM, a.fl_total_mt) - 1;
-    const int n_last = (int)__umulhi((unsigned)g_last, a.fl_div_mts);
+    const int n_last = fl_sample_of(a, g_last);
     const unsigned p_first = (unsigned)(g0 - n_first * MTS) * 32u;
     const unsigned L = (unsigned)(32 * TM + (n_last - n_first + 1) * HALO);
     tc.tt = tt;

@@ -1108,6 +1108,18 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     const bool plain_store = pool_out == nullptr && d->out1_w == nullptr && !d->skip_main_store;   // gradient stores are fine
     if (S >= 1 && S * hpwp <= 10 * 34 && d->src_mode == UNCL_SRC_PLAIN && !prev && plain_store && ssr == nullptr &&
         (d->res == nullptr || !d->res_batch_stride0 || S == 1)) {
+      // Round 5: the flat M-tiles of conv3x3_flat.hip cut these maps finer (a 12 x 12 output fills 144 of its 192 slots against
+      // 144 of 256 here) and run them on the producer / consumer structure; same cost figure, the four-wave kernel's step
+      // priced UNCL_FLAT_SMALL per cent dearer (it stages and multiplies in turn); 0 = keep whole-sample tiles
+      static const int small_pct = [] { const char* e = getenv("UNCL_FLAT_SMALL"); return e ? atoi(e) : 125; }();
+      if (g_use_flat && small_pct > 0 && pc_ok && pc_mode == 0) {
+        const int n_cu = uncl_cu_count();
+        const long long steps = (long long)((d->N + S - 1) / S) * a.n_ct;
+        const double cost = n_cu > 0 ? (double)((steps + n_cu - 1) / n_cu) * 2.35 * small_pct / 100. : 0.;
+        PipeArgs b = a;
+        const int rc = uncl_conv3x3_flat_launch(b, d->dtype, pc_mode, g_use_flat >= 2 ? g_use_flat : 0, g_use_flat >= 2 ? 0. : cost, s);
+        if (rc != UNCL_ERR_ARG) return rc;
+      }
       a.flat_S = S; a.flat_hw = howo;
       a.Hout = 8; a.Wout = 32;      // the store loop's view of the tile: 256 consecutive pixels
       a.tiles_x = a.tiles_y = 1;
