@@ -17,6 +17,7 @@ LAYERS = {
     "up1a": ("ssr", 128, 512, 64, 57, 2), "up0a": ("ssr", 256, 1024, 128, 24, 2),
     "d1a": ("plain", 64, 64, 128, 61, 0), "d2a": ("plain", 128, 128, 256, 28, 0),
     "up0b": ("plain", 128, 128, 128, 26, 2), "up1b": ("plain", 64, 64, 64, 59, 2),
+    "d3a": ("plain", 256, 256, 256, 12, 0), "d3b": ("plain", 256, 256, 256, 10, 2), "d2b": ("plain", 256, 256, 256, 26, 0),
 }
 
 
