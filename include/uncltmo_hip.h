@@ -553,6 +553,16 @@ int uncl_nce_loss(const void* anchor, const void* pos, const void* neg, int dtyp
 int uncl_nce_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
                       int neg_shared, float k, float c, const void* workspace, const float* upstream, void* g_anchor, void* g_pos,
                       void* g_neg, int grad_dtype, int pos_row, int neg_row, const int* shared_rows, void* stream);
+/* The similarity on its own, for the forms of nce() the fused pair does not cover -- several positives and / or negatives per
+ * anchor (GanTrainerImg.py:410-439 loops over both lists): sims[n] = {s(a_n, pos_n), s(a_n, neg_n)} (device fp32, N x 2), same
+ * workspace size as uncl_nce_loss; the caller assembles its logits (InfoNCE :431-433, LMCL :441-450) from the columns.  The backward
+ * takes g_sims[n] = {dL/ds_pos, dL/ds_neg} and writes (accumulate = 0) or adds fp32 gradients of the tensors whose pointer is given;
+ * a row shared by all samples receives the sum. */
+int uncl_nce_similarity(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw, int pos_shared,
+                        int neg_shared, float k, float c, float* sims, void* workspace, void* stream);
+int uncl_nce_similarity_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw,
+                                 int pos_shared, int neg_shared, float k, float c, const float* g_sims, float* g_anchor,
+                                 float* g_pos, float* g_neg, int accumulate, void* stream);
 /* err = sum_i weights[i] * terms[i][0] over device scalars, and its backward out[i] = g[0] * weights[i]: the weighting of
  * the loss terms in update_g_d_loss / train_G (GanTrainerImg.py:285-313,330-339) as one launch per direction.
  * `terms` is a HOST array of n device pointers, `weights` a host array, n <= UNCL_WSUM_MAX. */

@@ -35,6 +35,28 @@ def nce(anchor, positive, negative, k, c):
     return F.cross_entropy(logits, torch.zeros(anchor.shape[0], dtype=torch.long))
 
 
+def lmcl_loss(logits):
+    """GanTrainerImg.py:441-450 on a list of (N,1) similarities, the first one positive: -log(exp(s_pos) / sum_j exp(s_neg_j))."""
+    neg = torch.cat(logits[1:], dim=1)
+    return -torch.log(logits[0].exp() / neg.exp().sum(dim=1, keepdim=True)).mean()
+
+
+def nce_lists(anchor, positives, negatives, k, c, form="InfoNCE"):
+    """GanTrainerImg.py:410-439 with any number of positives and negatives: every positive meets ALL negatives in one
+    (Q+1)-way cross-entropy against class 0 (:431-433) or in lmcl_loss (:434-435); the mean over the positives is returned (:439)."""
+    neg = [nce_similarity(anchor, f, k, c) for f in negatives]
+    loss = 0
+    for f in positives:
+        pos = [nce_similarity(anchor, f, k, c)]
+        if form == "InfoNCE":
+            loss = loss + F.cross_entropy(torch.cat(pos + neg, dim=1), torch.zeros(anchor.shape[0], dtype=torch.long))
+        elif form == "LMCL":
+            loss = loss + lmcl_loss(pos + neg)
+        else:
+            raise TypeError("%s is not found in loss/adversarial.py" % form)
+    return loss / len(positives)
+
+
 def tmqi_scores_frames(fake):
     """Naturalness of each (N,1,H,W) frame scaled by 255, as the trainers do (GanTrainerImg.py:388-397)."""
     imgs = fake.permute(0, 2, 3, 1).detach().cpu().numpy()

@@ -25,6 +25,8 @@ import _ref_shims  # noqa: E402
 DropPath = _ref_shims.install()
 
 from uncltmo_amd import synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from nce_cases import NCE_LISTS_CASES, nce_lists_inputs  # noqa: E402
 
 torch.manual_seed(999)
 torch.set_num_threads(8)
@@ -258,6 +260,22 @@ def capture_losses(out):
     l.backward()
     out["loss.contrast_l1"] = np.float64(l.item())
     out.update(summarize(fk2.grad, "loss.contrast_l1.g", 512))
+
+
+def capture_nce_lists(out):
+    """nce() (GanTrainerImg.py:410-439) and lmcl_loss (:441-450) of the reference with several positives and / or negatives: the
+    loss and the gradients of the anchor, of the first positive and of the last negative."""
+    tr, mod = make_trainer(False)
+    for tag, shape, n_pos, n_neg, shared, k, c in NCE_LISTS_CASES:
+        for form in ("InfoNCE", "LMCL"):
+            an, pos, neg = nce_lists_inputs(tag, shape, n_pos, n_neg, shared)
+            an.requires_grad_(True); pos[0].requires_grad_(True); neg[-1].requires_grad_(True)
+            negs = [f.repeat(shape[0], 1, 1, 1) if shared else f for f in neg]
+            l = tr.nce(an, pos, negs, form, k, c)
+            l.backward()
+            key = "%s.%s" % (tag, form)
+            out[key] = np.float64(l.item())
+            out[key + ".ga"], out[key + ".gp0"], out[key + ".gn_last"] = an.grad.numpy(), pos[0].grad.numpy(), neg[-1].grad.numpy()
 
 
 def capture_step(out, video, epochs):
@@ -595,7 +613,7 @@ def capture_tester(out):
 
 def main():
     which = sys.argv[1:] or ["generator", "generator_inorm", "generator_bnorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
-                             "inference", "tmqi", "loader", "patchd_grad", "tester"]
+                             "inference", "tmqi", "loader", "patchd_grad", "tester", "nce_lists"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
@@ -603,7 +621,8 @@ def main():
             "generator_inorm": lambda o: capture_generator_inorm(o), "generator_bnorm": lambda o: capture_generator_bnorm(o),
             "loader": lambda o: capture_loader(o),
             "tiler": lambda o: capture_tiler(o), "patchd_grad": lambda o: capture_patchd_grad(o),
-            "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o), "tester": lambda o: capture_tester(o)}
+            "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o), "tester": lambda o: capture_tester(o),
+            "nce_lists": lambda o: capture_nce_lists(o)}
     for name in which:
         out = {}
         jobs[name](out)

@@ -110,6 +110,14 @@ def test_round5_entry_points_refuse_bad_arguments_before_any_launch():
     assert lib.uncl_optical_flow(None, C.addressof(buf), 270, 480, C.addressof(buf), C.addressof(buf), need, None) == ERR_ARG
     old = lib.uncl_conv3x3_set_flat(0)
     assert lib.uncl_conv3x3_set_flat(old) == 0 and lib.uncl_conv3x3_flat_count() >= 0
+    # the similarity pair behind nce() with longer lists: every tensor, the result and the workspace are required; fp16 is refused
+    pb = C.addressof(buf)
+    assert lib.uncl_nce_similarity(pb, pb, None, _hip.F32, 2, 8, 4, 0, 0, 1.0, 1e-2, pb, pb, None) == ERR_ARG
+    assert lib.uncl_nce_similarity(pb, pb, pb, _hip.F32, 2, 8, 4, 0, 0, 1.0, 1e-2, None, pb, None) == ERR_ARG
+    assert lib.uncl_nce_similarity(pb, pb, pb, _hip.F32, 0, 8, 4, 0, 0, 1.0, 1e-2, pb, pb, None) == ERR_ARG
+    assert lib.uncl_nce_similarity_backward(pb, pb, pb, _hip.F32, 2, 8, 4, 0, 0, 1.0, 1e-2, None, pb, None, None, 0, None) == ERR_ARG
+    assert lib.uncl_nce_similarity_backward(pb, pb, pb, _hip.F16, 2, 8, 4, 0, 0, 1.0, 1e-2, pb, pb, None, None, 0, None) == ERR_ARG
+    assert lib.uncl_nce_similarity_backward(pb, pb, pb, _hip.F32, 2, 8, 4, 0, 0, 1.0, 1e-2, pb, None, None, None, 0, None) == 0   # nothing asked for
 
 
 def test_relative_pos_buffer_matches_reference_golden(golden):

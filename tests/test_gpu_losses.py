@@ -122,6 +122,40 @@ def test_contrastive_d_loss_golden(golden):
     assert rel_l2(rg.grad.cpu(), rc.grad) < 1e-5 and rel_l2(fg.grad.cpu(), fc.grad) < 1e-5
 
 
+def test_nce_with_longer_lists_golden_and_trainer_dispatch(golden):
+    """nce() with several positives / negatives (GanTrainerImg.py:410-439) and lmcl_loss (:441-450): losses.nce_lists against the
+    reference's own outputs, through the trainer method that used to refuse them; bf16 features against the oracle"""
+    from nce_cases import NCE_LISTS_CASES, nce_lists_inputs
+    from uncltmo_amd.trainer_img import GanTrainer
+    g = golden("nce_lists")
+    tr = GanTrainer.__new__(GanTrainer)
+    for tag, shape, n_pos, n_neg, shared, k, c in NCE_LISTS_CASES:
+        for form in ("InfoNCE", "LMCL"):
+            an, pos, neg = [t.cuda() if torch.is_tensor(t) else [x.cuda() for x in t] for t in nce_lists_inputs(tag, shape, n_pos, n_neg, shared)]
+            an.requires_grad_(True); pos[0].requires_grad_(True); neg[-1].requires_grad_(True)
+            l = tr.nce(an, pos, neg, form, k, c)           # shared negatives stay single rows: no repeat needed here
+            l.backward()
+            key = "%s.%s" % (tag, form)
+            np.testing.assert_allclose(l.item(), g[key], rtol=2e-5)
+            assert rel_l2(an.grad.cpu(), torch.from_numpy(g[key + ".ga"])) < 1e-4, key
+            assert rel_l2(pos[0].grad.cpu(), torch.from_numpy(g[key + ".gp0"])) < 1e-4, key
+            assert rel_l2(neg[-1].grad.cpu(), torch.from_numpy(g[key + ".gn_last"])) < 1e-4, key
+    # bf16 channel-last features, two positives and two negatives, one of each a row of the anchor itself
+    fea = torch.rand(4, 8, 12, 12, generator=torch.Generator().manual_seed(7))
+    oth = torch.rand(2, 4, 8, 12, 12, generator=torch.Generator().manual_seed(8))
+    fb = fea.cuda().to(torch.bfloat16).requires_grad_(True)
+    ob = oth.cuda().to(torch.bfloat16)
+    lb = HL.nce_lists(fb, [ob[0], fb[2:3]], [ob[1], fb[1:2]], 1, 1e-2)
+    fr = fb.detach().float().cpu().requires_grad_(True)
+    orf = ob.float().cpu()
+    lr_ = OL.nce_lists(fr, [orf[0], fr[2:3].repeat(4, 1, 1, 1)], [orf[1], fr[1:2].repeat(4, 1, 1, 1)], 1, 1e-2)
+    np.testing.assert_allclose(lb.item(), lr_.item(), rtol=1e-4)
+    lb.backward(); lr_.backward()
+    assert fb.grad.dtype == torch.bfloat16 and rel_l2(fb.grad.float().cpu(), fr.grad) < 6e-3
+    with pytest.raises(TypeError):
+        tr.nce(fb, [ob[0], ob[1]], [ob[1]], "nope", 1, 1e-2)
+
+
 def test_nce_golden_and_shared_rows(golden):
     g = golden("losses")
     for tag, shape, (k, c) in [("nce_d", (4, 2, 1, 1), (1, 1e-2)), ("nce_d2", (4, 2, 1, 1), (1e3, 2)),

@@ -164,6 +164,24 @@ def test_tiler(golden, sdG):
     assert OT.tile_count(1024, 1024) == 25 and OT.tile_count(2160, 3840) == 220
 
 
+def test_nce_with_longer_lists_matches_reference_golden(golden):
+    """nce() with several positives / negatives and lmcl_loss (GanTrainerImg.py:410-450): oracle/losses.py:nce_lists against the
+    reference's own method (tests/golden/make_golden.py nce_lists)"""
+    from nce_cases import NCE_LISTS_CASES, nce_lists_inputs
+    g = golden("nce_lists")
+    for tag, shape, n_pos, n_neg, shared, k, c in NCE_LISTS_CASES:
+        for form in ("InfoNCE", "LMCL"):
+            an, pos, neg = nce_lists_inputs(tag, shape, n_pos, n_neg, shared)
+            an.requires_grad_(True); pos[0].requires_grad_(True); neg[-1].requires_grad_(True)
+            l = OL.nce_lists(an, pos, [f.repeat(shape[0], 1, 1, 1) if shared else f for f in neg], k, c, form)
+            l.backward()
+            key = "%s.%s" % (tag, form)
+            np.testing.assert_allclose(l.item(), g[key], rtol=1e-6)
+            np.testing.assert_allclose(an.grad.numpy(), g[key + ".ga"], rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(pos[0].grad.numpy(), g[key + ".gp0"], rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(neg[-1].grad.numpy(), g[key + ".gn_last"], rtol=1e-4, atol=1e-8)
+
+
 def inference_inputs():
     """Same synthetic frame / stand-in generator output as tests/golden/make_golden.py:inference_inputs."""
     rgb = torch.from_numpy(synth.hash_uniform("inf_rgb", 3 * 300 * 280).reshape(3, 300, 280).copy()).float() ** 4 * 1000 - 0.01

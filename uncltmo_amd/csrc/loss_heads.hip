@@ -126,6 +126,16 @@ __global__ void nce_ce_kernel(const float* __restrict__ partial, int blocks, int
   if (threadIdx.x == 0) loss[0] = ((accumulate_loss & 1) ? loss[0] : 0.f) + (float)(sl * (double)w / (double)N);
 }
 
+// the similarities themselves (uncl_nce_similarity): the same finishing sums as nce_ce_kernel, no cross-entropy
+__global__ void nce_sims_final_kernel(const float* __restrict__ partial, int blocks, int N, double inv_hw, float* __restrict__ sims) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * N) return;
+  const int n = i >> 1, j = i & 1;
+  double sacc = 0.0;
+  for (int b = 0; b < blocks; ++b) sacc += (double)partial[((size_t)n * blocks + b) * 2 + j];
+  sims[i] = (float)(sacc * inv_hw);
+}
+
 // pass 3: gradients.  One thread per element e, looping over the samples, so that a positive / negative that is
 // ONE row shared by every sample (stride 0, GanTrainerImg.py:401-402) gets its summed gradient without atomics.
 template <typename T>
@@ -668,6 +678,51 @@ extern "C" int uncl_nce_backward(const void* anchor, const void* pos, const void
   else if (grad_dtype == UNCL_BF16) UNCL_NCE_BWD(bf16_t, bf16_t);
   else UNCL_NCE_BWD(bf16_t, float);
 #undef UNCL_NCE_BWD
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// The similarity by itself, for NCE forms the fused pair above does not cover (several positives / negatives per anchor,
+// GanTrainerImg.py:410-439 with longer lists): sims[n] = {s(a_n, pos_n), s(a_n, neg_n)}; the caller builds its logits from them.
+extern "C" int uncl_nce_similarity(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E, int hw,
+                                   int pos_shared, int neg_shared, float k, float c, float* sims, void* workspace, void* stream) {
+  if (!anchor || !pos || !neg || !sims || !workspace || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+  const int blocks = (int)((E + 255) / 256 < 256 ? (E + 255) / 256 : 256);
+  const size_t ps = pos_shared ? 0 : (size_t)E, qs = neg_shared ? 0 : (size_t)E;
+  if (dtype == UNCL_F32)
+    hipLaunchKernelGGL(nce_sim_kernel<float>, dim3(blocks, N), dim3(256), 0, st, (const float*)anchor, (const float*)pos,
+                       (const float*)neg, (size_t)E, ps, qs, k, c, partial, (const int*)nullptr);
+  else if (dtype == UNCL_BF16)
+    hipLaunchKernelGGL(nce_sim_kernel<bf16_t>, dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)anchor, (const bf16_t*)pos,
+                       (const bf16_t*)neg, (size_t)E, ps, qs, k, c, partial, (const int*)nullptr);
+  else
+    return UNCL_ERR_ARG;
+  UNCL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nce_sims_final_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, st, partial, blocks, N, 1.0 / (double)hw, sims);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+// ... and its backward: g_sims[n] = {dL/ds(a_n, pos_n), dL/ds(a_n, neg_n)} (device, fp32) -> fp32 gradients of the three tensors
+// (each optional; a shared row receives the sum over the samples), written or accumulated.
+extern "C" int uncl_nce_similarity_backward(const void* anchor, const void* pos, const void* neg, int dtype, int N, long long E,
+                                            int hw, int pos_shared, int neg_shared, float k, float c, const float* g_sims,
+                                            float* g_anchor, float* g_pos, float* g_neg, int accumulate, void* stream) {
+  if (!anchor || !pos || !neg || !g_sims || N <= 0 || E <= 0 || hw <= 0) return UNCL_ERR_ARG;
+  if (!g_anchor && !g_pos && !g_neg) return UNCL_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t ps = pos_shared ? 0 : (size_t)E, qs = neg_shared ? 0 : (size_t)E;
+  const int gblocks = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
+  if (dtype == UNCL_F32)
+    hipLaunchKernelGGL(nce_grad_kernel<float>, dim3(gblocks), dim3(256), 0, st, (const float*)anchor, (const float*)pos,
+                       (const float*)neg, (size_t)E, ps, qs, N, k, c, 1.f / (float)hw, g_sims, g_anchor, g_pos, g_neg, accumulate);
+  else if (dtype == UNCL_BF16)
+    hipLaunchKernelGGL(nce_grad_kernel<bf16_t>, dim3(gblocks), dim3(256), 0, st, (const bf16_t*)anchor, (const bf16_t*)pos,
+                       (const bf16_t*)neg, (size_t)E, ps, qs, N, k, c, 1.f / (float)hw, g_sims, g_anchor, g_pos, g_neg, accumulate);
+  else
+    return UNCL_ERR_ARG;
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

@@ -171,6 +171,87 @@ def nce(anchor, positive, negative, k, c, hw=None, form="InfoNCE"):
     return _NceFn.apply(anchor, pos_in, neg_in, hw, k, c, pos_shared, neg_shared, pos_row, neg_row, None, form == "LMCL")
 
 
+class _SimPairFn(torch.autograd.Function):
+    """(anchor, x1, x2) -> (s(anchor, x1), s(anchor, x2)), each (N,), s(a,b) = mean_hw sum_c a b / (c + k|a-b|)
+    (GanTrainerImg.py:421-429): the building block of nce() with longer positive / negative lists.  x1 / x2: the anchor's shape, or
+    a leading dim of 1 (one row for every sample).  fp32 gradients from uncl_nce_similarity_backward, cast to the inputs' dtypes."""
+
+    @staticmethod
+    def forward(ctx, anchor, x1, x2, hw, k, c):
+        lib = _hip.lib()
+        if anchor.dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError("uncltmo_amd nce: features must be bfloat16 or float32, got %s" % anchor.dtype)
+        if x1.dtype != anchor.dtype or x2.dtype != anchor.dtype:
+            raise TypeError("uncltmo_amd nce: anchor, positives and negatives must share one dtype")
+        n = anchor.shape[0]
+        a = anchor.detach().contiguous()
+        E = a.numel() // n
+        xs, shared = [], []
+        for x in (x1, x2):
+            sh = x.shape[0] == 1 and n != 1
+            if (not sh and x.shape != anchor.shape) or (sh and x.shape[1:] != anchor.shape[1:]):
+                raise ValueError("uncltmo_amd nce: a positive / negative must have the anchor's shape or a leading dimension of 1")
+            xs.append(x.detach().contiguous())
+            shared.append(sh)
+        code = _hip.BF16 if a.dtype == torch.bfloat16 else _hip.F32
+        ws = torch.empty(lib.uncl_nce_workspace_bytes(n), dtype=torch.uint8, device=a.device)
+        sims = torch.empty(n, 2, dtype=torch.float32, device=a.device)
+        _hip.check(lib.uncl_nce_similarity(a.data_ptr(), xs[0].data_ptr(), xs[1].data_ptr(), code, n, E, hw, int(shared[0]),
+                                           int(shared[1]), float(k), float(c), sims.data_ptr(), ws.data_ptr(), _hip.stream_ptr()),
+                   "uncl_nce_similarity")
+        ctx.saved = (a, xs[0], xs[1])
+        ctx.args = (code, n, E, hw, int(shared[0]), int(shared[1]), float(k), float(c))
+        ctx.dt = (anchor.dtype, x1.dtype, x2.dtype)
+        ctx.shapes = (anchor.shape, x1.shape, x2.shape)
+        return sims[:, 0], sims[:, 1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        lib = _hip.lib()
+        a, p, q = ctx.saved
+        code, n, E, hw, ps, qs, k, c = ctx.args
+        need = ctx.needs_input_grad
+        gs = torch.stack([g1.detach().float(), g2.detach().float()], 1).contiguous()
+        out = [torch.empty(t.shape, dtype=torch.float32, device=a.device) if nd else None for t, nd in zip((a, p, q), need[:3])]
+        P = lambda t: t.data_ptr() if t is not None else None
+        _hip.check(lib.uncl_nce_similarity_backward(a.data_ptr(), p.data_ptr(), q.data_ptr(), code, n, E, hw, ps, qs, k, c,
+                                                    gs.data_ptr(), P(out[0]), P(out[1]), P(out[2]), 0, _hip.stream_ptr()),
+                   "uncl_nce_similarity_backward")
+        res = [None if t is None else t.to(dt).reshape(sh) for t, dt, sh in zip(out, ctx.dt, ctx.shapes)]
+        return (res[0], res[1], res[2], None, None, None)
+
+
+def nce_lists(anchor, positives, negatives, k, c, hw=None, form="InfoNCE"):
+    """nce() of the trainers with ANY number of positives and negatives (GanTrainerImg.py:410-439): per positive p the logits
+    [s(a,p), s(a,n_1), ..., s(a,n_Q)] go through the 2..(Q+1)-way cross-entropy with class 0 ('InfoNCE', :431-433) or lmcl_loss
+    ('LMCL', :441-450: -log(exp(s_p) / sum_j exp(s_nj))), averaged over the positives.  The similarities come from the HIP kernels
+    two at a time (uncl_nce_similarity); the logits are (N, Q+1) device tensors.  The published call sites (one positive, one
+    negative) use the fused nce() above instead."""
+    if form not in ("InfoNCE", "LMCL"):
+        raise TypeError("%s is not found in loss/adversarial.py" % form)
+    if len(positives) == 0 or len(negatives) == 0:
+        raise ValueError("uncltmo_amd nce: at least one positive and one negative")
+    if hw is None:
+        hw = anchor.shape[-1] * anchor.shape[-2]
+    xs = list(negatives) + list(positives)
+    sims = []
+    for i in range(0, len(xs), 2):
+        pair = xs[i:i + 2]
+        s1, s2 = _SimPairFn.apply(anchor, pair[0], pair[-1], hw, k, c)
+        sims += [s1, s2][:len(pair)]
+    neg, pos = sims[:len(negatives)], sims[len(negatives):]
+    n = anchor.shape[0]
+    loss = None
+    for sp in pos:
+        if form == "InfoNCE":
+            logits = torch.stack([sp] + neg, 1)
+            l = torch.nn.functional.cross_entropy(logits, torch.zeros(n, dtype=torch.long, device=logits.device))
+        else:
+            l = -(sp - torch.logsumexp(torch.stack(neg, 1), 1)).mean()
+        loss = l if loss is None else loss + l
+    return loss / len(pos)
+
+
 class _FrameStatsFn(torch.autograd.Function):
     """(N,1,H,W) fp32 -> (mean (N,), mean Gaussian local variance (N,)) with analytic backward."""
 

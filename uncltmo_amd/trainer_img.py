@@ -234,12 +234,14 @@ class GanTrainer:
         return L.nce_rows(fea_fake, bw, k, constant)
 
     def nce(self, fea_anchor, feas_positive, feas_negative, cl_loss_type, k, constant):
-        """GanTrainerImg.py:410-439 with one positive and one negative (every published call site); cl_loss_type 'InfoNCE'
-        (2-way cross-entropy) or 'LMCL' (lmcl_loss, :441-450: -log(exp(s_pos) / exp(s_neg)) = s_neg - s_pos)."""
+        """GanTrainerImg.py:410-439; cl_loss_type 'InfoNCE' (cross-entropy of [s_pos, s_neg...] against class 0) or 'LMCL'
+        (lmcl_loss, :441-450: -log(exp(s_pos) / sum exp(s_neg))).  One positive and one negative (every published call site) is
+        one fused launch per direction (L.nce); longer lists go through L.nce_lists."""
         if cl_loss_type not in ("InfoNCE", "LMCL"):
             raise TypeError("%s is not found in loss/adversarial.py" % cl_loss_type)        # the reference's message (:437)
         if len(feas_positive) != 1 or len(feas_negative) != 1:
-            raise NotImplementedError("HIP nce covers one positive and one negative (all call sites of the published trainers)")
+            # longer lists (no published call site): similarities from the HIP kernels, the (N, Q+1) logits assembled on the device
+            return L.nce_lists(fea_anchor, list(feas_positive), list(feas_negative), k, constant, form=cl_loss_type)
         return L.nce(fea_anchor, feas_positive[0], feas_negative[0], k, constant, form=cl_loss_type)
 
     def lmcl_loss(self, logits):
