@@ -582,6 +582,11 @@ int uncl_tmqi_naturalness(const float* x, int F, int frame_h, int frame_w, int h
  * Used by the reference's evaluators (Tester.py:339, TesterImg.py:335), not by the training step. */
 size_t uncl_tmqi_workspace_bytes(int H, int W);
 int uncl_tmqi(const float* hdr, const float* ldr, int H, int W, float ldr_scale, double* out, void* workspace, void* stream);
+/* the same, also writing the per-level structural-fidelity maps the reference returns as `s_maps` (TMQI.py:152-157, 203-205):
+ * s_maps = HOST array of five device pointers, level l receiving (H_l - 10) x (W_l - 10) doubles row-major, H_l = H >> l, W_l = W >> l;
+ * NULL = uncl_tmqi */
+int uncl_tmqi_maps(const float* hdr, const float* ldr, int H, int W, float ldr_scale, double* out, double* const* s_maps,
+                   void* workspace, void* stream);
 /* gx[n] (+)= gscale[n] * d mean(Gaussian local variance of x[n]) / dx */
 int uncl_gauss_var_backward(const float* x, const float* gscale, float* gx, int N, int H, int W, int accumulate, void* stream);
 /* Backward of uncl_gauss_stats for NHWC tensors (the video generator's per-frame features, Unet.py:274-278):

@@ -68,8 +68,8 @@ def _conv_valid(img, win):
     return np.einsum("ijkl,kl->ij", v, win[::-1, ::-1])
 
 
-def s_local(img1, img2, sf, C1=0.01, C2=10.0):
-    """TMQI.py:178-207: one pyramid level's local structural fidelity map mean."""
+def s_local(img1, img2, sf, C1=0.01, C2=10.0, want_map=False):
+    """TMQI.py:178-207: one pyramid level's local structural fidelity map mean (and, on request, the map: the reference returns both)."""
     win = _gauss2d()
     mu1, mu2 = _conv_valid(img1, win), _conv_valid(img2, win)
     s1 = np.sqrt(np.maximum(_conv_valid(img1 * img1, win) - mu1 * mu1, 0))
@@ -80,16 +80,21 @@ def s_local(img1, img2, sf, C1=0.01, C2=10.0):
     sig = u / 3.0
     p1, p2 = _norm_cdf(s1, u, sig), _norm_cdf(s2, u, sig)
     s_map = ((2 * p1 * p2 + C1) / (p1 ** 2 + p2 ** 2 + C1)) * ((s12 + C2) / (s1 * s2 + C2))
-    return float(np.mean(s_map))
+    return (float(np.mean(s_map)), s_map) if want_map else float(np.mean(s_map))
 
 
-def structural_fidelity(L_hdr, L_ldr, levels=5):
+def structural_fidelity(L_hdr, L_ldr, levels=5, maps=None):
     """TMQI.py:149-172: five dyadic levels (2x2 mean, keep every second sample), product of weighted level means."""
     f = 32.0
     out = []
     for _ in range(levels):
         f = f / 2
-        out.append(s_local(L_hdr, L_ldr, f))
+        if maps is None:
+            out.append(s_local(L_hdr, L_ldr, f))
+        else:
+            sl, sm = s_local(L_hdr, L_ldr, f, want_map=True)
+            out.append(sl)
+            maps.append(sm)
         k = np.ones((2, 2)) / 4.0
         L_hdr = _conv_valid(L_hdr, k)[::2, ::2]
         L_ldr = _conv_valid(L_ldr, k)[::2, ::2]
@@ -97,13 +102,14 @@ def structural_fidelity(L_hdr, L_ldr, levels=5):
     return S, out
 
 
-def tmqi(hdr, ldr):
-    """TMQI.py:107-146 (`original` branch): grayscale hdr (any range) and ldr ([0,255]) -> (Q, S, N, s_local[5])."""
+def tmqi(hdr, ldr, maps=None):
+    """TMQI.py:107-146 (`original` branch): grayscale hdr (any range) and ldr ([0,255]) -> (Q, S, N, s_local[5]); `maps`: a list
+    that receives the five per-level maps (the reference's fifth return value `s_maps`, :152-157)."""
     hdr = np.asarray(hdr, dtype=np.float64)
     ldr = np.asarray(ldr, dtype=np.float64)
     N = naturalness(ldr)
     factor = float(2 ** 32 - 1.0)
     L_hdr = factor * (hdr - hdr.min()) / (hdr.max() - hdr.min())
-    S, sl = structural_fidelity(L_hdr, ldr)
+    S, sl = structural_fidelity(L_hdr, ldr, maps=maps)
     Q = A_Q * (S ** ALPHA) + (1.0 - A_Q) * (N ** BETA)
     return Q, S, N, sl

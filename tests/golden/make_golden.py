@@ -533,6 +533,19 @@ def capture_tmqi(out):
         print("captured tmqi", salt, Q, S, N, s_local, flush=True)
 
 
+def capture_tmqi_maps(out):
+    """The per-level structural-fidelity maps `s_maps` the reference's TMQI returns as its fifth value (TMQI.py:152-157, 203-205):
+    shape, sum, |sum| and 256 hashed samples of each of the five maps, same inputs as capture_tmqi."""
+    import TMQI as ref_tmqi
+    for (h, w), salt in (((256, 256), "a"), ((200, 176), "b")):
+        hdr, ldr = tmqi_inputs(h, w, salt)
+        _, _, _, s_local, s_maps = ref_tmqi.TMQI()(hdr, ldr)
+        assert len(s_maps) == 5
+        for l, m in enumerate(s_maps):
+            out.update(summarize(torch.from_numpy(np.ascontiguousarray(m)), "tmqi.%s.map%d" % (salt, l)))
+            assert abs(float(np.mean(m)) - s_local[l]) < 1e-12
+
+
 def tester_inputs():
     """Three synthetic linear-radiance frames (H,W,3) of one scene and the scene's brightness factor; shared with
     tests/test_oracle_golden.py and tests/test_gpu_inference.py."""
@@ -613,7 +626,7 @@ def capture_tester(out):
 
 def main():
     which = sys.argv[1:] or ["generator", "generator_inorm", "generator_bnorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
-                             "inference", "tmqi", "loader", "patchd_grad", "tester", "nce_lists"]
+                             "inference", "tmqi", "loader", "patchd_grad", "tester", "nce_lists", "tmqi_maps"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
@@ -622,7 +635,7 @@ def main():
             "loader": lambda o: capture_loader(o),
             "tiler": lambda o: capture_tiler(o), "patchd_grad": lambda o: capture_patchd_grad(o),
             "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o), "tester": lambda o: capture_tester(o),
-            "nce_lists": lambda o: capture_nce_lists(o)}
+            "nce_lists": lambda o: capture_nce_lists(o), "tmqi_maps": lambda o: capture_tmqi_maps(o)}
     for name in which:
         out = {}
         jobs[name](out)

@@ -120,10 +120,19 @@ def test_full_tmqi_matches_reference_golden(golden, shape, salt):
     from uncltmo_amd.tmqi import TMQI
     g = golden("tmqi")
     hdr, ldr = tmqi_inputs(shape[0], shape[1], salt)
-    Q, S, N, sl = TMQI()(torch.from_numpy(hdr).float().cuda(), torch.from_numpy(ldr).float().cuda())
+    Q, S, N, sl, maps = TMQI()(torch.from_numpy(hdr).float().cuda(), torch.from_numpy(ldr).float().cuda())
     # the device takes fp32 images (the goldens were computed from the float64 arrays): 1e-5 covers the input rounding
     np.testing.assert_allclose([Q, S, N], g["tmqi.%s.QSN" % salt], rtol=2e-5)
     np.testing.assert_allclose(sl, g["tmqi.%s.s_local" % salt], rtol=2e-5)
+    # the per-level maps (the reference's `s_maps`): against the reference's own maps, and consistent with the level means
+    from conftest import check_summary
+    gm = golden("tmqi_maps")
+    assert len(maps) == 5
+    for l, m in enumerate(maps):
+        assert m.dtype == torch.float64 and tuple(m.shape) == ((shape[0] >> l) - 10, (shape[1] >> l) - 10)
+        check_summary(m, gm, "tmqi.%s.map%d" % (salt, l), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(float(m.mean()), sl[l], rtol=1e-12)
+    assert TMQI()(torch.from_numpy(hdr).float().cuda(), torch.from_numpy(ldr).float().cuda(), with_maps=False)[4] is None
 
 
 def test_full_tmqi_large_frame_vs_oracle():
@@ -131,7 +140,7 @@ def test_full_tmqi_large_frame_vs_oracle():
     from uncltmo_amd.tmqi import TMQI
     hdr, ldr = tmqi_inputs(400, 528, "c")
     h32, l32 = torch.from_numpy(hdr).float(), torch.from_numpy(ldr / 255.0).float()
-    Q, S, N, sl = TMQI()(h32.cuda(), l32.cuda(), ldr_scale=255.0)
+    Q, S, N, sl, _ = TMQI()(h32.cuda(), l32.cuda(), ldr_scale=255.0, with_maps=False)
     rQ, rS, rN, rsl = OT.tmqi(h32.double().numpy(), (l32 * 255.0).double().numpy())
     np.testing.assert_allclose([Q, S, N], [rQ, rS, rN], rtol=1e-6)
     np.testing.assert_allclose(sl, rsl, rtol=1e-6)

@@ -225,6 +225,21 @@ def test_full_tmqi_matches_reference_class(golden):
         np.testing.assert_allclose(sl, g["tmqi.%s.s_local" % salt], rtol=1e-9)
 
 
+def test_tmqi_per_level_maps_match_reference_class(golden):
+    """the reference's fifth return value, `s_maps` (TMQI.py:152-157): shapes, sums and hashed samples of the five maps"""
+    from oracle import tmqi as OT
+    g = golden("tmqi_maps")
+    for (h, w), salt in (((256, 256), "a"), ((200, 176), "b")):
+        hdr, ldr = tmqi_inputs(h, w, salt)
+        maps = []
+        _, _, _, sl = OT.tmqi(hdr, ldr, maps=maps)
+        assert len(maps) == 5
+        for l, m in enumerate(maps):
+            assert m.shape == ((h >> l) - 10, (w >> l) - 10)
+            check_summary(torch.from_numpy(np.ascontiguousarray(m)), g, "tmqi.%s.map%d" % (salt, l), rtol=1e-6, atol=1e-7)   # (samples are stored as fp32)
+            np.testing.assert_allclose(m.mean(), sl[l], rtol=1e-12)
+
+
 def test_loader_hdr_branch_oracle_vs_reference_golden(golden):
     """oracle/data_loader.py's HDR branch against the reference's own npy_loader output (make_golden.py loader)"""
     from oracle import data_loader as OD

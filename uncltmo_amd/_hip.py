@@ -239,6 +239,7 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_void_p]),
     "uncl_tmqi_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "uncl_tmqi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uncl_tmqi_maps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uncl_frame_workspace_bytes": (C.c_size_t, []),
     "uncl_hdr_log_gray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),

@@ -83,7 +83,7 @@ __device__ __forceinline__ double norm_cdf(double x, double u, double sig) {
 
 // column pass + s_map (TMQI.py:183-205) + per-workgroup partial sum of the map
 __global__ __launch_bounds__(256) void colpass_smap_kernel(const double* __restrict__ rp, int h, int wo, double u, double sig,
-                                                           double* __restrict__ partial, GaussD gw) {
+                                                           double* __restrict__ partial, GaussD gw, double* __restrict__ smap) {
   const int ho = h - (GW - 1);
   const size_t total = (size_t)ho * wo, plane = (size_t)h * wo;
   double acc = 0.0;
@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void colpass_smap_kernel(const double* __restr
     const double s1 = sqrt(fmax(m[2] - mu1 * mu1, 0.0)), s2 = sqrt(fmax(m[3] - mu2 * mu2, 0.0));
     const double s12 = m[4] - mu1 * mu2;
     const double p1 = norm_cdf(s1, u, sig), p2 = norm_cdf(s2, u, sig);
-    acc += ((2.0 * p1 * p2 + 0.01) / (p1 * p1 + p2 * p2 + 0.01)) * ((s12 + 10.0) / (s1 * s2 + 10.0));
+    const double sm = ((2.0 * p1 * p2 + 0.01) / (p1 * p1 + p2 * p2 + 0.01)) * ((s12 + 10.0) / (s1 * s2 + 10.0));
+    if (smap) smap[i] = sm;            // the level's structural-fidelity map (TMQI.py:203-205: `s_map`), (ho, wo) row-major
+    acc += sm;
   }
   __shared__ double red[256];
   red[threadIdx.x] = acc;
@@ -160,9 +162,14 @@ extern "C" size_t uncl_tmqi_workspace_bytes(int H, int W) {
 // hdr: fp32 (H,W) luminance in any range; ldr: fp32 (H,W) tone-mapped luminance, multiplied by ldr_scale (255 for [0,1]
 // images) before use.  out (device, 8 doubles): Q, S, N, s_local[0..4].  The smallest pyramid level must still hold an
 // 11x11 window: H, W >= 176.
-extern "C" int uncl_tmqi(const float* hdr, const float* ldr, int H, int W, float ldr_scale, double* out, void* workspace,
-                         void* stream) {
+// s_maps (optional): HOST array of five device pointers, level l receiving its (H_l - 10, W_l - 10) fp64 map, H_l = H >> l
+// (TMQI.py:152-157: the `s_maps` the reference returns beside the per-level means)
+extern "C" int uncl_tmqi_maps(const float* hdr, const float* ldr, int H, int W, float ldr_scale, double* out, double* const* s_maps,
+                              void* workspace, void* stream) {
   if (!hdr || !ldr || !out || !workspace || H < 176 || W < 176) return UNCL_ERR_ARG;
+  if (s_maps)
+    for (int l = 0; l < LEVELS; ++l)
+      if (!s_maps[l]) return UNCL_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t px = (size_t)H * W;
   double* a0 = reinterpret_cast<double*>(workspace);
@@ -197,7 +204,8 @@ extern "C" int uncl_tmqi(const float* hdr, const float* ldr, int H, int W, float
     const double u = 128.0 / (1.4 * csf), sig = u / 3.0;
     hipLaunchKernelGGL(rowpass_kernel, dim3(nb((size_t)h * wo, 4096)), dim3(256), 0, st, ca, cb, h, w, rp, gw);
     const int bp = nb((size_t)ho * wo, PB);
-    hipLaunchKernelGGL(colpass_smap_kernel, dim3(bp), dim3(256), 0, st, rp, h, wo, u, sig, partial, gw);
+    hipLaunchKernelGGL(colpass_smap_kernel, dim3(bp), dim3(256), 0, st, rp, h, wo, u, sig, partial, gw,
+                       s_maps ? s_maps[l] : (double*)nullptr);
     hipLaunchKernelGGL(level_final_kernel, dim3(1), dim3(64), 0, st, partial, bp, (double)ho * (double)wo, out + 3 + l);
     if (l + 1 < LEVELS) {
       const int h2 = h / 2, w2 = w / 2;   // ceil((h-1)/2)
@@ -212,4 +220,9 @@ extern "C" int uncl_tmqi(const float* hdr, const float* ldr, int H, int W, float
   hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, st, out);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
+}
+
+extern "C" int uncl_tmqi(const float* hdr, const float* ldr, int H, int W, float ldr_scale, double* out, void* workspace,
+                         void* stream) {
+  return uncl_tmqi_maps(hdr, ldr, H, W, ldr_scale, out, nullptr, workspace, stream);
 }

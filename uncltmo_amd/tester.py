@@ -56,7 +56,7 @@ def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame
         color = frame_util.back_to_color_and_crop(padded[i], fake, lohi, None, diffY, diffX)
         ldr = frame_util.to_uint8_outlier(color, on_device=True)          # (H,W,3) uint8
         results.append(ldr)
-        score = tmqi(originals[i].permute(1, 2, 0).contiguous(), ldr.float())[0]
+        score = tmqi(originals[i].permute(1, 2, 0).contiguous(), ldr.float(), with_maps=False)[0]
         total += score
     tmqi_scene = total / len(rgb_frames)
     if (align_fn is None and flow is None and flow_images is None) or len(results) < 2:
