@@ -74,6 +74,13 @@ def test_state_dict_contract_and_no_cpu_fallback():
         d(torch.zeros(1, 1, 256, 256))
     with pytest.raises(NotImplementedError):
         UNet(1, 1, "sigmoid", 5, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
+    # stretch_g: the reference builds a parameter-free module it never calls (Unet_singleFrame.py:169-175): the two names it knows
+    # are accepted with the state_dict of 'none', an unknown one fails like the reference's dictionary lookup
+    for name in ("batchMax", "instanceMinMax"):
+        gs = UNet(*(args[:12] + (name,) + args[13:]))
+        assert list(gs.state_dict().keys()) == list(UNet(*args).state_dict().keys())
+    with pytest.raises(KeyError):
+        UNet(*(args[:12] + ("minmax",) + args[13:]))
     # a reference-format checkpoint loads with strict=True (also through a DataParallel 'module.' prefix)
     g = UNet(*args)
     from oracle.state import generator_state

@@ -94,8 +94,12 @@ class _GeneratorBase(nn.Module):
             unsupported.append("unet_norm=%s (HIP path covers 'none', 'instance_norm' and, for inference, 'batch_norm')" % unet_norm)
         if last_layer not in _LAST:
             unsupported.append("last_layer=%s" % last_layer)
-        if stretch_g not in ("none", None):
-            unsupported.append("stretch_g=%s" % stretch_g)
+        # stretch_g: the reference builds Blocks.BatchMaxNormalization / MinMaxNormalization into `self.stretch` (parameter-free,
+        # Unet_singleFrame.py:169-175, Unet.py:203-209) and its forward never calls it: every accepted value computes what 'none'
+        # computes, with the same state_dict.  An unknown name fails where the reference's dictionary lookup does.
+        if stretch_g not in ("none", None, "batchMax", "instanceMinMax"):
+            raise KeyError(stretch_g)
+        self.stretch_g = "none" if stretch_g is None else stretch_g
         if unsupported:
             raise NotImplementedError("generator configuration outside the published topology: " + "; ".join(unsupported))
         self.to_crop = to_crop
