@@ -572,6 +572,13 @@ int uncl_weighted_sum_backward(const float* g, const float* weights, int n, floa
 /* w * mean_n |a_n - b_n| over strided per-sample scalars (nn.L1Loss on per-frame means, GanTrainerImg.py:308-313) */
 int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b_stride, int N, float w, float* loss, float* g_a,
                   float* g_b, int accumulate_loss, void* stream);
+/* The two L1 terms of pseudo_label_loss (GanTrainerImg.py:360-367) in one launch.  stats: (N,2) fp32, row i = {mean, mean Gaussian
+ * local variance} of patch i (uncl_gauss_stats with C = 1); row: DEVICE int, the pseudo label's patch (the arg-max
+ * uncl_tmqi_naturalness wrote).  loss2[j] = mean_i |stats[i][j] - stats[row][j]|; grad (N,2) = d loss2[j] / d stats[i][j], the label
+ * row receiving minus the sum of the others' signs / N (nn.L1Loss against the expanded row).  The backward scales the columns by
+ * the two upstream device scalars into out (2,N): [0] per-patch gradients of the means, [1] of the local variances. */
+int uncl_l1_to_row(const float* stats, int N, const int* row, float* loss2, float* grad, void* stream);
+int uncl_l1_to_row_backward(const float* grad, int N, const float* g_mean_term, const float* g_var_term, float* out, void* stream);
 /* TMQI statistical naturalness in fp64 (TMQI.py:210-242) of every h x w patch of fp32 frames scaled by `scale` (255);
  * best_worst (optional int32[2]): first arg-max / arg-min (GanTrainerImg.py:357-359, 398-402) */
 int uncl_tmqi_naturalness(const float* x, int F, int frame_h, int frame_w, int h, int w, float scale, double* scores,

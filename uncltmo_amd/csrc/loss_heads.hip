@@ -288,6 +288,40 @@ __global__ void l1_pairs_kernel(const float* a, int a_stride, const float* b, in
   if (threadIdx.x == 0) loss[0] = (accumulate_loss ? loss[0] : 0.f) + (float)(sl * (double)w / (double)N);
 }
 
+// The two L1 terms of pseudo_label_loss (GanTrainerImg.py:360-367) in one launch: per-patch statistics s[i] = {mean, mean local
+// variance}, the pseudo label is row r = row[0] (chosen on the device), L_j = mean_i |s[i][j] - s[r][j]|.  grad[i][j] = dL_j / ds[i][j]:
+// sign / N for the patches, minus the sum of the signs / N for the label row itself (what autograd's expand + index_select backward
+// add up to; its own |0| term contributes nothing).
+__global__ void l1_to_row_kernel(const float* __restrict__ s, int N, const int* __restrict__ row, float* __restrict__ loss,
+                                 float* __restrict__ grad) {
+  __shared__ double sl[2];
+  __shared__ int ssum[2];
+  if (threadIdx.x < 2) { sl[threadIdx.x] = 0.0; ssum[threadIdx.x] = 0; }
+  __syncthreads();
+  const int r = min(max(row[0], 0), N - 1);
+  for (int i = threadIdx.x; i < N; i += blockDim.x)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float d = s[2 * i + j] - s[2 * r + j];
+      const int sg = d > 0.f ? 1 : (d < 0.f ? -1 : 0);
+      atomicAdd(&sl[j], (double)fabsf(d));
+      atomicAdd(&ssum[j], sg);
+      grad[2 * i + j] = (float)sg / (float)N;
+    }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    loss[threadIdx.x] = (float)(sl[threadIdx.x] / (double)N);
+    grad[2 * r + threadIdx.x] = -(float)ssum[threadIdx.x] / (float)N;
+  }
+}
+// out[0][i] = grad[i][0] * g0, out[1][i] = grad[i][1] * g1: the per-patch gradients of the two statistics, ready for
+// uncl_add_per_sample_const / uncl_gauss_var_backward
+__global__ void l1_to_row_bwd_kernel(const float* __restrict__ grad, int N, const float* __restrict__ g0, const float* __restrict__ g1,
+                                     float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { out[i] = grad[2 * i] * g0[0]; out[N + i] = grad[2 * i + 1] * g1[0]; }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // TMQI statistical naturalness, fp64 (TMQI.py:210-242): u = mean(L), sig = mean over 11x11 blocks (zero padded to the
 // next multiple of 11, always at least one extra) of the population std; N = beta_pdf(sig/64.29)/C0 * gauss(u)
@@ -757,6 +791,22 @@ extern "C" int uncl_l1_pairs(const float* a, int a_stride, const float* b, int b
   if (!a || !b || !loss || N <= 0) return UNCL_ERR_ARG;
   hipLaunchKernelGGL(l1_pairs_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, a_stride, b, b_stride, N,
                      w, loss, g_a, g_b, accumulate_loss);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_l1_to_row(const float* stats, int N, const int* row, float* loss2, float* grad, void* stream) {
+  if (!stats || !row || !loss2 || !grad || N <= 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(l1_to_row_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), stats, N, row, loss2, grad);
+  UNCL_CHECK_LAUNCH();
+  return UNCL_OK;
+}
+
+extern "C" int uncl_l1_to_row_backward(const float* grad, int N, const float* g_mean_term, const float* g_var_term, float* out,
+                                       void* stream) {
+  if (!grad || !g_mean_term || !g_var_term || !out || N <= 0) return UNCL_ERR_ARG;
+  hipLaunchKernelGGL(l1_to_row_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), grad, N,
+                     g_mean_term, g_var_term, out);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }

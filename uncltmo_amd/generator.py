@@ -270,6 +270,9 @@ class _GeneratorBase(nn.Module):
                     wd_off.append(offs[0])
                 else:                                # Conv2d (Cout,Cin,k,k): read as a ConvTranspose2d weight, flipped for 3x3
                     wd_off.append(job(src, src.numel(), shape[1], shape[0], k, 1, 1 if k == 3 else 0))
+        # the learned position table (1,256,12,12) as node-major (144,256) rows in the compute dtype: one more item of the batched
+        # re-layout (a 1x1 "transposed" weight is exactly a 2-D transpose) instead of a transpose copy and a dtype copy per step
+        pe_off = job(sd["gcn.pos_embed"].detach().reshape(256, 144), 256 * 144, 144, 256, 1, 1, 0)
         flat = torch.empty(total, dtype=tdt, device=dev)
         keep.append(flat)
         esz = flat.element_size()
@@ -283,9 +286,7 @@ class _GeneratorBase(nn.Module):
         wd = [flat[o:] for o in wd_off]            # views: .data_ptr() is the packed data-gradient weight
         self._wd = wd
         self._ssr_fused = ssr_fused                # decoder stages whose skip-concat data-gradient weights are interleaved
-        pe = sd["gcn.pos_embed"].detach().reshape(256, 144).t().contiguous().to(tdt)    # (144,256) NHWC
-        keep.append(pe)
-        gw.pos_embed = pe.data_ptr()
+        gw.pos_embed = flat.data_ptr() + pe_off * esz                                    # (144,256) NHWC
         gw.relative_pos = f32("gcn.module.0.0.relative_pos")
         gw.outc_w, gw.outc_b = f32("outc.conv.weight"), f32("outc.conv.bias")
         gw.act = _ACT[self.activation]

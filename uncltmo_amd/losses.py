@@ -18,11 +18,11 @@ def _scalar(dev):
 
 class _CganFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, real, fake):
+    def forward(ctx, real, fake, weight=1.0):
         n = real.numel()
         r, f = real.detach().reshape(n).float().contiguous(), fake.detach().reshape(n).float().contiguous()
         loss, grf = _scalar(r.device), torch.empty(2, n, dtype=torch.float32, device=r.device)    # both gradients in ONE tensor:
-        _hip.check(_hip.lib().uncl_cgan_loss(r.data_ptr(), f.data_ptr(), n, 1.0, loss.data_ptr(), grf[0].data_ptr(),
+        _hip.check(_hip.lib().uncl_cgan_loss(r.data_ptr(), f.data_ptr(), n, float(weight), loss.data_ptr(), grf[0].data_ptr(),
                                              grf[1].data_ptr(), 0, _hip.stream_ptr()), "uncl_cgan_loss")   # one multiply in backward
         ctx.save_for_backward(grf)
         ctx.shapes = (real.shape, fake.shape)
@@ -32,11 +32,13 @@ class _CganFn(torch.autograd.Function):
     def backward(ctx, g):
         (grf,) = ctx.saved_tensors
         t = grf * g
-        return t[0].reshape(ctx.shapes[0]), t[1].reshape(ctx.shapes[1])
+        return t[0].reshape(ctx.shapes[0]), t[1].reshape(ctx.shapes[1]), None
 
 
-def contrastive_D_loss(real_logits, fake_logits):
-    return _CganFn.apply(real_logits, fake_logits)
+def contrastive_D_loss(real_logits, fake_logits, weight=1.0):
+    """GanTrainerImg.py:219-229; `weight` (python float): the caller's loss weight applied inside the kernel -- loss and gradients
+    come out scaled, with no scalar-multiply launch (and autograd node) around the head"""
+    return _CganFn.apply(real_logits, fake_logits, float(weight))
 
 
 def _dense(t):
@@ -274,6 +276,48 @@ class _FrameStatsFn(torch.autograd.Function):
         _hip.check(lib.uncl_gauss_var_backward(xf.data_ptr(), g_var.float().contiguous().data_ptr(), gx.data_ptr(), n, h, w, 1,
                                                _hip.stream_ptr()), "uncl_gauss_var_backward")
         return gx.reshape(n, 1, h, w)
+
+
+class _PseudoTermsFn(torch.autograd.Function):
+    """(4N,1,128,128) patches + the device index of the pseudo label -> the two L1 terms of pseudo_label_loss (GanTrainerImg.py:
+    360-367): |patch mean - label's mean| and |patch contrast - label's contrast| averaged over the patches.  One statistics pass and
+    one launch for both terms forward; backward: one launch that applies the two upstream scalars, then the two statistics
+    backward kernels (before: index_select / expand / L1 as autograd nodes -- seven launches forward, twelve backward)."""
+
+    @staticmethod
+    def forward(ctx, patches, row):
+        n, _, h, w = patches.shape
+        xf = patches.detach().reshape(n, h, w).float().contiguous()
+        st = gauss_stats(xf, n, h, w, 1)                       # (n, 2, 1)
+        loss2 = torch.empty(2, dtype=torch.float32, device=xf.device)
+        grad = torch.empty(n, 2, dtype=torch.float32, device=xf.device)
+        _hip.check(_hip.lib().uncl_l1_to_row(st.data_ptr(), n, row.data_ptr(), loss2.data_ptr(), grad.data_ptr(), _hip.stream_ptr()),
+                   "uncl_l1_to_row")
+        ctx.save_for_backward(xf, grad)
+        return loss2[0], loss2[1]
+
+    @staticmethod
+    def backward(ctx, g_mean_term, g_var_term):
+        xf, grad = ctx.saved_tensors
+        n, h, w = xf.shape
+        lib = _hip.lib()
+        gs = torch.empty(2, n, dtype=torch.float32, device=xf.device)
+        _hip.check(lib.uncl_l1_to_row_backward(grad.data_ptr(), n, g_mean_term.detach().float().contiguous().data_ptr(),
+                                               g_var_term.detach().float().contiguous().data_ptr(), gs.data_ptr(), _hip.stream_ptr()),
+                   "uncl_l1_to_row_backward")
+        gx = torch.empty_like(xf)
+        _hip.check(lib.uncl_add_per_sample_const(gx.data_ptr(), gs[0].data_ptr(), h * w, n, 1.0 / (h * w), 0, _hip.stream_ptr()),
+                   "uncl_add_per_sample_const")
+        _hip.check(lib.uncl_gauss_var_backward(xf.data_ptr(), gs[1].data_ptr(), gx.data_ptr(), n, h, w, 1, _hip.stream_ptr()),
+                   "uncl_gauss_var_backward")
+        return gx.reshape(n, 1, h, w), None
+
+
+def pseudo_label_pair(patches, best_worst):
+    """the (mean term, contrast term) of pseudo_label_loss for `patches` with the label row best_worst[0] (device int32)"""
+    if best_worst.dtype != torch.int32 or not best_worst.is_cuda:
+        raise TypeError("uncltmo_amd: the pseudo label's index must be a device int32 tensor (tmqi_naturalness's best_worst)")
+    return _PseudoTermsFn.apply(patches, best_worst.detach())
 
 
 def frame_stats(x):

@@ -119,8 +119,8 @@ class GanTrainer:
         self.optimizerD.step()
         self.D_losses.append(self.errD.detach())
 
-    def contrastive_D_loss(self, real_logits, fake_logits):
-        return L.contrastive_D_loss(real_logits, fake_logits)
+    def contrastive_D_loss(self, real_logits, fake_logits, weight=1.0):
+        return L.contrastive_D_loss(real_logits, fake_logits, weight)
 
     def _d_batched(self, tensors):
         """netD on several (N,1,256,256) batches in ONE call: the discriminator has no cross-sample operation (Discriminator.py:
@@ -147,7 +147,8 @@ class GanTrainer:
                 fake = crop_input_hdr_batch(fake, self.final_shape_addition, self.final_shape_addition)
         (d_real_pos, _), (d_fake, _) = self._d_batched([_flat(real_ldr_pos), fake.detach()])
         scale = 1.0 if epoch <= self.epoch_step1 else 1e-6
-        self.errD = float(self.adv_weight_list[0]) * scale * self.contrastive_D_loss(d_real_pos, d_fake)
+        # (GanTrainerImg.py:217: adv_weight * [1 | 1e-6] * loss -- the weight goes into the loss kernel)
+        self.errD = self.contrastive_D_loss(d_real_pos, d_fake, weight=float(self.adv_weight_list[0]) * scale)
         self.errD.backward()
 
     # ---------------------------------------------------------------- G step (GanTrainerImg.py:262-339, 452-461)
@@ -216,10 +217,8 @@ class GanTrainer:
         n = fake.shape[0]
         scores, bw = L.tmqi_naturalness(fake, patch=128)
         patches = fake.reshape(n, 1, 2, 128, 2, 128).permute(0, 2, 4, 1, 3, 5).reshape(4 * n, 1, 128, 128)
-        m, v = L.frame_stats(patches)
-        best = bw[0:1].long()                 # a 1-element index tensor: m[0-dim tensor] would read the index back to the host
-        return [(1.0, L.l1_mean(m, m.index_select(0, best).expand_as(m))),
-                (1.0, L.l1_mean(v, v.index_select(0, best).expand_as(v)))]
+        lm, lv = L.pseudo_label_pair(patches, bw)      # both L1 terms against the label row bw[0], index never leaves the device
+        return [(1.0, lm), (1.0, lv)]
 
     def pseudo_label_loss(self, fake, hdr_input):
         return L.weighted_sum(self.pseudo_label_terms(fake, hdr_input))
@@ -252,6 +251,12 @@ class GanTrainer:
 
     def update_struct_loss(self, hdr_input, hdr_input_original_gray_norm, fake):
         if self.struct_loss_factor:
-            self.errG_struct = self.struct_loss_factor * self.struct_loss(fake, hdr_input_original_gray_norm, hdr_input,
-                                                                          self.pyramid_weight_list)
+            # GanTrainerImg.py:458-459: factor * struct_loss(...).  The pyramid weights are python floats on their way into the loss
+            # kernel (sum_l w_l loss_l): the factor rides on them instead of being a scalar-multiply launch forward and backward
+            f = float(self.struct_loss_factor)
+            if isinstance(self.struct_loss, StructLoss):
+                self.errG_struct = self.struct_loss(fake, hdr_input_original_gray_norm, hdr_input,
+                                                    [f * float(w) for w in self.pyramid_weight_list])
+            else:
+                self.errG_struct = f * self.struct_loss(fake, hdr_input_original_gray_norm, hdr_input, self.pyramid_weight_list)
             self.G_loss_struct.append(self.errG_struct.detach())
