@@ -125,7 +125,10 @@ def skip_concat(x2, x1, con_operator="square_and_square_root"):
 def up_block(sd, p, x1, x2, con_operator, activation="relu", unet_norm="none", training=False):
     """ConvT 2x2 stride 2, replicate-pad x1 up to x2's size (right/bottom get the odd pixel), concat,
     double transposed conv.  unet_parts.py:283-335 (pad :292-298)."""
-    x1 = F.conv_transpose2d(x1, sd[p + ".up.weight"], sd[p + ".up.bias"], stride=2)
+    if p + ".up.1.weight" in sd:       # bilinear=1 (unet_parts.py:256-259): nn.Upsample(scale_factor=2) [nearest] + 1x1 convolution
+        x1 = F.conv2d(F.interpolate(x1, scale_factor=2), sd[p + ".up.1.weight"], sd[p + ".up.1.bias"])
+    else:
+        x1 = F.conv_transpose2d(x1, sd[p + ".up.weight"], sd[p + ".up.bias"], stride=2)
     dy = x2.shape[2] - x1.shape[2]
     dx = x2.shape[3] - x1.shape[3]
     if dx or dy:

@@ -375,6 +375,41 @@ def capture_generator_inorm(out):
         out["inorm.gradval." + k] = g[torch.from_numpy(pos_)].numpy()
 
 
+from generator_variants import GENERATOR_VARIANTS  # noqa: E402
+
+
+def capture_generator_variants(out):
+    """The reference generator built with the skip operators that are sub-sets of the published one (unet_parts.py:311-332) and /
+    or the bilinear decoder path (nn.Upsample + 1x1 convolution, unet_parts.py:256-259): state_dict keys and shapes, eval forward
+    on two frames, and the parameter gradients of a smooth loss (norm + 64 hashed elements per tensor)."""
+    from utils import model_save_util
+    for tag, op, bil in GENERATOR_VARIANTS:
+        G = model_save_util.create_G_net2("unet", DEV, False, 1, "sigmoid", 32, op, 4, 0, "none", "none", "relu", True, 1, 1, bil,
+                                          "replicate", 2, 0)
+        synth.fill_state_dict(G, "g0")
+        sdk = G.state_dict()
+        out[tag + ".keys"] = np.array(list(sdk.keys()))
+        out[tag + ".shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sdk.values()])
+        G.eval()
+        x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+        y, up = G(x)
+        out.update(summarize(y.detach(), tag + ".x_out", 2048))
+        out.update(summarize(up.detach(), tag + ".up_x"))
+        wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
+        G.zero_grad()
+        ((y * wy).sum() + 1e-3 * up.sum()).backward()
+        for k, v in G.named_parameters():
+            if v.grad is None:
+                continue
+            g = v.grad.double().reshape(-1)
+            n = g.numel()
+            pos_ = (synth.hash_uniform("gpos:" + k, min(64, n)) * n).astype(np.int64) % n
+            out[tag + ".grad." + k] = np.float64(g.norm().item())
+            out[tag + ".gradpos." + k] = pos_
+            out[tag + ".gradval." + k] = g[torch.from_numpy(pos_)].numpy()
+        print("captured generator variant", tag, len(sdk), float(y.sum()), flush=True)
+
+
 def capture_generator_bnorm(out):
     """The reference generator built with unet_norm='batch_norm' (unet_parts.py:20-21, 34-35: nn.BatchNorm2d between every 3x3
     convolution and its activation): state_dict keys / shapes, the eval forward (running statistics) on two frames, and -- for the
@@ -626,7 +661,7 @@ def capture_tester(out):
 
 def main():
     which = sys.argv[1:] or ["generator", "generator_inorm", "generator_bnorm", "video", "disc", "losses", "img_step", "vid_step", "vid_c4", "tiler",
-                             "inference", "tmqi", "loader", "patchd_grad", "tester", "nce_lists", "tmqi_maps"]
+                             "inference", "tmqi", "loader", "patchd_grad", "tester", "nce_lists", "tmqi_maps", "generator_variants"]
     jobs = {"generator": lambda o: capture_generator(o), "video": lambda o: capture_video(o),
             "disc": lambda o: capture_discriminator(o), "losses": lambda o: capture_losses(o),
             "img_step": lambda o: capture_step(o, False, [0, 7, 10]),
@@ -635,7 +670,8 @@ def main():
             "loader": lambda o: capture_loader(o),
             "tiler": lambda o: capture_tiler(o), "patchd_grad": lambda o: capture_patchd_grad(o),
             "inference": lambda o: capture_inference(o), "tmqi": lambda o: capture_tmqi(o), "tester": lambda o: capture_tester(o),
-            "nce_lists": lambda o: capture_nce_lists(o), "tmqi_maps": lambda o: capture_tmqi_maps(o)}
+            "nce_lists": lambda o: capture_nce_lists(o), "tmqi_maps": lambda o: capture_tmqi_maps(o),
+            "generator_variants": lambda o: capture_generator_variants(o)}
     for name in which:
         out = {}
         jobs[name](out)

@@ -1,0 +1,102 @@
+"""Generator configurations outside the published one that run on the published kernels: skip operators that are sub-sets of
+[x2, x1, x2^2, sqrt(x2 + eps)] (unet_parts.py:311-332: original_unet, square, square_root -- zero weights for the members they leave
+out) and the bilinear decoder path (nn.Upsample + 1x1 convolution, unet_parts.py:256-259 = a 2x2 stride-2 transposed convolution
+with one weight on all four taps).  Against the reference's own outputs and parameter gradients (tests/golden/generator_variants.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_summary
+from generator_variants import GENERATOR_VARIANTS
+from uncltmo_amd import params, state_spec, synth
+from uncltmo_amd.generator import UNet
+
+pytestmark = pytest.mark.gpu
+
+
+def make(op, bil, dtype):
+    net = UNet(1, 1, "sigmoid", 4, params.get_layer_factor(op), op, 32, bil, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0,
+               compute_dtype=dtype)
+    synth.fill_state_dict(net, "g0")
+    return net.cuda()
+
+
+def inputs():
+    return torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("tag,op,bil", GENERATOR_VARIANTS)
+def test_forward_matches_reference_golden(golden, tag, op, bil):
+    g = golden("generator_variants")
+    net = make(op, bil, "fp32").eval()
+    assert [(k, ",".join(str(d) for d in v.shape)) for k, v in net.state_dict().items()] == list(zip(g[tag + ".keys"], g[tag + ".shapes"]))
+    with torch.no_grad():
+        y, up = net(inputs().cuda())
+        check_summary(y.cpu(), g, tag + ".x_out", rtol=3e-4, atol=2e-6)
+        check_summary(up.float().cpu(), g, tag + ".up_x", rtol=3e-4, atol=2e-5)
+        # the 16-bit inference paths (fused decoder loaders included) against the fp32 run
+        for dtype, tol in (("bf16", 3e-2), ("fp16", 7e-3)):
+            y16, _ = make(op, bil, dtype).eval()(inputs().cuda())
+            assert rel(y16.float().cpu(), y.cpu()) < tol, (dtype, rel(y16.float().cpu(), y.cpu()))
+
+
+@pytest.mark.parametrize("tag,op,bil", GENERATOR_VARIANTS)
+def test_fp32_gradients_match_reference_golden(golden, tag, op, bil):
+    """fp32 parity mode: every parameter's gradient against the reference's norm and 64 sampled elements.  The gates are those of
+    tests/test_gpu_backward.py's conditioning note: decoder / graph tensors 2e-3, encoder tensors (behind sqrt(x2 + 1e-8) where the
+    operator has it) 3e-2"""
+    g = golden("generator_variants")
+    net = make(op, bil, "fp32").train()
+    net.drop_path_prob = 0.0
+    wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
+    y, up = net(inputs().cuda())
+    ((y * wy.cuda()).sum() + 1e-3 * up.sum()).backward()
+    bad = {}
+    for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(p.shape), k
+        gr = p.grad.double().reshape(-1).cpu()
+        ref_n = float(g["%s.grad.%s" % (tag, k)])
+        idx = torch.from_numpy(g["%s.gradpos.%s" % (tag, k)])
+        rms = ref_n / max(gr.numel(), 1) ** 0.5
+        e_samp = (gr[idx] - torch.from_numpy(g["%s.gradval.%s" % (tag, k)])).norm().item() / (len(idx) ** 0.5 * rms + 1e-30)
+        gate = 2e-3 if (k.startswith("up_path") or k.startswith("outc") or k.startswith("gcn")) else 3e-2
+        if abs(gr.norm().item() - ref_n) > gate * ref_n or e_samp > 3 * gate:
+            bad[k] = (gr.norm().item(), ref_n, e_samp)
+    assert not bad, bad
+
+
+def test_bf16_training_step_of_a_variant_runs_and_descends():
+    """bf16 fast path, square operator with the bilinear decoder: gradients land on the variant's own parameter shapes and an
+    SGD step along them lowers the loss"""
+    net = make("square", 1, "bf16").train()
+    net.drop_path_prob = 0.0
+    x = inputs().cuda()
+    wy = (0.5 + synth.smooth_hdr_frames(2, salt="bwy")).cuda()
+
+    def loss():
+        y, up = net(x)
+        return (y * wy).sum() + 1e-3 * up.float().sum()
+
+    l0 = loss()
+    l0.backward()
+    with torch.no_grad():
+        for p in net.parameters():
+            if not p.requires_grad:
+                continue
+            assert p.grad is not None and p.grad.shape == p.shape
+            p.add_(p.grad, alpha=-1e-7)
+    assert loss().item() < l0.item()
+
+
+def test_unsupported_variants_are_still_refused():
+    with pytest.raises(NotImplementedError):
+        UNet(1, 1, "sigmoid", 4, 3, "gamma", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
+    with pytest.raises(NotImplementedError):      # layer_factor must be the operator's member count (the reference would fail at the concat)
+        UNet(1, 1, "sigmoid", 4, 4, "square", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)

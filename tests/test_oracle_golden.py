@@ -164,6 +164,31 @@ def test_tiler(golden, sdG):
     assert OT.tile_count(1024, 1024) == 25 and OT.tile_count(2160, 3840) == 220
 
 
+def test_generator_variants_state_dict_and_oracle_forward_backward(golden):
+    """skip operators original_unet / square / square_root (unet_parts.py:311-332) and the bilinear decoder path (:256-259):
+    state_spec's keys and shapes are the reference's state_dict, the oracle's forward and parameter gradients are the reference's"""
+    from generator_variants import GENERATOR_VARIANTS
+    from uncltmo_amd import params
+    g = golden("generator_variants")
+    x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
+    wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
+    for tag, op, bil in GENERATOR_VARIANTS:
+        spec = state_spec.generator_spec(32, params.get_layer_factor(op), "none", bil)
+        assert [k for k, _, _ in spec] == list(g[tag + ".keys"])
+        assert [",".join(str(d) for d in s_) for _, s_, _ in spec] == list(g[tag + ".shapes"])
+        sd = {k: v.clone().requires_grad_(not k.endswith("relative_pos")) for k, v in synth_state(spec, "g0").items()}
+        y, up = OG.unet_image_forward(sd, x, con_operator=op)
+        check_summary(y, g, tag + ".x_out", rtol=2e-4, atol=1e-6)
+        check_summary(up, g, tag + ".up_x", rtol=2e-4, atol=1e-5)
+        ((y * wy).sum() + 1e-3 * up.sum()).backward()
+        for k, v in sd.items():
+            if v.grad is None:
+                continue
+            gr = v.grad.double().reshape(-1)
+            ref_n = float(g["%s.grad.%s" % (tag, k)])
+            assert abs(gr.norm().item() - ref_n) <= 2e-3 * ref_n + 1e-9, (tag, k, gr.norm().item(), ref_n)
+
+
 def test_nce_with_longer_lists_matches_reference_golden(golden):
     """nce() with several positives / negatives and lmcl_loss (GanTrainerImg.py:410-450): oracle/losses.py:nce_lists against the
     reference's own method (tests/golden/make_golden.py nce_lists)"""

@@ -129,7 +129,7 @@ class _GradSet:
             g[nm + ".bias"] = self.gb[i]
         for q, gw_, gb_ in zip(self.bn_names, self.g_bn_w, self.g_bn_b):
             g[q + ".weight"], g[q + ".bias"] = gw_, gb_
-        return g
+        return self.module._variant_grads(g)
 
     def finish(self, last_run):
         """Unpack everything after the last uncl_gen_backward call of a pass (`last_run(ev)` makes that call).  With a
@@ -141,6 +141,11 @@ class _GradSet:
             last_run(None)
             self.unpack()
             return self.grads()
+        if self.module._is_variant():
+            # the variants' gradients are sums / concatenations of the published-layout buffers (generator._variant_grads): copies
+            # made before the collectives have finished would hold this rank's values only
+            raise NotImplementedError("uncltmo_amd: data-parallel training covers the published generator configuration; "
+                                      "con_operator / bilinear variants train on one GPU")
         self.reduced = True     # the buffers now belong to the reducer: the caller hands autograd NO parameter gradients
         if red.in_stream or torch.cuda.is_current_stream_capturing():
             # everything on the caller's stream: the pass, the re-layout, then the collectives in order (a captured step: one

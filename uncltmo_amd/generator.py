@@ -82,12 +82,20 @@ class _GeneratorBase(nn.Module):
             assert 0, "Unsupported network request: {}".format(network)
         if activation not in _ACT:
             assert 0, "Unsupported activation: {%s}" % (activation)
-        if con_operator not in (params.square_and_square_root,):
+        # skip operators that are SUB-SETS of the published four-member concatenation [x2, x1, x2^2, sqrt(x2 + eps)] run on its
+        # kernels with zero weights for the members they leave out (unet_parts.py:311-332; exact: the left-out products are 0);
+        # 'gamma' (a 0.02 power) and the manual-d form have members of their own and stay refused
+        if con_operator not in (params.square_and_square_root, params.original_unet, params.square, params.square_root):
             unsupported.append("con_operator=%s" % con_operator)
-        if depth != 4 or filters != 32 or layer_factor != 4:
-            unsupported.append("depth/filters/layer_factor=%s/%s/%s" % (depth, filters, layer_factor))
-        if not doubleConvTranspose or up_mode or bilinear or convtranspose_kernel != 2:
-            unsupported.append("decoder must be doubleConvTranspose=1, up_mode=0, bilinear=0, convtranspose_kernel=2")
+        elif layer_factor != params.get_layer_factor(con_operator):
+            unsupported.append("layer_factor=%s does not match con_operator=%s (the reference's first decoder convolution would "
+                               "refuse the concatenation)" % (layer_factor, con_operator))
+        if depth != 4 or filters != 32:
+            unsupported.append("depth/filters=%s/%s" % (depth, filters))
+        # bilinear=1: nn.Upsample(scale_factor=2) [nearest] + Conv2d 1x1 (unet_parts.py:256-259) IS a stride-2 2x2 transposed
+        # convolution whose four taps all hold the 1x1 weight: same kernels, the weight is replicated when it is packed
+        if not doubleConvTranspose or up_mode or convtranspose_kernel != 2:
+            unsupported.append("decoder must be doubleConvTranspose=1, up_mode=0, convtranspose_kernel=2")
         if n_channels != 1 or output_dim != 1:
             unsupported.append("n_channels/output_dim must be 1")
         if unet_norm not in ("none", None, "instance_norm", "batch_norm"):
@@ -105,6 +113,9 @@ class _GeneratorBase(nn.Module):
         self.to_crop = to_crop
         self.unet_norm = unet_norm if unet_norm not in (None,) else "none"
         self.con_operator = con_operator
+        self.layer_factor = int(layer_factor)
+        self.bilinear = int(bool(bilinear))
+        self.filters = filters
         self.network = network
         self.depth = depth
         self.activation = activation
@@ -114,7 +125,7 @@ class _GeneratorBase(nn.Module):
         self.chunk = chunk
         self.drop_path_prob = 0.05          # dpr = linspace(0.05, 0.1, 1)[0] (Unet_singleFrame.py:62)
         self.forced_drop_keep = None        # optional (2, N) 0/1 keep flags for deterministic train-mode runs
-        for key, shape, kind in generator_spec(filters, layer_factor, self.unet_norm):
+        for key, shape, kind in self._own_spec():
             if kind == "buffer":
                 _attach(self, key, sincos_relative_pos(), False)
             elif kind == "embed":
@@ -141,11 +152,65 @@ class _GeneratorBase(nn.Module):
         return super().zero_grad(set_to_none=set_to_none)
 
     # --- initialisation: what `create_G_net*` + `set_parallel_net(use_xaviar=True)` leave behind
+    def _own_spec(self):
+        """state_dict layout of THIS configuration (skip operator's member count, bilinear up path)"""
+        return generator_spec(self.filters, self.layer_factor, self.unet_norm, self.bilinear)
+
+    def _is_variant(self):
+        return self.layer_factor != 4 or self.bilinear != 0
+
+    def _published_state(self, sd):
+        """name -> tensor in the PUBLISHED layout the kernels are packed from: the skip-concat convolutions padded to four members
+        with zero weights where this configuration's operator has none, the 1x1 weight of a bilinear `up` replicated over the four
+        taps of the 2x2 transposed convolution it equals.  Identity for the published configuration."""
+        if not self._is_variant():
+            return sd
+        out = dict(sd)
+        for i in range(4):
+            p = "up_path.%d" % i
+            if self.layer_factor != 4:
+                w = sd[p + ".conv.conv.weight"].detach().float()            # (m C, Cout, 3, 3), members [x2, x1, (x2^2 | sqrt)]
+                c = w.shape[0] // self.layer_factor
+                zero = torch.zeros_like(w[:c])
+                third = w[2 * c:3 * c] if self.layer_factor == 3 else zero
+                sq, rt = (third, zero) if self.con_operator == params.square else (zero, third)
+                out[p + ".conv.conv.weight"] = torch.cat([w[:2 * c], sq, rt], 0)
+            if self.bilinear:
+                v = sd[p + ".up.1.weight"].detach().float()                 # Conv2d (Cout, Cin, 1, 1)
+                co, ci = v.shape[0], v.shape[1]
+                out[p + ".up.weight"] = v.reshape(co, ci).t().reshape(ci, co, 1, 1).expand(ci, co, 2, 2).contiguous()
+                out[p + ".up.bias"] = sd[p + ".up.1.bias"]
+        return out
+
+    def _variant_grads(self, g):
+        """published-layout gradients (autograd._GradSet.grads) -> this configuration's parameters: the members the operator has,
+        the sum over the four taps for a bilinear `up`"""
+        if not self._is_variant():
+            return g
+        g = dict(g)
+        for i in range(4):
+            p = "up_path.%d" % i
+            if self.layer_factor != 4:
+                w = g[p + ".conv.conv.weight"]
+                c = w.shape[0] // 4
+                if self.layer_factor == 2:
+                    g[p + ".conv.conv.weight"] = w[:2 * c]
+                elif self.con_operator == params.square:
+                    g[p + ".conv.conv.weight"] = w[:3 * c]
+                else:
+                    g[p + ".conv.conv.weight"] = torch.cat([w[:2 * c], w[3 * c:]], 0)
+            if self.bilinear:
+                w = g.pop(p + ".up.weight")                                 # (Cin, Cout, 2, 2)
+                g[p + ".up.1.weight"] = w.sum(dim=(2, 3)).t().reshape(w.shape[1], w.shape[0], 1, 1)
+                g[p + ".up.1.bias"] = g.pop(p + ".up.bias")
+        return g
+
     def reset_parameters(self):
         """Conv2d: xavier_normal(gain sqrt 2), zero bias (model_save_util.py:41-47); the class-name test there does
         not match ConvTranspose2d, which keeps PyTorch's default init; the graph block re-inits its convs with
         kaiming_normal / zero bias first (Unet_singleFrame.py:83-90) and xavier then overrides them."""
-        for key, shape, kind in generator_spec():
+        own = self._own_spec()
+        for key, shape, kind in own:
             t = dict(self.named_parameters()).get(key)
             if t is None:
                 continue
@@ -160,8 +225,8 @@ class _GeneratorBase(nn.Module):
                     t.uniform_(-bound, bound)
                 elif kind == "bias":
                     wkey = key[:-4] + "weight"
-                    wshape = dict((k, s) for k, s, _ in generator_spec())[wkey]
-                    wkind = dict((k, kd) for k, _, kd in generator_spec())[wkey]
+                    wshape = dict((k, s) for k, s, _ in own)[wkey]
+                    wkind = dict((k, kd) for k, _, kd in own)[wkey]
                     if wkind == "conv":
                         t.zero_()
                     else:
@@ -180,6 +245,7 @@ class _GeneratorBase(nn.Module):
             tuple((k, v.data_ptr(), v._version, getattr(v, "_uncl_epoch", 0)) for k, v in sd.items())
         if key == self._pack_key:
             return self._packed
+        sd = self._published_state(sd)
         lib = _hip.lib()
         dev = sd["outc.conv.weight"].device
         if dev.type != "cuda":
