@@ -100,3 +100,36 @@ def test_unsupported_variants_are_still_refused():
         UNet(1, 1, "sigmoid", 4, 3, "gamma", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
     with pytest.raises(NotImplementedError):      # layer_factor must be the operator's member count (the reference would fail at the concat)
         UNet(1, 1, "sigmoid", 4, 4, "square", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
+
+
+def test_video_generator_variant_forward_and_backward_through_time_vs_oracle():
+    """the recurrent generator (Unet.py:213-289) shares the decoder: `square` operator + bilinear path, fp32 mode, a two-frame clip
+    of batch 2 against the oracle's autograd (forward 1e-4; decoder / graph gradients 2e-3, encoder 3e-2 as above)"""
+    from oracle import generator as OG
+    from uncltmo_amd.generator import UNetVideo
+    op, bil = "square", 1
+    net = UNetVideo(1, 1, "sigmoid", 4, params.get_layer_factor(op), op, 32, bil, "unet", 0, 0, "none", "none", "relu", 1, "replicate",
+                    2, 0, compute_dtype="fp32")
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().train()
+    net.drop_path_prob = 0.0
+    x = torch.stack([torch.cat([synth.smooth_hdr_frames(1, salt="vv%d_%d" % (b, t)) for t in range(2)], 0) for b in range(2)], 0)
+    wy = 0.5 + synth.smooth_hdr_frames(4, salt="vvw").reshape(2, 2, 1, 256, 256)
+    y, f = net(x.cuda())
+    ((y * wy.cuda()).sum() + 1e-2 * f.sum()).backward()
+    sd = {k: v.detach().cpu().double().requires_grad_(v.requires_grad) for k, v in net.state_dict().items()}
+    for k, p in net.named_parameters():
+        sd[k].requires_grad_(p.requires_grad)
+    yo, fo = OG.unet_video_forward(sd, x.double(), con_operator=op)       # (DropPath off on both sides: nothing else differs in training mode)
+    assert rel(y.detach().cpu(), yo.detach()) < 1e-4 and rel(f.detach().cpu(), fo.detach()) < 1e-3
+    ((yo * wy.double()).sum() + 1e-2 * fo.sum()).backward()
+    bad = {}
+    for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        gate = 2e-3 if (k.startswith("up_path") or k.startswith("outc") or k.startswith("gcn")) else 3e-2
+        e = rel(p.grad.cpu(), sd[k].grad)
+        if e > gate:
+            bad[k] = e
+    assert not bad, bad
