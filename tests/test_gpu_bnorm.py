@@ -64,17 +64,70 @@ def test_eval_forward_vs_oracle_other_statistics():
             net.state_dict()["up_path.3.conv.norm.running_mean"].add_(0.05)
 
 
-def test_state_dict_loads_strict_and_video_training_is_refused():
-    from uncltmo_amd.generator import UNetVideo
+def test_state_dict_loads_strict():
     net = make("bf16")
     sd = synth.bnorm_state(synth_state(state_spec.generator_spec(unet_norm="batch_norm"), "g0"))
     net.load_state_dict(sd, strict=True)              # the reference's checkpoint layout (model_save_util.py:188-198)
     y, _ = net(inputs().cuda())
     assert torch.isfinite(y).all()
-    vid = UNetVideo(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "batch_norm", "none", "relu", 1,
-                    "replicate", 2, 0, compute_dtype="bf16").cuda().train()
-    with pytest.raises(NotImplementedError):
-        vid(torch.zeros(1, 2, 1, 256, 256, device="cuda"))
+
+
+def _video_oracle(x, wy, dt, sd0):
+    full = {}
+    for k, v in sd0.items():
+        if v.dtype != torch.float32:
+            full[k] = v.clone()
+        elif k.endswith("relative_pos") or "running_" in k:
+            full[k] = v.clone().to(dt)
+        else:
+            full[k] = v.clone().to(dt).requires_grad_(True)
+    B, T = x.shape[0], x.shape[1]
+    yo, fo = OG.unet_video_forward(full, x.to(dt), unet_norm="batch_norm", training=True, drop_keep=torch.ones(T, 2, B))
+    ((yo * wy.to(dt)).sum() + 1e-2 * fo.sum()).backward()
+    return yo.detach(), fo.detach(), full, {k: v.grad.double() for k, v in full.items() if getattr(v, "grad", None) is not None}
+
+
+def test_video_generator_trains_with_batch_statistics_fp32_vs_oracle():
+    """the recurrent generator with unet_norm='batch_norm' in training mode (Unet.py:213-289 around unet_parts.py:20-21, 72-73): batch
+    statistics per FRAME call, the running statistics advanced once per frame (two frames: two updates, num_batches_tracked 2), the
+    hand-off channels taken from the previous frame's normalised activations, and the backward pass through time through the
+    statistics -- against the oracle's autograd, gated like the image generator's test below (encoder tensors by the oracle's own
+    fp32-vs-fp64 distance)"""
+    from uncltmo_amd.generator import UNetVideo
+    sd0 = synth.bnorm_state(synth_state(state_spec.generator_spec(unet_norm="batch_norm"), "g0"))
+    net = UNetVideo(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "batch_norm", "none", "relu", 1,
+                    "replicate", 2, 0, compute_dtype="fp32")
+    net.load_state_dict(sd0, strict=True)
+    net = net.cuda().train()
+    net.forced_drop_keep = torch.ones(2, 3)
+    x = torch.stack([torch.cat([synth.smooth_hdr_frames(1, salt="vb%d_%d" % (b, t)) for t in range(2)], 0) for b in range(3)], 0)
+    wy = 0.5 + synth.smooth_hdr_frames(6, salt="vbw").reshape(3, 2, 1, 256, 256)
+    y, f = net(x.cuda())
+    assert y.requires_grad
+    ((y * wy.cuda()).sum() + 1e-2 * f.sum()).backward()
+    yo, fo, full32, ref32 = _video_oracle(x, wy, torch.float32, sd0)
+    _, _, _, ref64 = _video_oracle(x, wy, torch.float64, sd0)
+    assert rel(y.detach().cpu(), yo) < 1e-4 and rel(f.detach().cpu(), fo) < 1e-4
+    bufs = dict(net.named_buffers())
+    for k, v in full32.items():
+        if "running_" in k:
+            assert rel(bufs[k].cpu(), v) < 1e-4, k
+        elif k.endswith("num_batches_tracked"):
+            assert int(bufs[k]) == int(v) == 2, k
+    got = {k: p.grad.detach().double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    assert len(got) == 57 + 36
+    dead = {c + ".bias" for c, _ in state_spec.batch_norm_layers()}
+    bad = {}
+    for k, gk in got.items():
+        if k in dead:
+            assert gk.abs().max().item() < 1e-3 * ref64[k[:-4] + "weight"].abs().max().item(), k
+            continue
+        own = rel(ref32[k], ref64[k])
+        e64 = rel(gk, ref64[k])
+        gate = 1e-4 if (k.startswith("outc.") or k.startswith("up_path.3.")) else (3e-3 if k.startswith("up_path.2.") else max(3e-2, 5.0 * own))
+        if e64 > gate:
+            bad[k] = (e64, own, gate)
+    assert not bad, bad
 
 
 def _train_net(dtype):

@@ -1062,7 +1062,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   if (w->norm < 0 || w->norm > 2) return UNCL_ERR_ARG;
   // batch_norm (2) is a TRAINING mode of this entry (eval folds the running statistics into the weights on the host): the whole
   // batch in one chunk, activations kept, the layers' parameters announced with uncl_gen_set_bn
-  if (w->norm == 2 && (!r->keep_activations || chunk != r->N || !t_bn.set || r->prev_workspace != nullptr)) return UNCL_ERR_ARG;
+  if (w->norm == 2 && (!r->keep_activations || chunk != r->N || !t_bn.set)) return UNCL_ERR_ARG;
   Layout L = make_layout(n_alloc, w->dtype, w->norm && r->keep_activations);
   if (r->workspace_bytes < L.total) return UNCL_ERR_ARG;
   const size_t es = uncl_is_h16(w->dtype) ? 2 : 4;

@@ -430,8 +430,6 @@ class _GeneratorBase(nn.Module):
         if bn_train:
             # batch statistics (unet_parts.py:72-73 in training mode): the whole batch in one chunk with its normalised
             # pre-activations kept, also under no_grad -- the reference's module updates its running statistics there too
-            if prev_ws is not None:
-                raise NotImplementedError("uncltmo_amd: the video generator with unet_norm='batch_norm' trains on the reference only")
             keep_act, chunk = True, 0
             arrs, _bnkeep = self._bn_arrays()
             _hip.check(lib.uncl_gen_set_bn(arrs[0], arrs[1], arrs[2], arrs[3], 0.1, None, None), "uncl_gen_set_bn")
@@ -541,12 +539,10 @@ class UNetVideo(_GeneratorBase):
         if x.dim() != 5:
             raise ValueError("video generator expects (B,T,1,H,W)")
         self._check_input(x, 3)
-        if self._bn_train():
-            raise NotImplementedError("uncltmo_amd: the video generator with unet_norm='batch_norm' is built for inference; training "
-                                      "with batch statistics covers the image generator")
-        if self.unet_norm == "batch_norm":
+        bn_train = self._bn_train()        # batch statistics per frame call, like the reference's modules inside its frame loop
+        if self.unet_norm == "batch_norm" and not bn_train:
             self._warn_detached(x)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.unet_norm != "batch_norm":
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and (self.unet_norm != "batch_norm" or bn_train):
             from .autograd import generator_video_apply
             x_out, feats = generator_video_apply(self, x)
             if apply_crop and self.to_crop:
