@@ -122,6 +122,34 @@ def test_contrastive_d_loss_golden(golden):
     assert rel_l2(rg.grad.cpu(), rc.grad) < 1e-5 and rel_l2(fg.grad.cpu(), fc.grad) < 1e-5
 
 
+@pytest.mark.parametrize("n,row,ties", [(8, 3, False), (128, 0, False), (128, 127, True), (300, 17, True), (1, 0, False)])
+def test_pseudo_label_l1_pair_against_torch_autograd(n, row, ties):
+    """uncl_l1_to_row (the two L1 terms of pseudo_label_loss against the label row, GanTrainerImg.py:360-367) and its backward
+    against nn.L1Loss on the index_select / expand form the trainer used to build: losses, gradients of every row, the label row's
+    own (minus the sum of the others' signs), ties (sign 0), more rows than one workgroup has threads"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(11 + n)
+    st = torch.rand(n, 2, generator=g)
+    if ties:
+        st[n // 3] = st[row]
+        st[n - 1 - (row == n - 1), 0] = st[row, 0]
+    ref = st.clone().requires_grad_(True)
+    idx = torch.tensor([row])
+    l0 = torch.nn.L1Loss()(ref[:, 0], ref[:, 0].index_select(0, idx).expand(n))
+    l1 = torch.nn.L1Loss()(ref[:, 1], ref[:, 1].index_select(0, idx).expand(n))
+    (0.7 * l0 - 1.3 * l1).backward()
+    lib = _hip.lib()
+    sd, rd = st.cuda().contiguous(), torch.tensor([row, 0], dtype=torch.int32, device="cuda")
+    loss2 = torch.empty(2, device="cuda")
+    grad = torch.empty(n, 2, device="cuda")
+    _hip.check(lib.uncl_l1_to_row(sd.data_ptr(), n, rd.data_ptr(), loss2.data_ptr(), grad.data_ptr(), _hip.stream_ptr()), "l1_to_row")
+    np.testing.assert_allclose(loss2.cpu().numpy(), [l0.item(), l1.item()], rtol=1e-6, atol=1e-8)
+    out = torch.empty(2, n, device="cuda")
+    g0, g1 = torch.tensor([0.7], device="cuda"), torch.tensor([-1.3], device="cuda")
+    _hip.check(lib.uncl_l1_to_row_backward(grad.data_ptr(), n, g0.data_ptr(), g1.data_ptr(), out.data_ptr(), _hip.stream_ptr()), "l1_to_row_bwd")
+    np.testing.assert_allclose(out.t().cpu().numpy(), ref.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_nce_with_longer_lists_golden_and_trainer_dispatch(golden):
     """nce() with several positives / negatives (GanTrainerImg.py:410-439) and lmcl_loss (:441-450): losses.nce_lists against the
     reference's own outputs, through the trainer method that used to refuse them; bf16 features against the oracle"""
