@@ -417,13 +417,38 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const T* __restrict_
     for (int t = 0; t < 10; ++t) acc[c][t] = 0.f;
   const int v = threadIdx.x & 3;
   const size_t P = (size_t)N * Ho * Wo;
-  for (size_t p = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); p < P; p += (size_t)gridDim.x * 64) {
-    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((size_t)Wo * Ho));
-    float g[8];
+  // two waves per SIMD (512 workgroups: the partial-sum workspace) cannot cover a load -> 80 FMAs chain by themselves: the next
+  // pixel's ten loads are requested before this pixel's arithmetic (same sums in the same order; 71 -> see DESIGN 3.3)
+  // pixel index -> (n, oy, ox): the three 64-bit divisions of the straightforward form were more instructions than the 80 FMAs they
+  // feed; below 2^24 pixels (N <= 260 at 254 x 254) two reciprocal multiplies are exact (x < 2^24, divisor < 2^16)
+  const bool small = P < ((size_t)1 << 24) && Wo < 65536 && Ho < 65536;
+  const unsigned mw = (unsigned)(((unsigned long long)1 << 32) / (unsigned)Wo) + 1u, mh = (unsigned)(((unsigned long long)1 << 32) / (unsigned)Ho) + 1u;
+  auto load_px = [&](size_t p, float (&g)[8], float (&in)[9]) __attribute__((always_inline)) {
+    int ox, oy, n;
+    if (small) {
+      const unsigned pp = (unsigned)p, row = __umulhi(pp, mw);
+      ox = (int)(pp - row * (unsigned)Wo);
+      n = (int)__umulhi(row, mh);
+      oy = (int)(row - (unsigned)n * (unsigned)Ho);
+    } else {
+      ox = (int)(p % Wo); oy = (int)((p / Wo) % Ho); n = (int)(p / ((size_t)Wo * Ho));
+    }
     ld8(G + p * 32 + v * 8, g);
-    float in[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) in[t] = x[((size_t)n * H + oy + t / 3) * W + ox + t % 3];
+  };
+  const size_t stride = (size_t)gridDim.x * 64;
+  size_t p = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  float gn[8], inn[9];
+  if (p < P) load_px(p, gn, inn);
+  while (p < P) {
+    float g[8], in[9];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g[c] = gn[c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) in[t] = inn[t];
+    p += stride;
+    if (p < P) load_px(p, gn, inn);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
 #pragma unroll
