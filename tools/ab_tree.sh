@@ -1,5 +1,5 @@
 #!/bin/bash
-# run on the GPU box: the training step of this tree against a second tree (an older commit unpacked under build/base_tree with the
+# run on the GPU box: the training step of this tree against a second tree (an older commit unpacked under tools/_ab/base_tree (git archive <commit> | tar -x -C tools/_ab/base_tree) with the
 # current library copied in), interleaved.   tools/ab_tree.sh <other tree> <reps> [train|train_video]
 OTHER=$1; REPS=${2:-2}; MODE=${3:-train}
 for rep in $(seq 1 $REPS); do
