@@ -51,7 +51,10 @@ extern "C" {
 #define UNCL_SRC_CONCAT2 3    /* x = cat[src0, src1]  ("original_unet" operator, unet_parts.py:311-312)    */
 #define UNCL_SRC_IMAGE1 4     /* uncl_conv3x3_pipe only: x = act(conv3x3_valid(src0; pre_w, pre_b)), the 32-channel first
                                  layer (unet_parts.py:19) recomputed from the fp32 one-channel image src0 (N, H+2, W+2)
-                                 inside the loader, so inc.conv.conv's output never goes to HBM (inference)         */
+                                 inside the loader, so inc.conv.conv's output never goes to HBM (inference).
+                                 Optional: src1 = DEVICE int32[N], element offsets of the samples' (H+2) x (W+2) windows inside
+                                 src0, src1_W = row pitch of src0 in pixels, src1_H = rows of src0 in all (checked builds): the
+                                 samples are tiles cut out of larger frames (model_save_util.py:409-486's crops read in place) */
 
 #define UNCL_SRC_CONCAT_SSR_UP 5 /* uncl_conv3x3_pipe only: UNCL_SRC_CONCAT_SSR with up() fused: src1 (N, H/2, W/2, 32) is the
                                  INPUT of the 2x2 stride-2 ConvTranspose2d (unet_parts.py:269,288; weights up_w, up_b), whose
@@ -380,6 +383,14 @@ typedef struct uncl_gen_run {
    * clip_T * N samples (uncl_gen_bwd.clip_T). */
   int clip_T;
   int clip_t;
+  /* Tiles read in place (inference, 16-bit dtypes, norm 0, no kept activations: the configurations whose first layer is rebuilt in
+   * the second layer's loader): x_tile_off != NULL says x is a stack of x_rows rows of x_pitch fp32 pixels (whole frames one
+   * behind the other) and tile i's 256 x 256 window starts x_tile_off[i] pixels into it (DEVICE int32[N]; uncl_tile_offsets fills
+   * it for the reference's overlap tiling) -- the tiler's gather pass and its N x 256 KB copy disappear.  UNCL_ERR_ARG where the
+   * first layer is not fused (the caller gathers then). */
+  const int32_t* x_tile_off;
+  int x_pitch;
+  int x_rows;
 } uncl_gen_run;
 
 /* Backward of uncl_gen_forward (bf16, keep_activations = 1, save_preact = 1): gradients of every generator parameter
@@ -621,6 +632,9 @@ int uncl_tile_count(int H, int W);
 /* frames: fp32 (F,H,W).  tiles: fp32 (F*T, 256, 256), tile t of frame f at index f*T + t (row-major). */
 int uncl_tile_gather(const float* frames, float* tiles, int F, int H, int W, void* stream);
 int uncl_tile_blend(const float* tiles, float* frames, int F, int H, int W, void* stream);
+/* offsets_host[f * T + t] (HOST int32[F * uncl_tile_count(H, W)], no GPU work): where tile t of frame f starts inside the stack of
+ * frames, in pixels, in uncl_tile_gather's tile order -- for uncl_gen_run.x_tile_off (tiles read in place, no gather pass) */
+int uncl_tile_offsets(int F, int H, int W, int32_t* offsets_host);
 
 /* ------------------------------------------------------------------------------------------------------
  * Inference pre- / post-processing either side of the tiler, fp32 planes.

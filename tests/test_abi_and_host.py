@@ -117,6 +117,14 @@ def test_round5_entry_points_refuse_bad_arguments_before_any_launch():
     assert lib.uncl_optical_flow(None, C.addressof(buf), 270, 480, C.addressof(buf), C.addressof(buf), need, None) == ERR_ARG
     old = lib.uncl_conv3x3_set_flat(0)
     assert lib.uncl_conv3x3_set_flat(old) == 0 and lib.uncl_conv3x3_flat_count() >= 0
+    # tile origins of the overlap tiler (model_save_util.py:417-441: stride 192, last tile edge-aligned), frames outermost
+    T = lib.uncl_tile_count(600, 1024)
+    assert T == 3 * 5
+    off = (C.c_int32 * (2 * T))()
+    assert lib.uncl_tile_offsets(2, 600, 1024, off) == 0
+    ys, xs = [0, 192, 600 - 256], [0, 192, 384, 576, 1024 - 256]
+    assert list(off) == [(f * 600 + y) * 1024 + x for f in range(2) for y in ys for x in xs]
+    assert lib.uncl_tile_offsets(2, 256, 1024, off) == ERR_ARG and lib.uncl_tile_offsets(1, 600, 1024, None) == ERR_ARG
     # the similarity pair behind nce() with longer lists: every tensor, the result and the workspace are required; fp16 is refused
     pb = C.addressof(buf)
     assert lib.uncl_nce_similarity(pb, pb, None, _hip.F32, 2, 8, 4, 0, 0, 1.0, 1e-2, pb, pb, None) == ERR_ARG

@@ -237,6 +237,24 @@ def _standin(p, **kw):
     return p * (0.5 + xx + 2.0 * yy), None
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_tiles_read_in_place_equal_the_gathered_ones(dtype, monkeypatch):
+    """the tiler's gather folded into the first layer's loader (uncl_gen_run.x_tile_off): same tiles, same kernels, so the tone-mapped
+    frames must be IDENTICAL to the gather-then-run path; odd frame sizes (unaligned tile origins, a last tile that overlaps its
+    neighbour almost completely), several frames, and the two-stream split (>= 64 tiles)"""
+    from uncltmo_amd import tiler
+    net = make_g(dtype)
+    for (F, H, W) in ((1, 300, 517), (3, 600, 1024), (8, 1024, 1024)):
+        frames = synth.hdr_frames(F, H, W, salt="tip%d" % H).cuda()
+        monkeypatch.setenv("UNCL_TILES_IN_PLACE", "0")
+        ref = tiler.test_big_size_image2(frames, net, 0, 0, 0)
+        monkeypatch.setenv("UNCL_TILES_IN_PLACE", "1")
+        assert net.infer_frames(frames.reshape(F, H, W)) is not None
+        got = tiler.test_big_size_image2(frames, net, 0, 0, 0)
+        assert torch.equal(ref, got), (F, H, W)
+    assert make_g("fp32").infer_frames(synth.hdr_frames(1, 300, 300, salt="tipf").cuda().reshape(1, 300, 300)) is None   # fp32: gathered
+
+
 def test_tiler_blend_weights_exact(golden):
     g = golden("tiler")
     x = synth.hdr_frames(1, 272, 272, salt="tile272").cuda()

@@ -58,6 +58,7 @@ class GenRun(C.Structure):
         ("x", C.c_void_p), ("out", C.c_void_p), ("up_x", C.c_void_p), ("knn_idx", C.c_void_p),
         ("drop_scale", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("save_preact", C.c_int), ("prev_workspace", C.c_void_p), ("clip_T", C.c_int), ("clip_t", C.c_int),
+        ("x_tile_off", C.c_void_p), ("x_pitch", C.c_int), ("x_rows", C.c_int),
     ]
 
 
@@ -256,6 +257,7 @@ SIGNATURES = {
     "uncl_tile_count": (C.c_int, [C.c_int, C.c_int]),
     "uncl_tile_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uncl_tile_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uncl_tile_offsets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 

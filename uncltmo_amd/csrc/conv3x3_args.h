@@ -30,6 +30,8 @@ struct PipeArgs {
   const float* pre_w;   // (32,1,3,3)
   const float* pre_b;   // (32) or NULL
   int imgH, imgW;
+  const int* img_off;   // MODE 3, optional: element offset of sample n's (imgH x imgW) window inside `img` (tiles cut out of larger frames);
+  int imgP;             //          row pitch of `img` in elements (imgW when img_off is NULL: samples back to back)
   int flat_S, flat_hw, flat_N;  // FLAT: whole samples per tile, output pixels per sample, samples in the batch
   const bf16_t* up_w;   // MODE 4: packed [4 taps][32 cout][32 cin] weights of the 2x2 stride-2 transposed conv
   const float* up_b;    // MODE 4: its bias (32) or NULL

@@ -1342,13 +1342,14 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     if (MODE == 3) {
       // the image patch under the halo tile: first-layer pixel (y, x) reads image rows y..y+2, columns x..x+2.  Rows and
       // columns past the image only feed outputs that are never stored (valid convolution), so they are clamped.
-      const float* ib = a.img + (size_t)n * a.imgH * a.imgW;
+      if (a.img_off) UNCL_CHK(a.chk, a.img_off + n, 4);
+      const float* ib = a.img + (a.img_off ? (size_t)a.img_off[n] : (size_t)n * a.imgH * a.imgW);
 #pragma unroll
       for (int k = 0; k < IRN; ++k) {
         const int idx = min(ptid + k * NPROD, PN3 - 1);
         const int pr = idx / PW3, pcl = idx - pr * PW3;
-        UNCL_CHK(a.chk, ib + (size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pcl, a.imgW - 1), 4);
-        ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pcl, a.imgW - 1)];
+        UNCL_CHK(a.chk, ib + (size_t)min(iy0 + pr, a.imgH - 1) * a.imgP + min(ix0 + pcl, a.imgW - 1), 4);
+        ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgP + min(ix0 + pcl, a.imgW - 1)];
       }
     } else if (!X_LOAD) {
       // x2^2 / sqrt(x2): staged from the x2 registers

@@ -209,13 +209,14 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && MPW == 2) ? 3 : 2) void con
     if (MODE == 3) {
       // the image patch under the halo tile: first-layer pixel (y, x) reads image rows y..y+2, columns x..x+2.  Rows and
       // columns past the image only feed outputs that are never stored (valid convolution), so they are clamped.
-      const float* ib = a.img + (size_t)n * a.imgH * a.imgW;
+      if (a.img_off) UNCL_CHK(a.chk, a.img_off + n, 4);
+      const float* ib = a.img + (a.img_off ? (size_t)a.img_off[n] : (size_t)n * a.imgH * a.imgW);
 #pragma unroll
       for (int k = 0; k < IRN; ++k) {
         const int idx = min(tid + k * NTHR, PN3 - 1);
         const int pr = idx / PW3, pc = idx - pr * PW3;
-        UNCL_CHK(a.chk, ib + (size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pc, a.imgW - 1), 4);
-        ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgW + min(ix0 + pc, a.imgW - 1)];
+        UNCL_CHK(a.chk, ib + (size_t)min(iy0 + pr, a.imgH - 1) * a.imgP + min(ix0 + pc, a.imgW - 1), 4);
+        ir[k] = ib[(size_t)min(iy0 + pr, a.imgH - 1) * a.imgP + min(ix0 + pc, a.imgW - 1)];
       }
       xvalid = 0xffffffffu;
     } else if (reuse) {
@@ -978,9 +979,13 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   if (d->out != nullptr && (d->out_H != a.Hout || d->out_W != a.Wout)) return UNCL_ERR_ARG;
   a.pH = a.Hout / 2; a.pW = a.Wout / 2;
   a.out1_act = d->out1_act; a.skip_main = d->skip_main_store;
-  a.img = nullptr; a.pre_w = nullptr; a.pre_b = nullptr; a.imgH = a.imgW = 0;
+  a.img = nullptr; a.pre_w = nullptr; a.pre_b = nullptr; a.imgH = a.imgW = 0; a.img_off = nullptr; a.imgP = 0;
   if (d->src_mode == UNCL_SRC_IMAGE1) {
     a.img = (const float*)d->src0; a.pre_w = d->pre_w; a.pre_b = d->pre_b; a.imgH = d->src0_H; a.imgW = d->src0_W;
+    // tiles cut out of larger frames (the tiler's gather folded into this loader): src1 = DEVICE int32[N] element offsets of the
+    // tiles' top-left pixels inside src0, src1_W = the frames' row pitch
+    a.img_off = (const int*)d->src1; a.imgP = d->src1 != nullptr ? d->src1_W : d->src0_W;
+    if (d->src1 != nullptr && d->src1_W < d->src0_W) return UNCL_ERR_ARG;
     a.s0H = d->H; a.s0W = d->W; a.s0C = 32;
   }
   a.up_w = (const bf16_t*)d->up_w; a.up_b = d->up_b;
@@ -1005,9 +1010,15 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     // the tensors this launch may touch, from the descriptor's own dimensions (16-bit elements unless stated)
     const unsigned long long es = 2, N = (unsigned long long)d->N;
     uncl_chk_reset(a.chk);
-    if (d->src_mode == UNCL_SRC_IMAGE1) uncl_chk_add(a.chk, d->src0, N * d->src0_H * d->src0_W * 4);          // fp32 image
-    else uncl_chk_add(a.chk, d->src0, N * d->src0_H * d->src0_W * d->src0_C * es);
-    uncl_chk_add(a.chk, d->src1, N * d->src1_H * d->src1_W * d->src1_C * es);
+    if (d->src_mode == UNCL_SRC_IMAGE1 && d->src1 != nullptr) {          // tiles inside frames: src1_H rows of src1_W fp32 pixels, the offset table
+      uncl_chk_add(a.chk, d->src0, (unsigned long long)d->src1_H * d->src1_W * 4);
+      uncl_chk_add(a.chk, d->src1, N * 4);
+    } else if (d->src_mode == UNCL_SRC_IMAGE1) {
+      uncl_chk_add(a.chk, d->src0, N * d->src0_H * d->src0_W * 4);          // fp32 image
+    } else {
+      uncl_chk_add(a.chk, d->src0, N * d->src0_H * d->src0_W * d->src0_C * es);
+      uncl_chk_add(a.chk, d->src1, N * d->src1_H * d->src1_W * d->src1_C * es);
+    }
     uncl_chk_add(a.chk, d->prev0, N * d->src0_H * d->src0_W * d->src0_C * es);
     uncl_chk_add(a.chk, d->weight, 9ull * d->Cout * d->Cin * es);
     uncl_chk_add(a.chk, d->bias, (unsigned long long)d->Cout * 4);

@@ -173,6 +173,10 @@ struct Ctx {
   int fuse_in;       // inference: inc.conv.conv is recomputed inside inc.conv.conv1's loader (its output never goes to HBM)
   int norm;          // InstanceNorm between conv and activation (unet_norm = 'instance_norm')
   int norm_keep;     // ... and keep zhat / rstd for the backward pass
+  // tiles read in place (uncl_gen_run.x_tile_off): the stack of frames, this chunk's slice of the offset table, row pitch, rows
+  const float* x_frames = nullptr;
+  const int32_t* x_off = nullptr;
+  int x_pitch = 0, x_rows = 0;
   hipStream_t s;
   float slope() const { return w->act == UNCL_ACT_LRELU ? 0.2f : 0.f; }
   // norm + activation (+ residual) of the conv output just written to `p` (the buffer `buf`'s extent), in place
@@ -371,11 +375,13 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
     uncl_conv_desc d = base_desc(c, W_INC1, 3, 0, 32, 32, w->act);
     d.src_mode = UNCL_SRC_IMAGE1;
     d.src0 = x; d.src0_H = S_IN; d.src0_W = S_IN; d.src0_C = 1;
+    if (c.x_off != nullptr) { d.src0 = c.x_frames; d.src1 = c.x_off; d.src1_W = c.x_pitch; d.src1_H = c.x_rows; }
     d.pre_w = w->inc0_w; d.pre_b = w->inc0_b;
     d.H = S_INC0; d.W = S_INC0;
     set_out(d, c.ptr(B_X0), B_X0);
     RUN(run3(c, W_INC1, d, c.ptr(B_X0P)));
   } else {
+    if (c.x_off != nullptr) return UNCL_ERR_ARG;       // tiles in place need the fused first layer: the caller gathers instead
     RUN(uncl_conv_in_c1(x, w->inc0_w, w->inc0_b, c.ptr(B_INC0), w->dtype, c.n, S_IN, S_IN, 32, c.norm ? UNCL_ACT_NONE : w->act, c.s));
     if (c.norm) RUN(c.post_norm(c.ptr(B_INC0), B_INC0));
     RUN(conv3(c, W_INC1, B_INC0, B_X0, 32, 32, 0, false, 0, -1, B_X0P));
@@ -1051,6 +1057,10 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
   if (w->dtype != UNCL_F32 && !uncl_is_h16(w->dtype)) return UNCL_ERR_ARG;
   // fp16 is the inference dtype (BASELINE configs[4]): no kept activations for a backward pass, no clip recurrence
   if (w->dtype == UNCL_F16 && (r->keep_activations || r->save_preact || r->prev_workspace != nullptr)) return UNCL_ERR_ARG;
+  // tiles read in place: only where the first layer is rebuilt in the second layer's loader (the conditions of Ctx::fuse_in below)
+  if (r->x_tile_off != nullptr && (r->x_pitch < 256 || r->x_rows < 256 || !uncl_is_h16(w->dtype) || r->keep_activations || r->save_preact ||
+                                   r->prev_workspace != nullptr || w->norm != 0))
+    return UNCL_ERR_ARG;
   int chunk = r->chunk;
   if (chunk <= 0 || chunk > r->N) chunk = r->N;
   // clip layout: one workspace for clip_T frames of N samples, this call is frame clip_t (see uncl_gen_run)
@@ -1122,6 +1132,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
       c.norm_keep = w->norm && r->keep_activations;
       c.rstd_base = reinterpret_cast<float*>(reinterpret_cast<char*>(r->workspace) + L.off[B_RSTD]);
       c.n_total = r->N; c.n0 = n0;
+      c.x_frames = r->x; c.x_off = r->x_tile_off ? r->x_tile_off + n0 : nullptr; c.x_pitch = r->x_pitch; c.x_rows = r->x_rows;
       c.s = st;
       Layout Lc = L;
       for (int b = 0; b < B_COUNT; ++b) Lc.off[b] = L.off[b] + L.per_n[b] * (size_t)n0;
@@ -1171,6 +1182,7 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     c.norm_keep = w->norm && r->keep_activations;
     c.rstd_base = reinterpret_cast<float*>(reinterpret_cast<char*>(r->workspace) + L.off[B_RSTD]);
     c.n_total = r->N; c.n0 = n0;
+    c.x_frames = r->x; c.x_off = r->x_tile_off ? r->x_tile_off + n0 : nullptr; c.x_pitch = r->x_pitch; c.x_rows = r->x_rows;
     c.s = (split2 && n0 > 0) ? ss->side[part_idx - 1] : main_s;
     // with keep_activations every tile owns its slice of each buffer; otherwise the chunk's slices are reused.
     // Buffers are addressed per tile, so a chunk at tile offset n0 starts per_n*n0 bytes into each buffer.

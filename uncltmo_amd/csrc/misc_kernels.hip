@@ -823,6 +823,23 @@ extern "C" int uncl_tile_gather(const float* frames, float* tiles, int F, int H,
   return UNCL_OK;
 }
 
+// offsets_host[f * T + t] = element offset of tile t of frame f (uncl_tile_gather's order: rows of tiles, frames outermost) inside
+// the stack of F frames of H x W pixels: what uncl_gen_run.x_tile_off / uncl_conv_desc.src1 (UNCL_SRC_IMAGE1) take once it is on
+// the device.  HOST array of F * uncl_tile_count(H, W) ints; no GPU work.
+extern "C" int uncl_tile_offsets(int F, int H, int W, int32_t* offsets_host) {
+  AxisPlan py, px;
+  if (!offsets_host || F <= 0) return UNCL_ERR_ARG;
+  if (make_axis_plan(H, &py) != UNCL_OK || make_axis_plan(W, &px) != UNCL_OK) return UNCL_ERR_ARG;
+  if ((long long)F * H * W >= (1ll << 31)) return UNCL_ERR_ARG;
+  const int T = py.count * px.count;
+  for (int f = 0; f < F; ++f)
+    for (int t = 0; t < T; ++t) {
+      const int ty = t / px.count, tx = t - ty * px.count;
+      offsets_host[f * T + t] = (int32_t)(((long long)f * H + py.start[ty]) * W + px.start[tx]);
+    }
+  return UNCL_OK;
+}
+
 extern "C" int uncl_tile_blend(const float* tiles, float* frames, int F, int H, int W, void* stream) {
   AxisPlan py, px;
   if (!frames || !tiles || F <= 0) return UNCL_ERR_ARG;

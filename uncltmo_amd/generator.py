@@ -417,13 +417,16 @@ class _GeneratorBase(nn.Module):
         return (keep / keep_prob).contiguous()
 
     def _run(self, x_flat, need_feat, prev_ws=None, keep_act=False, slot=0, want_knn=False, save_preact=False,
-             return_drop=False, clip=None):
+             return_drop=False, clip=None, tiles_in_place=None):
         """x_flat: (N,256,256) fp32 on the GPU.  Returns (out (N,1,256,256) fp32, up_x NHWC or None, knn or None, ws).
         clip = (T, t): frame t of a T-frame clip in ONE workspace laid out for T * N samples (uncl_gen_run.clip_T; the previous
         frame is that workspace's slice t - 1, prev_ws stays None)."""
         lib = _hip.lib()
         gw, _keep = self._packed_weights()
         n = x_flat.shape[0]
+        if tiles_in_place is not None:
+            # x_flat is a stack of whole frames (F, H, W); tiles_in_place = device int32 offsets of the 256 x 256 tiles inside it
+            n = int(tiles_in_place.numel())
         dev = x_flat.device
         chunk = self.chunk if self.chunk and self.chunk > 0 else 0
         bn_train = self._bn_train()
@@ -450,6 +453,8 @@ class _GeneratorBase(nn.Module):
         run.drop_scale = ds.data_ptr() if ds is not None else None
         run.workspace, run.workspace_bytes = ws.data_ptr(), nbytes
         run.prev_workspace = prev_ws.data_ptr() if prev_ws is not None else None
+        if tiles_in_place is not None:
+            run.x_tile_off, run.x_pitch, run.x_rows = tiles_in_place.data_ptr(), int(x_flat.shape[2]), int(x_flat.shape[0] * x_flat.shape[1])
         run.save_preact = int(save_preact)
         if clip is not None:
             run.clip_T, run.clip_t = int(clip[0]), int(clip[1])
@@ -507,6 +512,30 @@ class UNet(_GeneratorBase):
         return True
 
     @torch.no_grad()
+    def infer_frames(self, frames):
+        """The tiler's gather folded into the first layer's loader: frames (F,H,W) fp32 on the device -> the tone-mapped 256 x 256 overlap
+        tiles (F*T,1,256,256) in uncl_tile_gather's order, read in place (model_save_util.py:409-486's crops are never copied out).
+        None where this configuration's first layer is not rebuilt in the second layer's loader (fp32, a norm between them): the
+        caller gathers then."""
+        gw, _ = self._packed_weights()
+        if self._dtype_code() not in (_hip.BF16, _hip.F16) or gw.norm != 0 or os.environ.get("UNCL_TILES_IN_PLACE", "1") == "0":
+            return None
+        F, H, W = frames.shape
+        key = (F, H, W, frames.device)
+        cache = self.__dict__.setdefault("_tile_off_cache", {})
+        off = cache.get(key)
+        if off is None:
+            lib = _hip.lib()
+            T = lib.uncl_tile_count(int(H), int(W))
+            if T <= 0:
+                raise ValueError("tiler needs H > 256 and W > 256 (got %dx%d)" % (H, W))
+            host = (C.c_int32 * (F * T))()
+            if lib.uncl_tile_offsets(int(F), int(H), int(W), host) != 0:
+                return None                                  # (more than 2^31 pixels in the stack: gather instead)
+            off = cache[key] = torch.tensor(list(host), dtype=torch.int32).to(frames.device)
+        out, _, _, _ = self._run(frames.float().contiguous(), need_feat=False, tiles_in_place=off)
+        return out
+
     def infer(self, x, want_knn=False):
         """Inference entry used by the tiler: (N,1,256,256) -> (N,1,256,256); skips writing up_x to HBM."""
         self._check_input(x, 2)
