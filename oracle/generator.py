@@ -125,7 +125,12 @@ def skip_concat(x2, x1, con_operator="square_and_square_root"):
 def up_block(sd, p, x1, x2, con_operator, activation="relu", unet_norm="none", training=False):
     """ConvT 2x2 stride 2, replicate-pad x1 up to x2's size (right/bottom get the odd pixel), concat,
     double transposed conv.  unet_parts.py:283-335 (pad :292-298)."""
-    if p + ".up.1.weight" in sd:       # bilinear=1 (unet_parts.py:256-259): nn.Upsample(scale_factor=2) [nearest] + 1x1 convolution
+    if p + ".up.weight" not in sd and p + ".up.1.weight" not in sd:
+        # up_mode=1 (unet_parts.py:284-288): zero-insertion upsampling -- x1 lands on the even pixels, zeros in between
+        w = x1.new_zeros(2, 2)
+        w[0, 0] = 1
+        x1 = F.conv_transpose2d(x1, w.expand(x1.size(1), 1, 2, 2), stride=2, groups=x1.size(1))
+    elif p + ".up.1.weight" in sd:       # bilinear=1 (unet_parts.py:256-259): nn.Upsample(scale_factor=2) [nearest] + 1x1 convolution
         x1 = F.conv2d(F.interpolate(x1, scale_factor=2), sd[p + ".up.1.weight"], sd[p + ".up.1.bias"])
     else:
         x1 = F.conv_transpose2d(x1, sd[p + ".up.weight"], sd[p + ".up.bias"], stride=2)

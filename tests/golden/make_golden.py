@@ -380,12 +380,13 @@ from generator_variants import GENERATOR_VARIANTS  # noqa: E402
 
 def capture_generator_variants(out):
     """The reference generator built with the skip operators that are sub-sets of the published one (unet_parts.py:311-332) and /
-    or the bilinear decoder path (nn.Upsample + 1x1 convolution, unet_parts.py:256-259): state_dict keys and shapes, eval forward
+    or the bilinear decoder path (nn.Upsample + 1x1 convolution, unet_parts.py:256-259) or the parameter-free zero-insertion
+    upsampling (`up_mode`, unet_parts.py:284-288): state_dict keys and shapes, eval forward
     on two frames, and the parameter gradients of a smooth loss (norm + 64 hashed elements per tensor)."""
     from utils import model_save_util
-    for tag, op, bil in GENERATOR_VARIANTS:
+    for tag, op, bil, upm in GENERATOR_VARIANTS:
         G = model_save_util.create_G_net2("unet", DEV, False, 1, "sigmoid", 32, op, 4, 0, "none", "none", "relu", True, 1, 1, bil,
-                                          "replicate", 2, 0)
+                                          "replicate", 2, upm)
         synth.fill_state_dict(G, "g0")
         sdk = G.state_dict()
         out[tag + ".keys"] = np.array(list(sdk.keys()))

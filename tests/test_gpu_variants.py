@@ -1,7 +1,8 @@
 """Generator configurations outside the published one that run on the published kernels: skip operators that are sub-sets of
 [x2, x1, x2^2, sqrt(x2 + eps)] (unet_parts.py:311-332: original_unet, square, square_root -- zero weights for the members they leave
-out) and the bilinear decoder path (nn.Upsample + 1x1 convolution, unet_parts.py:256-259 = a 2x2 stride-2 transposed convolution
-with one weight on all four taps).  Against the reference's own outputs and parameter gradients (tests/golden/generator_variants.npz)."""
+out), the bilinear decoder path (nn.Upsample + 1x1 convolution, unet_parts.py:256-259 = a 2x2 stride-2 transposed convolution
+with one weight on all four taps) and the parameter-free zero-insertion upsampling (`up_mode`, unet_parts.py:284-288 = the same
+convolution with an identity on one tap, no bias).  Against the reference's own outputs and parameter gradients (tests/golden/generator_variants.npz)."""
 import numpy as np
 import pytest
 import torch
@@ -14,8 +15,8 @@ from uncltmo_amd.generator import UNet
 pytestmark = pytest.mark.gpu
 
 
-def make(op, bil, dtype):
-    net = UNet(1, 1, "sigmoid", 4, params.get_layer_factor(op), op, 32, bil, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0,
+def make(op, bil, dtype, upm=0):
+    net = UNet(1, 1, "sigmoid", 4, params.get_layer_factor(op), op, 32, bil, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, upm,
                compute_dtype=dtype)
     synth.fill_state_dict(net, "g0")
     return net.cuda()
@@ -30,10 +31,10 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("tag,op,bil", GENERATOR_VARIANTS)
-def test_forward_matches_reference_golden(golden, tag, op, bil):
+@pytest.mark.parametrize("tag,op,bil,upm", GENERATOR_VARIANTS)
+def test_forward_matches_reference_golden(golden, tag, op, bil, upm):
     g = golden("generator_variants")
-    net = make(op, bil, "fp32").eval()
+    net = make(op, bil, "fp32", upm).eval()
     assert [(k, ",".join(str(d) for d in v.shape)) for k, v in net.state_dict().items()] == list(zip(g[tag + ".keys"], g[tag + ".shapes"]))
     with torch.no_grad():
         y, up = net(inputs().cuda())
@@ -41,17 +42,17 @@ def test_forward_matches_reference_golden(golden, tag, op, bil):
         check_summary(up.float().cpu(), g, tag + ".up_x", rtol=3e-4, atol=2e-5)
         # the 16-bit inference paths (fused decoder loaders included) against the fp32 run
         for dtype, tol in (("bf16", 3e-2), ("fp16", 7e-3)):
-            y16, _ = make(op, bil, dtype).eval()(inputs().cuda())
+            y16, _ = make(op, bil, dtype, upm).eval()(inputs().cuda())
             assert rel(y16.float().cpu(), y.cpu()) < tol, (dtype, rel(y16.float().cpu(), y.cpu()))
 
 
-@pytest.mark.parametrize("tag,op,bil", GENERATOR_VARIANTS)
-def test_fp32_gradients_match_reference_golden(golden, tag, op, bil):
+@pytest.mark.parametrize("tag,op,bil,upm", GENERATOR_VARIANTS)
+def test_fp32_gradients_match_reference_golden(golden, tag, op, bil, upm):
     """fp32 parity mode: every parameter's gradient against the reference's norm and 64 sampled elements.  The gates are those of
     tests/test_gpu_backward.py's conditioning note: decoder / graph tensors 2e-3, encoder tensors (behind sqrt(x2 + 1e-8) where the
     operator has it) 3e-2"""
     g = golden("generator_variants")
-    net = make(op, bil, "fp32").train()
+    net = make(op, bil, "fp32", upm).train()
     net.drop_path_prob = 0.0
     wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
     y, up = net(inputs().cuda())

@@ -172,8 +172,8 @@ def test_generator_variants_state_dict_and_oracle_forward_backward(golden):
     g = golden("generator_variants")
     x = torch.cat([synth.hdr_frames(1, salt="gA"), synth.smooth_hdr_frames(1, salt="gB")], 0)
     wy = 0.5 + synth.smooth_hdr_frames(2, salt="bwy")
-    for tag, op, bil in GENERATOR_VARIANTS:
-        spec = state_spec.generator_spec(32, params.get_layer_factor(op), "none", bil)
+    for tag, op, bil, upm in GENERATOR_VARIANTS:
+        spec = state_spec.generator_spec(32, params.get_layer_factor(op), "none", bil, upm)
         assert [k for k, _, _ in spec] == list(g[tag + ".keys"])
         assert [",".join(str(d) for d in s_) for _, s_, _ in spec] == list(g[tag + ".shapes"])
         sd = {k: v.clone().requires_grad_(not k.endswith("relative_pos")) for k, v in synth_state(spec, "g0").items()}

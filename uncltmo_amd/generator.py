@@ -94,8 +94,10 @@ class _GeneratorBase(nn.Module):
             unsupported.append("depth/filters=%s/%s" % (depth, filters))
         # bilinear=1: nn.Upsample(scale_factor=2) [nearest] + Conv2d 1x1 (unet_parts.py:256-259) IS a stride-2 2x2 transposed
         # convolution whose four taps all hold the 1x1 weight: same kernels, the weight is replicated when it is packed
-        if not doubleConvTranspose or up_mode or convtranspose_kernel != 2:
-            unsupported.append("decoder must be doubleConvTranspose=1, up_mode=0, convtranspose_kernel=2")
+        # up_mode=1: the parameter-free zero-insertion upsampling (unet_parts.py:284-288) is the same transposed convolution with an
+        # identity on tap (0, 0), zeros on the other three and no bias
+        if not doubleConvTranspose or convtranspose_kernel != 2:
+            unsupported.append("decoder must be doubleConvTranspose=1, convtranspose_kernel=2")
         if n_channels != 1 or output_dim != 1:
             unsupported.append("n_channels/output_dim must be 1")
         if unet_norm not in ("none", None, "instance_norm", "batch_norm"):
@@ -115,6 +117,7 @@ class _GeneratorBase(nn.Module):
         self.con_operator = con_operator
         self.layer_factor = int(layer_factor)
         self.bilinear = int(bool(bilinear))
+        self.up_mode = int(bool(up_mode))
         self.filters = filters
         self.network = network
         self.depth = depth
@@ -154,10 +157,10 @@ class _GeneratorBase(nn.Module):
     # --- initialisation: what `create_G_net*` + `set_parallel_net(use_xaviar=True)` leave behind
     def _own_spec(self):
         """state_dict layout of THIS configuration (skip operator's member count, bilinear up path)"""
-        return generator_spec(self.filters, self.layer_factor, self.unet_norm, self.bilinear)
+        return generator_spec(self.filters, self.layer_factor, self.unet_norm, self.bilinear, self.up_mode)
 
     def _is_variant(self):
-        return self.layer_factor != 4 or self.bilinear != 0
+        return self.layer_factor != 4 or self.bilinear != 0 or self.up_mode != 0
 
     def _published_state(self, sd):
         """name -> tensor in the PUBLISHED layout the kernels are packed from: the skip-concat convolutions padded to four members
@@ -175,7 +178,12 @@ class _GeneratorBase(nn.Module):
                 third = w[2 * c:3 * c] if self.layer_factor == 3 else zero
                 sq, rt = (third, zero) if self.con_operator == params.square else (zero, third)
                 out[p + ".conv.conv.weight"] = torch.cat([w[:2 * c], sq, rt], 0)
-            if self.bilinear:
+            if self.up_mode:
+                c = sd[p + ".conv.conv.weight"].shape[0] // self.layer_factor       # channels entering `up`
+                w = torch.zeros(c, c, 2, 2, dtype=torch.float32, device=sd[p + ".conv.conv.weight"].device)
+                w[:, :, 0, 0] = torch.eye(c, device=w.device)
+                out[p + ".up.weight"], out[p + ".up.bias"] = w, torch.zeros(c, dtype=torch.float32, device=w.device)
+            elif self.bilinear:
                 v = sd[p + ".up.1.weight"].detach().float()                 # Conv2d (Cout, Cin, 1, 1)
                 co, ci = v.shape[0], v.shape[1]
                 out[p + ".up.weight"] = v.reshape(co, ci).t().reshape(ci, co, 1, 1).expand(ci, co, 2, 2).contiguous()
@@ -199,7 +207,10 @@ class _GeneratorBase(nn.Module):
                     g[p + ".conv.conv.weight"] = w[:3 * c]
                 else:
                     g[p + ".conv.conv.weight"] = torch.cat([w[:2 * c], w[3 * c:]], 0)
-            if self.bilinear:
+            if self.up_mode:
+                g.pop(p + ".up.weight", None)
+                g.pop(p + ".up.bias", None)
+            elif self.bilinear:
                 w = g.pop(p + ".up.weight")                                 # (Cin, Cout, 2, 2)
                 g[p + ".up.1.weight"] = w.sum(dim=(2, 3)).t().reshape(w.shape[1], w.shape[0], 1, 1)
                 g[p + ".up.1.bias"] = g.pop(p + ".up.bias")

@@ -6,11 +6,12 @@ ConvTranspose2d weights are (Cin, Cout, kh, kw) — transposed layers are flagge
 """
 
 
-def generator_spec(filters=32, layer_factor=4, unet_norm="none", bilinear=0):
+def generator_spec(filters=32, layer_factor=4, unet_norm="none", bilinear=0, up_mode=0):
     """[(key, shape, kind)], kind in {"conv", "convT", "bias", "buffer", "embed"} in state_dict order.  `layer_factor` = members of
     the skip concatenation (4 for the published square_and_square_root, 2 for original_unet, 3 for square / square_root:
     unet_parts.py:311-332; the first decoder convolution takes layer_factor x C channels).  `bilinear` = 1: the decoder's `up` is
-    nn.Sequential(nn.Upsample(scale_factor=2), nn.Conv2d(C, C, 1)) (unet_parts.py:256-259), key `...up.1`.  With
+    nn.Sequential(nn.Upsample(scale_factor=2), nn.Conv2d(C, C, 1)) (unet_parts.py:256-259), key `...up.1`; `up_mode` = 1: the
+    parameter-free zero-insertion upsampling of unet_parts.py:284-288 (no `up` entries at all).  With
     unet_norm='batch_norm' every 3x3 convolution of the double-conv blocks is followed by its nn.BatchNorm2d entries
     (unet_parts.py:20-21, 34-35: `norm` after `conv`, `norm1` after `conv1`), kinds "bn_weight", "bn_bias", "bn_mean", "bn_var",
     "bn_count"; InstanceNorm2d (no affine, no running statistics) adds nothing."""
@@ -51,7 +52,9 @@ def generator_spec(filters=32, layer_factor=4, unet_norm="none", bilinear=0):
     for i in range(4):
         out = ch // 2 if i < 2 else f
         p = "up_path.%d" % i
-        if bilinear:
+        if up_mode:
+            pass
+        elif bilinear:
             conv(p + ".up.1", ch, ch, 1)
         else:
             conv(p + ".up", ch, ch, 2, transposed=True)
