@@ -527,9 +527,11 @@ class UNet(_GeneratorBase):
         """The tiler's gather folded into the first layer's loader: frames (F,H,W) fp32 on the device -> the tone-mapped 256 x 256 overlap
         tiles (F*T,1,256,256) in uncl_tile_gather's order, read in place (model_save_util.py:409-486's crops are never copied out).
         None where this configuration's first layer is not rebuilt in the second layer's loader (fp32, a norm between them): the
-        caller gathers then."""
+        caller gathers then.  OFF unless UNCL_TILES_IN_PLACE=1: measured at 8 x 1024^2, the first layer's launch takes 0.416 instead
+        of 0.351 ms when its 16-row patches come from 4 KB-pitch frame rows instead of a cache-warm 256 KB tile (the gather it
+        saves is 0.016 ms), the whole forward is a tie at best."""
         gw, _ = self._packed_weights()
-        if self._dtype_code() not in (_hip.BF16, _hip.F16) or gw.norm != 0 or os.environ.get("UNCL_TILES_IN_PLACE", "1") == "0":
+        if self._dtype_code() not in (_hip.BF16, _hip.F16) or gw.norm != 0 or os.environ.get("UNCL_TILES_IN_PLACE", "0") != "1":
             return None
         F, H, W = frames.shape
         key = (F, H, W, frames.device)
