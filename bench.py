@@ -61,12 +61,38 @@ WORKLOADS = {
                name="4K HDR inference: whole 2160x3840 frames per GPU -> 220 overlap tiles of 256x256 each, tiled UNet forward, "
                     "eval mode, random-init weights (BASELINE.json configs[4]; quote it with --dtype fp16)"),
 }
-# (Cin, Cout, output extent, taps) of the 26 packed-weight layers in uncl_gen_layer_name order: FLOP = 2 taps Cin Cout Hout^2
-LAYER_SHAPES = [(32, 32, 252, 9), (32, 64, 124, 9), (64, 64, 122, 9), (64, 128, 59, 9), (128, 128, 57, 9), (128, 256, 26, 9),
-                (256, 256, 24, 9), (256, 256, 10, 9), (256, 256, 12, 9), (256, 256, 12, 1), (128, 512, 12, 1), (512, 256, 12, 1),
-                (256, 256, 12, 1), (256, 256, 12, 1), (256, 256, 24, 1), (1024, 128, 26, 9), (128, 128, 28, 9), (128, 128, 56, 1),
-                (512, 64, 59, 9), (64, 64, 61, 9), (64, 64, 122, 1), (256, 32, 124, 9), (32, 32, 126, 9), (32, 32, 252, 1),
-                (128, 32, 254, 9), (32, 32, 256, 9)]
+# The 26 packed-weight layers in uncl_gen_layer_name order: (name, Cin, Cout, output extent, taps, transposed 3x3).
+# Two FLOP figures per layer.  `gflop` is SURVEY.md section 2.3A / 8(d)'s ALGORITHMIC count, the convention of GFLOP_PER_TILE: 2 MAC over
+# the OUTPUT pixels of a convolution and over the INPUT pixels of a stride-1 transposed 3x3 (what a MAC hook on nn.ConvTranspose2d
+# counts: 4682.0 MFLOP for up_path.3.conv.conv); `gflop_executed` is what the implicit GEMM multiplies, 2 MAC over the output pixels of
+# every layer (4756.6 for that one: the transposed layers run as full-padding convolutions).  Fractions are quoted on the first.
+LAYER_TABLE = [("inc.conv.conv1", 32, 32, 252, 9, False), ("down_path.0.mpconv.1.conv", 32, 64, 124, 9, False),
+               ("down_path.0.mpconv.1.conv1", 64, 64, 122, 9, False), ("down_path.1.mpconv.1.conv", 64, 128, 59, 9, False),
+               ("down_path.1.mpconv.1.conv1", 128, 128, 57, 9, False), ("down_path.2.mpconv.1.conv", 128, 256, 26, 9, False),
+               ("down_path.2.mpconv.1.conv1", 256, 256, 24, 9, False), ("down_path.3.mpconv.1.conv", 256, 256, 10, 9, False),
+               ("down_path.3.mpconv.1.conv1", 256, 256, 12, 9, True), ("gcn.module.0.0.fc1.0", 256, 256, 12, 1, False),
+               ("gcn.module.0.0.graph_conv.gconv.nn.0", 128, 512, 12, 1, False), ("gcn.module.0.0.fc2.0", 512, 256, 12, 1, False),
+               ("gcn.module.0.1.fc1.0", 256, 256, 12, 1, False), ("gcn.module.0.1.fc2.0", 256, 256, 12, 1, False),
+               ("up_path.0.up", 256, 256, 24, 1, False), ("up_path.0.conv.conv", 1024, 128, 26, 9, True),
+               ("up_path.0.conv.conv1", 128, 128, 28, 9, True), ("up_path.1.up", 128, 128, 56, 1, False),
+               ("up_path.1.conv.conv", 512, 64, 59, 9, True), ("up_path.1.conv.conv1", 64, 64, 61, 9, True),
+               ("up_path.2.up", 64, 64, 122, 1, False), ("up_path.2.conv.conv", 256, 32, 124, 9, True),
+               ("up_path.2.conv.conv1", 32, 32, 126, 9, True), ("up_path.3.up", 32, 32, 252, 1, False),
+               ("up_path.3.conv.conv", 128, 32, 254, 9, True), ("up_path.3.conv.conv1", 32, 32, 256, 9, True)]
+# the two layers without a packed weight of their own (computed inside a neighbouring launch on every path): name, MFLOP per tile
+FUSED_LAYERS = [("inc.conv.conv", 2.0 * 9 * 1 * 32 * 254 * 254 / 1e6), ("outc.conv", 2.0 * 1 * 32 * 1 * 256 * 256 / 1e6)]
+
+
+def layer_gflops(tiles):
+    """[(name, gflop in the survey's convention, gflop executed)] for `tiles` tile forwards; the first column sums to
+    GFLOP_PER_TILE x tiles (tests/test_bench_launcher.py)."""
+    rows = []
+    for name, cin, cout, ho, taps, transposed in LAYER_TABLE:
+        hs = ho - 2 if transposed else ho
+        rows.append((name, 2.0 * taps * cin * cout * hs * hs * tiles / 1e9, 2.0 * taps * cin * cout * ho * ho * tiles / 1e9))
+    for name, mflop in FUSED_LAYERS:
+        rows.append((name, mflop * tiles / 1e3, mflop * tiles / 1e3))
+    return rows
 
 
 def parse(argv=None):
@@ -930,20 +956,26 @@ def infer_bench(a, rk):
         lib.uncl_gen_set_streams(1)
         layers = []
         peak_l = PEAK_BF16_TFLOPS
-        for i, (cin, cout, ho, taps) in enumerate(LAYER_SHAPES):
+        table = layer_gflops(FRAMES * TILES_PER_FRAME)
+        for i in range(len(LAYER_TABLE)):
+            name, gfl, gfl_x = table[i]
+            assert lib.uncl_gen_layer_name(i).decode() == name, (i, name)
             lib.uncl_prof_enable(i, 64)
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
             nl = lib.uncl_prof_read(buf, 4096)
-            gfl = 2.0 * taps * cin * cout * ho * ho * FRAMES * TILES_PER_FRAME / 1e9
-            ent = {"layer": lib.uncl_gen_layer_name(i).decode(), "gflop": round(gfl, 1)}
+            ent = {"layer": name, "gflop": round(gfl, 2), "gflop_executed": round(gfl_x, 2)}
             per_fwd = sum(buf[k] for k in range(nl)) / 2.0          # two forwards were timed
             if nl > 0 and per_fwd > 0:
-                ent.update({"ms": round(per_fwd, 4), "tflops": round(gfl / per_fwd, 1), "frac": round(gfl / per_fwd / peak_l, 4)})
+                ent.update({"ms": round(per_fwd, 4), "tflops": round(gfl / per_fwd, 1), "frac": round(gfl / per_fwd / peak_l, 4),
+                            "frac_executed": round(gfl_x / per_fwd / peak_l, 4)})
             else:
                 ent.update({"ms": None, "note": "computed inside a neighbouring launch on this path"})
             layers.append(ent)
+        for name, gfl, gfl_x in table[len(LAYER_TABLE):]:
+            layers.append({"layer": name, "gflop": round(gfl, 2), "gflop_executed": round(gfl_x, 2), "ms": None,
+                           "note": "computed inside a neighbouring launch on every path"})
         lib.uncl_gen_set_streams(int(os.environ.get("UNCL_STREAMS", "2")))
     lib.uncl_prof_enable(-1, 0)
     assert torch.isfinite(out).all()
@@ -1030,12 +1062,19 @@ def infer_bench(a, rk):
                          "hbm_gbps": (traffic / dom_ms / 1e6 if traffic and dom_ms > 0 else None),
                          "launches": nrec, "avg_launch_ms": dom_ms, "tiles_per_launch": tiles_per_launch,
                          "gflop_per_tile": dom_gflop,
+                         # (4.6820 GFLOP per tile for the 3x3 over the concatenation, + 0.1300 for the up-conv rebuilt in its
+                         # loader; the implicit GEMM itself multiplies 4.7566 + the recomputed halo)
+                         "frac_survey_convention": dom_tflops / peak,
+                         "frac_survey_convention_conv_only": (DOM_GFLOP_PER_TILE_F32 * tiles_per_launch / dom_ms / peak if dom_ms > 0 else 0.0),
                          "exclusive": {"achieved": excl_tflops, "frac": excl_tflops / peak, "avg_launch_ms": excl_ms,
                                        "tiles_per_launch": excl_tiles,
                                        "note": "same kernel, single stream, 3 untimed steps after the timed region"}}},
     })
     if layers is not None:
         line["roofline"]["layers"] = layers
+        line["roofline"]["layers_convention"] = ("gflop / tflops / frac: SURVEY 8(d)'s algorithmic count (transposed 3x3 layers over their INPUT "
+                                                 "pixels; the column sums to 18.2858 GFLOP x tiles); gflop_executed / frac_executed: 2 MAC "
+                                                 "over the output pixels, what the implicit GEMM multiplies")
     if sustained is not None:
         sustained["frac"] = GFLOP_PER_TILE * FRAMES * TILES_PER_FRAME / sustained["ms_per_step_median"] / peak
         line["sustained"] = sustained

@@ -74,6 +74,13 @@ def test_state_dict_contract_and_no_cpu_fallback():
         d(torch.zeros(1, 1, 256, 256))
     with pytest.raises(NotImplementedError):
         UNet(1, 1, "sigmoid", 5, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
+    # sub-set skip operators run on the four-member kernels with zero weights: with a leaky ReLU the unused sqrt(x2) member is a
+    # NaN for negative skip values and NaN * 0 = NaN -- refused, never a silent NaN (the published operator accepts leakyrelu)
+    for op, lf in (("original_unet", 2), ("square", 3), ("square_root", 3)):
+        UNet(1, 1, "sigmoid", 4, lf, op, 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)
+        with pytest.raises(NotImplementedError, match="leakyrelu"):
+            UNet(1, 1, "sigmoid", 4, lf, op, 32, 0, "unet", 0, 0, "none", "none", "leakyrelu", 1, "replicate", 2, 0)
+    UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "leakyrelu", 1, "replicate", 2, 0)
     # stretch_g: the reference builds a parameter-free module it never calls (Unet_singleFrame.py:169-175): the two names it knows
     # are accepted with the state_dict of 'none', an unknown one fails like the reference's dictionary lookup
     for name in ("batchMax", "instanceMinMax"):

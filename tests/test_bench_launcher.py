@@ -235,3 +235,20 @@ def test_fault_classification_against_a_memory_map(tmp_path):
     assert "not allocator memory" in fault(0x100000)["where"]
     assert bench.classify_fault("no fault here") is None
     assert "no memory map" in bench.classify_fault("Memory access fault by GPU node-2 on address 0x1000. Reason: x")["where"]
+
+
+def test_layer_table_sums_to_the_surveys_gflop_per_tile():
+    """roofline.layers[*].gflop is SURVEY.md 2.3A / 8(d)'s algorithmic count: transposed 3x3 layers over their INPUT pixels (4682.0 MFLOP
+    for up_path.3.conv.conv, not the 4756.6 the implicit GEMM multiplies), inc.conv.conv and outc.conv listed though they never
+    launch on their own -- so that the column sums to the 18.2858 GFLOP per tile the whole-forward fraction is quoted on."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rows = bench.layer_gflops(200)
+    assert len(rows) == 28 and len({r[0] for r in rows}) == 28
+    assert abs(sum(r[1] for r in rows) - 200 * bench.GFLOP_PER_TILE) < 0.1          # 3657.2 GFLOP at 200 tiles
+    by = {r[0]: r for r in rows}
+    assert abs(by["up_path.3.conv.conv"][1] / 200 - 4.6820) < 1e-4 and abs(by["up_path.3.conv.conv"][2] / 200 - 4.7566) < 1e-4
+    assert abs(by["inc.conv.conv1"][1] / 200 - 1.1705) < 1e-4 and by["inc.conv.conv1"][1] == by["inc.conv.conv1"][2]
+    assert abs(by["down_path.3.mpconv.1.conv1"][1] / 200 - 0.1180) < 1e-4
+    assert all(r[2] >= r[1] for r in rows)
+    assert abs(bench.DOM_GFLOP_PER_TILE - (by["up_path.3.conv.conv"][1] + by["up_path.3.up"][1]) / 200) < 2e-4

@@ -57,6 +57,7 @@ LAYERS = {
     "up3b": ("plain", 32, 32, 32, 254, 2, False),      # single chunk: UNCL_PC_NK1=1
     "inc1": ("plain", 32, 32, 32, 254, 0, False),
     "tail": ("tail", 32, 128, 32, 252, 2, False),       # the fused last decoder stage (up3f + second 3x3 + outconv in one launch)
+    "o1c": ("o1c", 32, 32, 32, 254, 2, False),         # inference's last layer: plain source, only the fused 1x1 tail is stored (O1C)
     "incf": ("image1", 1, 32, 32, 256, 0, True),        # the product's first layer: inc.conv.conv rebuilt by the staging waves
 }
 
@@ -120,6 +121,11 @@ def main():
         d.weight, d.bias, d.act = w.data_ptr(), b.data_ptr(), _hip.ACT_RELU
         d.out, d.out_H, d.out_W, d.out_C = out.data_ptr(), ho, ho, cout
         plp = pl.data_ptr() if pool else None
+        if mode == "o1c":
+            ow = torch.rand(32, device="cuda", generator=g) - 0.5; ob = torch.zeros(1, device="cuda"); o1 = torch.empty(n, ho, ho, device="cuda")
+            keep += [ow, ob, o1]
+            d.out1_w, d.out1_b, d.out1, d.out1_act = ow.data_ptr(), ob.data_ptr(), o1.data_ptr(), _hip.ACT_SIGMOID
+            d.skip_main_store = 1
         if mode == "tail":
             w1 = rnd(9, 32, 32, scale=0.05); b1 = torch.zeros(32, device="cuda"); ow = torch.rand(32, device="cuda", generator=g) - 0.5
             ob = torch.zeros(1, device="cuda"); o1 = torch.empty(n, ho + 2, ho + 2, device="cuda"); keep += [w1, b1, ow, ob, o1]

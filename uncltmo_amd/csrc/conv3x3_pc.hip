@@ -62,6 +62,10 @@
 #ifndef UNCL_PC_XA_SPLIT
 #define UNCL_PC_XA_SPLIT 0
 #endif
+// parked epilogue of the four-chunk concat layer: the staging iteration (chunk of the next tile) in which the parked tile is stored
+#ifndef UNCL_PC_EPO_Q
+#define UNCL_PC_EPO_Q 2
+#endif
 
 namespace {
 
@@ -198,7 +202,12 @@ __device__ __forceinline__ PcAcc pc_mm(const V& a, const V& b, const PcAcc& c, i
 // SSRB (round 5, training): the launch is the data gradient of a skip-concat layer and its epilogue the backward of the skip
 // operator -- see PipeArgs.ssr_x2.  64-channel tiles = [g0 | g1 | g2 | g3] of 16 skip channels each (the weights' cout order is
 // interleaved by the pack kernel), so a lane holds all four members of its four channels in its own accumulators.
-template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool TAIL = false, bool EPO = false, bool SSRB = false>
+// O1C (round 6, inference's last layer): the tile's only result is the fused 1x1 tail (outconv + last activation, unet_parts.py:338-345;
+// Unet_singleFrame.py:207-209) computed by the multiplying waves straight from their accumulators -- outc_row: bias, rounding and
+// packed ReLU on the registers, two MFMAs against the three 16-bit pieces of the fp32 outconv weights, two adds -- with the weight
+// fragments built ONCE per workgroup by the staging waves (LDS, then two registers per multiplying wave for the launch).  No 32-channel
+// store, no parked tile: the 16 x 32 tile leaves as 2 KB of fp32.
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool TAIL = false, bool EPO = false, bool SSRB = false, int O1C = 0>
 // (NT == 1 && MPW == 2 with four staging waves: 8-row tiles, 64 KB of LDS and <= 128 registers, TWO workgroups per CU, so that
 // one workgroup's epilogue runs under the other's MFMAs -- the single-chunk 32-channel layers spend 52 - 61 % of a multiplying
 // wave's time in the epilogue)
@@ -222,7 +231,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   constexpr int XBYTES = 4 * XPL, WBYTES = 4 * WPL;
   // streamed weights: two stages of [activations | weights]; resident weights: [X stage 0 | X stage 1 | nk weight chunks]
   constexpr int STAGE = RESW ? XBYTES : XBYTES + WBYTES;
-  static_assert(MODE != 4 || (NT == 1 && (MPW == 4 || TAIL)), "fused up-conv: 16 x 32 tiles of 32 channels");
+  static_assert(MODE != 4 || (NT == 1 && (MPW == 4 || TAIL || (MPW == 3 && EPO))), "fused up-conv: 16 x 32 (12 x 32: fused last stage, parked epilogue) tiles of 32 channels");
   static_assert(MODE != 5 || (NT == 1 && MPW == 4 && !TAIL && !RESW), "fused 64-channel up-conv: 16 x 32 tiles of 32 channels, streamed weights");
   static_assert(MODE != 3 || (NT == 1 && RESW), "fused first layer: 32 -> 32 channels, one chunk, resident weights");
   static_assert(MPW != 3 || TAIL || EPO, "12-row tiles: the fused last stage, or a parked epilogue (whose pooled copy does not need row pairs per wave)");
@@ -247,9 +256,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   float* const sB1 = sO1 + 64;                                        // TAIL: bias of the second layer (32)
   char* const sW1 = reinterpret_cast<char*>(sB1 + 32);                // TAIL: the second layer's weights, [4 planes][9 taps x 32 rows]
   char* const sCarry = sW1 + 4 * W1PL;                                // TAIL: [2][4 planes][2 rows x HW] last two intermediate rows
-  static_assert(!EPO || (NT == 1 && !TAIL && (MODE == 0 || MODE == 3) && RESW), "parked epilogue: 32-channel tiles, resident weights");
+  static_assert(!EPO || (NT == 1 && !TAIL && (MODE == 0 || MODE == 3 || MODE == 4) && RESW), "parked epilogue: 32-channel tiles, resident weights");
   constexpr int PARKB = TH * 32 * 4 * 16;                             // EPO: one parked tile, [row][K-slot][pixel] 16-byte vectors
+  // Single-chunk layers park into two buffers (the tile's own barrier is the only hand-over).  The four-chunk concat layer (MODE 4,
+  // round 6: 12-row tiles, whose stages leave 24 KB of the 160) has ONE: a tile is parked at the end of its last chunk and stored by
+  // the staging waves during chunk UNCL_PC_EPO_Q of the NEXT tile, i.e. at least one barrier before the next tile is parked.
+  constexpr int NPARK = MODE == 4 ? 1 : 2;
   char* const sPark = MODE == 3 ? reinterpret_cast<char*>(sP + 2 * PN3) : reinterpret_cast<char*>(sO1 + 64);     // EPO: [2][PARKB]
+  static_assert(!O1C || (NT == 1 && MODE == 0 && RESW && !TAIL && !EPO && !SSRB), "accumulator-direct 1x1 tail: 32-channel tiles, plain source, resident weights");
+  char* const sO1F = reinterpret_cast<char*>(sO1 + 64);               // O1C: the outconv's two A fragments, [2][64 lanes] 16-byte vectors
   float* const sUpB = sO1 + 64;                                       // MODE 5: the up-conv's bias (64) ...
   char* const sUpW = reinterpret_cast<char*>(sUpB + 64);              // ... and its packed weights [4 taps][64 cout][64 cin] (32 KB)
 
@@ -803,7 +818,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     int pk = 0;                           // tiles parked so far: tile k goes to buffer k & 1
     auto park = [&](int tp) __attribute__((always_inline)) {
       const float* sBt = sBias + tp * CT;
-      char* const pb = sPark + (pk & 1) * PARKB + ((cw * MPW * 4 + lh) * 32 + lr) * 16;
+      char* const pb = sPark + (NPARK == 2 ? (pk & 1) : 0) * PARKB + ((cw * MPW * 4 + lh) * 32 + lr) * 16;
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + 16 * qp + 4 * lh);
@@ -897,8 +912,76 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         __builtin_amdgcn_raw_buffer_store_b128(w1, r1, so, 0, 0);
       }
     };
+    // O1C: rows of the tile -> outc_row -> last activation -> fp32 (the lower half-wave holds the sums)
+    vec o1c_w[2];
+    auto epilogue_o1c = [&](const TileCur& c, int tp) __attribute__((always_inline)) {
+      // Straight-line code: the four rows' chains (rounding -> two MFMAs -> sum -> activation) interleave only if nothing between
+      // them branches.  The activation selector is wave-uniform and tested once per tile, not once per row (uncl_act's switch was a
+      // dozen scalar branches per row); rows and columns outside the map add 2^30 to the store's offset, which the buffer
+      // descriptor (one per sample, num_records = its bytes) drops, as in epilogue_lean; the upper half-wave (whose registers do
+      // not hold the sums) is dropped the same way.
+      constexpr unsigned BAD = 0x40000000u;
+      const float* sBt = sBias + tp * CT;
+      const int y0 = c.ty * TH + cw * MPW, ox = c.tx * TW + lr;
+      const unsigned sample = (unsigned)(a.Hout * a.Wout) * 4u;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out1) + (size_t)c.n * sample, (short)0,
+                                                                          (int)sample, 0x00020000);
+      const unsigned loff = ((unsigned)ox * 4u) | ((lh == 0 && ox < a.Wout) ? 0u : BAD);
+      const unsigned rowb = (unsigned)a.Wout * 4u;
+      // outc_row with the tile's bias quads read once (not once per row): the same operations on the same values
+      f32x4 bq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(sBt + 8 * q + 4 * lh);
+      const float ob = sO1[32];
+      typedef float f32x2o __attribute__((ext_vector_type(2)));
+      typedef short s16x8o __attribute__((ext_vector_type(8)));
+      vec Bf[MPW][2];
+#pragma unroll
+      for (int m = 0; m < MPW; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const PcAcc& v = acc[m][0];
+          vec o;
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            const int q = 2 * ks + hq;
+            const f32x2o s0 = f32x2o{v[4 * q], v[4 * q + 1]} + f32x2o{bq[q][0], bq[q][1]};
+            const f32x2o s1 = f32x2o{v[4 * q + 2], v[4 * q + 3]} + f32x2o{bq[q][2], bq[q][3]};
+            o[4 * hq] = (T)s0[0]; o[4 * hq + 1] = (T)s0[1]; o[4 * hq + 2] = (T)s1[0]; o[4 * hq + 3] = (T)s1[1];
+          }
+          s16x8o si = __builtin_bit_cast(s16x8o, o);
+          si = __builtin_elementwise_max(si, s16x8o{0, 0, 0, 0, 0, 0, 0, 0});        // ReLU on the rounded values
+          Bf[m][ks] = __builtin_bit_cast(vec, si);
+        }
+      float tot[MPW];
+      f32x16 dd[MPW];
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) dd[m] = mfma32x16(o1c_w[0], Bf[m][0], zero16);
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) dd[m] = mfma32x16(o1c_w[1], Bf[m][1], dd[m]);
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) tot[m] = ((dd[m][2] + dd[m][1]) + dd[m][0]) + ob;     // smallest piece first, as outc_row
+      if (a.out1_act == UNCL_ACT_SIGMOID) {
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) tot[m] = uncl_sigmoid(tot[m]);
+      } else {
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) tot[m] = uncl_act(tot[m], a.out1_act);
+      }
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) {
+        const int oy = y0 + m;                                     // wave-uniform
+        const unsigned off = loff + (((unsigned)oy * rowb) | (oy < a.Hout ? 0u : BAD));
+#ifdef UNCL_CHECKED
+        if (off < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.out1) + (size_t)c.n * sample + off, 4);
+#endif
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[m]), rs, off, 0, 0);
+      }
+    };
     auto run_epilogue = [&](const TileCur& c, auto tp) __attribute__((always_inline)) {      // (generic: instantiated only where called)
-      if constexpr (SSRB) {
+      if constexpr (O1C != 0) {
+        epilogue_o1c(c, tp);
+      } else if constexpr (SSRB) {
         epilogue_ssr(c);
       } else if constexpr (EPO) {
         if (!PC_ABL(16)) park(tp);
@@ -1090,6 +1173,186 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     if (MODE == 3 || UPT) pc_barrier();     // the staging waves' first image patch / the up-conv's resident weights
     pc_barrier();     // stage 0 is staged
     PCT(2)
+    if constexpr (O1C == 1) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) o1c_w[ks] = *reinterpret_cast<const vec*>(sO1F + (ks * 64 + lane) * 16);
+    }
+    if constexpr (O1C == 2) {
+      // =================================================================================================================
+      // Two accumulator sets (round 6): tile t multiplies into one set while tile t - 1 leaves from the other -- its rounding, the
+      // outconv's eight MFMAs, the activation and the stores are issued in the MFMA stream's shadow (the matrix pipe holds the
+      // SIMD's issue port for 8 of an MFMA's 32 cycles; this wave is alone with one staging wave on its SIMD).  With one set the
+      // multiplying waves of this layer spent 44 % of their time in that epilogue beside staging waves that idled 73 %
+      // (tools/pc_phase_timing.py --layers o1c).  200+ registers: four staging waves (two waves per SIMD).  A tile's first MFMA
+      // per accumulator takes an inline-zero C: nothing to clear.  Same MFMA order per accumulator -> the same bits as O1C == 1.
+      // =================================================================================================================
+      static_assert(NT == 1 && PW == 4, "two accumulator sets: 32-channel tiles, two waves per SIMD");
+      PcAcc acc2[MPW][NT];
+      auto col_into = [&](auto set_tag, int col) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
+        PcAcc (&ac)[MPW][NT] = *(SET ? &acc2 : &acc);
+        const int fs = col & 1;
+        if (col == 0) {
+#pragma unroll
+          for (int m = 0; m < MPW; ++m) ac[m][0] = pc_mm(A[fs][0][0], B[fs][m], zero16, 0);
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 1; ty < 3; ++ty) ac[m][0] = pc_mm(A[fs][ty][0], B[fs][m + ty], ac[m][0], ty);
+        } else {
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) ac[m][0] = pc_mm(A[fs][ty][0], B[fs][m + ty], ac[m][0], ty);
+        }
+      };
+      typedef float f32x2o __attribute__((ext_vector_type(2)));
+      typedef short s16x8o __attribute__((ext_vector_type(8)));
+      // the leaving tile, two rows at a time, in three pieces: rounding (bias, ReLU on the rounded pair: outc_row's operations), the
+      // outconv's MFMAs, sums + activation + stores (epilogue_o1c's).  Row pairs and sched_barriers between the tap columns bound
+      // the live ranges: everything at once (the scheduler's choice when left alone) is 266 registers, and a spilled register's
+      // reload waits on vmcnt, i.e. on the wave's output stores (0.364 against 0.250 ms with four spill reloads per tile)
+      constexpr int HP = MPW / 2;
+      static_assert(MPW % 2 == 0, "row pairs");
+      auto leave_bf = [&](auto set_tag, auto h_tag, vec (&Bf)[2][2]) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value, H = decltype(h_tag)::value;
+        PcAcc (&ac)[MPW][NT] = *(SET ? &acc2 : &acc);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const PcAcc& v = ac[2 * H + r][0];
+            vec o;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+              const int q = 2 * ks + hq;
+              const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + 8 * q + 4 * lh);
+              const f32x2o s0 = f32x2o{v[4 * q], v[4 * q + 1]} + f32x2o{bq[0], bq[1]};
+              const f32x2o s1 = f32x2o{v[4 * q + 2], v[4 * q + 3]} + f32x2o{bq[2], bq[3]};
+              o[4 * hq] = (T)s0[0]; o[4 * hq + 1] = (T)s0[1]; o[4 * hq + 2] = (T)s1[0]; o[4 * hq + 3] = (T)s1[1];
+            }
+            s16x8o si = __builtin_bit_cast(s16x8o, o);
+            si = __builtin_elementwise_max(si, s16x8o{0, 0, 0, 0, 0, 0, 0, 0});
+            Bf[r][ks] = __builtin_bit_cast(vec, si);
+          }
+      };
+      // (the outconv's fragments are read from LDS where they are used: eight registers held for the launch were the ones spilled)
+      auto leave_mm = [&](const vec (&Bf)[2][2], f32x16 (&dd)[2]) __attribute__((always_inline)) {
+        const vec w0 = *reinterpret_cast<const vec*>(sO1F + lane * 16), w1 = *reinterpret_cast<const vec*>(sO1F + (64 + lane) * 16);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) dd[r] = mfma32x16(w0, Bf[r][0], zero16);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) dd[r] = mfma32x16(w1, Bf[r][1], dd[r]);
+      };
+      // (this instantiation IS the sigmoid's -- the launcher takes it only then: a branch inside the tile's body ends the scheduling
+      // region the leaving tile is interleaved in, and the matrix pipe then idles for the length of the activation)
+      auto leave_fin = [&](const TileCur& c, auto h_tag, const f32x16 (&dd)[2]) __attribute__((always_inline)) {
+        constexpr int H = decltype(h_tag)::value;
+        constexpr unsigned BAD = 0x40000000u;
+        const int y0 = c.ty * TH + cw * MPW + 2 * H, ox = c.tx * TW + lr;
+        const unsigned sample = (unsigned)(a.Hout * a.Wout) * 4u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out1) + (size_t)c.n * sample, (short)0,
+                                                                            (int)sample, 0x00020000);
+        const unsigned loff = ((unsigned)ox * 4u) | ((lh == 0 && ox < a.Wout) ? 0u : BAD);
+        const unsigned rowb = (unsigned)a.Wout * 4u;
+        const float ob = sO1[32];
+        float tot[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) tot[r] = uncl_sigmoid(((dd[r][2] + dd[r][1]) + dd[r][0]) + ob);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int oy = y0 + r;
+          const unsigned off = loff + (((unsigned)oy * rowb) | (oy < a.Hout ? 0u : BAD));
+#ifdef UNCL_CHECKED
+          if (off < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.out1) + (size_t)c.n * sample + off, 4);
+#endif
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[r]), rs, off, 0, 0);
+        }
+      };
+      // per tap column: its MFMAs, the next column's fragment reads (one per MFMA gap), and `valu` vector instructions of the leaving
+      // tile per gap
+      auto sched_col = [&](auto mm_tag, auto reads_tag, auto valu_tag) __attribute__((always_inline)) {
+        constexpr int MM = decltype(mm_tag)::value, READS = decltype(reads_tag)::value, VALU = decltype(valu_tag)::value;
+#pragma unroll
+        for (int k = 0; k < MM; ++k) {
+          if (k < READS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (VALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+        }
+      };
+      int s = 0;
+      rd(smem, wres, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      // the tile entering set SET; `leaving`: the tile in the other set (cursor lc) leaves beside it
+      auto tile_step = [&](auto set_tag, auto leaving_tag, const TileCur& lc, bool more) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool LEAVING = decltype(leaving_tag)::value != 0;
+        static_assert(MPW == 4, "two row pairs");
+        const char* const st = smem + (s & 1) * STAGE;
+        vec Bf0[2][2], Bf1[2][2];
+        f32x16 dd0[2], dd1[2];
+        // column 0: rows 0 / 1 of the leaving tile are rounded
+        rd(st, wres, 1, 1); col_into(set_tag, 0);
+        if (LEAVING) leave_bf(IntTag<SET ^ 1>{}, IntTag<0>{}, Bf0);
+        sched_col(IntTag<NMM>{}, IntTag<NRD>{}, IntTag<(LEAVING ? 4 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // column 1: their outconv MFMAs; rows 2 / 3 are rounded (the leaving set is dead from here on)
+        rd(st, wres, 0, 2); col_into(set_tag, 1);
+        if (LEAVING) { leave_mm(Bf0, dd0); leave_bf(IntTag<SET ^ 1>{}, IntTag<1>{}, Bf1); }
+        sched_col(IntTag<NMM + (LEAVING ? 4 : 0)>{}, IntTag<NRD>{}, IntTag<(LEAVING ? 4 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // column 2: the outconv MFMAs of rows 2 / 3
+        rd(st, wres, 1, 3); col_into(set_tag, 2);
+        if (LEAVING) leave_mm(Bf1, dd1);
+        sched_col(IntTag<NMM + (LEAVING ? 4 : 0)>{}, IntTag<NRD>{}, IntTag<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // columns 3, 4: sums, activation, stores
+        rd(st, wres, 0, 4); col_into(set_tag, 3);
+        if (LEAVING) leave_fin(lc, IntTag<0>{}, dd0);
+        sched_col(IntTag<NMM>{}, IntTag<NRD>{}, IntTag<(LEAVING ? 4 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        rd(st, wres, 1, 5); col_into(set_tag, 4);
+        if (LEAVING) leave_fin(lc, IntTag<1>{}, dd1);
+        sched_col(IntTag<NMM>{}, IntTag<NRD>{}, IntTag<(LEAVING ? 4 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        col_into(set_tag, 5);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pc_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ++s;
+        if (more) {
+          rd(smem + (s & 1) * STAGE, wres, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        }
+      };
+      TileCur lc = cc;                     // the leaving tile's coordinates
+      int t = tile0;
+      tile_step(IntTag<0>{}, IntTag<0>{}, lc, t + 1 < tile_end);
+      ++t;
+      int last = 0;                        // the set of the last tile multiplied
+      for (;;) {
+        if (t >= tile_end) { last = 0; break; }
+        lc = cc; cc.kc = a.nk - 1; cur_next<TAIL>(cc, a, tile_end);
+        tile_step(IntTag<1>{}, IntTag<1>{}, lc, t + 1 < tile_end);
+        ++t;
+        if (t >= tile_end) { last = 1; break; }
+        lc = cc; cc.kc = a.nk - 1; cur_next<TAIL>(cc, a, tile_end);
+        tile_step(IntTag<0>{}, IntTag<1>{}, lc, t + 1 < tile_end);
+        ++t;
+      }
+      {
+        vec Bf0[2][2], Bf1[2][2];
+        f32x16 dd0[2], dd1[2];
+        if (last == 0) { leave_bf(IntTag<0>{}, IntTag<0>{}, Bf0); leave_bf(IntTag<0>{}, IntTag<1>{}, Bf1); }
+        else { leave_bf(IntTag<1>{}, IntTag<0>{}, Bf0); leave_bf(IntTag<1>{}, IntTag<1>{}, Bf1); }
+        leave_mm(Bf0, dd0);
+        leave_mm(Bf1, dd1);
+        leave_fin(cc, IntTag<0>{}, dd0);
+        leave_fin(cc, IntTag<1>{}, dd1);
+      }
+      return;
+    }
     // The barrier of a chunk sits between its LAST fragment read and the MFMAs of its last tap column: "done with the stage" is
     // true as soon as column 5's fragments have landed, and the twelve-plus MFMAs still to go then cover the LDS latency of the
     // next chunk's first fragments (a wave alone on its SIMD has nobody else to hide it: the MFMA phase ran at 80 - 84 % of its
@@ -1145,6 +1408,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   // producers
   // ===================================================================================================================
   if ((a.pc_prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
+  PCT_DECL          // (timing builds: declared before the staging lambdas, which stamp inside the fused first layer's rebuild)
   const int ptid = tid - NCW * 64;
   const int pwave = wave - NCW;
   // per-thread constants of the staging pattern (identical for every step): regular slot j = halo pixel (hy0 + RSTEP*j, hx),
@@ -1539,6 +1803,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           }
         }
       }
+      PCT_K(0, 1)       // (fused first layer, timing builds: slot 1 = the rebuild, slot 2 = parking the next patch)
 #pragma unroll
       for (int k = 0; k < IRN; ++k)
         if (ptid + k * NPROD < PN3) reinterpret_cast<unsigned*>(sP)[(p3par ^ 1) * PN3 + ptid + k * NPROD] = pack_head_tail(ir[k]);
@@ -1679,7 +1944,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
     typedef short s16x8s __attribute__((ext_vector_type(8)));
     constexpr unsigned BAD = 0x40000000u;
-    const char* const pb = sPark + (spk & 1) * PARKB;
+    const char* const pb = sPark + (NPARK == 2 ? (spk & 1) : 0) * PARKB;
     const int slot = ptid & 3, px = (ptid >> 2) & 15;
     const int y0 = sc.ty * TH, x0 = sc.tx * TW;
     const unsigned sample = (unsigned)(a.Hout * a.Wout * a.oC) * 2u;
@@ -1765,6 +2030,26 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     }
   };
   if (a.out1_w != nullptr && ptid < 33) { UNCL_CHK(a.chk, ptid < 32 ? a.out1_w + ptid : a.out1_b, 4); sO1[ptid] = ptid < 32 ? a.out1_w[ptid] : a.out1_b[0]; }     // fused 1x1 tail (CT == 32)
+  if (O1C && ptid < 128) {
+    // the outconv's A fragments as outc_frags builds them: lane (row fr, K-slot fh) of K-step ks holds piece fr (of three 16-bit pieces,
+    // rows 0..2; zero elsewhere) of weights 16 ks + 8 (j >> 2) + 4 fh + (j & 3)
+    const int ks = ptid >> 6, fr = ptid & 31, fh = (ptid >> 5) & 1;
+    vec fv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      UNCL_CHK(a.chk, a.out1_w + 16 * ks + 8 * (j >> 2) + 4 * fh + (j & 3), 4);
+      float w = a.out1_w[16 * ks + 8 * (j >> 2) + 4 * fh + (j & 3)];
+      T piece = (T)0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const T h = (T)w;
+        if (fr == t) piece = h;
+        w -= (float)h;
+      }
+      fv[j] = piece;
+    }
+    *reinterpret_cast<vec*>(sO1F + ptid * 16) = fv;
+  }
   if (TAIL && ptid < 32) { if (a.tail_b != nullptr) UNCL_CHK(a.chk, a.tail_b + ptid, 4); sB1[ptid] = a.tail_b != nullptr ? a.tail_b[ptid] : 0.f; }
   if (UPT) {
     // the up-conv's weights and bias become resident (read again per slice and tile by every staging wave)
@@ -1814,7 +2099,6 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   }
   write_step(smem, IntTag<0>{});
   load_next(IntTag<1>{});
-  PCT_DECL
   pc_barrier();                         // stage 0 is staged
   PCT(3)
   // iteration s (the consumers multiply chunk s): chunk s + 1 goes from registers to the stage the consumers left at the
@@ -1822,20 +2106,23 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   int s = 0;
   auto iter = [&](auto q_tag) __attribute__((always_inline)) {
     constexpr int Q = decltype(q_tag)::value;
-    if (EPO && s > 0 && s % a.nk == 0) store_parked();     // the tile that ended with chunk s - 1
+    if (EPO && NPARK == 2 && s > 0 && s % a.nk == 0) { store_parked(); if (MODE == 3) { PCT_K(0, 0) } }     // the tile that ended with chunk s - 1
+    // (one buffer, four chunks per tile: the previous tile leaves during this tile's chunk UNCL_PC_EPO_Q -- 2: the lightest staging
+    // iteration, the plain x2 slice; 3 would race with the multiplying waves' next park)
+    if (EPO && NPARK == 1 && Q == UNCL_PC_EPO_Q && s >= a.nk) store_parked();
     if (s + 1 >= total) {
       pc_barrier();                     // the consumers' last chunk
       if (EPO) store_parked();          // ... and its tile
       return true;
     }
     write_step(smem + ((Q + 1) & 1) * STAGE, IntTag<(Q + 1) & 3>{});
-    PCT_K(1, Q)
+    PCT_K(1, MODE == 3 ? 2 : Q)
     load_next(IntTag<(Q + 2) & 3>{});
     // the next tile's x1 chunk (chunk s + 3 / s + 2): one half of its source tiles per iteration, so that neither iteration
     // outlasts the multiplying waves' chunk by much
     if (TAIL && Q == 1 && s + 3 < total) up_compute(IntTag<0>{}, IntTag<MT_PER / 2>{});
     if (TAIL && Q == 2 && s + 2 < total) up_compute(IntTag<MT_PER / 2>{}, IntTag<MT_PER>{});
-    PCT_K(2, Q)
+    PCT_K(2, MODE == 3 ? 3 : Q)
     pc_barrier();
     PCT_K(3, 4 + Q)
     ++s;
@@ -1859,11 +2146,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
 }
 
 template <int NT, int MPW>
-constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, int upc = 0, bool epo = false) {
+constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, int upc = 0, int epo = 0, bool o1c = false) {
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
   return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0) +
          (upc ? 64 * 4 + 4 * upc * upc * 2 : 0) +      // (the up-conv's bias and weights, where they are resident)
-         (epo ? 2 * (size_t)(MPW * 4) * 32 * 4 * 16 : 0);   // (two parked tiles)
+         (size_t)epo * (MPW * 4) * 32 * 4 * 16 +            // (`epo` parked tiles)
+         (o1c ? 2048 : 0);                                  // (the outconv's A fragments)
 }
 
 // fused last decoder stage: one workgroup per CU walks an even share of the (strip, row tile) steps
@@ -1890,18 +2178,18 @@ int launch_tail(PipeArgs& a, hipStream_t s) {
   return UNCL_OK;
 }
 
-template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool EPO = false, bool SSRB = false>
+template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool EPO = false, bool SSRB = false, int O1C = 0>
 int launch_pc(PipeArgs& a, hipStream_t s) {
   constexpr int UPC_LDS = MODE == 5 ? 64 : (MODE == 4 && PW == 8 && UNCL_PC_UP_TILE ? 32 : 0);
-  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS, EPO);
+  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS, EPO ? (MODE == 4 ? 1 : 2) : 0, O1C != 0);
   static_assert(pc_lds_bytes<NT, MPW>(false, 0, false, UPC_LDS) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
-  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW, false, EPO, SSRB>;
+  auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW, false, EPO, SSRB, O1C>;
   static UnclDevOnce attr_done;
   if (attr_done.need()) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(RESW && !EPO ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, UPC_LDS) : lds)) != hipSuccess)
+                            (int)(RESW && !EPO && !O1C ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, UPC_LDS) : lds)) != hipSuccess)
       return UNCL_ERR_LAUNCH;
     attr_done.done();
   }
@@ -1966,6 +2254,15 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
     static const int epo_on = [] { const char* e = getenv("UNCL_PC_EPO"); return e ? atoi(e) : 1; }();
     const bool epo = epo_on && resw && a.nk == 1 && fwd_relu && a.lean && a.out1_w == nullptr && !a.skip_main;
     if (epo && mode == 0) return launch_pc<T, 1, 4, 0, 8, true, true>(a, s);
+    // inference's last layer: only the one-channel map is wanted -> the 1x1 tail straight from the accumulators (O1C)
+    static const int o1c_on = [] { const char* e = getenv("UNCL_PC_O1C"); return e ? atoi(e) : 2; }();
+    if (o1c_on && mode == 0 && resw && a.nk == 1 && fwd_relu && a.lean && a.out1_w != nullptr && a.skip_main && a.pool_out == nullptr) {
+      static const int o1c_prio = [] { const char* e = getenv("UNCL_PC_O1C_PRIO"); return e ? atoi(e) : -1; }();
+      if (o1c_prio >= 0) a.pc_prio = o1c_prio;
+      // two accumulator sets, four staging waves (the sigmoid's instantiation: the activation is compiled in, see tile_step)
+      if (o1c_on >= 2 && a.out1_act == UNCL_ACT_SIGMOID) return launch_pc<T, 1, 4, 0, 4, true, false, false, 2>(a, s);
+      return launch_pc<T, 1, 4, 0, 8, true, false, false, 1>(a, s);
+    }
     if (mode == 3) return resw && a.nk == 1 ? launch_pc<T, 1, 4, 3, 8, true>(a, s) : UNCL_ERR_ARG;
     if (resw) {
       if (mode == 0) return launch_pc<T, 1, 4, 0, 8, true>(a, s);
@@ -1984,8 +2281,21 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
     // stages; 252 rows are 21 tiles exactly)
     static const int epo_on = [] { const char* e = getenv("UNCL_PC_EPO"); return e ? atoi(e) : 1; }();
     if (a.pool_out != nullptr && !fwd_relu) return UNCL_ERR_ARG;
+    if (mode == 4) {
+      // the four-chunk concat layer with the fused up-conv (inference's dominant launch): parked epilogue, one buffer
+      if (!(epo_on && resw && a.nk == 4 && fwd_relu && a.lean && a.out1_w == nullptr && !a.skip_main && a.pool_out == nullptr)) return UNCL_ERR_ARG;
+      return launch_pc<T, 1, 3, 4, 8, true, true>(a, s);
+    }
     if (!(epo_on && resw && a.nk == 1 && fwd_relu && a.lean && a.out1_w == nullptr && !a.skip_main)) return UNCL_ERR_ARG;
-    if (mode == 3) return launch_pc<T, 1, 3, 3, 8, true, true>(a, s);
+    if (mode == 3) {
+      // the fused first layer waits for its STAGING waves (round 6, tools/pc_phase_timing.py: per tile 1840 cycles storing the parked
+      // tile + 1970 rebuilding the next halo tile, the multiplying waves 40 % at the barrier): they get the raised priority here, not
+      // the multiplying waves -- same-box A/B 0.346 -> 0.327 ms per 200 tiles (the multi-chunk layers lose 6 % that way)
+      static const int prio3 = [] { const char* e = getenv("UNCL_PC_PRIO3"); return e ? atoi(e) : 2; }();
+      static const bool prio_env = getenv("UNCL_PC_PRIO") != nullptr;
+      if (!prio_env) a.pc_prio = prio3;
+      return launch_pc<T, 1, 3, 3, 8, true, true>(a, s);
+    }
     if (mode == 0) return launch_pc<T, 1, 3, 0, 8, true, true>(a, s);
     return UNCL_ERR_ARG;
   }

@@ -1064,6 +1064,20 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   const bool pc_ok = g_use_pc && pc_mode >= (g_use_pc >= 2 ? 0 : 1) && a.nk >= 1 && d->res == nullptr &&
                      ((d->out1_w == nullptr && !d->skip_main_store) || (g_use_pc == 3 && d->Cout == 32 && d->out1_b != nullptr));
   if (d->Cout == 32) {
+    // Round 6: inference's last layer (plain 32 -> 32 source, only the one-channel map wanted) on the producer / consumer structure
+    // with the 1x1 tail straight from the accumulators (conv3x3_pc.hip, O1C): 16-row tiles, resident weights, eight staging waves
+    // that do nothing but load -- the four-wave form below reads its 10 x 34 halo per 8 x 32 outputs through waves that also
+    // multiply.  Same arithmetic per output (outc_row): the two forms agree to fp32 reassociation of the three partial dot products.
+    static const int o1c_on = [] { const char* e = getenv("UNCL_PC_O1C"); return e ? atoi(e) : 1; }();      // 0: the four-wave form (A/B)
+    if (o1c_on && g_use_pc >= 2 && pc_mode == 0 && a.nk == 1 && d->out1_w != nullptr && d->skip_main_store && d->out1_b != nullptr &&
+        d->out1 != nullptr && a.slope == 0.f && d->res == nullptr && pool_out == nullptr && mask == nullptr && !accumulate) {
+      PipeArgs b = a;
+      b.n_ct = 1;
+      b.tiles_x = (a.Wout + 31) / 32; b.tiles_y = (a.Hout + 15) / 16;
+      b.total_tiles = d->N * b.tiles_x * b.tiles_y;
+      const int rc = uncl_conv3x3_pc_launch(b, d->dtype, 1, 4, 0, s);
+      if (rc != UNCL_ERR_ARG) return rc;
+    }
     // 8-row tiles at three workgroups per CU (50 KB LDS, 168 VGPRs) overlap the serial load / stage / store phases of the
     // single-chunk 32 -> 32 transposed layers better than 16-row tiles at two (measured: up_path.{2,3}.conv.conv1 -9 %);
     // the valid 32 -> 32 layer and the multi-chunk concat layers are faster (or read less) with the larger tile
@@ -1095,6 +1109,18 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
       // the fused first layer: 12-row tiles with the epilogue parked for the staging waves (conv3x3_pc.hip, EPO)
       static const int epo12 = [] { const char* e = getenv("UNCL_PC_EPO12"); return e ? atoi(e) : 1; }();
       if (epo12 && pc_mode == 3 && a.nk == 1 && d->out1_w == nullptr && !d->skip_main_store) {
+        PipeArgs b = a;
+        b.tiles_y = (a.Hout + 11) / 12;
+        b.total_tiles = d->N * b.tiles_x * b.tiles_y;
+        const int rc = uncl_conv3x3_pc_launch(b, d->dtype, 1, 3, pc_mode, s);
+        if (rc != UNCL_ERR_ARG) return rc;
+      }
+      // Round 6, built and measured, OFF (UNCL_PC_EPO4=1 turns it on): the concat layer with the fused 32-channel up-conv (inference's
+      // dominant launch) on 12-row tiles with the epilogue parked for the staging waves (conv3x3_pc.hip, EPO with one buffer).  Its
+      // multiplying waves spend 19 % of their time storing, but its staging waves are 64 % busy already: with the parked tile to
+      // store and 14 halo rows per 12 outputs they become what the launch waits for -- same-box A/B 0.772 -> 0.831 ms per 200 tiles
+      static const int epo4 = [] { const char* e = getenv("UNCL_PC_EPO4"); return e ? atoi(e) : 0; }();
+      if (epo4 && pc_mode == 4 && a.nk == 4 && d->out1_w == nullptr && !d->skip_main_store && pool_out == nullptr) {
         PipeArgs b = a;
         b.tiles_y = (a.Hout + 11) / 12;
         b.total_tiles = d->N * b.tiles_x * b.tiles_y;

@@ -58,18 +58,6 @@ _LAST = {"sigmoid": _hip.ACT_SIGMOID, "tanh": _hip.ACT_TANH, "msig": _hip.ACT_MS
 class _GeneratorBase(nn.Module):
     """Parameter container + packing cache shared by the image and video generators."""
 
-
-    def _warn_detached(self, x):
-        """The reference back-propagates through an eval-mode BatchNorm; the folded inference path here cannot.  A caller with grad
-        enabled and something that requires grad gets outputs detached from the graph: say so (once per module) instead of handing
-        back zero / missing gradients silently."""
-        if torch.is_grad_enabled() and not getattr(self, "_warned_detached", False) and \
-                (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            import warnings
-            warnings.warn("uncltmo_amd: the batch_norm generator in eval() mode runs the folded inference path, which has no backward "
-                          "pass: its outputs are detached from the autograd graph (call it under torch.no_grad(), or use train() mode "
-                          "to back-propagate)", RuntimeWarning, stacklevel=3)
-            self._warned_detached = True
     def __init__(self, n_channels, output_dim, last_layer, depth, layer_factor, con_operator, filters, bilinear,
                  network, dilation, to_crop, unet_norm, stretch_g, activation, doubleConvTranspose,
                  padding_mode, convtranspose_kernel, up_mode=True, recurrent_ch_ratio=1 / 32,
@@ -90,6 +78,12 @@ class _GeneratorBase(nn.Module):
         elif layer_factor != params.get_layer_factor(con_operator):
             unsupported.append("layer_factor=%s does not match con_operator=%s (the reference's first decoder convolution would "
                                "refuse the concatenation)" % (layer_factor, con_operator))
+        # ... exact only while every product with a zero weight is finite: the loaders still evaluate sqrt(x2 + 1e-8) and x2^2 for the
+        # members an operator leaves out, and with a leaky ReLU x2 < 0 makes the square root a NaN (NaN * 0 = NaN in the matrix
+        # cores, forward and backward) where the reference has no such member and stays finite
+        elif con_operator != params.square_and_square_root and activation == "leakyrelu":
+            unsupported.append("con_operator=%s with activation=leakyrelu (the sub-set operators run on the four-member kernels, "
+                               "whose square-root member is NaN for negative skip values)" % con_operator)
         if depth != 4 or filters != 32:
             unsupported.append("depth/filters=%s/%s" % (depth, filters))
         # bilinear=1: nn.Upsample(scale_factor=2) [nearest] + Conv2d 1x1 (unet_parts.py:256-259) IS a stride-2 2x2 transposed
@@ -101,7 +95,7 @@ class _GeneratorBase(nn.Module):
         if n_channels != 1 or output_dim != 1:
             unsupported.append("n_channels/output_dim must be 1")
         if unet_norm not in ("none", None, "instance_norm", "batch_norm"):
-            unsupported.append("unet_norm=%s (HIP path covers 'none', 'instance_norm' and, for inference, 'batch_norm')" % unet_norm)
+            unsupported.append("unet_norm=%s (HIP path covers 'none', 'instance_norm' and 'batch_norm')" % unet_norm)
         if last_layer not in _LAST:
             unsupported.append("last_layer=%s" % last_layer)
         # stretch_g: the reference builds Blocks.BatchMaxNormalization / MinMaxNormalization into `self.stretch` (parameter-free,
@@ -145,6 +139,18 @@ class _GeneratorBase(nn.Module):
         self._pack_key = None
         self._packed = None
         self._ws = {}
+
+    def _warn_detached(self, x):
+        """The reference back-propagates through an eval-mode BatchNorm; the folded inference path here cannot.  A caller with grad
+        enabled and something that requires grad gets outputs detached from the graph: say so (once per module) instead of handing
+        back zero / missing gradients silently."""
+        if torch.is_grad_enabled() and not getattr(self, "_warned_detached", False) and \
+                (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            import warnings
+            warnings.warn("uncltmo_amd: the batch_norm generator in eval() mode runs the folded inference path, which has no backward "
+                          "pass: its outputs are detached from the autograd graph (call it under torch.no_grad(), or use train() mode "
+                          "to back-propagate)", RuntimeWarning, stacklevel=3)
+            self._warned_detached = True
 
     def zero_grad(self, set_to_none=True):
         """nn.Module.zero_grad + the data-parallel reducer's pending passes: gradients of a backward pass whose optimiser step
@@ -549,6 +555,7 @@ class UNet(_GeneratorBase):
         out, _, _, _ = self._run(frames.float().contiguous(), need_feat=False, tiles_in_place=off)
         return out
 
+    @torch.no_grad()
     def infer(self, x, want_knn=False):
         """Inference entry used by the tiler: (N,1,256,256) -> (N,1,256,256); skips writing up_x to HBM."""
         self._check_input(x, 2)
