@@ -43,6 +43,7 @@ struct PipeArgs {
   const float* tail_b;  // its bias (32) or NULL
   int oH, oW;           // extent of the final one-channel map: Hout + 2, Wout + 2
   int o1_lds_off;       // conv3x3_pipe: byte offset of the parked outconv fragments in LDS (register-direct 1x1 tail)
+  int epo2;             // conv3x3_pc, 8-row 64-channel tiles: 1 = the launcher asks for the parked epilogue (round 6)
   // conv3x3_pc, gradient mode, SSRB epilogue: this launch is the data gradient of a skip-concat layer (cout' = 4 C in the interleaved
   // order of uncl_pack_item.cout_order = 1) and its epilogue is the backward of the skip operator (unet_parts.py:319-322):
   // g_x2 = (g0 + 2 x2 g2 + g3 / (2 sqrt(x2 + 1e-8))) relu'(x2) [written or accumulated], g_x1 = g1; the 4 C-channel gradient of

@@ -256,12 +256,19 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
   float* const sB1 = sO1 + 64;                                        // TAIL: bias of the second layer (32)
   char* const sW1 = reinterpret_cast<char*>(sB1 + 32);                // TAIL: the second layer's weights, [4 planes][9 taps x 32 rows]
   char* const sCarry = sW1 + 4 * W1PL;                                // TAIL: [2][4 planes][2 rows x HW] last two intermediate rows
-  static_assert(!EPO || (NT == 1 && !TAIL && (MODE == 0 || MODE == 3 || MODE == 4) && RESW), "parked epilogue: 32-channel tiles, resident weights");
-  constexpr int PARKB = TH * 32 * 4 * 16;                             // EPO: one parked tile, [row][K-slot][pixel] 16-byte vectors
+  static_assert(!EPO || (!TAIL && RESW && ((NT == 1 && (MODE == 0 || MODE == 3 || MODE == 4)) || (NT == 2 && MODE == 0 && MPW == 2))),
+                "parked epilogue: 32-channel tiles, or 8-row 64-channel tiles of a plain source; resident weights");
+  // EPO: one parked tile, [row][K-slot][pixel] 16-byte vectors.  64-channel tiles (round 6) pad a K-slot's 32 pixels by one vector: the
+  // staging waves read eight slots of one pixel with neighbouring lanes, and at a 512-byte pitch all of them start on one bank
+  constexpr int PSL = NT == 2 ? 33 * 16 : 32 * 16;                    // bytes per (row, K-slot)
+  constexpr int PARKB = TH * (NT * 4) * PSL;
   // Single-chunk layers park into two buffers (the tile's own barrier is the only hand-over).  The four-chunk concat layer (MODE 4,
   // round 6: 12-row tiles, whose stages leave 24 KB of the 160) has ONE: a tile is parked at the end of its last chunk and stored by
   // the staging waves during chunk UNCL_PC_EPO_Q of the NEXT tile, i.e. at least one barrier before the next tile is parked.
   constexpr int NPARK = MODE == 4 ? 1 : 2;
+  // (64-channel tiles: two buffers for a single-chunk layer, ONE -- stored during the next tile's first chunk -- for two chunks, whose
+  // second weight chunk takes the room: a run-time mask on the buffer index)
+  const int park_mask = NPARK == 2 && (NT == 1 || a.nk == 1) ? 1 : 0;
   char* const sPark = MODE == 3 ? reinterpret_cast<char*>(sP + 2 * PN3) : reinterpret_cast<char*>(sO1 + 64);     // EPO: [2][PARKB]
   static_assert(!O1C || (NT == 1 && MODE == 0 && RESW && !TAIL && !EPO && !SSRB), "accumulator-direct 1x1 tail: 32-channel tiles, plain source, resident weights");
   char* const sO1F = reinterpret_cast<char*>(sO1 + 64);               // O1C: the outconv's two A fragments, [2][64 lanes] 16-byte vectors
@@ -818,14 +825,16 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     int pk = 0;                           // tiles parked so far: tile k goes to buffer k & 1
     auto park = [&](int tp) __attribute__((always_inline)) {
       const float* sBt = sBias + tp * CT;
-      char* const pb = sPark + (NPARK == 2 ? (pk & 1) : 0) * PARKB + ((cw * MPW * 4 + lh) * 32 + lr) * 16;
+      char* const pb = sPark + (pk & park_mask) * PARKB + (cw * MPW * (NT * 4) + lh) * PSL + lr * 16;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + 16 * qp + 4 * lh);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBt + 16 * qp + 8 + 4 * lh);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 4 * lh);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sBt + nt * 32 + 16 * qp + 8 + 4 * lh);
 #pragma unroll
         for (int m = 0; m < MPW; ++m) {
-          const PcAcc& v = acc[m][0];
+          const PcAcc& v = acc[m][nt];
           auto p4 = [&](int q, const f32x4& b) __attribute__((always_inline)) {
             const f32x2 s0 = f32x2{v[4 * q], v[4 * q + 1]} + f32x2{b[0], b[1]};
             const f32x2 s1 = f32x2{v[4 * q + 2], v[4 * q + 3]} + f32x2{b[2], b[3]};
@@ -839,7 +848,7 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
           const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
           s16x8 si = __builtin_bit_cast(s16x8, w);
           si = __builtin_elementwise_max(si, s16x8{0, 0, 0, 0, 0, 0, 0, 0});    // ReLU on the rounded values
-          *reinterpret_cast<s16x8*>(pb + ((m * 4 + 2 * qp) * 32) * 16) = si;
+          *reinterpret_cast<s16x8*>(pb + (m * (NT * 4) + nt * 4 + 2 * qp) * PSL) = si;
         }
       }
       ++pk;
@@ -1944,9 +1953,12 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
     typedef short s16x8s __attribute__((ext_vector_type(8)));
     constexpr unsigned BAD = 0x40000000u;
-    const char* const pb = sPark + (NPARK == 2 ? (spk & 1) : 0) * PARKB;
-    const int slot = ptid & 3, px = (ptid >> 2) & 15;
-    const int y0 = sc.ty * TH, x0 = sc.tx * TW;
+    constexpr int NSL = NT * 4;                      // K-slots (16-byte vectors) per pixel of the tile
+    constexpr int PXW = 64 / NSL;                    // pixels per wave store: 16 x 64 B (32-channel tiles), 8 x 128 B (64-channel tiles)
+    constexpr int NH = 32 / PXW;                     // wave stores per tile row
+    const char* const pb = sPark + (spk & park_mask) * PARKB;
+    const int slot = ptid & (NSL - 1), px = (ptid / NSL) & (PXW - 1);
+    const int y0 = sc.ty * TH, x0 = sc.tx * TW, co = sc.ct * CT;
     const unsigned sample = (unsigned)(a.Hout * a.Wout * a.oC) * 2u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (size_t)sc.n * sample, (short)0,
                                                                         (int)sample, 0x00020000);
@@ -1958,20 +1970,20 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
     const unsigned prowb = (unsigned)(a.pW * a.oC) * 2u;
 #pragma unroll
     for (int rp = pwave; rp < TH / 2; rp += PW) {
-      s16x8s v[2][2];
+      s16x8s v[2][NH];
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          v[dy][h] = *reinterpret_cast<const s16x8s*>(pb + (((2 * rp + dy) * 4 + slot) * 32 + 16 * h + px) * 16);
+        for (int h = 0; h < NH; ++h)
+          v[dy][h] = *reinterpret_cast<const s16x8s*>(pb + ((2 * rp + dy) * NSL + slot) * PSL + (PXW * h + px) * 16);
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy) {
         const int oy = y0 + 2 * rp + dy;
         const unsigned ro = ((unsigned)oy * rowb) | (oy < a.Hout ? 0u : BAD);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int ox = x0 + 16 * h + px;
-          const unsigned off = (((unsigned)(ox * a.oC + 8 * slot) * 2u) | (ox < a.Wout ? 0u : BAD)) + ro;
+        for (int h = 0; h < NH; ++h) {
+          const int ox = x0 + PXW * h + px;
+          const unsigned off = (((unsigned)(ox * a.oC + co + 8 * slot) * 2u) | (ox < a.Wout ? 0u : BAD)) + ro;
 #ifdef UNCL_CHECKED
           if (off < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.out) + (size_t)sc.n * sample + off, 16);
 #endif
@@ -1983,14 +1995,15 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
         const int gy = (y0 >> 1) + rp;
         const unsigned ro = ((unsigned)gy * prowb) | (gy < a.pH ? 0u : BAD);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
           s16x8s m = __builtin_elementwise_max(v[0][h], v[1][h]);
           u32x4s u = __builtin_bit_cast(u32x4s, m), o;
+          // the neighbouring pixel's lane: lane ^ 4 (four K-slots per pixel) / lane ^ 8 (eight)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = (unsigned)__builtin_amdgcn_ds_swizzle((int)u[i], 0x101F);      // lane ^ 4: the neighbouring pixel
+          for (int i = 0; i < 4; ++i) o[i] = (unsigned)__builtin_amdgcn_ds_swizzle((int)u[i], NSL == 4 ? 0x101F : 0x201F);
           m = __builtin_elementwise_max(m, __builtin_bit_cast(s16x8s, o));
-          const int gx = (x0 >> 1) + 8 * h + (px >> 1);
-          const unsigned off = (((unsigned)(gx * a.oC + 8 * slot) * 2u) | (gx < a.pW ? 0u : BAD)) + ro;
+          const int gx = (x0 >> 1) + (PXW / 2) * h + (px >> 1);
+          const unsigned off = (((unsigned)(gx * a.oC + co + 8 * slot) * 2u) | (gx < a.pW ? 0u : BAD)) + ro;
           if ((px & 1) == 0) {
 #ifdef UNCL_CHECKED
             if (off < BAD) UNCL_CHK(a.chk, reinterpret_cast<const char*>(a.pool_out) + (size_t)sc.n * psample + off, 16);
@@ -2150,7 +2163,7 @@ constexpr size_t pc_lds_bytes(bool resw, int nk, bool patch, int upc = 0, int ep
   constexpr size_t xb = 4 * (size_t)pc_plane((MPW * 4 + 2) * 34), wb = 4 * (size_t)pc_plane(9 * NT * 32);
   return (resw ? 2 * xb + nk * wb : 2 * (xb + wb)) + 4 * NT * 32 * 4 + 64 * 4 + (patch ? 2 * (size_t)(MPW * 4 + 4) * 36 * 4 : 0) +
          (upc ? 64 * 4 + 4 * upc * upc * 2 : 0) +      // (the up-conv's bias and weights, where they are resident)
-         (size_t)epo * (MPW * 4) * 32 * 4 * 16 +            // (`epo` parked tiles)
+         (size_t)epo * (MPW * 4) * (NT * 4) * (NT == 2 ? 33 * 16 : 32 * 16) +      // (`epo` parked tiles)
          (o1c ? 2048 : 0);                                  // (the outconv's A fragments)
 }
 
@@ -2181,7 +2194,7 @@ int launch_tail(PipeArgs& a, hipStream_t s) {
 template <typename T, int NT, int MPW, int MODE, int PW, bool RESW, bool EPO = false, bool SSRB = false, int O1C = 0>
 int launch_pc(PipeArgs& a, hipStream_t s) {
   constexpr int UPC_LDS = MODE == 5 ? 64 : (MODE == 4 && PW == 8 && UNCL_PC_UP_TILE ? 32 : 0);
-  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS, EPO ? (MODE == 4 ? 1 : 2) : 0, O1C != 0);
+  const size_t lds = pc_lds_bytes<NT, MPW>(RESW, a.nk, MODE == 3, UPC_LDS, EPO ? ((MODE == 4 || (NT == 2 && a.nk > 1)) ? 1 : 2) : 0, O1C != 0);
   static_assert(pc_lds_bytes<NT, MPW>(false, 0, false, UPC_LDS) <= 163840, "one workgroup's LDS");
   if (lds > 163840) return UNCL_ERR_ARG;
   auto kern = conv3x3_pc_kernel<T, NT, MPW, MODE, PW, RESW, false, EPO, SSRB, O1C>;
@@ -2189,7 +2202,8 @@ int launch_pc(PipeArgs& a, hipStream_t s) {
   if (attr_done.need()) {
     // the largest footprint this instance can be launched with (resident weights: up to four chunks of 32 / two of 64 channels)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(RESW && !EPO && !O1C ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, UPC_LDS) : lds)) != hipSuccess)
+                            (int)(RESW && !EPO && !O1C ? pc_lds_bytes<NT, MPW>(true, 4 / NT, MODE == 3, UPC_LDS)
+                                                       : (EPO ? (size_t)163840 : lds))) != hipSuccess)     // (parked tiles: chunk count decides)
       return UNCL_ERR_LAUNCH;
     attr_done.done();
   }
@@ -2337,6 +2351,10 @@ static int pc_launch_t(PipeArgs& a, int nt, int mpw, int mode, hipStream_t s) {
     // 8-row tiles) 0.166 -> 0.155 ms; forcing 8-row tiles with eight staging waves where 16-row tiles with four are chosen today
     // loses (down_path.1 second conv 0.202 -> 0.219), so the choice between the two tile heights stays as it was.
     static const int pw8 = [] { const char* e = getenv("UNCL_PC_NT2_PW8"); return e ? atoi(e) : 1; }();
+    // parked epilogue (the launcher asks for it through a.epo2): one cout tile, one or two resident chunks, forward store (+ pooled copy)
+    if (a.epo2 && mode == 0 && resw && a.nk <= 2 && fwd_relu && a.lean && a.out1_w == nullptr && !a.skip_main)
+      return launch_pc<T, 2, 2, 0, 8, true, true>(a, s);
+    if (a.epo2) return UNCL_ERR_ARG;
     if (pw8 && mode == 0) return resw ? launch_pc<T, 2, 2, 0, 8, true>(a, s) : launch_pc<T, 2, 2, 0, 8, false>(a, s);
     if (pw8 >= 2 && mode == 1 && !resw) return launch_pc<T, 2, 2, 1, 8, false>(a, s);
     if (resw) {

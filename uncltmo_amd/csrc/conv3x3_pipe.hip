@@ -992,6 +992,7 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
   a.flat_S = 0; a.flat_hw = 0; a.flat_N = d->N;
   a.nk = d->Cin / 32;
   a.tail_w = (const bf16_t*)d->tail_w; a.tail_b = d->tail_b; a.oH = a.oW = 0;
+  a.epo2 = 0;
   a.ssr_x2 = nullptr; a.ssr_gx2 = nullptr; a.ssr_gx1 = nullptr; a.ssr_C = 0; a.ssr_acc = 0;
   if (ssr != nullptr) {
     // data gradient of a skip-concat layer, skip operator's backward in the epilogue: plain source, 4 C output channels in the
@@ -1175,6 +1176,19 @@ static int conv3x3_pipe_impl(const uncl_conv_desc* d, void* pool_out, const void
     const int tall_tiles = d->N * a.tiles_x * ((a.Hout + 15) / 16) * a.n_ct;
     static const int tall_min = [] { const char* e = getenv("UNCL_PC_TALL_MIN"); return e ? atoi(e) : 256; }();
     const bool go_tall = tall && ((a.Hout + 15) / 16) * 16 <= ((a.Hout + 7) / 8) * 8 && tall_tiles >= tall_min;
+    // Round 6, built and measured, OFF (UNCL_PC_EPO2=1 turns it on): one cout tile, at most two K-chunks, forward store (the two layers
+    // of down_path.0) on 8-row tiles with the epilogue PARKED for the staging waves.  On 16-row tiles their multiplying waves spend 41 -
+    // 52 % of a tile's time issuing its 64 KB of stores beside staging waves that idle 70 - 80 % (tools/pc_phase_timing.py --layers
+    // d0a,d0b) -- but what they wait for is HBM, not the issue slot: the two launches move 0.62 / 0.92 GB at 4.4 / 4.0 TB/s as they
+    // are, and the parked form (bit-identical, every conv test green with it on) took 0.154 / 0.250 ms against 0.142 / 0.228
+    static const int epo2 = [] { const char* e = getenv("UNCL_PC_EPO2"); return e ? atoi(e) : 0; }();
+    if (epo2 && pc_mode == 0 && a.n_ct == 1 && a.nk <= 2 && a.Hout >= 100 && ssr == nullptr && mask == nullptr && !accumulate &&
+        a.slope == 0.f && d->out1_w == nullptr && !d->skip_main_store) {
+      PipeArgs b = a;
+      b.epo2 = 1;
+      const int rc = uncl_conv3x3_pc_launch(b, d->dtype, 2, 2, pc_mode, s);
+      if (rc != UNCL_ERR_ARG) return rc;
+    }
     if (g_use_flat && (pc_mode == 0 || pc_mode == 1) && pool_out == nullptr && ssr == nullptr) {
       // flat M-tiles (conv3x3_flat.hip) where the rectangles above leave a large part of their pixels outside the map: the 24 ..
       // 61-pixel levels.  Chosen by the same cost figure for both tilings: rounds of the persistent grid x (M-tiles per wave +
