@@ -131,7 +131,10 @@ int uncl_conv3x3_pipe(const uncl_conv_desc* d, void* pool_out, void* stream);
  * planes, resident weights where they fit) for the concat-source layers only; 2 (default) = for every layer they build
  * (plain sources and single-chunk layers too; measured faster on all of them); 3 = also the layers with a fused 1x1 tail
  * (measured slower there).  All give bit-identical results; the switch
- * exists for same-process A/B timing and for the tests that compare the structures.  Returns the previous setting. */
+ * exists for same-process A/B timing and for the tests that compare the structures.  Returns the previous setting; on = -1 only
+ * queries it (the host side packs the weights of uncl_conv3x3_dgrad_ssr -- producer / consumer kernel only -- accordingly).  Round 6:
+ * with 2 or 3, inference's last layer (fused 1x1 tail, main store skipped) runs on the producer / consumer kernel with the tail
+ * computed from two accumulator sets (UNCL_PC_O1C=0: the four-wave form). */
 int uncl_conv3x3_set_pc(int on);
 /* Tiling of the 64-channel-tile 3x3 layers (forward and data gradient) whose maps fill rectangular 8 / 16 x 32-pixel tiles badly
  * -- the 24 .. 61-pixel levels of unet_parts.py:56-87, 98-112, 149-162, 311-332: 1 (default) = flat M-tiles (csrc/conv3x3_flat.hip:

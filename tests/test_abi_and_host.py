@@ -195,9 +195,11 @@ def test_gradient_allreduce_equals_mean_of_rank_gradients():
 class _FakeG(torch.nn.Module):
     """stands in for the HIP generator: parameters + the attribute DistributedOptimizer looks for"""
 
-    def __init__(self):
+    def __init__(self, variant=False):
         super().__init__()
-        self.dec = torch.nn.Parameter(torch.zeros(6, 4))
+        # (variant: a configuration whose decoder parameter is a SUB-SET of the published-layout buffer the kernels write -- rows
+        # [0:2] and [3:5] of the six, like a skip operator with fewer members: generator._variant_grads)
+        self.dec = torch.nn.Parameter(torch.zeros(4 if variant else 6, 4))
         self.enc = torch.nn.Parameter(torch.zeros(5, 3))
         self.bias = torch.nn.Parameter(torch.zeros(7))
         self.pe = torch.nn.Parameter(torch.zeros(3, 2))
@@ -218,19 +220,26 @@ class _FakePass:
         return {"enc": self.flat[:15].view(5, 3), "dec": self.flat[15:].view(6, 4), "bias": self.small[:7],
                 "pe": self.small[7:].view(2, 3).t().contiguous()}
 
-    def finish(self, red):
+    @staticmethod
+    def variant_post(g):
+        """published layout -> the variant's parameters (a copy: must run after the collectives)"""
+        g = dict(g)
+        g["dec"] = torch.cat([g["dec"][:2], g["dec"][3:5]], 0)
+        return g
+
+    def finish(self, red, post=None):
         if red.in_stream:                               # the captured-step form of _GradSet.finish: synchronous, caller's stream
             g = self.grads()
             for t in (self.flat, self.small, g["pe"]):
                 red.launch_in_stream(t, self)
-            red.keep(self, g)
+            red.keep(self, g, post)
             return g
         red.launch(self.flat[self.cut:], self)          # decoder half: launched while the encoder's kernels still run
         g = self.grads()                                # pos_embed's transposed copy is made before the in-place reductions
         red.launch(self.flat[:self.cut], self)
         red.launch(self.small, self)
         red.launch(g["pe"], self)
-        red.keep(self, g)
+        red.keep(self, g, post)
         return g
 
 
@@ -248,13 +257,14 @@ def _reducer_worker(rank, world, port, q):
         raise AssertionError("module= of a foreign network was accepted")
     except ValueError:
         pass
-    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad", "in_stream", "extra_params"):
-        net = _FakeG()
+    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad", "in_stream", "extra_params", "variant", "variant_in_stream"):
+        variant = case.startswith("variant")
+        net = _FakeG(variant)
         extra = torch.nn.Parameter(torch.zeros(4)) if case == "extra_params" else None
         opt = DistributedOptimizer(torch.optim.SGD(list(net.parameters()) + ([extra] if extra is not None else []), lr=1.0), module=net)
         red = net._grad_reducer
         assert red.active()
-        red.in_stream = case == "in_stream"
+        red.in_stream = case in ("in_stream", "variant_in_stream")
         if extra is not None:
             extra.grad = torch.full((4,), float(rank + 1))     # mean over the two ranks: 1.5
         if case == "skipped_step":
@@ -265,10 +275,11 @@ def _reducer_worker(rank, world, port, q):
         if case == "accumulate_into_grad":
             for p in net.parameters():
                 p.grad = torch.ones_like(p)
-        passes = [_FakePass(rank, 1)] + ([_FakePass(rank, 2)] if case == "two_pass" else [])
+        passes = [_FakePass(rank, 1)] + ([_FakePass(rank, 2)] if case in ("two_pass", "variant") else [])
+        post = _FakePass.variant_post if variant else None
         for ps in passes:
-            local = {k: v.clone().numpy() for k, v in ps.grads().items()}
-            ps.finish(red)
+            local = {k: v.clone().numpy() for k, v in (post(ps.grads()) if variant else ps.grads()).items()}
+            ps.finish(red, post)
             assert all(p.grad is None for p in net.parameters()) or case == "accumulate_into_grad"
             out.setdefault(case + ".local", []).append(local)
         opt.step()
@@ -294,7 +305,9 @@ def test_grad_reducer_world2_single_pass_two_pass_and_skipped_step():
         p.join(timeout=60)
     for r in range(2):
         np.testing.assert_allclose(got[r]["extra_params"]["extra"], -1.5, rtol=1e-6)
-    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad", "in_stream", "extra_params"):
+    # "variant": the reducer is handed the PUBLISHED layout and the re-layout as a function it applies after the collectives (round 6:
+    # skip-operator / bilinear variants of the generator train data-parallel): the parameter is the mean of the ranks' SLICED gradients
+    for case in ("one_pass", "two_pass", "skipped_step", "accumulate_into_grad", "in_stream", "extra_params", "variant", "variant_in_stream"):
         n_pass = len(got[0][case + ".local"])
         for k in ("enc", "dec", "bias", "pe"):
             mean = sum(got[r][case + ".local"][i][k] for r in range(2) for i in range(n_pass)) / 2.0

@@ -120,6 +120,55 @@ def test_concat_ssr_layers_at_full_size(name, c, cout, hs, h1):
     assert_elementwise(from_nhwc(out), ref, "bf16", name)
 
 
+FLAT_PLAIN = [e for e in ENCODER if e[3] <= 61 and e[2] >= 64 and not e[5]]      # the <= 61-pixel levels without a pooled copy
+
+
+@pytest.mark.parametrize("mpw", [2, 3])
+@pytest.mark.parametrize("name,cin,cout,h,pad,pool", FLAT_PLAIN)
+def test_plain_layers_at_full_size_on_forced_flat_tiles(name, cin, cout, h, pad, pool, mpw):
+    """The flat M-tiles (csrc/conv3x3_flat.hip) are the product's default on these levels at inference batch sizes, but at a test's
+    batch the launcher's cost figure keeps the rectangles -- so far the flat kernel met torch only through `flat == rectangular, bit
+    for bit`.  Here it is FORCED (uncl_conv3x3_set_flat(mpw): that many M-tiles per multiplying wave wherever the kernel applies) and
+    gated element by element against the fp32 convolution of the same operands, at the real layer sizes."""
+    lib = _hip.lib()
+    n = 5
+    x = q(rnd(n, cin, h, h, seed=121).abs())
+    wt = q(rnd(cout, cin, 3, 3, seed=122, scale=0.05)) if pad == 0 else q(rnd(cin, cout, 3, 3, seed=122, scale=0.05))
+    b = rnd(cout, seed=123, scale=0.3)
+    ref = conv_ref(x, wt, b, pad)
+    old = lib.uncl_conv3x3_set_flat(mpw)
+    try:
+        out, _ = run_plain(x, wt, b, pad, pool=False)
+    finally:
+        lib.uncl_conv3x3_set_flat(old)
+    assert_elementwise(from_nhwc(out), ref, "bf16", "%s, flat tiles x%d" % (name, mpw))
+
+
+@pytest.mark.parametrize("mpw", [2, 3])
+@pytest.mark.parametrize("name,c,cout,hs,h1", [("up_path.0.conv.conv", 256, 128, 24, 24), ("up_path.1.conv.conv", 128, 64, 57, 56)])
+def test_concat_ssr_layers_at_full_size_on_forced_flat_tiles(name, c, cout, hs, h1, mpw):
+    """the two skip-concat layers the forward runs on flat tiles, forced onto them at a test's batch size, against torch"""
+    lib = _hip.lib()
+    n = 3
+    x2 = q(rnd(n, c, hs, hs, seed=131).abs() * (rnd(n, c, hs, hs, seed=132) > -0.4))
+    x1 = q(rnd(n, c, h1, h1, seed=133))
+    wt, b = q(rnd(4 * c, cout, 3, 3, seed=134, scale=0.03)), rnd(cout, seed=135, scale=0.3)
+    d = hs - h1
+    x1p = F.pad(x1, (d // 2, d - d // 2, d // 2, d - d // 2), mode="replicate")
+    cat = torch.cat([x2, x1p, q(x2 ** 2), q(torch.sqrt(x2 + 1e-8))], 1)
+    ref = F.relu(F.conv_transpose2d(cat, wt, b))
+    out = nan_out(n, hs + 2, hs + 2, cout)
+    old = lib.uncl_conv3x3_set_flat(mpw)
+    try:
+        run_pipe(dtype=BF, ksize=3, pad=2, src_mode=_hip.SRC_CONCAT_SSR, N=n, H=hs, W=hs, Cin=4 * c, Cout=cout, src0=to_nhwc(x2, BF),
+                 src0_H=hs, src0_W=hs, src0_C=c, src1=to_nhwc(x1, BF), src1_H=h1, src1_W=h1, src1_C=c,
+                 weight=pack_weight(wt, BF, transposed=True, flip=True), bias=b.cuda(), act=_hip.ACT_RELU, out=out, out_H=hs + 2,
+                 out_W=hs + 2, out_C=cout)
+    finally:
+        lib.uncl_conv3x3_set_flat(old)
+    assert_elementwise(from_nhwc(out), ref, "bf16", "%s, flat tiles x%d" % (name, mpw))
+
+
 @pytest.mark.parametrize("c,h,w,n", [(32, 126, 126, 2), (64, 61, 61, 3), (64, 9, 23, 2), (64, 17, 40, 2)])
 def test_fused_upconv_concat_layer_at_full_size(c, h, w, n):
     """up_path.3 / up_path.2: the 2x2 stride-2 transposed conv (32 -> 32, 64 -> 64 channels) recomputed in the concat layer's

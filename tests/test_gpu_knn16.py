@@ -7,7 +7,9 @@ matrix of those values (normalise, |a|^2 - 2ab + |b|^2, + relative_pos).  Requir
   * the nine selected distances are the nine smallest of the fp64 row, in ascending order, within 1e-6;
   * exact ties resolve to the lower node index (constant rows: every candidate ties);
   * the matrix-core kernel and the VALU kernel (uncl_gcn_set_knn_mfma(0)) pick the same indices on >= 99.9 % of the entries
-    (the fraction DESIGN.md states), and wherever they differ the two candidates are within 1e-6 of each other.
+    (the fraction DESIGN.md states), and wherever they differ the two candidates are within 1e-6 of each other;
+  * on every row whose ten smallest fp64 distances are pairwise more than 1e-5 apart the two kernels agree on 100 % of the indices,
+    and those are the fp64 top-9 in fp64 order.
 """
 import pytest
 import torch
@@ -101,10 +103,19 @@ def test_knn16_mfma_equals_valu_kernel(dt):
         a, b = run_knn(x16, rel, 1), run_knn(x16, rel, 0)
         same = (a == b)
         assert same.float().mean().item() >= 0.999, (dt, nodes, with_rel, same.float().mean().item())
+        ref = ref_dist64(x16, rel)
         if not same.all():
-            ref = ref_dist64(x16, rel)
             da, db = torch.gather(ref, 2, a), torch.gather(ref, 2, b)
             assert (da - db).abs()[~same].max().item() < 2 * TOL
+        # Round 6: wherever the selection is WELL SEPARATED in the fp64 yardstick -- every gap between consecutive sorted distances up
+        # to the 10th neighbour exceeds 1e-5, ten times what either kernel's fp32 arithmetic can move a distance -- the two kernels must
+        # pick identical indices in identical order, 100 % of such rows (bit-exact index parity with the reference itself is a
+        # property of the fp32 mode; the 16-bit graph is pinned by this yardstick)
+        srt = torch.sort(ref, dim=2).values[..., :K + 1]
+        well = (srt.diff(dim=-1) > 1e-5).all(-1)                      # (N, nodes): the first ten distances are pairwise separated
+        assert well.float().mean().item() > 0.5, "the gate below needs rows to apply to"
+        assert torch.equal(a[well], b[well]), (dt, nodes, with_rel, (a[well] != b[well]).sum().item())
+        assert torch.equal(a[well], torch.topk(ref, K, dim=2, largest=False).indices[well]), (dt, nodes, with_rel)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

@@ -96,6 +96,48 @@ def test_bf16_training_step_of_a_variant_runs_and_descends():
     assert loss().item() < l0.item()
 
 
+@pytest.mark.parametrize("op,bil,upm", [("square", 1, 0), ("original_unet", 0, 0), ("square_root", 0, 1)])
+def test_variant_gradients_through_the_data_parallel_reducer_equal_the_plain_pass(op, bil, upm):
+    """Round 6: variant generators train data-parallel.  The reducer is handed the PUBLISHED-layout buffers and applies the variant's
+    re-layout (slices of the skip-concat weights, tap sums of a bilinear `up`) after the collectives (distributed.GradReducer.keep(...,
+    post)).  On one GPU over RCCL (world size 1, forced data-parallel path) the gradients that arrive in .grad after
+    DistributedOptimizer.synchronize() must equal the plain backward pass's bit for bit (fp32 mode: deterministic)."""
+    import os
+    import torch.distributed as td
+    from uncltmo_amd.distributed import DistributedOptimizer
+    x = inputs().cuda()
+    wy = (0.5 + synth.smooth_hdr_frames(2, salt="bwy")).cuda()
+    grads = []
+    os.environ["UNCL_FORCE_DIST"] = "1"
+    td.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29900 + os.getpid() % 90), rank=0, world_size=1,
+                          device_id=torch.device("cuda", 0))
+    try:
+        for wrap in (False, True):
+            net = make(op, bil, "fp32", upm).train()
+            net.drop_path_prob = 0.0
+            opt = torch.optim.SGD([q for q in net.parameters() if q.requires_grad], lr=0.0)
+            if wrap:
+                opt = DistributedOptimizer(opt, module=net)
+                assert net._grad_reducer.active()
+            y, up = net(x)
+            ((y * wy).sum() + 1e-3 * up.float().sum()).backward()
+            if wrap:
+                assert all(q.grad is None for q in net.parameters())          # the buffers belong to the reducer until step()
+                opt.synchronize()
+            torch.cuda.synchronize()
+            grads.append({k: q.grad.clone() for k, q in net.named_parameters() if q.requires_grad})
+            net = opt = None
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            assert grads[0][k].shape == grads[1][k].shape and torch.equal(grads[0][k], grads[1][k]), k
+    finally:
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        td.destroy_process_group()
+        os.environ.pop("UNCL_FORCE_DIST", None)
+
+
 def test_unsupported_variants_are_still_refused():
     with pytest.raises(NotImplementedError):
         UNet(1, 1, "sigmoid", 4, 3, "gamma", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0)

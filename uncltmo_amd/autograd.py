@@ -119,8 +119,9 @@ class _GradSet:
                 (1 if (transposed and k == 3) else 0), 0
         _hip.check(lib.uncl_unpack_conv_wgrads(items, hi - lo, _hip.stream_ptr()), "uncl_unpack_conv_wgrads")
 
-    def grads(self):
-        """state_dict name -> gradient tensor (views of self.flat / self.small)"""
+    def grads(self, published=False):
+        """state_dict name -> gradient tensor (views of self.flat / self.small); `published`: in the PUBLISHED layout the kernels
+        write (a variant configuration's own parameters are slices / sums of these: generator._variant_grads)"""
         g = {"inc.conv.conv.weight": self.g_inc_w, "inc.conv.conv.bias": self.g_inc_b,
              "outc.conv.weight": self.g_oc_w.reshape(1, 32, 1, 1), "outc.conv.bias": self.g_oc_b,
              "gcn.pos_embed": self.g_pe.t().reshape(1, 256, 12, 12).contiguous()}
@@ -129,7 +130,7 @@ class _GradSet:
             g[nm + ".bias"] = self.gb[i]
         for q, gw_, gb_ in zip(self.bn_names, self.g_bn_w, self.g_bn_b):
             g[q + ".weight"], g[q + ".bias"] = gw_, gb_
-        return self.module._variant_grads(g)
+        return g if published else self.module._variant_grads(g)
 
     def finish(self, last_run):
         """Unpack everything after the last uncl_gen_backward call of a pass (`last_run(ev)` makes that call).  With a
@@ -141,21 +142,21 @@ class _GradSet:
             last_run(None)
             self.unpack()
             return self.grads()
-        if self.module._is_variant():
-            # the variants' gradients are sums / concatenations of the published-layout buffers (generator._variant_grads): copies
-            # made before the collectives have finished would hold this rank's values only
-            raise NotImplementedError("uncltmo_amd: data-parallel training covers the published generator configuration; "
-                                      "con_operator / bilinear variants train on one GPU")
+        # A variant configuration's gradients (skip-operator sub-sets, bilinear / parameter-free `up`) are slices, concatenations and
+        # tap sums of the published-layout buffers (generator._variant_grads): copies made before the collectives have finished
+        # would hold this rank's values only.  So the reducer is handed the PUBLISHED layout and the module's re-layout as a
+        # function it applies in finish(), after the collectives and the division by the world size (round 6; before: refused).
+        post = self.module._variant_grads if self.module._is_variant() else None
         self.reduced = True     # the buffers now belong to the reducer: the caller hands autograd NO parameter gradients
         if red.in_stream or torch.cuda.is_current_stream_capturing():
             # everything on the caller's stream: the pass, the re-layout, then the collectives in order (a captured step: one
             # stream, no cross-stream edge; the exchange is exposed, 19.7 MB over xGMI)
             last_run(None)
             self.unpack()
-            g = self.grads()
+            g = self.grads(published=True)
             for t in (self.flat, self.small, g["gcn.pos_embed"]):
                 red.launch_in_stream(t, self)
-            red.keep(self, g)
+            red.keep(self, g, post)
             return g
         ev = torch.cuda.Event()
         ev.record()             # torch creates the hipEvent lazily: record once so that the raw handle exists, the library
@@ -166,11 +167,11 @@ class _GradSet:
             self.unpack(self.DEC0, len(self.names))
             red.launch(self.flat[cut:], self)
         self.unpack(0, self.DEC0)
-        g = self.grads()        # pos_embed's gradient is a transposed COPY of its slot in `small`, made before the reductions
+        g = self.grads(published=True)      # pos_embed's gradient is a transposed COPY of its slot in `small`, made before the reductions
         red.launch(self.flat[:cut], self)
         red.launch(self.small, self)
         red.launch(g["gcn.pos_embed"], self)
-        red.keep(self, g)
+        red.keep(self, g, post)
         return g
 
 

@@ -919,6 +919,7 @@ extern "C" int uncl_conv3x3_set_flat(int on) {
 }
 extern "C" int uncl_conv3x3_set_pc(int on) {
   const int old = g_use_pc;
+  if (on == -1) return old;          // query: the host packs the fused skip backward's weights only where this structure runs them
   g_use_pc = on < 0 ? 0 : (on > 3 ? 3 : on);
   return old;
 }

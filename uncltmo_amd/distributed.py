@@ -100,11 +100,14 @@ class GradReducer:
         td.all_reduce(tensor, op=td.ReduceOp.SUM, group=self.group)
         self._open["work"].append((None, tensor))
 
-    def keep(self, owner, grads):
+    def keep(self, owner, grads, post=None):
         """end of a pass: `grads` (state_dict name -> view of the buffers just launched) and the owner (which keeps the
-        buffers alive) stay here until finish()"""
+        buffers alive) stay here until finish().  `post`: a function applied to `grads` in finish(), AFTER the collectives and the
+        averaging -- the re-layout of a variant generator's parameters (slices / tap sums of the published-layout buffers:
+        generator._variant_grads), which must not copy anything while the reductions are in flight"""
         ps = self._open if self._open is not None and self._open["owner"] is owner else {"owner": owner, "work": [], "grads": None}
         ps["grads"] = grads
+        ps["post"] = post
         self._passes.append(ps)
         self._open = None
 
@@ -130,6 +133,8 @@ class GradReducer:
                     work.wait()              # the current stream waits for the collective; the host does not block
                 if world > 1:
                     t.div_(world)
+            if ps.get("post") is not None:
+                ps["grads"], ps["post"] = ps["post"](ps["grads"]), None
         for k, p in named_params:
             if not p.requires_grad:
                 continue

@@ -217,12 +217,16 @@ def warp_flow(img_u8, flow):
     return out
 
 
-def compute_flow(img_to_align, img_source):
+def compute_flow(img_to_align, img_source, unit_range=None):
     """GanTrainer.compute_flow (GanTrainer.py:620-646; the evaluator's optical flow, Tester.py:379-384): both frames (H,W,C) or
     (H,W), in [0, 255] (or [0, 1] floats, scaled like the reference does), on the GPU -> (H,W,2) fp32 field f with
     img_to_align(p + f(p)) ~ img_source(p), i.e. what `align_frames` / `warp_flow` take.  Channel 0 of each frame is used, as in the
     reference.  The reference's estimator is cv2 DeepFlow (absent here: parity unpinned); this is pyramidal Lucas-Kanade on the
-    device (csrc/flow.hip, oracle/flow.py)."""
+    device (csrc/flow.hip, oracle/flow.py): motions beyond about one pixel per pyramid level and iteration (x 4 iterations) are
+    clamped, and warp errors computed through it are NOT numerically comparable with the reference's published (DeepFlow) ones.
+    `unit_range`: None = the reference's heuristic (a float frame whose maximum is <= 1 is taken as [0, 1] and brought to 8 bits:
+    one host synchronisation per frame, and a dark frame already on the 0 .. 255 scale is misread, as in the reference); True /
+    False state the range and skip both."""
     _need_gpu(img_to_align, "img_to_align")
     _need_gpu(img_source, "img_source")
 
@@ -231,7 +235,7 @@ def compute_flow(img_to_align, img_source):
         if t.dtype == torch.uint8:
             return t.float().contiguous()
         t = t.float()
-        if float(t.max()) <= 1.0:                       # GanTrainer.py:632-637: [0, 1] images are brought to 8 bits first
+        if unit_range if unit_range is not None else float(t.max()) <= 1.0:    # GanTrainer.py:632-637: [0, 1] images -> 8 bits first
             t = (t * 255).clamp(0, 255)
         return torch.floor(t).contiguous()              # astype(np.uint8) truncates
 
@@ -250,13 +254,14 @@ def compute_flow(img_to_align, img_source):
     return flow
 
 
-def align_frames(img_to_align, flow):
-    """GanTrainer.align_frames (GanTrainer.py:648-666): 8-bit conversion of a [0, 1] image, then warp_flow."""
+def align_frames(img_to_align, flow, unit_range=None):
+    """GanTrainer.align_frames (GanTrainer.py:648-666): 8-bit conversion of a [0, 1] image, then warp_flow.  `unit_range` as in
+    compute_flow (None: the reference's max() <= 1 test, one host synchronisation)."""
     _need_gpu(img_to_align, "img_to_align")
     t = img_to_align
     if t.dtype != torch.uint8:
         t = t.float()
-        if float(t.max()) <= 1.0:
+        if unit_range if unit_range is not None else float(t.max()) <= 1.0:
             t = (t * 255).clamp(0, 255)
         t = t.to(torch.uint8)
     return warp_flow(t if t.dim() == 3 else t.unsqueeze(-1), flow)

@@ -258,7 +258,11 @@ class _GeneratorBase(nn.Module):
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
         code = self._dtype_code()
-        key = (code, self.training and self.unet_norm == "batch_norm") + \
+        # the fused skip backward (uncl_conv3x3_dgrad_ssr) exists in the producer / consumer kernel only and wants its weights in the
+        # interleaved cout order: packed that way only while that structure is on (uncl_conv3x3_set_pc / UNCL_PC, UNCL_SSR_FUSED), and
+        # both switches are part of the key -- toggling them re-packs instead of leaving a pack the other path cannot read
+        ssr_on = code == _hip.BF16 and os.environ.get("UNCL_SSR_FUSED", "1") != "0" and _hip.lib().uncl_conv3x3_set_pc(-1) != 0
+        key = (code, self.training and self.unet_norm == "batch_norm", ssr_on) + \
             tuple((k, v.data_ptr(), v._version, getattr(v, "_uncl_epoch", 0)) for k, v in sd.items())
         if key == self._pack_key:
             return self._packed
@@ -340,7 +344,7 @@ class _GeneratorBase(nn.Module):
                     # the skip-concat layers of the last two decoder stages: cout order interleaved for the data-gradient launch
                     # whose epilogue is the skip operator's backward (uncl_conv3x3_dgrad_ssr; the up-sampled map has the skip's
                     # extent there -- up_path.1 has the 56 -> 57 replicate pad, up_path.0 runs on flat tiles)
-                    order = 1 if (code == _hip.BF16 and name in SSR_FUSED_LAYERS and os.environ.get("UNCL_SSR_FUSED", "1") != "0") else 0
+                    order = 1 if (ssr_on and name in SSR_FUSED_LAYERS) else 0
                     if order:
                         ssr_fused |= 1 << int(name.split(".")[1])
                     wd_off.append(job(src, src.numel(), shape[0], shape[1], 3, 0, 0, order))

@@ -228,7 +228,8 @@ def nce_lists(anchor, positives, negatives, k, c, hw=None, form="InfoNCE"):
     [s(a,p), s(a,n_1), ..., s(a,n_Q)] go through the 2..(Q+1)-way cross-entropy with class 0 ('InfoNCE', :431-433) or lmcl_loss
     ('LMCL', :441-450: -log(exp(s_p) / sum_j exp(s_nj))), averaged over the positives.  The similarities come from the HIP kernels
     two at a time (uncl_nce_similarity); the logits are (N, Q+1) device tensors.  The published call sites (one positive, one
-    negative) use the fused nce() above instead."""
+    negative) use the fused nce() above instead -- THIS form is not on the published step path: its last reduction over the
+    (N, Q+1) logits (a few hundred floats) is torch's cross_entropy / logsumexp, the only PyTorch arithmetic kernels in the package."""
     if form not in ("InfoNCE", "LMCL"):
         raise TypeError("%s is not found in loss/adversarial.py" % form)
     if len(positives) == 0 or len(negatives) == 0:

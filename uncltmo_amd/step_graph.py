@@ -55,14 +55,20 @@ class _Snapshot:
             for net in (getattr(trainer, "netG", None), getattr(trainer, "netD", None)):
                 if net is not None:
                     self.buffers += [(b, b.detach().clone()) for _, b in net.named_buffers()]
-        self.rng = torch.cuda.get_rng_state() if torch.cuda.is_available() else None
+        # the random-number streams a warm-up step can draw from: the HOST generator (host-side augmentation, a keep mask built on the
+        # host) and the generator of the device the trainer's parameters live on (DropPath).  Covered: netG / netD buffers only -- a
+        # stateful loss module or a caller's own buffers are not snapshotted.
+        self.dev = next((p.device for p, _ in self.params if p.is_cuda), None)
+        self.rng_host = torch.get_rng_state()
+        self.rng = torch.cuda.get_rng_state(self.dev) if self.dev is not None else None
 
     def restore(self):
         with torch.no_grad():
             for b, saved in self.buffers:
                 b.copy_(saved)
+            torch.set_rng_state(self.rng_host)
             if self.rng is not None:
-                torch.cuda.set_rng_state(self.rng)
+                torch.cuda.set_rng_state(self.rng, self.dev)
             for p, saved in self.params:
                 p.copy_(saved)                                       # bumps ._version: the weight packs are rebuilt
                 p.grad = None

@@ -32,7 +32,10 @@ def eval_on_video(G_net, rgb_frames, f_factor, final_shape_addition=0, add_frame
     the mean TMQI over the frames, the tone-mapped 8-bit frames (H,W,3) and, when `align_fn(frame1_u8, frame0_u8)` (the
     caller's optical-flow alignment of frame 1 onto frame 0) is given, the reference's two warp errors.  `flow` (H,W,2 fp32 on the
     GPU: the inverse flow the reference gets from cv2 DeepFlow, Tester.py:379-384) instead of `align_fn` aligns on the device with
-    frame_util.warp_flow (= align_frames / warp_flow, GanTrainer.py:584-595, 652-666): no host round trip."""
+    frame_util.warp_flow (= align_frames / warp_flow, GanTrainer.py:584-595, 652-666): no host round trip.
+    `flow_images=(frame1, frame0)`: the flow is ESTIMATED here by frame_util.compute_flow -- pyramidal Lucas-Kanade, not the
+    reference's cv2 DeepFlow: warp_mse / warp_rel obtained this way are LK-based and NOT numerically comparable with warp errors
+    published for the reference (pass the reference's own field as `flow=`, or its alignment as `align_fn`, for that)."""
     if len(rgb_frames) == 0:
         raise ValueError("eval_on_video needs at least one frame")
     originals, padded, grays = [], [], []
