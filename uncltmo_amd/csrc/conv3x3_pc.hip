@@ -1748,67 +1748,84 @@ __global__ __launch_bounds__((4 + PW) * 64, PW == 8 ? 3 : (NT == 1 && MPW == 2 ?
       for (int i = 0; i < 16; ++i) preBv[i] = preB[i];
       constexpr int MT3 = (NPIX + 31) / 32, IT3 = (MT3 + PW - 1) / PW;
       static_assert(HW == 34 && NPIX < 2048, "the reciprocal multiply below divides by 34");
+      // Round 6: the wave's M-tiles in PHASES -- every tile's taps gathered, then every tile's MFMAs, then every tile's rounding and
+      // LDS writes -- as straight-line code.  One tile after the other behind a wave-uniform `if (mt < MT3)` each was two dependent
+      // chains (LDS gather -> two MFMAs -> rounding -> LDS write: 985 cycles per tile in the stamped build, on the waves the whole
+      // launch waits for) that the compiler could not interleave across the branch.  A wave past the last M-tile (one of the eight,
+      // at 15 M-tiles) computes a clamped copy of the last one and stores nothing.
+      typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+      vec Bh[IT3], Bl[IT3];
 #pragma unroll
       for (int i = 0; i < IT3; ++i) {
-        const int mt = pwave + PW * i;           // wave-uniform
-        if (mt < MT3 && !PC_ABL(4)) {
-          const int pix = mt * 32 + lr;
-          const int pcl = min(pix, NPIX - 1);
-          const int py = (pcl * 241) >> 13, px = pcl - py * HW;   // / 34 for pcl < 2048 (HW == 34)
-          const unsigned* pp = sPt + py * PW3 + px;
-          unsigned tp[8];
+        const int pcl = min((pwave + PW * i) * 32 + lr, NPIX - 1);
+        const int py = (pcl * 241) >> 13, px = pcl - py * HW;   // / 34 for pcl < 2048 (HW == 34)
+        const unsigned* pp = sPt + py * PW3 + px;
+        unsigned tp[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int o0 = (j / 3) * PW3 + j % 3;  // tap j (lower half-wave)
-            unsigned u = pp[lh ? 2 * PW3 + 2 : o0];   // upper half-wave: tap 8 in slot 0
-            if (j > 0) u = lh ? 0u : u;
-            tp[j] = u;
+        for (int j = 0; j < 8; ++j) {
+          const int o0 = (j / 3) * PW3 + j % 3;  // tap j (lower half-wave)
+          unsigned u = pp[lh ? 2 * PW3 + 2 : o0];   // upper half-wave: tap 8 in slot 0
+          if (j > 0) u = lh ? 0u : u;
+          tp[j] = u;
+        }
+        // heads of taps (2k, 2k + 1) -> register k of the head fragment, tails -> the tail fragment: one v_perm_b32 each
+        u32x4p bh, bl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bh[k] = __builtin_amdgcn_perm(tp[2 * k + 1], tp[2 * k], 0x07060302u);
+          bl[k] = __builtin_amdgcn_perm(tp[2 * k + 1], tp[2 * k], 0x05040100u);
+        }
+        Bh[i] = __builtin_bit_cast(vec, bh);
+        Bl[i] = __builtin_bit_cast(vec, bl);
+      }
+      // the bias is the first MFMA's C operand (sixteen adds per lane and 32 pixels otherwise: the staging waves of this layer issue
+      // ~8 vector instructions per MFMA of the whole kernel)
+      f32x16 c3[IT3];
+#pragma unroll
+      for (int i = 0; i < IT3; ++i) c3[i] = mfma32x16(preA, Bh[i], preBv);
+#pragma unroll
+      for (int i = 0; i < IT3; ++i) c3[i] = mfma32x16(preA, Bl[i], c3[i]);
+      if (PC_ABL(4)) {
+#pragma unroll
+        for (int i = 0; i < IT3; ++i) asm volatile("" ::"v"(c3[i][0]), "v"(c3[i][15]));     // (a 64-byte operand breaks the HOST pass: every stub of the kernel vanishes)
+      } else if (a.slope == 0.f) {
+        // ReLU on the rounded pair (rounding is sign-symmetric), like the multiplying waves' epilogue.  The two half-waves
+        // hold the two halves of a pixel's 16-byte K-slot: v_permlane32_swap turns quads (2 qp, 2 qp + 1) into one whole slot
+        // per lane (lower half-wave: plane 2 qp, upper: 2 qp + 1), i.e. one ds_write_b128 whose eight-lane groups cover the 32
+        // banks exactly -- the 8-byte half-slot stores were two-way bank conflicts (lanes lr and lr + 8)
+        typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+        typedef short s16x8w __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int i = 0; i < IT3; ++i) {
+          const int mt = pwave + PW * i, pix = mt * 32 + lr;
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            vec4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = (T)c3[i][8 * qp + e]; o1[e] = (T)c3[i][8 * qp + 4 + e]; }
+            const u32x2w d0 = __builtin_bit_cast(u32x2w, o0), d1 = __builtin_bit_cast(u32x2w, o1);
+            const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
+            const u32x4w w = {sx[0], sy[0], sx[1], sy[1]};
+            s16x8w si = __builtin_bit_cast(s16x8w, w);
+            si = __builtin_elementwise_max(si, s16x8w{0, 0, 0, 0, 0, 0, 0, 0});
+            if (mt < MT3 && pix < NPIX) *reinterpret_cast<s16x8w*>(st + (2 * qp + lh) * XPL + pix * 16) = si;
           }
-          // heads of taps (2k, 2k + 1) -> register k of the head fragment, tails -> the tail fragment: one v_perm_b32 each
-          typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
-          u32x4p bh, bl;
+        }
+      } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            bh[k] = __builtin_amdgcn_perm(tp[2 * k + 1], tp[2 * k], 0x07060302u);
-            bl[k] = __builtin_amdgcn_perm(tp[2 * k + 1], tp[2 * k], 0x05040100u);
-          }
-          const vec Bh = __builtin_bit_cast(vec, bh), Bl = __builtin_bit_cast(vec, bl);
-          // the bias is the first MFMA's C operand (sixteen adds per lane and 32 pixels otherwise: the staging waves of this
-          // layer issue ~8 vector instructions per MFMA of the whole kernel)
-          f32x16 c3 = mfma32x16(preA, Bh, preBv);
-          c3 = mfma32x16(preA, Bl, c3);
-          if (a.slope == 0.f) {
-            // ReLU on the rounded pair (rounding is sign-symmetric), like the multiplying waves' epilogue.  The two half-waves
-            // hold the two halves of a pixel's 16-byte K-slot: v_permlane32_swap turns quads (2 qp, 2 qp + 1) into one whole slot
-            // per lane (lower half-wave: plane 2 qp, upper: 2 qp + 1), i.e. one ds_write_b128 whose eight-lane groups cover the 32
-            // banks exactly -- the 8-byte half-slot stores were two-way bank conflicts (lanes lr and lr + 8)
-            typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
-            typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
-            typedef short s16x8w __attribute__((ext_vector_type(8)));
+        for (int i = 0; i < IT3; ++i) {
+          const int mt = pwave + PW * i, pix = mt * 32 + lr;
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {
-              vec4 o0, o1;
+          for (int q = 0; q < 4; ++q) {
+            vec4 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { o0[e] = (T)c3[8 * qp + e]; o1[e] = (T)c3[8 * qp + 4 + e]; }
-              const u32x2w d0 = __builtin_bit_cast(u32x2w, o0), d1 = __builtin_bit_cast(u32x2w, o1);
-              const auto sx = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
-              const auto sy = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
-              const u32x4w w = {sx[0], sy[0], sx[1], sy[1]};
-              s16x8w si = __builtin_bit_cast(s16x8w, w);
-              si = __builtin_elementwise_max(si, s16x8w{0, 0, 0, 0, 0, 0, 0, 0});
-              if (pix < NPIX) *reinterpret_cast<s16x8w*>(st + (2 * qp + lh) * XPL + pix * 16) = si;
+            for (int e = 0; e < 4; ++e) {
+              const float t = c3[i][4 * q + e];
+              o[e] = (T)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
             }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              vec4 o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float t = c3[4 * q + e];
-                o[e] = (T)(fmaxf(t, 0.f) + a.slope * fminf(t, 0.f));
-              }
-              if (pix < NPIX) *reinterpret_cast<vec4*>(st + q * XPL + pix * 16 + (lh << 3)) = o;
-            }
+            if (mt < MT3 && pix < NPIX) *reinterpret_cast<vec4*>(st + q * XPL + pix * 16 + (lh << 3)) = o;
           }
         }
       }

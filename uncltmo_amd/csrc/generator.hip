@@ -30,9 +30,6 @@ extern "C" int uncl_gen_set_deterministic(int on) { return g_bwd_det.exchange(on
 #ifndef UNCL_SPLIT_PCT_DEFAULT
 #define UNCL_SPLIT_PCT_DEFAULT 50
 #endif
-#ifndef UNCL_SKEW_DEFAULT
-#define UNCL_SKEW_DEFAULT 0
-#endif
 static int g_fuse_tail = [] { const char* e = getenv("UNCL_FUSE_TAIL"); return e ? atoi(e) : 0; }();
 // inference: up_path.2.up (64 -> 64 channels) recomputed inside up_path.2.conv.conv's loader (conv3x3_pc.hip, MODE 5)
 static int g_fuse_up64 = [] { const char* e = getenv("UNCL_FUSE_UP64"); return e ? atoi(e) : 1; }();
@@ -1210,32 +1207,14 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     // (same-box A/B: +0.3 ... +0.7 % per step against splitting it too, and the dominant kernel runs undisturbed)
     static const int tail_whole_on = [] { const char* e = getenv("UNCL_TAIL_WHOLE"); return e ? atoi(e) : 1; }();   // 0: A/B, every part runs its own last stage
     const bool tail_whole = split2 && tail_whole_on;
-    // SKEW (round 6): the second part starts when the first one is through its 252 ... 57 pixel encoder levels (SEG_A), not together
-    // with it.  Two parts in lockstep reach the bottleneck block -- ten dependent launches of 30 - 90 us that fill a fraction of the
-    // chip whatever the batch -- at the same time, and for ~0.33 ms of the step nothing else runs (the timeline of
-    // tools/fwd_timeline.sh); an unequal split (UNCL_SPLIT_PCT) moves them apart only by making the parts unequal.  With the
-    // start skewed by more than the block's length each part would cross it under the other's large launches.  Built, measured, OFF
-    // (UNCL_SKEW=1 turns it on): 3.83 -> 3.98 ms same box.  The large launches are persistent one-workgroup-per-CU grids that hold every
-    // CU for 100 - 250 us, so a part's small dependent launches wait for CUs instead of slipping in (the timeline of the skewed run:
-    // the graph block's launches took 76 / 141 / 102 us against 34 / 39 / 81 in lockstep, one up-conv 270 us), and the second part
-    // then runs its decoder alone at the end.
-    static const int skew_on = [] { const char* e = getenv("UNCL_SKEW"); return e ? atoi(e) : UNCL_SKEW_DEFAULT; }();
-    const int segs_all = tail_whole ? (SEG_A | SEG_B | SEG_C) : SEG_ALL;
-    int rc;
-    if (split2 && parts == 2 && skew_on && n0 == 0 && !clip) {
-      rc = run_chunk(c, r->x, r->out, up, r->knn_idx, r->drop_scale, r->drop_scale ? r->drop_scale + r->N : nullptr, SEG_A);
-      if (rc != UNCL_OK) { (void)join_sides(); return rc; }
-      if (hipEventRecord(ss->ev_fork2, main_s) != hipSuccess || hipStreamWaitEvent(ss->side[0], ss->ev_fork2, 0) != hipSuccess) {
-        (void)join_sides();
-        return UNCL_ERR_LAUNCH;
-      }
-      rc = run_chunk(c, r->x, r->out, up, r->knn_idx, r->drop_scale, r->drop_scale ? r->drop_scale + r->N : nullptr, segs_all & ~SEG_A);
-    } else {
-      rc = run_chunk(c, r->x + (size_t)n0 * 256 * 256, r->out + (size_t)n0 * 256 * 256, up,
-                     r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr,
-                     r->drop_scale ? r->drop_scale + n0 : nullptr,
-                     r->drop_scale ? r->drop_scale + r->N + n0 : nullptr, segs_all);
-    }
+    // (A staggered start -- the second part gated on an event behind the first part's 252 ... 57 pixel encoder levels, so that each
+    // part crosses the latency-bound bottleneck block under the other's large launches -- was measured in rounds 5 and 6 and lost both
+    // times, 3.83 -> 3.98 ms: the large launches are persistent one-workgroup-per-CU grids that hold every CU for 100 - 250 us, and a
+    // part's small dependent launches then wait for CUs instead of slipping in: DESIGN.md section 3.2.)
+    int rc = run_chunk(c, r->x + (size_t)n0 * 256 * 256, r->out + (size_t)n0 * 256 * 256, up,
+                       r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr,
+                       r->drop_scale ? r->drop_scale + n0 : nullptr,
+                       r->drop_scale ? r->drop_scale + r->N + n0 : nullptr, tail_whole ? (SEG_A | SEG_B | SEG_C) : SEG_ALL);
     if (rc != UNCL_OK) { (void)join_sides(); return rc; }
     if (tail_whole && n0 + this_chunk >= r->N) {
       // join, then the last decoder stage for the whole batch on the caller's stream

@@ -525,6 +525,17 @@ class UNet(_GeneratorBase):
             x_out = self._crop(x_out, diffY, diffX)
         return x_out, up_x
 
+    @torch.no_grad()
+    def forward_detached(self, x, apply_crop=True, diffY=0, diffX=0):
+        """forward() for a caller that wants x_out only and no graph -- the discriminator step's `fake` (GanTrainerImg.py:206-211
+        builds the generator's graph and detaches it): same arithmetic in the module's current mode (DropPath draws in train()),
+        but the 32-channel feature map is neither written nor returned, and the last layer takes the one-channel form."""
+        self._check_input(x, 2)
+        x_out, _, _, _ = self._run(x.detach().reshape(-1, 256, 256).float().contiguous(), need_feat=False)
+        if apply_crop and self.to_crop:
+            x_out = self._crop(x_out, diffY, diffX)
+        return x_out
+
     def _needs_autograd(self, x):
         # batch_norm in EVAL mode is an inference configuration: the folded weights have no backward pass of their own
         if self.unet_norm == "batch_norm" and not self.training:

@@ -108,6 +108,13 @@ class GanTrainer:
         Returns (fake (N,1,H,W), fea_fake (N,32,H,W))."""
         return self.netG(_flat(hdr_input), diffY=self.final_shape_addition, diffX=self.final_shape_addition)
 
+    def _generate_detached(self, hdr_input):
+        """the discriminator step's fake frames: no graph, no feature map (generator.UNet.forward_detached where the module has it)"""
+        fd = getattr(self.netG, "forward_detached", None)
+        if fd is None or type(self)._generate is not GanTrainer._generate:
+            return self._generate(hdr_input)[0]
+        return fd(_flat(hdr_input), diffY=self.final_shape_addition, diffX=self.final_shape_addition)
+
     def _last_regime_loss(self, cgan, fake, ldr_pos, hdr_input):
         # GanTrainerImg.py:332-335 references an undefined L_TV: reproduced on purpose
         raise NameError("name 'L_TV' is not defined")
@@ -140,7 +147,7 @@ class GanTrainer:
     def D_real_fake_pass(self, real_ldr_pos, real_ldr_neg, hdr_input, epoch):
         if not self.pre_train_mode:
             with torch.no_grad():
-                fake, _ = self._generate(hdr_input)
+                fake = self._generate_detached(hdr_input)
         else:
             fake = _flat(hdr_input)
             if self.to_crop:
