@@ -78,7 +78,12 @@ __device__ __forceinline__ V ld16v(const bf16_t* p) { return *reinterpret_cast<c
 template <typename V>
 __device__ __forceinline__ V ld16ov(const bf16_t* base, unsigned byte_off) {
   asm volatile("" : "+v"(byte_off));     // see ld16o
+#if defined(UNCL_LOAD_NT) && UNCL_LOAD_NT
+  // (A/B build, tools/ab_variants.sh: every 16-byte vector load of the 3x3 kernels non-temporal)
+  return __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off));
+#else
   return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
 }
 // wave-uniform base + 32-bit per-lane BYTE offset: lowers to global_load_dwordx4 v, v_off, s[base] (no address VGPR pair)
 __device__ __forceinline__ bf16x8 ld16o(const bf16_t* base, unsigned byte_off) {
