@@ -599,6 +599,27 @@ class UNetVideo(_GeneratorBase):
     stage are read from the previous frame's activations (kept in that frame's workspace), Unet.py:244,270.
     feats = [mean(up_x), mean(Gaussian local variance of up_x)] per channel (Unet.py:274-278)."""
 
+    @torch.no_grad()
+    def forward_detached(self, x, apply_crop=True, diffY=0, diffX=0):
+        """forward() for a caller that wants the frames only and no graph -- the discriminator step's `fake` clip (GanTrainer.py:206-
+        211): the same frame loop in the module's current mode (recurrent hand-off through the kept workspaces, DropPath draws in
+        train()), but neither the 32-channel feature map nor its per-frame Gaussian statistics are computed, and the last layer
+        takes the one-channel form.  Returns frames (B,T,1,H,W)."""
+        if x.dim() != 5:
+            raise ValueError("video generator expects (B,T,1,H,W)")
+        self._check_input(x, 3)
+        B, T = x.shape[0], x.shape[1]
+        xs = x.detach().reshape(B, T, 256, 256).transpose(0, 1).float().contiguous()
+        outs, prev_ws = [], None
+        for t in range(T):
+            out, _, _, ws = self._run(xs[t], need_feat=False, prev_ws=prev_ws, keep_act=True, slot=t)
+            outs.append(out.reshape(B, 1, 1, 256, 256))
+            prev_ws = ws
+        x_out = torch.cat(outs, 1)
+        if apply_crop and self.to_crop:
+            x_out = self._crop(x_out, diffY, diffX)
+        return x_out
+
     def forward(self, x, apply_crop=True, diffY=0, diffX=0):
         if x.dim() != 5:
             raise ValueError("video generator expects (B,T,1,H,W)")

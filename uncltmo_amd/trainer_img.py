@@ -110,8 +110,9 @@ class GanTrainer:
 
     def _generate_detached(self, hdr_input):
         """the discriminator step's fake frames: no graph, no feature map (generator.UNet.forward_detached where the module has it)"""
+        import os
         fd = getattr(self.netG, "forward_detached", None)
-        if fd is None or type(self)._generate is not GanTrainer._generate:
+        if fd is None or type(self)._generate is not GanTrainer._generate or os.environ.get("UNCL_D_DETACHED", "1") == "0":    # (0: A/B)
             return self._generate(hdr_input)[0]
         return fd(_flat(hdr_input), diffY=self.final_shape_addition, diffX=self.final_shape_addition)
 

@@ -17,6 +17,15 @@ class GanTrainer(_ImageTrainer):
         return (fake.reshape(-1, fake.shape[2], fake.shape[3], fake.shape[4]),
                 fea.reshape(-1, fea.shape[2], fea.shape[3], fea.shape[4]))
 
+    def _generate_detached(self, hdr_input):
+        """the discriminator step's fake clip: no graph, no feature map, no per-frame feature statistics"""
+        import os
+        fd = getattr(self.netG, "forward_detached", None)
+        if fd is None or os.environ.get("UNCL_D_DETACHED", "1") == "0":          # (0: the full forward, A/B)
+            return self._generate(hdr_input)[0]
+        fake = fd(hdr_input, diffY=self.final_shape_addition, diffX=self.final_shape_addition)
+        return fake.reshape(-1, fake.shape[2], fake.shape[3], fake.shape[4])
+
     def _last_regime_loss(self, cgan, fake, ldr_pos, hdr_input):
         """GanTrainer.py:332-337: adversarial term switched off, brightness + pseudo-label + total variation."""
         f = self.loss_g_d_factor
