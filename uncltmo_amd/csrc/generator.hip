@@ -1210,7 +1210,9 @@ extern "C" int uncl_gen_forward(const uncl_gen_weights* w, const uncl_gen_run* r
     // (A staggered start -- the second part gated on an event behind the first part's 252 ... 57 pixel encoder levels, so that each
     // part crosses the latency-bound bottleneck block under the other's large launches -- was measured in rounds 5 and 6 and lost both
     // times, 3.83 -> 3.98 ms: the large launches are persistent one-workgroup-per-CU grids that hold every CU for 100 - 250 us, and a
-    // part's small dependent launches then wait for CUs instead of slipping in: DESIGN.md section 3.2.)
+    // part's small dependent launches then wait for CUs instead of slipping in: DESIGN.md section 3.2.  Also measured in round 6
+    // and removed: the bottleneck block proper (down_path.3 + graph block) ONCE for the whole batch between a join and a second fork of
+    // the halves -- 3.81 -> 3.88 ms: two more synchronisation points cost more than the block's launches gain from running alone.)
     int rc = run_chunk(c, r->x + (size_t)n0 * 256 * 256, r->out + (size_t)n0 * 256 * 256, up,
                        r->knn_idx ? r->knn_idx + (size_t)n0 * NODES * 9 : nullptr,
                        r->drop_scale ? r->drop_scale + n0 : nullptr,
