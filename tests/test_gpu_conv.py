@@ -471,6 +471,49 @@ def test_pc_fused_outc_tail_bitwise(cin, h, w, n, skip, act1):
     assert rel_l2(g1.cpu().unsqueeze(1), ref1) < TOL[BF]
 
 
+@pytest.mark.parametrize("code", [_hip.BF16, _hip.F16])
+@pytest.mark.parametrize("h,w,n,act1", [(45, 61, 3, _hip.ACT_SIGMOID),        # 47 x 63 outputs: ragged in both directions
+                                        (14, 30, 5, _hip.ACT_SIGMOID),        # 16 x 32: one tile per sample, exact
+                                        (15, 31, 4, _hip.ACT_SIGMOID),        # 17 x 33: one row / one column past a tile border
+                                        (254, 254, 1, _hip.ACT_SIGMOID),      # the generator's own last layer
+                                        (30, 40, 2, _hip.ACT_TANH), (30, 40, 2, _hip.ACT_NONE), (30, 40, 2, _hip.ACT_MSIG)])
+def test_last_layer_one_channel_form_two_accumulator_sets(code, h, w, n, act1):
+    """Round 6: inference's last layer (32 -> 32 transposed 3x3 + ReLU + outconv + last activation, only the one-channel map stored) on
+    the producer / consumer structure with the 1x1 tail computed from the accumulators (`O1C`: two accumulator sets for the sigmoid,
+    one for the other activations) against the four-wave `O1D` form (same rounded channels, the three partial dot products summed
+    in the same order: 2e-6) and against torch; ragged extents, every pixel of the NaN-initialised output written, an odd tile count
+    per workgroup (the two sets alternate per tile: last tile in either set)."""
+    lib = _hip.lib()
+    tdt = _hip.torch_dtype(code)
+    x, wt, b = q(rnd(n, 32, h, w, seed=271), code), q(rnd(32, 32, 3, 3, seed=272, scale=0.1), code), rnd(32, seed=273)
+    w1, b1 = rnd(32, seed=274).cuda(), rnd(1, seed=275).cuda()
+    xd, wd, bd = to_nhwc(x, code), pack_weight(wt, code, transposed=True, flip=True), b.cuda()
+
+    def run():
+        out1 = torch.full((n, h + 2, w + 2), float("nan"), dtype=torch.float32, device="cuda")
+        run_pipe(dtype=code, ksize=3, pad=2, src_mode=_hip.SRC_PLAIN, N=n, H=h, W=w, Cin=32, Cout=32, src0=xd, src0_H=h, src0_W=w,
+                 src0_C=32, weight=wd, bias=bd, act=_hip.ACT_RELU, out=None, out_H=h + 2, out_W=w + 2, out_C=32, out1_w=w1, out1_b=b1,
+                 out1_act=act1, out1=out1, skip_main_store=1)
+        return out1
+
+    old = lib.uncl_conv3x3_set_pc(0)
+    try:
+        r1 = run()                                  # four-wave kernel
+        lib.uncl_conv3x3_set_pc(2)
+        g1 = run()                                  # the default: O1C
+        g2 = run()
+    finally:
+        lib.uncl_conv3x3_set_pc(old)
+    assert torch.isfinite(g1).all() and torch.isfinite(r1).all()
+    assert torch.equal(g1, g2)                      # run to run
+    assert (r1 - g1).abs().max().item() < 2e-6 * max(1.0, r1.abs().max().item())
+    up = F.relu(F.conv_transpose2d(x, wt, b))
+    ref1 = F.conv2d(q(up, code), w1.cpu().reshape(1, 32, 1, 1), b1.cpu())
+    ref1 = {_hip.ACT_SIGMOID: torch.sigmoid, _hip.ACT_TANH: torch.tanh, _hip.ACT_NONE: lambda t: t,
+            _hip.ACT_MSIG: lambda t: torch.sigmoid(3.0 * t)}[act1](ref1)
+    assert rel_l2(g1.cpu().unsqueeze(1), ref1) < (1.5e-2 if code == _hip.BF16 else 2e-3)
+
+
 @pytest.mark.parametrize("kind,c,cout,h,n,pool", [("plain", 64, 64, 124, 24, True),      # 24 x 4 x 8 = 768 tiles of 16 x 32 x 64
                                                    ("plain", 128, 128, 59, 48, True),    # 57 x 57 output, two cout tiles
                                                    ("ssr", 128, 64, 57, 96, False)])     # concat source, 59 x 59 output
