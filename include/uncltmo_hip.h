@@ -291,6 +291,10 @@ int uncl_head_handoff(void* g, const void* mask, float slope, const void* carry_
                       int prev_ch, void* stream);
 /* out = x with the first prev_ch channels of every pixel taken from prev: the mixed tensor a stage of frame k > 0 read */
 int uncl_mix_heads(const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream);
+/* Backward of the max-relative graph convolution (gcn_lib/torch_vertex.py:22-29; out[2c] = x_c, out[2c+1] = max_k (x_c[nbr_k] - x_c)).
+ * g_out: bf16 (N, n, 2C); x: bf16 (N, n, C); idx: (N, n, k) neighbour indices of the forward pass; g_x_bf16: bf16 (N, n, C) result.
+ * g_x_f32: N n C floats of scratch, used (and zeroed) only by the global-atomic form, i.e. when C % 32 != 0 or a sample's slice does
+ * not fit 64 KB of LDS. */
 int uncl_gcn_maxrel_backward(const void* g_out, const void* x, const int32_t* idx, float* g_x_f32, void* g_x_bf16, int N, int n,
                              int C, int k, void* stream);
 int uncl_conv_in_c1_wgrad(const void* G, const float* x, float* gw, float* gb, int N, int H, int W, int accumulate,

@@ -819,7 +819,6 @@ int backward_all(const BCtx& c) {
     RUN(c.colsum(tC, (long long)c.n * NODES, 512, b->gb[W_GGC]));
   }
   RUN(dgrad1(c, W_GGC, tC, 512, 512, c.sc.tD, nullptr, 4));
-  if (hipMemsetAsync(c.sc.f32, 0, (size_t)c.n * per256 * 4, c.s) != hipSuccess) return UNCL_ERR_LAUNCH;
   RUN(bwd_gcn_maxrel_backward(c.dt, c.sc.tD, c.F(B_GFC1), reinterpret_cast<const int32_t*>(c.F(B_KNN)), c.sc.f32, tB2, c.n, NODES,
                                256, 9, c.s));
   RUN(wgrad1(c, W_GFC1, c.F(B_X4), 256, 256, tB2, 256, 256, b->gw[W_GFC1], true));
