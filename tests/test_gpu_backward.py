@@ -381,6 +381,55 @@ def test_gauss_stats_backward_vs_autograd(n, h, c, accumulate):
     assert rel_l2(from_nhwc(gx), want) < 1e-2
 
 
+def _gauss_bwd_elementwise(cases):
+    """element by element against fp64 autograd of the oracle's statistics: the stored bf16 value is within one ulp (2^-8 relative)
+    of the fp64 gradient plus fp32 noise on the two terms whose difference it is (x wy wx - s)"""
+    worst = 0.0
+    for n, h, w, seed in cases:
+        x = q(rnd(n, 32, h, w, seed=seed).abs()).double().requires_grad_(True)
+        gst = rnd(n, 2, 32, seed=seed + 1).double()
+        f1 = x.mean(dim=(2, 3))
+        f2 = OG.local_variance(x, OG.gauss_window()).mean(dim=(2, 3))
+        ((f1 * gst[:, 0]).sum() + (f2 * gst[:, 1]).sum()).backward()
+        xd = to_nhwc(x.detach().float(), BF)
+        gx = torch.full_like(xd, float("nan"))
+        _hip.check(_hip.lib().uncl_gauss_stats_backward(xd.data_ptr(), BF, gst.float().cuda().data_ptr(), gx.data_ptr(), n, h, w, 32, 0,
+                                                        _hip.stream_ptr()), "gsb")
+        got = from_nhwc(gx).double()
+        want = x.grad
+        assert torch.isfinite(got).all()
+        # |x wy wx| <= 1 and s <= 1 here; their fp32 evaluation carries ~1e-6 of that, scaled like the gradient's variance term
+        scv = (gst[:, 1].abs() * 2.0 / ((h - 10) * (w - 10))).reshape(n, 32, 1, 1)
+        tol = want.abs() * 2.0 ** -8 + scv * 4e-6
+        excess = ((got - want).abs() / tol).max().item()
+        worst = max(worst, excess)
+        assert excess <= 1.0, (n, h, w, excess)
+    return worst
+
+
+_GAUSS_CASES = [(2, 16, 19, 80), (2, 21, 21, 70), (1, 37, 53, 72), (2, 45, 45, 74), (1, 64, 96, 76), (1, 256, 256, 78)]
+
+
+def test_gauss_stats_backward_two_pass_form_element_by_element():
+    """The two-pass form (band matrix A = G^T G per axis, truncated rows at both ends of an axis): every pixel, including the ten
+    rows / columns at each border where the weights differ per position, tiles that overhang the frame, and the smallest frame
+    the form takes (21: the two ends' truncations just do not meet; the 16 x 19 case falls back to the four-pass kernel)."""
+    _gauss_bwd_elementwise(_GAUSS_CASES)
+
+
+def test_gauss_stats_backward_four_pass_form_element_by_element():
+    """UNCL_GAUSS_BWD_FORM=0 (read once per process: a child) through the same gate -- the form the two-pass kernel replaced and
+    the fallback for frames under 21 pixels."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+            "from test_gpu_backward import _gauss_bwd_elementwise, _GAUSS_CASES\n"
+            "print('worst', _gauss_bwd_elementwise(_GAUSS_CASES))\n" % (root, root))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UNCL_GAUSS_BWD_FORM="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "worst" in r.stdout, r.stderr[-2000:]
+
+
 def test_video_generator_backward_through_time_vs_oracle_autograd():
     from uncltmo_amd.generator import UNetVideo
     net = UNetVideo(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,

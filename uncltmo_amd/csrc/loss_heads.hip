@@ -1013,6 +1013,204 @@ __global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32_kernel(const bf1
   }
 }
 
+// The same gradient in TWO passes (round 6).  s = G_y^T G_x^T M G_x G_y x with M the mask of valid window positions, and M is a
+// product of a row mask and a column mask, so s = A_y A_x x with the (H x H) band matrix A = G^T G of one axis:
+//   A[i][i + d] = sum_u g[u] g[u + d],  u from max(0, -d, i - Ho + 1) to min(10, 10 - d, i)                       (|d| <= 10)
+// -- the 21-tap autocorrelation of the window wherever i is ten or more pixels from both ends, ten truncated rows at each end
+// (GaussC::bt; the high end is the low end mirrored, the window is symmetric).  Two passes of 21 taps instead of four of 11:
+// per channel and 16 x 16 tile 17.5 k multiply-adds instead of 25.1 k, one fp32 intermediate (36 x 16) through LDS instead of
+// three, and the inputs of a run of four outputs read as 12 dwords (two 16-bit pixels each) instead of 14 single elements.
+// Interior tiles take the weights from scalar registers; a tile that touches an end of the axis reads a per-position row from
+// a small LDS table built at the start.  A wave works on TWO of its channels at a time (288 + 128 units over 64 lanes).
+// Measured (8 samples): 148 -> 144 us with scalar multiply-adds, 137 with the packed ones of gc_taps4 -- of which 42 us are the
+// load and store phases (-DUNCL_GC_ABL=1); the rest is instruction issue at two waves per SIMD (the planes' 44 KB per workgroup
+// allow no third workgroup per CU).
+struct GaussC { float c[2 * GW - 1]; float bt[GW - 1][2 * GW - 1]; };
+constexpr int CT = 2 * GW - 1 /*21 taps*/, CTP = 20 /*row pitch of the intermediate in floats: 4 CTP = 16 (mod 64) banks per run of rows*/;
+constexpr int GC_T = 2 * HI * CTP;             // floats of intermediate per wave (two channels)
+// four outputs of a 21-tap filter from 24 inputs: out[r] = sum_t w[t] in[r + t].  Packed fp32 multiply-adds on the ALIGNED input
+// pairs (in[2k], in[2k+1]) only: an even tap feeds output pairs (0,1), (2,3); an odd tap the pair (1,2) plus two single
+// multiply-adds for outputs 0 and 3 -- 52 instructions instead of 84.  Even and odd taps accumulate separately (fixed order).
+typedef float gc_f2 __attribute__((ext_vector_type(2)));
+template <typename WF>
+__device__ __forceinline__ void gc_taps4(const float (&in)[24], WF w, float (&out)[4]) {
+  gc_f2 e01 = {0.f, 0.f}, e23 = {0.f, 0.f}, o12 = {0.f, 0.f};
+  float o0 = 0.f, o3 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 21; t += 2) {
+    const float wt = w(t);
+    const gc_f2 wv = {wt, wt};
+    e01 = __builtin_elementwise_fma(wv, gc_f2{in[t], in[t + 1]}, e01);
+    e23 = __builtin_elementwise_fma(wv, gc_f2{in[t + 2], in[t + 3]}, e23);
+  }
+#pragma unroll
+  for (int t = 1; t < 21; t += 2) {
+    const float wt = w(t);
+    const gc_f2 wv = {wt, wt};
+    o12 = __builtin_elementwise_fma(wv, gc_f2{in[t + 1], in[t + 2]}, o12);
+    o0 = fmaf(wt, in[t], o0);
+    o3 = fmaf(wt, in[t + 3], o3);
+  }
+  out[0] = e01[0] + o0;
+  out[1] = e01[1] + o12[0];
+  out[2] = e23[0] + o12[1];
+  out[3] = e23[1] + o3;
+}
+template <int CH, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void gauss_stats_bwd32c_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gst,
+                                                                 bf16_t* __restrict__ gx, int H, int W, int tiles_x, GaussW gw, GaussC gc,
+                                                                 int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PS = GB_PS, NTHR = NWAVE * 64, OCT = CH / 8, SOP = HT * HT + 2;
+  bf16_t* sx = reinterpret_cast<bf16_t*>(smem);                                            // [CH][PS] input planes
+  float* tmp = reinterpret_cast<float*>(smem + CH * PS * 2);                               // per wave: T[2][HI][CTP]
+  bf16_t* so = reinterpret_cast<bf16_t*>(smem + CH * PS * 2 + NWAVE * GC_T * 4);           // [CH][SOP] result planes
+  float* wtab = reinterpret_cast<float*>(smem + CH * PS * 2 + NWAVE * GC_T * 4 + CH * SOP * 2);   // [2][HT][CT]: x rows, then y rows
+  const int c0 = blockIdx.z * CH;
+  const int n = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * HT, x0 = tx * HT;
+  const int Ho = H - (GW - 1), Wo = W - (GW - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* xn = x + (size_t)n * H * W * 32 + c0;
+  // interior along an axis: every output position of the tile is >= 10 from the low end and <= L - 11
+  const bool xin = x0 >= GW - 1 && x0 + HT - 1 <= W - GW, yin = y0 >= GW - 1 && y0 + HT - 1 <= H - GW;
+  for (int v = tid; v < (HI * HI / 2) * OCT; v += NTHR) {
+    const int pair = v / OCT, c8 = v - pair * OCT;
+    bf16x8 val[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int pix = 2 * pair + h2, ly = pix / HI, lx = pix - ly * HI;
+      const int gy = y0 - 10 + ly, gxx = x0 - 10 + lx;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) val[h2][i] = (bf16_t)0.f;
+      if (gy >= 0 && gy < H && gxx >= 0 && gxx < W)
+        val[h2] = *reinterpret_cast<const bf16x8*>(xn + ((size_t)gy * W + gxx) * 32 + c8 * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+      bf16x2_t pk;
+      pk[0] = val[0][i]; pk[1] = val[1][i];
+      *reinterpret_cast<bf16x2_t*>(sx + (c8 * 8 + i) * PS + ((2 * pair) / HI) * HIP + (2 * pair) % HI) = pk;
+    }
+  }
+  if (!xin || !yin) {
+    // per-position weight rows of this tile: position i of an axis of length L takes row i of the truncated table at the low end,
+    // row L - 1 - i mirrored at the high end, the autocorrelation in between
+    for (int v = tid; v < 2 * HT * CT; v += NTHR) {
+      const int ax = v / (HT * CT), r = v - ax * (HT * CT), pos = r / CT, d = r - pos * CT;
+      const int L = ax == 0 ? W : H, i = (ax == 0 ? x0 : y0) + pos;
+      float w = gc.c[d];
+      if (i < GW - 1) w = gc.bt[i][d];
+      else if (i > L - GW && i < L) w = gc.bt[L - 1 - i][CT - 1 - d];
+      wtab[v] = w;
+    }
+  }
+  __syncthreads();
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+  float* T = tmp + wave * GC_T;
+  constexpr int R = 4, NRT = HT / R /*4 runs across 16*/, UA = HI * NRT /*144 units of the first pass per channel*/;
+  // second pass: this lane's column pc and rows 4 pq .. 4 pq + 3; the window-count weights of its pixels
+  const int pc = lane & (HT - 1), pq = lane >> 4;
+  float wx1 = 0.f, wy4[R] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int gxv = x0 + pc;
+    if (gxv - t >= 0 && gxv - t < Wo) wx1 += gw.g[t];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int gyv = y0 + pq * R + r;
+      if (gyv - t >= 0 && gyv - t < Ho) wy4[r] += gw.g[t];
+    }
+  }
+#ifndef UNCL_GC_ABL
+#define UNCL_GC_ABL 0        // timing only: 1 no passes, 2 no first pass, 4 no second pass
+#endif
+  for (int cp = 0; cp < ((UNCL_GC_ABL & 1) ? 0 : CH / NWAVE); cp += 2) {
+    // 1: T[p][ly][c] = sum_d A_x[x0 + c][x0 + c + d] x[ly][c + 10 + d]          (HI rows x HT columns, two channels)
+    for (int u = lane; u < ((UNCL_GC_ABL & 2) ? 0 : 2 * UA); u += 64) {
+      const int p = u >= UA ? 1 : 0, v = u - p * UA;
+      const int run = v / HI, ly = v - run * HI, lx0 = run * R;
+      const bf16_t* sc_ = sx + (wave + NWAVE * (cp + p)) * PS + ly * HIP + lx0;
+      float in[R + CT - 1];
+#pragma unroll
+      for (int j = 0; j < (R + CT - 1) / 2; ++j) {
+        const unsigned w2 = *reinterpret_cast<const unsigned*>(sc_ + 2 * j);
+        in[2 * j] = __builtin_bit_cast(float, w2 << 16);
+        in[2 * j + 1] = __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+      }
+      float* tp = T + (p * HI + ly) * CTP + lx0;
+      if (xin) {
+        float o[R];
+        gc_taps4(in, [&](int t) __attribute__((always_inline)) { return gc.c[t]; }, o);
+#pragma unroll
+        for (int r = 0; r < R; ++r) tp[r] = o[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float* wr = wtab + (lx0 + r) * CT;
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc = fmaf(wr[t], in[r + t], acc);
+          tp[r] = acc;
+        }
+      }
+    }
+    WAVE_SYNC();
+    // 2: s[py][pc] = sum_d A_y[y0 + py][y0 + py + d] T[py + 10 + d][pc]; gradient = g_mean + sc (x wy wx - s)
+#pragma unroll
+    for (int p = 0; p < ((UNCL_GC_ABL & 4) ? 0 : 2); ++p) {
+      const int ch = wave + NWAVE * (cp + p);
+      const float gm = gst[((size_t)n * 2 + 0) * 32 + c0 + ch] / ((float)H * (float)W);
+      const float scv = gst[((size_t)n * 2 + 1) * 32 + c0 + ch] * 2.f / ((float)Ho * (float)Wo);
+      float in[R + CT - 1];
+      const float* tp = T + (p * HI + pq * R) * CTP + pc;
+#pragma unroll
+      for (int j = 0; j < R + CT - 1; ++j) in[j] = tp[j * CTP];
+      const bf16_t* sc_ = sx + ch * PS;
+      float s4[R];
+      if (yin) {
+        gc_taps4(in, [&](int t) __attribute__((always_inline)) { return gc.c[t]; }, s4);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float* wr = wtab + (HT + pq * R + r) * CT;
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc = fmaf(wr[t], in[r + t], acc);
+          s4[r] = acc;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int py = pq * R + r;
+        so[ch * SOP + py * HT + pc] = (bf16_t)(gm + scv * ((float)sc_[(py + 10) * HIP + pc + 10] * wy4[r] * wx1 - s4[r]));
+      }
+    }
+    WAVE_SYNC();
+  }
+  __syncthreads();
+#undef WAVE_SYNC
+  for (int v = tid; v < HT * HT * OCT; v += NTHR) {
+    const int pix = v / OCT, c8 = v - pix * OCT, ly = pix / HT, lx = pix - ly * HT;
+    const int gy = y0 + ly, gxx = x0 + lx;
+    if (gy < H && gxx < W) {
+      bf16_t* d = gx + ((size_t)n * H * W + (size_t)gy * W + gxx) * 32 + c0 + c8 * 8;
+      bf16x8 val;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) val[i] = so[(c8 * 8 + i) * SOP + pix];
+      if (accumulate) {
+        const bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) val[i] = (bf16_t)((float)old[i] + (float)val[i]);
+      }
+      *reinterpret_cast<bf16x8*>(d) = val;
+    }
+  }
+}
+
 // x, gx: NHWC (N,H,W,C) in dtype; g_stats: fp32 (N,2,C) = [d/d mean, d/d mean-local-variance] per (sample, channel)
 extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* g_stats, void* gx, int N, int H, int W, int C,
                                          int accumulate, void* stream) {
@@ -1038,6 +1236,36 @@ extern "C" int uncl_gauss_stats_backward(const void* x, int dtype, const float* 
       attr.done();
     }
     const int tx16 = (W + HT - 1) / HT, ty16 = (H + HT - 1) / HT;
+    // two 21-tap passes (default; needs both ends of an axis ten pixels apart: H, W >= 21) or the four 11-tap passes
+    // (UNCL_GAUSS_BWD_FORM=0; 8 / 32 samples at 256 x 256: 148 / 532 us against 137 / 476; load + store alone: 42 us at 8 samples)
+    static const int form = [] { const char* e = getenv("UNCL_GAUSS_BWD_FORM"); return e ? atoi(e) : 1; }();
+    if (form && H >= 2 * GW - 1 && W >= 2 * GW - 1) {
+      constexpr size_t ldsc = (size_t)16 * GB_PS * 2 + (size_t)4 * GC_T * 4 + (size_t)(HT * HT + 2) * 16 * 2 + (size_t)2 * HT * CT * 4;
+      static_assert(2 * ldsc <= 160 * 1024, "two workgroups per CU");
+      static UnclDevOnce attrc;
+      if (attrc.need()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_stats_bwd32c_kernel<16, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc) != hipSuccess)
+          return UNCL_ERR_LAUNCH;
+        attrc.done();
+      }
+      GaussC gc;
+      double gf[GW];
+      for (int k = 0; k < GW; ++k) gf[k] = (double)gw.g[k];             // the fp32 window the other kernels multiply with
+      for (int d = -(GW - 1); d <= GW - 1; ++d) {
+        for (int i = 0; i < GW; ++i) {                                   // i = GW - 1: the untruncated row = the autocorrelation
+          double a = 0.0;
+          for (int u = 0; u < GW; ++u)
+            if (u + d >= 0 && u + d < GW && u <= i) a += gf[u] * gf[u + d];
+          if (i < GW - 1) gc.bt[i][d + GW - 1] = (float)a;
+          else gc.c[d + GW - 1] = (float)a;
+        }
+      }
+      hipLaunchKernelGGL((gauss_stats_bwd32c_kernel<16, 4>), dim3(tx16 * ty16, N, 2), dim3(256), ldsc, st, (const bf16_t*)x, g_stats,
+                         (bf16_t*)gx, H, W, tx16, gw, gc, accumulate);
+      UNCL_CHECK_LAUNCH();
+      return UNCL_OK;
+    }
     static const int half_on = [] { const char* e = getenv("UNCL_GAUSS_BWD_HALF"); return e ? atoi(e) : 1; }();   // 0: one 32-channel workgroup per tile (8 / 32 samples: 151 / 575 us against 148 / 541)
     if (half_on)
       hipLaunchKernelGGL((gauss_stats_bwd32_kernel<16, 4>), dim3(tx16 * ty16, N, 2), dim3(256), lds16, st, (const bf16_t*)x, g_stats,
