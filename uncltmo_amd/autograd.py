@@ -248,7 +248,7 @@ class _VideoGeneratorFn(torch.autograd.Function):
         from .generator import gauss_stats
         B, T = x.shape[0], x.shape[1]
         dev = x.device
-        frames, outs, feats, leases = [], [], [], []
+        frames, feats, leases = [], [], []
         prev_ws = None
         use_clip = getattr(module, "clip_wgrad", None)
         if use_clip is None:     # UNCL_CLIP_WGRAD=0: the per-frame form (A/B timing)
@@ -261,30 +261,33 @@ class _VideoGeneratorFn(torch.autograd.Function):
             # the clip's frames one behind the other in ONE array (one copy instead of T): the deferred pass takes the first layer's
             # weight gradient over all T * B samples from frame 0's pointer (uncl_gen_bwd.clip_T)
             xs = x.detach().reshape(B, T, 256, 256).transpose(0, 1).float().contiguous().reshape(T * B, 256, 256)
+        # the frames' outputs frame-major in one array (one transposing copy at the end instead of a T-way cat), their DropPath
+        # flags drawn at once
+        out_all = torch.empty(T, B, 1, 256, 256, dtype=torch.float32, device=dev)
+        drops = module._drop_scales(T, B, dev)
         for t in range(T):
             xf = xs[t * B:(t + 1) * B] if use_clip else x[:, t].detach().reshape(B, 256, 256).float().contiguous()
             if use_clip:
                 out, up, _, ws, ds = module._run(xf, need_feat=True, keep_act=True, slot=("clipws", T), save_preact=True,
-                                                 return_drop=True, clip=(T, t))
+                                                 return_drop=True, clip=(T, t), drop=drops[t], out=out_all[t])
                 frames.append((xf, out, up, ws, ds))
                 feats.append(gauss_stats(up, B, 256, 256, 32).reshape(B, 1, 64, 1, 1))
-                outs.append(out.reshape(B, 1, 1, 256, 256))
                 continue
             lease = _WsLease(module, dev, ("clip", t))
             lease.install(("clip", t))
             out, up, _, ws, ds = module._run(xf, need_feat=True, prev_ws=prev_ws, keep_act=True, slot=("clip", t),
-                                             save_preact=True, return_drop=True)
+                                             save_preact=True, return_drop=True, drop=drops[t], out=out_all[t])
             lease.take(("clip", t))
             leases.append(lease)
             feats.append(gauss_stats(up, B, 256, 256, 32).reshape(B, 1, 64, 1, 1))
-            outs.append(out.reshape(B, 1, 1, 256, 256))
             frames.append((xf, out, up, ws, ds))
             prev_ws = ws
         if use_clip:
             lease.take(("clipws", T))
             leases.append(lease)
         ctx.module, ctx.frames, ctx.leases = module, frames, leases
-        return torch.cat(outs, 1), torch.cat(feats, 1)
+        from .generator import _batch_major
+        return _batch_major(out_all), torch.cat(feats, 1)
 
     @staticmethod
     def backward(ctx, g_out, g_feats):

@@ -437,8 +437,20 @@ class _GeneratorBase(nn.Module):
             keep = torch.empty(2, n, device=dev).bernoulli_(keep_prob)
         return (keep / keep_prob).contiguous()
 
+    def _drop_scales(self, T, n, dev):
+        """`_drop_scale` for the T frame calls of a clip: one draw of (T, 2, N) instead of T draws of (2, N) (the reference's
+        DropPath draws per call, timm/layers/drop.py; the flags of different frames are independent either way).  A list of T
+        (2, N) tensors, or of T `None`s in eval mode."""
+        if not self.training or self.drop_path_prob == 0.0:
+            return [None] * T
+        if self.forced_drop_keep is not None:
+            return [self._drop_scale(n, dev) for _ in range(T)]
+        keep_prob = 1.0 - self.drop_path_prob
+        allk = torch.empty(T, 2, n, device=dev).bernoulli_(keep_prob) / keep_prob
+        return [allk[t] for t in range(T)]
+
     def _run(self, x_flat, need_feat, prev_ws=None, keep_act=False, slot=0, want_knn=False, save_preact=False,
-             return_drop=False, clip=None, tiles_in_place=None):
+             return_drop=False, clip=None, tiles_in_place=None, drop="draw", out=None):
         """x_flat: (N,256,256) fp32 on the GPU.  Returns (out (N,1,256,256) fp32, up_x NHWC or None, knn or None, ws).
         clip = (T, t): frame t of a T-frame clip in ONE workspace laid out for T * N samples (uncl_gen_run.clip_T; the previous
         frame is that workspace's slice t - 1, prev_ws stays None)."""
@@ -462,10 +474,14 @@ class _GeneratorBase(nn.Module):
                 raise _hip.HipError("clip layout: keep_act, no prev_ws (implied), unet_norm 'none'")
             chunk = 0
         ws, nbytes = self._workspace(n * clip[0] if clip is not None else n, chunk, keep_act, dev, slot)
-        out = torch.empty(n, 1, 256, 256, dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty(n, 1, 256, 256, dtype=torch.float32, device=dev)
+        elif out.shape != (n, 1, 256, 256) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise _hip.HipError("generator: `out` must be a contiguous fp32 (N,1,256,256) tensor on the input's device")
         up = torch.empty(n, 256, 256, 32, dtype=_hip.torch_dtype(gw.dtype), device=dev) if need_feat else None
         knn = torch.empty(n, 144, 9, dtype=torch.int32, device=dev) if want_knn else None
-        ds = self._drop_scale(n, dev)
+        # drop: the caller's (2, N) DropPath multipliers (a clip draws its frames' flags at once: _drop_scales), None for none
+        ds = self._drop_scale(n, dev) if isinstance(drop, str) else drop
         run = _hip.GenRun()
         run.N, run.chunk, run.keep_activations = n, chunk, int(keep_act)
         run.x, run.out = x_flat.data_ptr(), out.data_ptr()
@@ -579,6 +595,13 @@ class UNet(_GeneratorBase):
         return (out, knn) if want_knn else out
 
 
+def _batch_major(out_all):
+    """(T,B,...) frame-major outputs -> a fresh contiguous (B,T,...) tensor (never an alias of the frames' own buffers, which a
+    backward pass still reads): one transposing copy."""
+    v = out_all.transpose(0, 1)
+    return v.clone() if v.is_contiguous() else v.contiguous()
+
+
 def gauss_stats(x_nhwc, n, h, w, c):
     """[mean(x), mean(Gaussian local variance)] per (sample, channel): fp32 (n, 2, c).  x_nhwc is a contiguous
     NHWC tensor (or an (n,h,w) fp32 image when c == 1).  Reference: Unet.py:112-123,274-278."""
@@ -610,12 +633,14 @@ class UNetVideo(_GeneratorBase):
         self._check_input(x, 3)
         B, T = x.shape[0], x.shape[1]
         xs = x.detach().reshape(B, T, 256, 256).transpose(0, 1).float().contiguous()
-        outs, prev_ws = [], None
+        # the frames' outputs one behind the other (frame-major), handed back with ONE transposing copy instead of a T-way cat
+        out_all = torch.empty(T, B, 1, 256, 256, dtype=torch.float32, device=x.device)
+        drops = self._drop_scales(T, B, x.device)
+        prev_ws = None
         for t in range(T):
-            out, _, _, ws = self._run(xs[t], need_feat=False, prev_ws=prev_ws, keep_act=True, slot=t)
-            outs.append(out.reshape(B, 1, 1, 256, 256))
+            _, _, _, ws = self._run(xs[t], need_feat=False, prev_ws=prev_ws, keep_act=True, slot=t, drop=drops[t], out=out_all[t])
             prev_ws = ws
-        x_out = torch.cat(outs, 1)
+        x_out = _batch_major(out_all)
         if apply_crop and self.to_crop:
             x_out = self._crop(x_out, diffY, diffX)
         return x_out
@@ -634,18 +659,19 @@ class UNetVideo(_GeneratorBase):
                 x_out = self._crop(x_out, diffY, diffX)
             return x_out, feats
         B, T = x.shape[0], x.shape[1]
-        outs, feats = [], []
+        feats = []
         prev_ws = None
         # the clip's frames one behind the other (one copy instead of T strided ones)
         xs = x.detach().reshape(B, T, 256, 256).transpose(0, 1).float().contiguous()
+        out_all = torch.empty(T, B, 1, 256, 256, dtype=torch.float32, device=x.device)
+        drops = self._drop_scales(T, B, x.device)
         for t in range(T):
             xf = xs[t]
-            out, up, _, ws = self._run(xf, need_feat=True, prev_ws=prev_ws, keep_act=True, slot=t)
+            _, up, _, ws = self._run(xf, need_feat=True, prev_ws=prev_ws, keep_act=True, slot=t, drop=drops[t], out=out_all[t])
             st = gauss_stats(up, B, 256, 256, 32)                      # (B,2,32)
             feats.append(st.reshape(B, 1, 64, 1, 1))
-            outs.append(out.reshape(B, 1, 1, 256, 256))
             prev_ws = ws
-        x_out = torch.cat(outs, 1)
+        x_out = _batch_major(out_all)
         if apply_crop and self.to_crop:
             x_out = self._crop(x_out, diffY, diffX)
         return x_out, torch.cat(feats, 1)
