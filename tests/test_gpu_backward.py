@@ -593,6 +593,50 @@ def test_bf16_backward_is_deterministic(n, video):
         assert rel_l2(fast[k].cpu(), runs[0][k].cpu()) < 2e-4, (k, rel_l2(fast[k].cpu(), runs[0][k].cpu()))
 
 
+def _det_train_pass(n, drop):
+    """one deterministic bf16 training pass of the image generator: outputs and every parameter gradient, on the host"""
+    net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0,
+               compute_dtype="bf16")
+    synth.fill_state_dict(net, "g0")
+    net = net.cuda().train()
+    if drop:
+        net.forced_drop_keep = [[1.0] * n, [1.0] * (n - 1) + [0.0]]        # DropPath scales in both residual branches
+    else:
+        net.drop_path_prob = 0.0
+    x = synth.smooth_hdr_frames(n, salt="gelu_fused").cuda()
+    old = _hip.lib().uncl_gen_set_deterministic(1)
+    try:
+        y, up = net(x)
+        (y.float().sum() + 1e-3 * up.float().sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        _hip.lib().uncl_gen_set_deterministic(old)
+    res = {"y": y.detach().float().cpu(), "up": up.detach().float().cpu()}
+    res.update({k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None})
+    return res
+
+
+@pytest.mark.parametrize("n,drop", [(3, False), (8, True)])
+def test_gelu_fused_into_the_graph_blocks_1x1_launches_is_bit_identical(n, drop, tmp_path):
+    """The training passes' GELUs ride in the store of the 1x1 launch before them (forward: pre-activation and activation from one
+    launch; backward: data gradient x gelu'(z)); UNCL_C1_GELU=0 (read once per process: a child) runs the convolution and the gelu
+    kernel as two launches.  Same rounding points -> same bits, outputs and all 58 parameter gradients (deterministic mode)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "two_launch.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+            "import torch\nfrom test_gpu_backward import _det_train_pass\n"
+            "torch.save(_det_train_pass(%d, %r), %r)\nprint('ok')\n" % (root, root, n, drop, out))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UNCL_C1_GELU="0"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    two = torch.load(out)
+    one = _det_train_pass(n, drop)
+    assert set(one) == set(two) and len(one) >= 58
+    for k in one:
+        assert torch.equal(one[k], two[k]), k
+
+
 def test_wgrad_scratch_form_equals_atomics_within_rounding():
     """the C-ABI switch itself: with a scratch buffer the kernels store partial sums and reduce them in a fixed order (twice the same
     bits), without one they use atomics; both are the same sums up to fp32 rounding order"""

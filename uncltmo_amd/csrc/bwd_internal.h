@@ -16,6 +16,11 @@ int bwd_mix_heads(int dtype, const void* x, const void* prev, void* out, long lo
 int bwd_gcn_maxrel_backward(int dtype, const void* g_out, const void* x, const int32_t* idx, float* g_x_f32, void* g_x_bf16, int N, int n, int C, int k, void* stream);
 int bwd_conv_in_c1_wgrad(int dtype, const void* G, const float* x, float* gw, float* gb, int N, int H, int W, int accumulate, void* workspace, void* stream);
 
+// conv_igemm.hip: bf16 1x1 convolution with the graph block's GELU fused into its store (gmode 1 forward + pre-activation to zbuf,
+// 2 data gradient x gelu'(zbuf)); > 0 (UNCL_GELU_NOT_FUSED) = not taken, run the two launches
+constexpr int UNCL_GELU_NOT_FUSED = 1;
+int uncl_conv1x1_gelu(const uncl_conv_desc* d, void* zbuf, int gmode, void* stream);
+
 // fp32 parity mode (bwd_f32.hip): deterministic plain-fp32 forms of the matrix-core backward kernels
 int bwd_wgrad_f32(const uncl_conv_desc* d, const void* gy, float* dw, hipStream_t s);
 int bwd_upconv2x2_wgrad_f32(const void* x, const void* gy, float* dw, int N, int H, int W, int C, int Cout, hipStream_t s);

@@ -366,6 +366,11 @@ struct C1Args {
   const bf16_t* res;    // same layout as out, or NULL
   bf16_t* out;
   int M, n_tiles, ld_in, ld_out, Cout, act, px_per_sample, res_b0, n_ct;
+  // GELU fused into the store (the graph block's training passes; same rounding points as the separate gelu kernels):
+  // gmode 1: zbuf <- the value as stored (pre-activation), out <- gelu of that ROUNDED value
+  // gmode 2: out <- the value as stored x gelu'(zbuf)           (data gradient through the GELU)
+  bf16_t* zbuf;
+  int gmode;
 };
 
 template <int CIN, int NT>
@@ -454,6 +459,21 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(const C1Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v4[r] += rr[r];
           }
+          if (a.gmode == 1) {
+            store4<bf16_t>(a.zbuf, opix + cb, v4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = uncl_gelu((float)(bf16_t)v4[r]);
+          } else if (a.gmode == 2) {
+            float zz[4];
+            load4<bf16_t>(a.zbuf, opix + cb, zz);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {          // as gelu_bwd_kernel (csrc/backward_kernels.hip) on the rounded gradient
+              const float x = zz[r];
+              const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+              const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+              v4[r] = (float)(bf16_t)v4[r] * (cdf + x * pdf);
+            }
+          }
           store4<bf16_t>(a.out, opix + cb, v4);
         }
     }
@@ -482,7 +502,7 @@ int launch_c1(const C1Args& a, int groups, hipStream_t s) {
 
 // returns C1_NOT_MINE when the descriptor is outside this kernel's scope (the caller then takes the generic path)
 constexpr int C1_NOT_MINE = 1;
-int conv1x1_direct(const uncl_conv_desc* d, hipStream_t s) {
+int conv1x1_direct(const uncl_conv_desc* d, hipStream_t s, void* zbuf = nullptr, int gmode = 0) {
   if (d->dtype != UNCL_BF16 || d->ksize != 1 || d->src_mode != UNCL_SRC_PLAIN || d->prev0 != nullptr || d->out1_w != nullptr ||
       d->skip_main_store || d->src1 != nullptr)
     return C1_NOT_MINE;
@@ -508,12 +528,24 @@ int conv1x1_direct(const uncl_conv_desc* d, hipStream_t s) {
   a.res = (const bf16_t*)d->res; a.out = (bf16_t*)d->out;
   a.M = (int)M; a.n_tiles = (int)((M + 127) / 128); a.ld_in = d->src0_C; a.ld_out = d->out_C; a.Cout = d->Cout; a.act = d->act;
   a.px_per_sample = d->H * d->W; a.res_b0 = d->res_batch_stride0; a.n_ct = d->Cout / (nt * 32);
+  a.zbuf = (bf16_t*)zbuf; a.gmode = zbuf ? gmode : 0;
   if (d->Cin == 128) return nt == 4 ? launch_c1<128, 4>(a, groups, s) : (nt == 2 ? launch_c1<128, 2>(a, groups, s) : launch_c1<128, 1>(a, groups, s));
   if (d->Cin == 256) return nt == 4 ? launch_c1<256, 4>(a, groups, s) : (nt == 2 ? launch_c1<256, 2>(a, groups, s) : launch_c1<256, 1>(a, groups, s));
   return nt == 2 ? launch_c1<512, 2>(a, groups, s) : launch_c1<512, 1>(a, groups, s);
 }
 
 }  // namespace
+
+// Internal (generator.hip): the bf16 1x1 convolution of `d` with the GELU of the graph block fused into its store -- gmode 1
+// forward (zbuf receives the pre-activation, d->out the activation), gmode 2 backward (d->out = conv x gelu'(zbuf)); zbuf has
+// d->out's layout.  Returns UNCL_GELU_NOT_FUSED (> 0) when the direct kernel does not take the descriptor: the caller then runs
+// the convolution and the gelu kernel as two launches.
+int uncl_conv1x1_gelu(const uncl_conv_desc* d, void* zbuf, int gmode, void* stream) {
+  if (d == nullptr || zbuf == nullptr || (gmode != 1 && gmode != 2)) return UNCL_ERR_ARG;
+  static const int on = [] { const char* e = getenv("UNCL_C1_GELU"); return e ? atoi(e) : 1; }();     // 0: two launches (A/B)
+  if (!on) return C1_NOT_MINE;
+  return conv1x1_direct(d, reinterpret_cast<hipStream_t>(stream), zbuf, gmode);
+}
 
 extern "C" int uncl_conv_igemm(const uncl_conv_desc* d, void* stream) {
   if (d == nullptr) return UNCL_ERR_ARG;

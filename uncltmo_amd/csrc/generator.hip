@@ -344,8 +344,10 @@ int up_stage(const Ctx& c, int wi_up, int x1, int skip, int upbuf, int abuf, int
   return UNCL_OK;
 }
 
+// zpre >= 0: buffer `zpre` receives the layer's output and `out` its GELU (the training passes keep both); one launch where the
+// direct 1x1 kernel takes it, else the convolution and the gelu kernel
 int conv1(const Ctx& c, int wi, int in, int out, int cin, int cout, int act, const void* res, int res_b0,
-          const float* scale, int groups = 0) {
+          const float* scale, int groups = 0, int zpre = -1) {
   uncl_conv_desc d = base_desc(c, wi, 1, 0, groups ? cin / groups : cin, groups ? cout / groups : cout, act);
   set_src0(d, c, in);
   d.src_mode = UNCL_SRC_PLAIN;
@@ -355,6 +357,15 @@ int conv1(const Ctx& c, int wi, int in, int out, int cin, int cout, int act, con
   if (groups) { d.z_mode = UNCL_Z_GROUPS; d.groups = groups; }
   set_out(d, c.ptr(out), out);
   d.out_H = 12; d.out_W = 12;
+  if (zpre >= 0) {
+    int rc = UNCL_GELU_NOT_FUSED;
+    if (c.w->dtype == UNCL_BF16) rc = uncl_conv1x1_gelu(&d, c.ptr(zpre), 1, c.s);
+    if (rc != UNCL_GELU_NOT_FUSED) return rc;
+    set_out(d, c.ptr(zpre), zpre);
+    d.out_H = 12; d.out_W = 12;
+    if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
+    return bwd_gelu_forward(c.w->dtype, c.ptr(zpre), c.ptr(out), (long long)c.n * NODES * cout, c.s);
+  }
   return uncl_conv_igemm(&d, c.s);
 }
 
@@ -427,15 +438,13 @@ int run_chunk(const Ctx& c, const float* x, float* out, void* up_x, int32_t* knn
     } else {
       RUN(uncl_gcn_maxrel(c.ptr(B_GFC1), knn, c.ptr(B_GMR), w->dtype, c.n, NODES, 256, 9, c.s));
       if (c.save_preact) {
-        RUN(conv1(c, W_GGC, B_GMR, B_GGCZ, 512, 512, UNCL_ACT_NONE, nullptr, 0, nullptr, 4));
-        RUN(bwd_gelu_forward(w->dtype, c.ptr(B_GGCZ), c.ptr(B_GGC), (long long)c.n * NODES * 512, c.s));
+        RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_NONE, nullptr, 0, nullptr, 4, B_GGCZ));
       } else {
         RUN(conv1(c, W_GGC, B_GMR, B_GGC, 512, 512, UNCL_ACT_GELU, nullptr, 0, nullptr, 4));
       }
       RUN(conv1(c, W_GFC2, B_GGC, B_GX1, 512, 256, UNCL_ACT_NONE, c.ptr(B_X4), 0, drop0));
       if (c.save_preact) {
-        RUN(conv1(c, W_FFC1, B_GX1, B_FHZ, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr));
-        RUN(bwd_gelu_forward(w->dtype, c.ptr(B_FHZ), c.ptr(B_FH), (long long)c.n * NODES * 256, c.s));
+        RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_NONE, nullptr, 0, nullptr, 0, B_FHZ));
       } else {
         RUN(conv1(c, W_FFC1, B_GX1, B_FH, 256, 256, UNCL_ACT_GELU, nullptr, 0, nullptr));
       }
@@ -698,13 +707,23 @@ int wgrad1(const BCtx& c, int wi, const void* x, int xc_total, int cin, const vo
   if (rc != UNCL_OK || !bias) return rc;
   return c.colsum(gy, (long long)c.n * NODES, gy_total, c.b->gb[wi]);
 }
-int dgrad1(const BCtx& c, int wi, const void* gy, int cin_d, int cout_d, void* out, const void* res, int groups = 0) {
+// gelu_z != NULL: the result is multiplied by gelu'(gelu_z) (the pre-activation this gradient flows back through), in the same
+// launch where the direct 1x1 kernel takes it
+int dgrad1(const BCtx& c, int wi, const void* gy, int cin_d, int cout_d, void* out, const void* res, int groups = 0,
+           const void* gelu_z = nullptr) {
   uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, groups ? cin_d / groups : cin_d, groups ? cout_d / groups : cout_d);
   d.src0 = gy; d.src0_H = 12; d.src0_W = 12; d.src0_C = cin_d;
   d.weight = c.b->wd[wi];
   d.res = res;
   d.out = out; d.out_H = 12; d.out_W = 12; d.out_C = cout_d;
   if (groups) { d.z_mode = UNCL_Z_GROUPS; d.groups = groups; }
+  if (gelu_z != nullptr) {
+    int rc = UNCL_GELU_NOT_FUSED;
+    if (c.dt == UNCL_BF16) rc = uncl_conv1x1_gelu(&d, const_cast<void*>(gelu_z), 2, c.s);
+    if (rc != UNCL_GELU_NOT_FUSED) return rc;
+    if ((rc = uncl_conv_igemm(&d, c.s)) != UNCL_OK) return rc;
+    return bwd_gelu_backward(c.dt, out, gelu_z, out, (long long)c.n * 144 * cout_d, c.s);
+  }
   return uncl_conv_igemm(&d, c.s);
 }
 
@@ -801,15 +820,13 @@ int backward_all(const BCtx& c) {
   // FFN: GOUT = drop1 * fc2(gelu(fc1(GX1))) + GX1
   RUN(bwd_scale_rows(c.dt, c.G(B_GOUT), drop1, tA1, c.n, per256, c.s));
   RUN(wgrad1(c, W_FFC2, c.F(B_FH), 256, 256, tA1, 256, 256, b->gw[W_FFC2], true));
-  RUN(dgrad1(c, W_FFC2, tA1, 256, 256, tB1, nullptr));
-  RUN(bwd_gelu_backward(c.dt, tB1, c.F(B_FHZ), tB1, (long long)c.n * per256, c.s));
+  RUN(dgrad1(c, W_FFC2, tA1, 256, 256, tB1, nullptr, 0, c.F(B_FHZ)));
   RUN(wgrad1(c, W_FFC1, c.F(B_GX1), 256, 256, tB1, 256, 256, b->gw[W_FFC1], true));
   RUN(dgrad1(c, W_FFC1, tB1, 256, 256, c.G(B_GX1), c.G(B_GOUT)));
   // Grapher: GX1 = drop0 * fc2(gelu(gconv(maxrel(fc1(X4))))) + X4
   RUN(bwd_scale_rows(c.dt, c.G(B_GX1), drop0, tA2, c.n, per256, c.s));
   RUN(wgrad1(c, W_GFC2, c.F(B_GGC), 512, 512, tA2, 256, 256, b->gw[W_GFC2], true));
-  RUN(dgrad1(c, W_GFC2, tA2, 256, 512, tC, nullptr));
-  RUN(bwd_gelu_backward(c.dt, tC, c.F(B_GGCZ), tC, (long long)c.n * per512, c.s));
+  RUN(dgrad1(c, W_GFC2, tA2, 256, 512, tC, nullptr, 0, c.F(B_GGCZ)));
   if (!c.defer) {  // grouped 1x1: four independent 128 -> 128 blocks, one launch (grid.y = group)
     uncl_conv_desc d = bdesc(c, 1, 0, 12, 12, 128, 128);
     d.src0 = c.F(B_GMR); d.src0_H = 12; d.src0_W = 12; d.src0_C = 512;
