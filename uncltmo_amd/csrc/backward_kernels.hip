@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void maxrel_bwd_lds_kernel(const T* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[node * MRB_PITCH + q * 8 + e] = 0.f;
   }
-  for (int u = tid; u < n * k; u += 256) sidx[u] = idx[b * n * k + u];
+  for (int u = tid; u < n * k; u += 256) sidx[u] = min(max(idx[b * n * k + u], 0), n - 1);      // (an index outside the graph must not leave the LDS image)
   __syncthreads();
   for (int u = tid; u < units; u += 256) {
     const int q = u / n, node = u - q * n;
