@@ -60,7 +60,7 @@ def check(x16, idx, g16):
     assert torch.isfinite(got).all()
     # one rounding to bf16 (2^-9 relative) of a sum whose fp32 accumulation order is free: allow one ulp of the result plus the
     # fp32 noise of the largest partial sum
-    scale = ref.abs().clamp_min(1e-3)
+    scale = ref.abs().clamp_min(1e-2)
     err = ((got - ref).abs() / scale).max().item()
     assert err <= 2.0 ** -7, err
     return got
@@ -94,6 +94,6 @@ def test_global_atomic_form_still_agrees(tmp_path):
     for (N, n, Cc, k, ties) in [(32, 144, 256, 9, False), (3, 144, 256, 9, True), (2, 37, 64, 5, False)]:
         old = torch.load(str(tmp_path / "g") + "_%d_%d.pt" % (N, n))
         new = run_kernel(*make_case(N, n, Cc, k, seed=N * 1000 + n, ties=ties)).double().cpu()
-        scale = old.abs().clamp_min(1e-3)
+        scale = old.abs().clamp_min(1e-2)
         assert ((new - old).abs() / scale).max().item() <= 2.0 ** -7
         assert (new == old).double().mean().item() > 0.99      # all but the entries that sit on a rounding boundary
