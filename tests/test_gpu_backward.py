@@ -593,17 +593,21 @@ def test_bf16_backward_is_deterministic(n, video):
         assert rel_l2(fast[k].cpu(), runs[0][k].cpu()) < 2e-4, (k, rel_l2(fast[k].cpu(), runs[0][k].cpu()))
 
 
-def _det_train_pass(n, drop):
-    """one deterministic bf16 training pass of the image generator: outputs and every parameter gradient, on the host"""
-    net = UNet(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1, "replicate", 2, 0,
-               compute_dtype="bf16")
+def _det_train_pass(n, drop, video=0):
+    """one deterministic bf16 training pass of the image generator (video = T > 0: of the video generator on n clips of T frames):
+    outputs and every parameter gradient, on the host"""
+    from uncltmo_amd.generator import UNetVideo
+    net = (UNetVideo if video else UNet)(1, 1, "sigmoid", 4, 4, "square_and_square_root", 32, 0, "unet", 0, 0, "none", "none", "relu", 1,
+                                         "replicate", 2, 0, compute_dtype="bf16")
     synth.fill_state_dict(net, "g0")
     net = net.cuda().train()
     if drop:
         net.forced_drop_keep = [[1.0] * n, [1.0] * (n - 1) + [0.0]]        # DropPath scales in both residual branches
     else:
         net.drop_path_prob = 0.0
-    x = synth.smooth_hdr_frames(n, salt="gelu_fused").cuda()
+    x = synth.smooth_hdr_frames(n * max(video, 1), salt="gelu_fused").cuda()
+    if video:
+        x = x.reshape(n, video, 1, 256, 256)
     old = _hip.lib().uncl_gen_set_deterministic(1)
     try:
         y, up = net(x)
@@ -632,6 +636,35 @@ def test_gelu_fused_into_the_graph_blocks_1x1_launches_is_bit_identical(n, drop,
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
     two = torch.load(out)
     one = _det_train_pass(n, drop)
+    assert set(one) == set(two) and len(one) >= 58
+    for k in one:
+        assert torch.equal(one[k], two[k]), k
+
+
+@pytest.mark.parametrize("n,T,clip", [(2, 3, 1), (1, 2, 0)])
+def test_head_handoff_folded_into_the_pool_backward_is_bit_identical(n, T, clip, tmp_path):
+    """Clips: the hand-off of the recurrent head channels on the gradient of an encoder stage's pooled input rides in the max-pool
+    backward that reads it (`bwd_pool_backward_handoff`); UNCL_POOL_HANDOFF=0 (a child) runs the two kernels.  Backward through time
+    over T frames, clip layout and per-frame layout: outputs, statistics and all parameter gradients equal bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "two_launch.pt")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+            "import torch\nfrom test_gpu_backward import _det_train_pass\n"
+            "torch.save(_det_train_pass(%d, False, %d), %r)\nprint('ok')\n" % (root, root, n, T, out))
+    env = dict(os.environ, UNCL_POOL_HANDOFF="0", UNCL_CLIP_WGRAD=str(clip))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    two = torch.load(out)
+    old_env = os.environ.get("UNCL_CLIP_WGRAD")
+    os.environ["UNCL_CLIP_WGRAD"] = str(clip)
+    try:
+        one = _det_train_pass(n, False, T)
+    finally:
+        if old_env is None:
+            os.environ.pop("UNCL_CLIP_WGRAD", None)
+        else:
+            os.environ["UNCL_CLIP_WGRAD"] = old_env
     assert set(one) == set(two) and len(one) >= 58
     for k in one:
         assert torch.equal(one[k], two[k]), k

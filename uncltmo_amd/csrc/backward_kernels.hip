@@ -168,10 +168,13 @@ __global__ __launch_bounds__(256) void ssr_bwd_kernel(const T* __restrict__ g_ca
 }
 
 // ---- 2x2 max-pool backward: the gradient of each pooled pixel goes to the first maximum of its window
+// (cin / cout / pc: the recurrent hand-off of a clip's head channels on g_pool, folded in -- what head_handoff_kernel without a mask
+// does to the first pc channels of every pooled pixel, with the same rounding: the head gradient leaves to cout and is replaced by
+// cin's; this kernel is the only reader of g_pool after that point)
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ g_pool, const T* __restrict__ x,
                                                        T* __restrict__ G_x, int N, int H, int W, int C, float slope,
-                                                       int accumulate) {
+                                                       int accumulate, const T* __restrict__ cin, T* __restrict__ cout, int pc) {
   const int VC = C / 8, Hp = H / 2, Wp = W / 2;
   const size_t total = (size_t)N * Hp * Wp * VC;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -181,7 +184,19 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ g_p
     const int py = (int)(r % Hp);
     const int n = (int)(r / Hp);
     float g[8], xs[4][8];
-    ld8(g_pool + (((size_t)n * Hp + py) * Wp + px) * C + v * 8, g);
+    const size_t ppix = ((size_t)n * Hp + py) * Wp + px;
+    ld8(g_pool + ppix * C + v * 8, g);
+    if (v == 0 && (cin != nullptr || cout != nullptr)) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < pc) {
+          float hx = g[c];
+          if (cout) { cout[ppix * pc + c] = (T)hx; hx = 0.f; }
+          if (cin) hx += (float)cin[ppix * pc + c];
+          g[c] = (float)(T)hx;          // (the separate kernel stored it in the gradient's type before this one read it)
+        }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       ld8(x + (((size_t)n * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + v * 8, xs[q]);
@@ -597,21 +612,28 @@ extern "C" int uncl_ssr_backward(const void* g_cat, const void* x2, void* G_x2, 
 
 template <typename T>
 static int pool_backward_t(const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope,
-                                  int accumulate, void* stream) {
-  if (!g_pool || !x || !G_x || C % 8 != 0) return UNCL_ERR_ARG;
+                                  int accumulate, void* stream, const void* cin = nullptr, void* cout = nullptr, int pc = 0) {
+  if (!g_pool || !x || !G_x || C % 8 != 0 || pc < 0 || pc > 8) return UNCL_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!accumulate && ((H & 1) || (W & 1))) {
     // odd sizes: the last row / column is outside every window and must read as zero
     if (hipMemsetAsync(G_x, 0, (size_t)N * H * W * C * sizeof(T), s) != hipSuccess) return UNCL_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3(nblocks((size_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, s, (const T*)g_pool,
-                     (const T*)x, (T*)G_x, N, H, W, C, slope, accumulate);
+                     (const T*)x, (T*)G_x, N, H, W, C, slope, accumulate, (const T*)cin, (T*)cout, pc);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
 int bwd_pool_backward(int dtype, const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope,
                                   int accumulate, void* stream) {
   return dtype == UNCL_F32 ? pool_backward_t<float>(g_pool, x, G_x, N, H, W, C, slope, accumulate, stream) : pool_backward_t<bf16_t>(g_pool, x, G_x, N, H, W, C, slope, accumulate, stream);
+}
+// the same with the head hand-off of a clip (bwd_head_handoff without a mask) applied to g_pool's first pc channels as they are read;
+// carries: (N * H/2 * W/2, pc) in the gradient's type, either may be NULL
+int bwd_pool_backward_handoff(int dtype, const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope,
+                              int accumulate, const void* carry_in, void* carry_out, int pc, void* stream) {
+  return dtype == UNCL_F32 ? pool_backward_t<float>(g_pool, x, G_x, N, H, W, C, slope, accumulate, stream, carry_in, carry_out, pc)
+                           : pool_backward_t<bf16_t>(g_pool, x, G_x, N, H, W, C, slope, accumulate, stream, carry_in, carry_out, pc);
 }
 extern "C" int uncl_pool_backward(const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope,
                                   int accumulate, void* stream) {

@@ -639,6 +639,18 @@ struct BCtx {
     const CarrySlot& k = kCarry[slot];
     return bwd_head_handoff(dt, g, mask, slope, cin(slot), cout(slot), (long long)n * k.pix, kDims[k.buf].c, k.pc, s);
   }
+  // an encoder stage's hand-off (on the gradient of its pooled input, no mask) and the max-pool backward that reads it: one launch
+  // for clips (UNCL_POOL_HANDOFF=0: two, for A/B and the bit-for-bit test)
+  int pool_handoff(int slot, const void* g_pool, const void* x, void* G_x, int H, int W, int C) const {
+    static const int fuse = [] { const char* e = getenv("UNCL_POOL_HANDOFF"); return e ? atoi(e) : 1; }();
+    const CarrySlot& k = kCarry[slot];
+    if (!video() || !fuse || k.pix != (H / 2) * (W / 2) || kDims[k.buf].c != C) {
+      const int rc = handoff(slot, const_cast<void*>(g_pool), nullptr);
+      if (rc != UNCL_OK) return rc;
+      return bwd_pool_backward(dt, g_pool, x, G_x, n, H, W, C, slope, 1, s);
+    }
+    return bwd_pool_backward_handoff(dt, g_pool, x, G_x, n, H, W, C, slope, 1, cin(slot), cout(slot), k.pc, s);
+  }
 };
 
 uncl_conv_desc bdesc(const BCtx& c, int ks, int pad, int h, int w, int cin, int cout) {
@@ -862,8 +874,7 @@ int backward_all(const BCtx& c) {
     RUN(wgrad3(c, W_D3A, B_X3P, 0, 256, 256, c.G(B_D3A), 10, 10, xm));
   }
   RUN(dgrad3(c, W_D3A, c.G(B_D3A), 10, 10, 256, 2, 256, c.sc.gpool, 12, 12, nullptr, 0));
-  RUN(c.handoff(3, c.sc.gpool, nullptr));
-  RUN(bwd_pool_backward(c.dt, c.sc.gpool, c.F(B_X3), c.G(B_X3), c.n, 24, 24, 256, c.slope, 1, c.s));
+  RUN(c.pool_handoff(3, c.sc.gpool, c.F(B_X3), c.G(B_X3), 24, 24, 256));
   for (int i = 0; i < 3; ++i) {
     const Enc& e = en[i];
     const int oh = kDims[e.out].h, mh = kDims[e.mid].h, ph = kDims[e.pooled].h, xh = kDims[e.xin].h;
@@ -875,8 +886,7 @@ int backward_all(const BCtx& c) {
     RUN(c.unnorm(c.G(e.mid), e.mid));
     RUN(wgrad3(c, e.wa, e.pooled, 0, e.cin, e.cout, c.G(e.mid), mh, mh, xm));
     RUN(dgrad3(c, e.wa, c.G(e.mid), mh, mh, e.cout, 2, e.cin, c.sc.gpool, ph, ph, nullptr, 0));
-    RUN(c.handoff(2 - i, c.sc.gpool, nullptr));
-    RUN(bwd_pool_backward(c.dt, c.sc.gpool, c.F(e.xin), c.G(e.xin), c.n, xh, xh, e.cin, c.slope, 1, c.s));
+    RUN(c.pool_handoff(2 - i, c.sc.gpool, c.F(e.xin), c.G(e.xin), xh, xh, e.cin));
   }
   // inc: conv1 (INC0 -> X0), conv (image -> INC0)
   RUN(c.unnorm(c.G(B_X0), B_X0));
