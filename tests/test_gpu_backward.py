@@ -642,17 +642,19 @@ def test_gelu_fused_into_the_graph_blocks_1x1_launches_is_bit_identical(n, drop,
 
 
 @pytest.mark.parametrize("n,T,clip", [(2, 3, 1), (1, 2, 0)])
-def test_head_handoff_folded_into_the_pool_backward_is_bit_identical(n, T, clip, tmp_path):
+def test_head_handoff_folded_into_its_neighbour_launches_is_bit_identical(n, T, clip, tmp_path):
     """Clips: the hand-off of the recurrent head channels on the gradient of an encoder stage's pooled input rides in the max-pool
-    backward that reads it (`bwd_pool_backward_handoff`); UNCL_POOL_HANDOFF=0 (a child) runs the two kernels.  Backward through time
-    over T frames, clip layout and per-frame layout: outputs, statistics and all parameter gradients equal bit for bit."""
+    backward that reads it (`bwd_pool_backward_handoff`), that of a decoder stage's input in the store of the up-conv's data-gradient
+    launch (`bwd_upconv2x2_dgrad_handoff`); UNCL_POOL_HANDOFF=0 UNCL_UP_HANDOFF=0 (a child) runs the hand-off kernel on its own.
+    Backward through time over T frames, clip layout and per-frame layout: outputs, statistics and all parameter gradients equal bit
+    for bit."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "two_launch.pt")
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
             "import torch\nfrom test_gpu_backward import _det_train_pass\n"
             "torch.save(_det_train_pass(%d, False, %d), %r)\nprint('ok')\n" % (root, root, n, T, out))
-    env = dict(os.environ, UNCL_POOL_HANDOFF="0", UNCL_CLIP_WGRAD=str(clip))
+    env = dict(os.environ, UNCL_POOL_HANDOFF="0", UNCL_UP_HANDOFF="0", UNCL_CLIP_WGRAD=str(clip))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
     two = torch.load(out)

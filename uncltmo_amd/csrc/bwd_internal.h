@@ -6,6 +6,7 @@
 int bwd_outc_backward(int dtype, const float* g_out, const float* x_out, const void* g_upx, const void* up_x, const float* w, void* G_up, float* gw, float* gb, long long P, int last_act, float slope, int accumulate, void* workspace /* 1024*33 floats */, void* stream);
 int bwd_ssr_backward(int dtype, const void* g_cat, const void* x2, void* G_x2, void* G_x1, int N, int H, int W, int C, int H1, int W1, float slope, int accumulate_x2, void* stream);
 int bwd_pool_backward(int dtype, const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope, int accumulate, void* stream);
+int bwd_upconv2x2_dgrad_handoff(const void* gy, const void* wt, const void* mask, float slope, void* gx, int N, int H, int W, int Cin, int Cout, const void* carry_in, void* carry_out, int pc, void* stream);
 int bwd_pool_backward_handoff(int dtype, const void* g_pool, const void* x, void* G_x, int N, int H, int W, int C, float slope, int accumulate, const void* carry_in, void* carry_out, int pc, void* stream);
 int bwd_gelu_forward(int dtype, const void* z, void* h, long long n, void* stream);
 int bwd_gelu_backward(int dtype, const void* g_h, const void* z, void* g_z, long long n, void* stream);

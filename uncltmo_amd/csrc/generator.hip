@@ -807,9 +807,18 @@ int backward_all(const BCtx& c) {
     if (c.dt == UNCL_F32)
       RUN(bwd_upconv2x2_dgrad_f32(c.G(q.up), b->wd[q.wi], c.video() ? nullptr : x1mask, c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
                                   c.s));
-    else
+    else {
+      // clips: the hand-off of this stage's input gradient rides in the launch's store (UNCL_UP_HANDOFF=0: its own launch)
+      static const int fuse = [] { const char* e = getenv("UNCL_UP_HANDOFF"); return e ? atoi(e) : 1; }();
+      const CarrySlot& ks = kCarry[slot];
+      if (c.video() && fuse && ks.pix == xh * xw && kDims[ks.buf].c == q.ch) {
+        RUN(bwd_upconv2x2_dgrad_handoff(c.G(q.up), b->wd[q.wi], x1mask, c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch, c.cin(slot),
+                                        c.cout(slot), ks.pc, c.s));
+        continue;
+      }
       RUN(uncl_upconv2x2_dgrad(c.G(q.up), b->wd[q.wi], c.video() ? nullptr : x1mask, c.slope, c.G(q.x1), c.n, xh, xw, q.ch, q.ch,
                                c.s));
+    }
     RUN(c.handoff(slot, c.G(q.x1), x1mask));
   }
   // the decoder's parameter gradients are final from here on (biases: staged column sums are flushed first)

@@ -276,6 +276,11 @@ struct UpBwdArgs {
   bf16_t* gx;           // (N,H,W,Cin)
   int H, W, Cin, M, n_tiles, rows;  // rows = the Cin slice a workgroup handles: 32, 64 or 128 (<= Cin)
   float slope;
+  // clips: the recurrent hand-off of the first pc channels (head_handoff_kernel, csrc/backward_kernels.hip) applied in the store,
+  // before the mask: carries are (M, pc) bf16, either may be NULL
+  const bf16_t* carry_in;
+  bf16_t* carry_out;
+  int pc;
 };
 
 template <int COUT>
@@ -349,12 +354,26 @@ __global__ __launch_bounds__(256) void upconv2x2_dgrad_kernel(const UpBwdArgs a)
       if (m >= a.M) continue;
       vec val = *reinterpret_cast<const vec*>(sO + p * (a.rows * 2) + ((sl ^ (p & (slots_o - 1))) << 4));
       const size_t off = (size_t)m * a.Cin + ct * a.rows + sl * 8;
-      if (a.mask != nullptr) {
-        float f[8], mk[8];
+      const bool head = ct == 0 && sl == 0 && (a.carry_in != nullptr || a.carry_out != nullptr);
+      if (a.mask != nullptr || head) {
+        float f[8];
         E::unpack(val, f);
-        E::unpack(*reinterpret_cast<const vec*>(a.mask + off), mk);
+        if (head) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = mk[i] > 0.f ? f[i] : a.slope * f[i];
+          for (int i = 0; i < 8; ++i)
+            if (i < a.pc) {
+              float hx = f[i];
+              if (a.carry_out) { a.carry_out[(size_t)m * a.pc + i] = (bf16_t)hx; hx = 0.f; }
+              if (a.carry_in) hx += (float)a.carry_in[(size_t)m * a.pc + i];
+              f[i] = hx;
+            }
+        }
+        if (a.mask != nullptr) {
+          float mk[8];
+          E::unpack(*reinterpret_cast<const vec*>(a.mask + off), mk);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = mk[i] > 0.f ? f[i] : a.slope * f[i];
+        }
         val = E::pack(f);
       }
       *reinterpret_cast<vec*>(a.gx + off) = val;
@@ -383,8 +402,22 @@ int launch_up_bwd(const UpBwdArgs& a, hipStream_t s) {
 
 // gy: (N,2H,2W,Cout) bf16; wt: packed [4][Cin][Cout] bf16 (uncl_pack_conv_weight on the (Cin,Cout,2,2) weight with
 // transposed=0, i.e. treating it as a Conv2d weight); gx: (N,H,W,Cin).  mask (optional): the activation x itself.
+static int upconv2x2_dgrad_impl(const void* gy, const void* wt, const void* mask, float slope, void* gx, int N, int H, int W,
+                                int Cin, int Cout, const void* carry_in, void* carry_out, int pc, void* stream);
 extern "C" int uncl_upconv2x2_dgrad(const void* gy, const void* wt, const void* mask, float slope, void* gx, int N, int H, int W,
                                     int Cin, int Cout, void* stream) {
+  return upconv2x2_dgrad_impl(gy, wt, mask, slope, gx, N, H, W, Cin, Cout, nullptr, nullptr, 0, stream);
+}
+// Internal (generator.hip, clips): the same launch with the head hand-off of the first pc (<= 8) channels folded into its store --
+// carry_out receives this frame's head gradient, carry_in replaces it (either may be NULL), then the mask is applied, as
+// bwd_head_handoff does after the plain launch
+int bwd_upconv2x2_dgrad_handoff(const void* gy, const void* wt, const void* mask, float slope, void* gx, int N, int H, int W, int Cin,
+                                int Cout, const void* carry_in, void* carry_out, int pc, void* stream) {
+  if (pc < 0 || pc > 8) return UNCL_ERR_ARG;
+  return upconv2x2_dgrad_impl(gy, wt, mask, slope, gx, N, H, W, Cin, Cout, carry_in, carry_out, pc, stream);
+}
+static int upconv2x2_dgrad_impl(const void* gy, const void* wt, const void* mask, float slope, void* gx, int N, int H, int W,
+                                int Cin, int Cout, const void* carry_in, void* carry_out, int pc, void* stream) {
   if (!gy || !wt || !gx || N <= 0 || Cin % 32 != 0) return UNCL_ERR_ARG;
   if (Cout != 32 && Cout != 64 && Cout != 128 && Cout != 256) return UNCL_ERR_ARG;
   if (Cin > 128 && Cin % 128 != 0) return UNCL_ERR_ARG;
@@ -393,6 +426,7 @@ extern "C" int uncl_upconv2x2_dgrad(const void* gy, const void* wt, const void* 
   UpBwdArgs a;
   a.gy = (const bf16_t*)gy; a.wt = (const bf16_t*)wt; a.mask = (const bf16_t*)mask; a.gx = (bf16_t*)gx;
   a.H = H; a.W = W; a.Cin = Cin; a.M = (int)M; a.n_tiles = (int)((M + 127) / 128); a.rows = Cin < 128 ? Cin : 128; a.slope = slope;
+  a.carry_in = (const bf16_t*)carry_in; a.carry_out = (bf16_t*)carry_out; a.pc = pc;
   // A workgroup stages its Cin slice of all four taps' weights (rows x Cout x 2 bytes each) one after the other before it multiplies:
   // on the 12 x 12 / 28 x 28 levels there are 18 - 72 workgroups of 128 rows and the launch takes 45 us whatever the batch (8 or 32
   // samples).  Narrower slices give proportionally more workgroups with proportionally shorter staging: down to 32 rows while the
