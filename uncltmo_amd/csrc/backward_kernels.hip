@@ -330,8 +330,10 @@ __global__ void head_handoff_kernel(T* __restrict__ g, const T* __restrict__ mas
 
 // out = x with the first pc channels of every pixel taken from prev (the mixed tensor a stage of frame k > 0 consumed)
 template <typename T>
+// (own / lag: a whole clip in one launch -- the first `own` pixels, frame 0, keep their own heads; pixel p >= own takes them from
+// pixel p - lag of `prev`, i.e. from the frame before it when prev == x and lag == own == one frame's pixels)
 __global__ void mix_heads_kernel(const T* __restrict__ x, const T* __restrict__ prev, T* __restrict__ out,
-                                 size_t npix, int C, int pc) {
+                                 size_t npix, int C, int pc, size_t own, size_t lag) {
   const int VC = C / 8;
   const size_t total = npix * VC;
   for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
@@ -339,9 +341,9 @@ __global__ void mix_heads_kernel(const T* __restrict__ x, const T* __restrict__ 
     const int v = (int)(t - pix * VC);
     float a[8];
     ld8(x + pix * C + v * 8, a);
-    if (v == 0) {
+    if (v == 0 && pix >= own) {
       float b[8];
-      ld8(prev + pix * C, b);
+      ld8(prev + (pix - lag) * C, b);
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (c < pc) a[c] = b[c];
@@ -733,15 +735,22 @@ extern "C" int uncl_head_handoff(void* g, const void* mask, float slope, const v
   return bwd_head_handoff(UNCL_BF16, g, mask, slope, carry_in, carry_out, npix, C, prev_ch, stream);
 }
 template <typename T>
-static int mix_heads_t(const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream) {
-  if (!x || !prev || !out || npix <= 0 || C % 8 != 0 || prev_ch <= 0 || prev_ch > 8) return UNCL_ERR_ARG;
+static int mix_heads_t(const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream, long long own = 0,
+                       long long lag = 0) {
+  if (!x || !prev || !out || npix <= 0 || C % 8 != 0 || prev_ch <= 0 || prev_ch > 8 || own < 0 || lag < 0 || lag > own) return UNCL_ERR_ARG;
   hipLaunchKernelGGL(mix_heads_kernel<T>, dim3(nblocks((size_t)npix * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const T*)x, (const T*)prev, (T*)out, (size_t)npix, C, prev_ch);
+                     (const T*)x, (const T*)prev, (T*)out, (size_t)npix, C, prev_ch, (size_t)own, (size_t)lag);
   UNCL_CHECK_LAUNCH();
   return UNCL_OK;
 }
 int bwd_mix_heads(int dtype, const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream) {
   return dtype == UNCL_F32 ? mix_heads_t<float>(x, prev, out, npix, C, prev_ch, stream) : mix_heads_t<bf16_t>(x, prev, out, npix, C, prev_ch, stream);
+}
+// a clip's frames one behind the other in x (npix pixels in all, frame_pix per frame): out = x with every frame's head channels taken
+// from the frame before it, frame 0 keeping its own -- one launch instead of a copy of frame 0 and a mix of the rest
+int bwd_mix_heads_clip(int dtype, const void* x, void* out, long long npix, long long frame_pix, int C, int prev_ch, void* stream) {
+  return dtype == UNCL_F32 ? mix_heads_t<float>(x, x, out, npix, C, prev_ch, stream, frame_pix, frame_pix)
+                           : mix_heads_t<bf16_t>(x, x, out, npix, C, prev_ch, stream, frame_pix, frame_pix);
 }
 extern "C" int uncl_mix_heads(const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream) {
   return bwd_mix_heads(UNCL_BF16, x, prev, out, npix, C, prev_ch, stream);

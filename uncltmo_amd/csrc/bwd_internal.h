@@ -15,6 +15,7 @@ int bwd_mask_minus(int dtype, const void* g, const void* x, const void* pe, void
 int bwd_sum_samples(int dtype, const void* g, float* out, int N, long long per, int accumulate, void* stream);
 int bwd_head_handoff(int dtype, void* g, const void* mask, float slope, const void* carry_in, void* carry_out, long long npix, int C, int prev_ch, void* stream);
 int bwd_mix_heads(int dtype, const void* x, const void* prev, void* out, long long npix, int C, int prev_ch, void* stream);
+int bwd_mix_heads_clip(int dtype, const void* x, void* out, long long npix, long long frame_pix, int C, int prev_ch, void* stream);
 int bwd_gcn_maxrel_backward(int dtype, const void* g_out, const void* x, const int32_t* idx, float* g_x_f32, void* g_x_bf16, int N, int n, int C, int k, void* stream);
 int bwd_conv_in_c1_wgrad(int dtype, const void* G, const float* x, float* gw, float* gb, int N, int H, int W, int accumulate, void* workspace, void* stream);
 

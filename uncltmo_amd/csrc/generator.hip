@@ -920,10 +920,8 @@ int deferred_wgrads(const BCtx& c, int nf, int T) {
   auto mixed_all = [&](int slot) -> const void* {
     const CarrySlot& k = kCarry[slot];
     if (T == 1) return c.F(k.buf);
-    const size_t fb = (size_t)nf * k.pix * kDims[k.buf].c * c.es;     // one frame of this buffer
-    const char* x = static_cast<const char*>(c.F(k.buf));
-    if (hipMemcpyAsync(c.sc.mix, x, fb, hipMemcpyDeviceToDevice, c.s) != hipSuccess) return nullptr;
-    if (bwd_mix_heads(c.dt, x + fb, x, c.sc.mix + fb, (long long)(T - 1) * nf * k.pix, kDims[k.buf].c, k.pc, c.s) != UNCL_OK)
+    if (bwd_mix_heads_clip(c.dt, c.F(k.buf), c.sc.mix, (long long)T * nf * k.pix, (long long)nf * k.pix, kDims[k.buf].c, k.pc, c.s) !=
+        UNCL_OK)
       return nullptr;
     return c.sc.mix;
   };
